@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""bench.py -- simplex pivots/sec + achieved HBM GB/s on the dense 8192 x 4096 f64 tableau.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" is one full simplex iteration of the hot path on the GPU: pricing arg-min over the
+reduced costs -> ratio-test arg-min -> Gauss-Jordan rank-1 update of the whole tableau
+(src/simplex.lisp:453-461), on BASELINE.json config 3: a dense random LP with 8192 variables and
+4096 <=-constraints, i.e. a 4097 x 12289 double-float tableau (402.8 MB), generated directly in
+HBM (inputs resident before the timed region starts).
+
+N = 1: one tableau on one GPU.  N > 1 (launched by torch.distributed.run, one rank per GPU):
+every rank iterates on its own independent LP of the same shape (different seed) -- the
+"independent LPs shard trivially" partition of the north star, no data-path collective -- and
+the value is the whole-job aggregate (sum of pivots over ranks / max-over-ranks time), weak
+scaling.  `--workload colpart` instead runs ONE tableau column-partitioned over the ranks with
+the per-pivot RCCL exchange (all-gather of the local pricing winners + broadcast of the entering
+column); see linear-programming_amd/colpart.py.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (n_vars, n_constraints, config id used for the seed)
+    "cfg3": (8192, 4096, 3),
+    "cfg2": (1024, 512, 2),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS) + ["colpart"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pivots", type=int, default=24)
+    ap.add_argument("--no-events", action="store_true",
+                    help="do not bracket the update launches with HIP events (roofline = null)")
+    return ap.parse_args()
+
+
+def cpu_baseline(lp, n, m, seed, pivots):
+    """The oracle (C restatement of the reference algorithm; the Lisp reference itself cannot
+    run here) timed on the host cores on the first `pivots` pivots of the same LP."""
+    import oracle
+    M, b = lp.synth.tableau(n, m, seed)
+    threads = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    st, npiv, _ = oracle.solve(M, b, max_pivots=pivots, omp=True)
+    t_omp = time.perf_counter() - t0
+    single = max(2, pivots // 6)
+    t0 = time.perf_counter()
+    st1, npiv1, _ = oracle.solve(M, b, max_pivots=single, omp=False)
+    t_one = time.perf_counter() - t0
+    return {
+        "value": npiv / t_omp, "unit": "pivots/s", "cores": threads, "kind": "port",
+        "sample": "first %d pivots of the same %dx%d LP, OpenMP row-parallel C restatement of "
+                  "src/simplex.lisp:337-461 (SBCL unavailable in the image); single-thread: "
+                  "%.3f pivots/s over the next %d pivots" % (npiv, n, m, npiv1 / t_one, npiv1),
+        "single_thread_value": npiv1 / t_one,
+        "GBps": 2.0 * (m + 1) * (n + m + 1) * 8 * npiv / t_omp / 1e9,
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    N = args.gpus
+    if world != N:
+        if world == 1 and N > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
+                     "--nproc-per-node %d" % (N, N))
+        N = world
+
+    import torch
+    import torch.distributed as dist
+    lp = importlib.import_module("linear-programming_amd")
+    if not torch.cuda.is_available() or lp.capi.device_count() < 1:
+        sys.exit("bench.py needs a GPU (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    if N > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if N > 1:
+            dist.barrier()
+
+    if args.workload == "colpart":
+        from importlib import import_module
+        colpart = import_module("linear-programming_amd.colpart")
+        rec = colpart.bench(args, rank, local_rank, N)
+        if rank == 0:
+            print(json.dumps(rec), flush=True)
+        if N > 1:
+            dist.destroy_process_group()
+        return
+
+    n, m, cfg = WORKLOADS[args.workload]
+    R, C = m + 1, n + m + 1
+    bytes_per_pivot = 2 * R * C * 8            # every element read once + written once
+    L = lp.capi.lib()
+    seed = lp.synth.seed_for(cfg, rank)
+    h = ctypes.c_void_p()
+    lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h), n, m, seed, 0, -1, local_rank),
+                  "mi355x_tab_create_synthetic")
+    npv = ctypes.c_int64(0)
+
+    # warm-up (untimed)
+    lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, args.warmup, 1), "warmup")
+    L.mi355x_tab_sync(h, ctypes.byref(npv))
+    if not args.no_events:
+        L.mi355x_tab_timing_enable(h, 1)
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, args.steps, 0), "timed steps")
+    rc = L.mi355x_tab_sync(h, ctypes.byref(npv))       # waits for the launch stream
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    done = npv.value - args.warmup
+    if rc != lp.capi.MI_MAX_PIVOTS or done != args.steps:
+        sys.exit("rank %d: the LP terminated (status %d) after %d of %d timed pivots -- "
+                 "use fewer steps" % (rank, rc, done, args.steps))
+
+    upd_avg_ms = None
+    if not args.no_events:
+        nl, sm, mn = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+        L.mi355x_tab_timing_read(h, ctypes.byref(nl), ctypes.byref(sm), ctypes.byref(mn))
+        if nl.value > 0:
+            upd_avg_ms = sm.value / nl.value
+
+    if N > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        value = N * args.steps / elapsed
+        roofline = None
+        if upd_avg_ms:
+            ach = bytes_per_pivot / (upd_avg_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                        "kernel": L.mi355x_update_kernel_name().decode(),
+                        "kernel_avg_us": upd_avg_ms * 1e3,
+                        "algorithmic_bytes_per_launch": bytes_per_pivot,
+                        "launches_timed": int(nl.value)}
+        rec = {
+            "metric": "simplex pivots/sec + achieved HBM GB/s, dense 8192x4096 f64 tableau"
+                      if args.workload == "cfg3" else "simplex pivots/sec (%s)" % args.workload,
+            "value": value, "unit": "pivots/s", "n_gpus": N, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config %d: dense random LP %d vars x %d <=-constraints, "
+                                   "%dx%d f64 tableau, one independent LP per GPU" % (cfg, n, m, R, C),
+                       "tableau_bytes": R * C * 8, "fp_tolerance": 1024,
+                       "parallelism": "independent LPs, %d rank(s), no collective" % N},
+            "whole_pivot_GBps": bytes_per_pivot * value / N / 1e9,
+            "roofline": roofline,
+        }
+        if N == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(lp, n, m, seed, args.cpu_pivots)
+        print(json.dumps(rec), flush=True)
+    L.mi355x_tab_destroy(h)
+    if N > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

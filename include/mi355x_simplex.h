@@ -1,0 +1,160 @@
+/*
+ * mi355x_simplex.h -- C ABI of libmi355x_simplex.so
+ *
+ * MI355X (gfx950) dense-simplex backend for the Common Lisp library
+ * neil-lindquist/linear-programming (v2.3.0).  This is the drop-in boundary:
+ * the entry points below are what a CFFI binding behind the library's
+ * `linear-programming:*solver*` hook (src/solver.lisp:39-56) calls in place of
+ * the Lisp loops of src/simplex.lisp.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain C, no callbacks, no ownership transfer: the caller owns every host
+ *     buffer, the library owns the device memory behind a handle;
+ *   - a tableau is the reference's `tableau-matrix` (src/simplex.lisp:48-58):
+ *     rows = constraint_count + 1 (last row = objective row),
+ *     cols = var_count + 1       (last column = right-hand side),
+ *     row-major, tightly packed doubles on the host side;
+ *   - every function returns a status (>= 0: outcome, < 0: error);
+ *     mi355x_last_error() gives the thread-local message of the last error;
+ *   - there is NO CPU fallback: without a gfx950 device every compute entry
+ *     point fails with MI_NO_DEVICE;
+ *   - a handle may be used from one thread at a time.
+ *
+ * Arithmetic contract (what makes results bit-identical to the reference's
+ * double-float path): IEEE binary64, product and difference rounded separately
+ * (no FMA) in the rank-1 update, true division for the pivot-row scaling and
+ * the ratio test, tolerances factor/8, factor/2 (and factor for the phase-1
+ * feasibility test) times Common Lisp's DOUBLE-FLOAT-EPSILON
+ * 1.1102230246251568e-16, strict comparison with lowest index winning ties.
+ */
+#ifndef MI355X_SIMPLEX_H
+#define MI355X_SIMPLEX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355X_SIMPLEX_ABI_VERSION 1
+
+/* outcomes (returned by the solve entry points) */
+#define MI_OK            0
+#define MI_OPTIMAL       0   /* find-entering-column returned NIL            simplex.lisp:455-456 */
+#define MI_UNBOUNDED     1   /* -> unbounded-problem-error                   simplex.lisp:458-459 */
+#define MI_INFEASIBLE    2   /* -> infeasible-problem-error                  simplex.lisp:405-407 */
+#define MI_MAX_PIVOTS    3   /* pivot cap reached (backend-specific; the reference has no cap) */
+#define MI_ART_NONZERO   4   /* "Artificial variable ~S still non-zero"       simplex.lisp:423-424 */
+#define MI_ART_STUCK     5   /* "Artificial variable still in basis and ..."  simplex.lisp:432-433 */
+/* errors */
+#define MI_BAD_ARG      -1
+#define MI_HIP_ERROR    -2
+#define MI_RCCL_ERROR   -3
+#define MI_NO_DEVICE    -4
+#define MI_NO_MEMORY    -5
+
+typedef struct mi355x_tab   mi355x_tab;     /* one tableau resident in HBM              */
+
+/* ---- library / device ------------------------------------------------------------- */
+int         mi355x_abi_version(void);
+int         mi355x_device_count(void);             /* number of gfx950 devices visible, 0 if none */
+const char *mi355x_last_error(void);               /* thread-local, never NULL */
+double      mi355x_epsilon(void);                  /* CL double-float-epsilon used by the tolerances */
+
+/* ---- tableau lifecycle  (tableau struct, src/simplex.lisp:48-58) ------------------- */
+/* Upload a tableau.  host_basis has rows-1 entries (tableau-basis-columns) or is NULL. */
+int  mi355x_tab_create(mi355x_tab **out, int64_t rows, int64_t cols,
+                       const double *host_matrix, const int64_t *host_basis, int device);
+/* Replace the contents of an existing handle (same shape). */
+int  mi355x_tab_upload(mi355x_tab *t, const double *host_matrix, const int64_t *host_basis);
+/* copy-tableau (src/simplex.lisp:61-71): device-to-device deep copy of matrix + basis. */
+int  mi355x_tab_copy(mi355x_tab **out, const mi355x_tab *src);
+/* Build the bench/test LP  max c'x, Ax <= b, x >= 0  directly in HBM
+ * (splitmix64 stream; identical doubles to linear-programming_amd/synth.py):
+ * tableau [A | I | b ; -c | 0 | 0], basis n_vars .. n_vars+n_cons-1.
+ * col_begin/col_end select a column slice [col_begin, col_end) of the
+ * var_count = n_vars+n_cons non-RHS columns (column-partitioned shards keep
+ * the RHS column as their last column); pass 0, -1 for the whole tableau. */
+int  mi355x_tab_create_synthetic(mi355x_tab **out, int64_t n_vars, int64_t n_cons,
+                                 uint64_t seed, int64_t col_begin, int64_t col_end, int device);
+void mi355x_tab_destroy(mi355x_tab *t);
+int  mi355x_tab_shape(const mi355x_tab *t, int64_t *rows, int64_t *cols, int64_t *ld);
+
+/* ---- the hot path ------------------------------------------------------------------ */
+/* n-pivot-row (src/simplex.lisp:337-359): normalise row `pivot_row` by its entry in
+ * `entering_col`, eliminate that column from every other row (objective row included),
+ * basis[pivot_row] = entering_col. */
+int  mi355x_tab_pivot(mi355x_tab *t, int64_t entering_col, int64_t pivot_row);
+/* find-entering-column (src/simplex.lisp:362-379): *col = column or -1 for NIL. */
+int  mi355x_tab_price(mi355x_tab *t, int is_max, double fp_factor, int64_t *col);
+/* find-pivoting-row (src/simplex.lisp:382-389): *row = row or -1 for NIL. */
+int  mi355x_tab_ratio(mi355x_tab *t, int64_t entering_col, double fp_factor, int64_t *row);
+/* n-solve-tableau, single-phase branch (src/simplex.lisp:453-461), entirely on the
+ * device.  max_pivots = 0: no cap (as the reference).  Returns MI_OPTIMAL,
+ * MI_UNBOUNDED or MI_MAX_PIVOTS; *n_pivots = pivots performed by this call. */
+int  mi355x_tab_solve(mi355x_tab *t, int is_max, double fp_factor, int64_t max_pivots,
+                      int64_t *n_pivots);
+/* n-solve-tableau, two-phase branch (src/simplex.lisp:402-452): `art` is the
+ * artificial tableau (a min problem), `main_tab` the main tableau with the same
+ * row count; both are modified.  n_pivots[0] = phase 1 (incl. drive-out pivots),
+ * n_pivots[1] = phase 2.  Returns MI_OPTIMAL / MI_UNBOUNDED / MI_INFEASIBLE /
+ * MI_ART_NONZERO / MI_ART_STUCK. */
+int  mi355x_solve_two_phase(mi355x_tab *art, mi355x_tab *main_tab, int main_is_max,
+                            double fp_factor, int64_t *n_pivots);
+
+/* ---- read-back (src/simplex.lisp:74-120 needs last row, last column, basis) -------- */
+/* Any pointer may be NULL.  host_matrix: rows*cols, host_basis: rows-1,
+ * last_row: cols (objective row), last_col: rows (RHS column). */
+int  mi355x_tab_download(mi355x_tab *t, double *host_matrix, int64_t *host_basis,
+                         double *last_row, double *last_col);
+/* (entering column, pivot row) of the pivots made by solve calls since the last
+ * upload / trace reset, oldest first; at most cap pairs are written, *n = number
+ * of pivots recorded on the device (tracing holds up to 2^20 pairs). */
+int  mi355x_tab_trace(mi355x_tab *t, int64_t *entering_cols, int64_t *pivot_rows,
+                      int64_t cap, int64_t *n);
+
+/* ---- asynchronous / measurement plumbing ------------------------------------------- */
+/* Run the handle's kernels on an existing HIP stream (hipStream_t as void*), e.g.
+ * torch.cuda.current_stream().cuda_stream.  NULL = the handle's own stream. */
+int  mi355x_tab_set_stream(mi355x_tab *t, void *hip_stream);
+/* Enqueue up to n_pivots iterations of price -> ratio -> pivot without any host
+ * synchronisation (kernels turn into no-ops once the tableau is optimal/unbounded).
+ * reset != 0 restarts the device-side pivot counter/status first. */
+int  mi355x_tab_solve_async(mi355x_tab *t, int is_max, double fp_factor, int64_t n_pivots,
+                            int reset);
+/* Wait for the stream; returns the device-side status (MI_OPTIMAL, MI_UNBOUNDED,
+ * MI_MAX_PIVOTS = still running when the enqueued pivots ran out) and the number of
+ * pivots done since the last reset. */
+int  mi355x_tab_sync(mi355x_tab *t, int64_t *n_pivots);
+/* Per-launch HIP-event timing of the rank-1 update kernel (the bandwidth kernel):
+ * enable != 0 brackets every update launch with an event pair on the launch stream
+ * (up to 4096 launches kept).  mi355x_tab_timing_read waits for the stream and returns
+ * the number of timed launches, their summed and minimum duration in milliseconds,
+ * then clears the record. */
+int  mi355x_tab_timing_enable(mi355x_tab *t, int enable);
+int  mi355x_tab_timing_read(mi355x_tab *t, int64_t *n_launches, double *sum_ms, double *min_ms);
+/* Name of the rank-1 update kernel as it appears in rocprofv3 kernel traces. */
+const char *mi355x_update_kernel_name(void);
+
+/* ---- column-partitioned tableau: per-shard steps (BASELINE config 5) --------------- */
+/* One pivot of a tableau whose non-RHS columns are split across shards (one shard =
+ * one handle = one GPU / rank; every shard keeps its own copy of the RHS column as its
+ * last column):
+ *   1. every shard: mi355x_shard_price      -> local best (value, GLOBAL column)
+ *   2. exchange (all-gather 16 B per shard), pick the lexicographic (value, column) best
+ *   3. owner shard: mi355x_shard_gather_col -> the entering column (rows doubles, device)
+ *   4. exchange (broadcast of that column from the owner)
+ *   5. every shard: mi355x_shard_pivot      -> ratio test on (column, own RHS copy),
+ *      normalise own slice of the pivot row, rank-1 update of own slice.
+ * col_offset = global index of the shard's first column.  Device pointers are raw
+ * device addresses (e.g. torch tensors' data_ptr()). */
+int  mi355x_shard_price(mi355x_tab *t, int is_max, int64_t col_offset,
+                        double *dev_value_out, int64_t *dev_col_out);
+int  mi355x_shard_gather_col(mi355x_tab *t, int64_t local_col, double *dev_col_out);
+int  mi355x_shard_pivot(mi355x_tab *t, const double *dev_col, int64_t global_col,
+                        int64_t col_offset, int is_owner, double fp_factor);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355X_SIMPLEX_H */

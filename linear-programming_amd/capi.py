@@ -1,0 +1,92 @@
+"""ctypes binding of libmi355x_simplex.so -- one Python function per C-ABI entry point of
+include/mi355x_simplex.h, nothing else.  Fails loudly when the library is missing."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmi355x_simplex.so")
+
+MI_OK = MI_OPTIMAL = 0
+MI_UNBOUNDED, MI_INFEASIBLE, MI_MAX_PIVOTS, MI_ART_NONZERO, MI_ART_STUCK = 1, 2, 3, 4, 5
+MI_BAD_ARG, MI_HIP_ERROR, MI_RCCL_ERROR, MI_NO_DEVICE, MI_NO_MEMORY = -1, -2, -3, -4, -5
+
+_i64, _dbl, _p, _int = ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, ctypes.c_int
+_pp = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> (restype, argtypes); kept in one table so tests can check it against the header
+SIGNATURES = {
+    "mi355x_abi_version": (_int, []),
+    "mi355x_device_count": (_int, []),
+    "mi355x_last_error": (ctypes.c_char_p, []),
+    "mi355x_epsilon": (_dbl, []),
+    "mi355x_tab_create": (_int, [_pp, _i64, _i64, _p, _p, _int]),
+    "mi355x_tab_upload": (_int, [_p, _p, _p]),
+    "mi355x_tab_copy": (_int, [_pp, _p]),
+    "mi355x_tab_create_synthetic": (_int, [_pp, _i64, _i64, ctypes.c_uint64, _i64, _i64, _int]),
+    "mi355x_tab_destroy": (None, [_p]),
+    "mi355x_tab_shape": (_int, [_p, _p, _p, _p]),
+    "mi355x_tab_pivot": (_int, [_p, _i64, _i64]),
+    "mi355x_tab_price": (_int, [_p, _int, _dbl, _p]),
+    "mi355x_tab_ratio": (_int, [_p, _i64, _dbl, _p]),
+    "mi355x_tab_solve": (_int, [_p, _int, _dbl, _i64, _p]),
+    "mi355x_solve_two_phase": (_int, [_p, _p, _int, _dbl, _p]),
+    "mi355x_tab_download": (_int, [_p, _p, _p, _p, _p]),
+    "mi355x_tab_trace": (_int, [_p, _p, _p, _i64, _p]),
+    "mi355x_tab_set_stream": (_int, [_p, _p]),
+    "mi355x_tab_solve_async": (_int, [_p, _int, _dbl, _i64, _int]),
+    "mi355x_tab_sync": (_int, [_p, _p]),
+    "mi355x_tab_timing_enable": (_int, [_p, _int]),
+    "mi355x_tab_timing_read": (_int, [_p, _p, _p, _p]),
+    "mi355x_update_kernel_name": (ctypes.c_char_p, []),
+    "mi355x_shard_price": (_int, [_p, _int, _i64, _p, _p]),
+    "mi355x_shard_gather_col": (_int, [_p, _i64, _p]),
+    "mi355x_shard_pivot": (_int, [_p, _p, _i64, _i64, _int, _dbl]),
+}
+# tuning hooks exported by the library but not part of include/mi355x_simplex.h
+_EXTRA = {
+    "mi355x_tune_variant_count": (_int, []),
+    "mi355x_tune_variant_name": (ctypes.c_char_p, [_int]),
+    "mi355x_tune_set_variant": (_int, [_int]),
+    "mi355x_tune_set_select_mode": (_int, [_int]),
+}
+
+_lib = None
+
+
+class ExtensionMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded shared library.  Raises if it has not been built -- there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ExtensionMissing(
+                "%s is missing: build it with `python linear-programming_amd/build.py` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for table in (SIGNATURES, _EXTRA):
+            for name, (res, args) in table.items():
+                fn = getattr(L, name)
+                fn.restype = res
+                fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class Mi355xError(RuntimeError):
+    def __init__(self, code, where):
+        msg = lib().mi355x_last_error().decode("utf-8", "replace")
+        super().__init__("%s failed with status %d: %s" % (where, code, msg))
+        self.code = code
+
+
+def check(code, where):
+    if code < 0:
+        raise Mi355xError(code, where)
+    return code
+
+
+def device_count():
+    return int(lib().mi355x_device_count())

@@ -1,0 +1,591 @@
+// simplex_capi.hip -- the C ABI of libmi355x_simplex.so (include/mi355x_simplex.h).
+//
+// Host side of the drop-in boundary: handle management, uploads/downloads between the
+// caller's tightly packed row-major host arrays and the padded HBM layout, the blind
+// enqueue loop that keeps the whole price -> ratio -> pivot iteration on the device, the
+// two-phase driver of src/simplex.lisp:402-452, and HIP-event timing of the update kernel.
+// No CPU compute path exists here: without a device every entry point fails.
+#include "../../include/mi355x_simplex.h"
+#include "simplex_kernels.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace mi355x;
+
+namespace {
+
+thread_local std::string g_err;
+int g_select_mode = 0;                    // 0 auto, 1 single workgroup, 2 split (tuning/test hook)
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(e_ == hipErrorOutOfMemory ? MI_NO_MEMORY : MI_HIP_ERROR,           \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,   \
+                        __LINE__);                                                         \
+    } while (0)
+
+constexpr int64_t kTraceCap   = 1 << 20;
+constexpr int     kTimingCap  = 4096;
+constexpr int64_t kLdAlign    = 16;       // doubles: rows start on 128-byte boundaries
+constexpr int     kPartCap    = 16384;
+
+int64_t padded_ld(int64_t cols) { return (cols + kLdAlign - 1) / kLdAlign * kLdAlign; }
+
+int device_count_checked()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+}  // namespace
+
+struct mi355x_tab {
+    int         device = 0;
+    TabView     v{};
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    Ctl        *h_ctl = nullptr;          // pinned host mirror of the control block
+    int64_t     pivots_before = 0;        // (unused by the ABI; kept for debugging)
+    int         n_part = 0;               // pricing partials left by the last update (0 = none)
+    int         part_is_max = -1;         // ... and the problem sense they were computed for
+    bool        timing = false;
+    int         n_timed = 0;
+    std::vector<hipEvent_t> ev0, ev1;
+};
+
+namespace {
+
+int use_device(const mi355x_tab *t)
+{
+    HIP_TRY(hipSetDevice(t->device));
+    return MI_OK;
+}
+
+void free_tab(mi355x_tab *t)
+{
+    if (!t) return;
+    (void)hipSetDevice(t->device);
+    if (t->own_stream) (void)hipStreamSynchronize(t->own_stream);
+    for (auto e : t->ev0) (void)hipEventDestroy(e);
+    for (auto e : t->ev1) (void)hipEventDestroy(e);
+    (void)hipFree(t->v.M);
+    (void)hipFree(t->v.basis);
+    (void)hipFree(t->v.col);
+    (void)hipFree(t->v.prow);
+    (void)hipFree(t->v.ctl);
+    (void)hipFree(t->v.trace_ec);
+    (void)hipFree(t->v.trace_cr);
+    (void)hipFree(t->v.part_v);
+    (void)hipFree(t->v.part_i);
+    if (t->h_ctl) (void)hipHostFree(t->h_ctl);
+    if (t->own_stream) (void)hipStreamDestroy(t->own_stream);
+    delete t;
+}
+
+// allocate an empty handle of the given shape on `device`
+int alloc_tab(mi355x_tab **out, int64_t rows, int64_t cols, int device)
+{
+    if (!out) return fail(MI_BAD_ARG, "out is NULL");
+    *out = nullptr;
+    if (rows < 1 || cols < 1) return fail(MI_BAD_ARG, "rows=%lld cols=%lld must be >= 1",
+                                          (long long)rows, (long long)cols);
+    if (rows > 65535LL * 16) return fail(MI_BAD_ARG, "rows=%lld exceeds the supported 1048560",
+                                         (long long)rows);
+    const int ndev = device_count_checked();
+    if (ndev <= 0) return fail(MI_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(MI_BAD_ARG, "device %d out of range [0,%d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    mi355x_tab *t = new (std::nothrow) mi355x_tab;
+    if (!t) return fail(MI_NO_MEMORY, "host allocation failed");
+    t->device = device;
+    t->v.rows = rows;
+    t->v.cols = cols;
+    t->v.ld = padded_ld(cols);
+    t->v.trace_cap = kTraceCap;
+    const size_t mbytes = (size_t)rows * (size_t)t->v.ld * sizeof(double);
+    hipError_t e;
+#define ALLOC(ptr, bytes)                                                                  \
+    if ((e = hipMalloc((void **)&(ptr), (bytes))) != hipSuccess) {                         \
+        free_tab(t);                                                                       \
+        return fail(e == hipErrorOutOfMemory ? MI_NO_MEMORY : MI_HIP_ERROR,                \
+                    "hipMalloc(%zu bytes) failed: %s", (size_t)(bytes), hipGetErrorString(e)); \
+    }
+    ALLOC(t->v.M, mbytes);
+    ALLOC(t->v.basis, std::max<int64_t>(rows - 1, 1) * sizeof(int64_t));
+    ALLOC(t->v.col, rows * sizeof(double));
+    ALLOC(t->v.prow, t->v.ld * sizeof(double));
+    ALLOC(t->v.ctl, sizeof(Ctl));
+    ALLOC(t->v.trace_ec, kTraceCap * sizeof(int64_t));
+    ALLOC(t->v.trace_cr, kTraceCap * sizeof(int64_t));
+    ALLOC(t->v.part_v, kPartCap * sizeof(double));
+    ALLOC(t->v.part_i, kPartCap * sizeof(int64_t));
+    t->v.part_cap = kPartCap;
+#undef ALLOC
+    if ((e = hipHostMalloc((void **)&t->h_ctl, sizeof(Ctl))) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&t->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+        free_tab(t);
+        return fail(MI_HIP_ERROR, "stream/pinned allocation failed: %s", hipGetErrorString(e));
+    }
+    t->stream = t->own_stream;
+    memset(t->h_ctl, 0, sizeof(Ctl));
+    if ((e = hipMemsetAsync(t->v.ctl, 0, sizeof(Ctl), t->stream)) != hipSuccess ||
+        (e = hipMemsetAsync(t->v.basis, 0, std::max<int64_t>(rows - 1, 1) * sizeof(int64_t),
+                            t->stream)) != hipSuccess) {
+        free_tab(t);
+        return fail(MI_HIP_ERROR, "memset failed: %s", hipGetErrorString(e));
+    }
+    *out = t;
+    return MI_OK;
+}
+
+int upload(mi355x_tab *t, const double *hm, const int64_t *hb)
+{
+    const TabView &v = t->v;
+    t->n_part = 0;
+    if (hm) {
+        if (v.ld != v.cols)    // zero the padding columns once per upload
+            HIP_TRY(hipMemsetAsync(v.M, 0, (size_t)v.rows * v.ld * sizeof(double), t->stream));
+        HIP_TRY(hipMemcpy2DAsync(v.M, v.ld * sizeof(double), hm, v.cols * sizeof(double),
+                                 v.cols * sizeof(double), v.rows, hipMemcpyHostToDevice, t->stream));
+    }
+    if (hb && v.rows > 1)
+        HIP_TRY(hipMemcpyAsync(v.basis, hb, (v.rows - 1) * sizeof(int64_t), hipMemcpyHostToDevice,
+                               t->stream));
+    launch_ctl_reset(v, 0, /*reset_trace=*/1, t->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(t->stream));   // host buffers may be released by the caller
+    return MI_OK;
+}
+
+int read_ctl(mi355x_tab *t)
+{
+    HIP_TRY(hipMemcpyAsync(t->h_ctl, t->v.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    return MI_OK;
+}
+
+// select of one iteration; prices from the partials of the preceding update when they exist
+void enqueue_select(mi355x_tab *t, int is_max, double f)
+{
+    const int np = (t->n_part > 0 && t->part_is_max == (is_max ? 1 : 0)) ? t->n_part : 0;
+    // single-workgroup select for small tableaux (fewest launches), split select for large
+    // ones (the strided column gather needs many workgroups' memory pipelines)
+    bool split = (t->v.rows > 1024 || t->v.ld > 4096);
+    if (g_select_mode == 1) split = false;
+    if (g_select_mode == 2) split = true;
+    if (split && select_split_supported(t->v)) launch_select_split(t->v, is_max, f, np, t->stream);
+    else                                       launch_select(t->v, is_max, f, np, t->stream);
+}
+
+// update of one iteration (+ optional event pair around it); prices the new objective row
+int enqueue_update(mi355x_tab *t, int is_max)
+{
+    const bool timed = t->timing && t->n_timed < kTimingCap;
+    if (timed) {
+        if ((int)t->ev0.size() <= t->n_timed) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            t->ev0.push_back(a);
+            t->ev1.push_back(b);
+        }
+        HIP_TRY(hipEventRecord(t->ev0[t->n_timed], t->stream));
+    }
+    t->n_part = launch_update(t->v, is_max ? 1.0 : -1.0, 1, t->stream);
+    t->part_is_max = is_max ? 1 : 0;
+    if (timed) {
+        HIP_TRY(hipEventRecord(t->ev1[t->n_timed], t->stream));
+        t->n_timed++;
+    }
+    return MI_OK;
+}
+
+int enqueue_iteration(mi355x_tab *t, int is_max, double f)
+{
+    enqueue_select(t, is_max, f);
+    return enqueue_update(t, is_max);
+}
+
+int status_to_rc(int32_t st) { return st == kRunning ? MI_MAX_PIVOTS : (int)st; }
+
+}  // namespace
+
+extern "C" {
+
+int mi355x_abi_version(void) { return MI355X_SIMPLEX_ABI_VERSION; }
+int mi355x_device_count(void) { return device_count_checked(); }
+const char *mi355x_last_error(void) { return g_err.c_str(); }
+double mi355x_epsilon(void) { return kClEpsilon; }
+const char *mi355x_update_kernel_name(void) { return update_kernel_symbol(); }
+
+int mi355x_tab_create(mi355x_tab **out, int64_t rows, int64_t cols, const double *host_matrix,
+                      const int64_t *host_basis, int device)
+{
+    if (!host_matrix) return fail(MI_BAD_ARG, "host_matrix is NULL");
+    mi355x_tab *t = nullptr;
+    int rc = alloc_tab(&t, rows, cols, device);
+    if (rc != MI_OK) return rc;
+    rc = upload(t, host_matrix, host_basis);
+    if (rc != MI_OK) { free_tab(t); return rc; }
+    *out = t;
+    return MI_OK;
+}
+
+int mi355x_tab_upload(mi355x_tab *t, const double *host_matrix, const int64_t *host_basis)
+{
+    if (!t) return fail(MI_BAD_ARG, "handle is NULL");
+    int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    return upload(t, host_matrix, host_basis);
+}
+
+int mi355x_tab_copy(mi355x_tab **out, const mi355x_tab *src)
+{
+    if (!src) return fail(MI_BAD_ARG, "src is NULL");
+    mi355x_tab *t = nullptr;
+    int rc = alloc_tab(&t, src->v.rows, src->v.cols, src->device);
+    if (rc != MI_OK) return rc;
+    hipError_t e = hipStreamSynchronize(src->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(t->v.M, src->v.M, (size_t)src->v.rows * src->v.ld * sizeof(double),
+                           hipMemcpyDeviceToDevice, t->stream);
+    if (e == hipSuccess && src->v.rows > 1)
+        e = hipMemcpyAsync(t->v.basis, src->v.basis, (src->v.rows - 1) * sizeof(int64_t),
+                           hipMemcpyDeviceToDevice, t->stream);
+    if (e == hipSuccess) { launch_ctl_reset(t->v, 0, 1, t->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    if (e != hipSuccess) { free_tab(t); return fail(MI_HIP_ERROR, "copy failed: %s", hipGetErrorString(e)); }
+    *out = t;
+    return MI_OK;
+}
+
+int mi355x_tab_create_synthetic(mi355x_tab **out, int64_t n_vars, int64_t n_cons, uint64_t seed,
+                                int64_t col_begin, int64_t col_end, int device)
+{
+    if (n_vars < 1 || n_cons < 1) return fail(MI_BAD_ARG, "n_vars and n_cons must be >= 1");
+    const int64_t vc = n_vars + n_cons;
+    if (col_end < 0) col_end = vc;
+    if (col_begin < 0 || col_begin >= col_end || col_end > vc)
+        return fail(MI_BAD_ARG, "bad column slice [%lld,%lld) of %lld", (long long)col_begin,
+                    (long long)col_end, (long long)vc);
+    mi355x_tab *t = nullptr;
+    int rc = alloc_tab(&t, n_cons + 1, (col_end - col_begin) + 1, device);
+    if (rc != MI_OK) return rc;
+    launch_synth_fill(t->v, n_vars, n_cons, seed, col_begin, col_end, t->stream);
+    launch_ctl_reset(t->v, 0, 1, t->stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    if (e != hipSuccess) { free_tab(t); return fail(MI_HIP_ERROR, "synthetic fill failed: %s", hipGetErrorString(e)); }
+    *out = t;
+    return MI_OK;
+}
+
+void mi355x_tab_destroy(mi355x_tab *t) { free_tab(t); }
+
+int mi355x_tab_shape(const mi355x_tab *t, int64_t *rows, int64_t *cols, int64_t *ld)
+{
+    if (!t) return fail(MI_BAD_ARG, "handle is NULL");
+    if (rows) *rows = t->v.rows;
+    if (cols) *cols = t->v.cols;
+    if (ld) *ld = t->v.ld;
+    return MI_OK;
+}
+
+int mi355x_tab_pivot(mi355x_tab *t, int64_t ec, int64_t cr)
+{
+    if (!t) return fail(MI_BAD_ARG, "handle is NULL");
+    if (ec < 0 || ec >= t->v.cols || cr < 0 || cr >= t->v.rows)
+        return fail(MI_BAD_ARG, "pivot (col %lld, row %lld) outside %lldx%lld", (long long)ec,
+                    (long long)cr, (long long)t->v.rows, (long long)t->v.cols);
+    int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    launch_prepare_pivot(t->v, ec, cr, t->stream);
+    launch_update(t->v, 1.0, 0, t->stream);
+    t->n_part = 0;
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    return MI_OK;
+}
+
+int mi355x_tab_price(mi355x_tab *t, int is_max, double f, int64_t *col)
+{
+    if (!t || !col) return fail(MI_BAD_ARG, "NULL argument");
+    int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    launch_price_only(t->v, is_max, f, t->stream);
+    HIP_TRY(hipGetLastError());
+    rc = read_ctl(t);
+    if (rc != MI_OK) return rc;
+    *col = t->h_ctl->ec;
+    return MI_OK;
+}
+
+int mi355x_tab_ratio(mi355x_tab *t, int64_t ec, double f, int64_t *row)
+{
+    if (!t || !row) return fail(MI_BAD_ARG, "NULL argument");
+    if (ec < 0 || ec >= t->v.cols) return fail(MI_BAD_ARG, "entering column %lld out of range", (long long)ec);
+    int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    launch_ratio_only(t->v, ec, f, t->stream);
+    HIP_TRY(hipGetLastError());
+    rc = read_ctl(t);
+    if (rc != MI_OK) return rc;
+    *row = t->h_ctl->cr;
+    return MI_OK;
+}
+
+int mi355x_tab_solve_async(mi355x_tab *t, int is_max, double f, int64_t n_pivots, int reset)
+{
+    if (!t) return fail(MI_BAD_ARG, "handle is NULL");
+    if (n_pivots < 0) return fail(MI_BAD_ARG, "n_pivots < 0");
+    int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    if (reset) launch_ctl_reset(t->v, 0, 0, t->stream);
+    for (int64_t i = 0; i < n_pivots; ++i) {
+        rc = enqueue_iteration(t, is_max, f);
+        if (rc != MI_OK) return rc;
+    }
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int mi355x_tab_sync(mi355x_tab *t, int64_t *n_pivots)
+{
+    if (!t) return fail(MI_BAD_ARG, "handle is NULL");
+    int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    rc = read_ctl(t);
+    if (rc != MI_OK) return rc;
+    if (n_pivots) *n_pivots = t->h_ctl->n_pivots;
+    return status_to_rc(t->h_ctl->status);
+}
+
+int mi355x_tab_solve(mi355x_tab *t, int is_max, double f, int64_t max_pivots, int64_t *n_pivots)
+{
+    if (!t) return fail(MI_BAD_ARG, "handle is NULL");
+    if (max_pivots < 0) return fail(MI_BAD_ARG, "max_pivots < 0");
+    int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    launch_ctl_reset(t->v, max_pivots, 0, t->stream);
+    // Blind enqueue in growing chunks; one status read-back per chunk.  Iterations enqueued
+    // past termination are no-ops on the device (kernels test ctl->status first).
+    int64_t chunk = 16;
+    for (;;) {
+        for (int64_t i = 0; i < chunk; ++i) {
+            rc = enqueue_iteration(t, is_max, f);
+            if (rc != MI_OK) return rc;
+        }
+        // the select of the NEXT iteration is what detects optimality / the cap
+        enqueue_select(t, is_max, f);
+        HIP_TRY(hipGetLastError());
+        rc = read_ctl(t);
+        if (rc != MI_OK) return rc;
+        if (t->h_ctl->status != kRunning) break;
+        // the extra select above already chose the next pivot (ctl->ec/cr, col, prow are
+        // set and it was counted): apply its update before continuing
+        rc = enqueue_update(t, is_max);
+        if (rc != MI_OK) return rc;
+        if (chunk < 512) chunk *= 2;
+    }
+    if (n_pivots) *n_pivots = t->h_ctl->n_pivots;
+    return (int)t->h_ctl->status;
+}
+
+int mi355x_solve_two_phase(mi355x_tab *art, mi355x_tab *mt, int main_is_max, double f,
+                           int64_t *n_pivots)
+{
+    if (!art || !mt) return fail(MI_BAD_ARG, "NULL handle");
+    if (art->v.rows != mt->v.rows || art->v.cols < mt->v.cols || art->device != mt->device)
+        return fail(MI_BAD_ARG, "artificial and main tableau do not match");
+    const int64_t m = mt->v.rows - 1, num_vars = mt->v.cols - 1, num_art_vars = art->v.cols - 1;
+    int64_t n1 = 0, n2 = 0;
+    if (n_pivots) { n_pivots[0] = 0; n_pivots[1] = 0; }
+    int rc = mi355x_tab_solve(art, /*is_max=*/0, f, 0, &n1);             // simplex.lisp:403
+    if (n_pivots) n_pivots[0] = n1;
+    if (rc != MI_OPTIMAL) return rc;
+    // (fp= 0 objective factor)                                             simplex.lisp:405-407
+    double art_obj = 0.0;
+    HIP_TRY(hipMemcpyAsync(&art_obj, art->v.M + m * art->v.ld + num_art_vars, sizeof(double),
+                           hipMemcpyDeviceToHost, art->stream));
+    HIP_TRY(hipStreamSynchronize(art->stream));
+    const double diff = 0.0 - art_obj;
+    if (!((diff < 0.0 ? -diff : diff) <= f * kClEpsilon)) return MI_INFEASIBLE;
+    // degenerate artificials still basic: pivot them out               simplex.lisp:419-434
+    std::vector<int64_t> basis((size_t)std::max<int64_t>(m, 1));
+    if (m > 0) {
+        HIP_TRY(hipMemcpyAsync(basis.data(), art->v.basis, m * sizeof(int64_t), hipMemcpyDeviceToHost,
+                               art->stream));
+        HIP_TRY(hipStreamSynchronize(art->stream));
+    }
+    std::vector<double> row;
+    for (int64_t i = 0; i < m; ++i) {
+        if (basis[i] < num_vars) continue;
+        row.resize((size_t)art->v.cols);
+        HIP_TRY(hipMemcpyAsync(row.data(), art->v.M + i * art->v.ld, art->v.cols * sizeof(double),
+                               hipMemcpyDeviceToHost, art->stream));
+        HIP_TRY(hipStreamSynchronize(art->stream));
+        if (row[num_art_vars] != 0.0) return MI_ART_NONZERO;
+        int64_t new_col = -1;
+        for (int64_t j = 0; j < num_vars; ++j) {
+            if (row[j] != 0.0 && std::find(basis.begin(), basis.begin() + m, j) == basis.begin() + m) {
+                new_col = j;
+                break;
+            }
+        }
+        if (new_col < 0) return MI_ART_STUCK;
+        rc = mi355x_tab_pivot(art, new_col, i);
+        if (rc != MI_OK) return rc;
+        basis[i] = new_col;
+        ++n1;
+    }
+    if (n_pivots) n_pivots[0] = n1;
+    // copy rows + basis, re-eliminate the objective row                simplex.lisp:437-451
+    HIP_TRY(hipStreamSynchronize(mt->stream));
+    launch_handover(art->v, mt->v, art->stream);
+    mt->n_part = 0;
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(art->stream));
+    rc = mi355x_tab_solve(mt, main_is_max, f, 0, &n2);                  // simplex.lisp:452
+    if (n_pivots) n_pivots[1] = n2;
+    return rc;
+}
+
+int mi355x_tab_download(mi355x_tab *t, double *hm, int64_t *hb, double *last_row, double *last_col)
+{
+    if (!t) return fail(MI_BAD_ARG, "handle is NULL");
+    int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    const TabView &v = t->v;
+    if (hm)
+        HIP_TRY(hipMemcpy2DAsync(hm, v.cols * sizeof(double), v.M, v.ld * sizeof(double),
+                                 v.cols * sizeof(double), v.rows, hipMemcpyDeviceToHost, t->stream));
+    if (hb && v.rows > 1)
+        HIP_TRY(hipMemcpyAsync(hb, v.basis, (v.rows - 1) * sizeof(int64_t), hipMemcpyDeviceToHost,
+                               t->stream));
+    if (last_row)
+        HIP_TRY(hipMemcpyAsync(last_row, v.M + (v.rows - 1) * v.ld, v.cols * sizeof(double),
+                               hipMemcpyDeviceToHost, t->stream));
+    if (last_col)
+        HIP_TRY(hipMemcpy2DAsync(last_col, sizeof(double), v.M + (v.cols - 1), v.ld * sizeof(double),
+                                 sizeof(double), v.rows, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    return MI_OK;
+}
+
+int mi355x_tab_trace(mi355x_tab *t, int64_t *ecs, int64_t *crs, int64_t cap, int64_t *n)
+{
+    if (!t) return fail(MI_BAD_ARG, "handle is NULL");
+    int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    rc = read_ctl(t);
+    if (rc != MI_OK) return rc;
+    const int64_t total = t->h_ctl->trace_n;
+    if (n) *n = total;
+    const int64_t k = std::min<int64_t>(std::min<int64_t>(total, cap), kTraceCap);
+    if (k > 0 && ecs) HIP_TRY(hipMemcpy(ecs, t->v.trace_ec, k * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (k > 0 && crs) HIP_TRY(hipMemcpy(crs, t->v.trace_cr, k * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+int mi355x_tab_set_stream(mi355x_tab *t, void *hip_stream)
+{
+    if (!t) return fail(MI_BAD_ARG, "handle is NULL");
+    int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    t->stream = hip_stream ? (hipStream_t)hip_stream : t->own_stream;
+    return MI_OK;
+}
+
+int mi355x_tab_timing_enable(mi355x_tab *t, int enable)
+{
+    if (!t) return fail(MI_BAD_ARG, "handle is NULL");
+    t->timing = enable != 0;
+    return MI_OK;
+}
+
+int mi355x_tab_timing_read(mi355x_tab *t, int64_t *n_launches, double *sum_ms, double *min_ms)
+{
+    if (!t) return fail(MI_BAD_ARG, "handle is NULL");
+    int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    double sum = 0.0, mn = 0.0;
+    for (int i = 0; i < t->n_timed; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, t->ev0[i], t->ev1[i]));
+        sum += ms;
+        if (i == 0 || ms < mn) mn = ms;
+    }
+    if (n_launches) *n_launches = t->n_timed;
+    if (sum_ms) *sum_ms = sum;
+    if (min_ms) *min_ms = mn;
+    t->n_timed = 0;
+    return MI_OK;
+}
+
+// ---- column-partitioned shards ------------------------------------------------------
+int mi355x_shard_price(mi355x_tab *t, int is_max, int64_t col_offset, double *dev_value_out,
+                       int64_t *dev_col_out)
+{
+    if (!t || !dev_value_out || !dev_col_out) return fail(MI_BAD_ARG, "NULL argument");
+    int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    launch_shard_price(t->v, is_max, col_offset, dev_value_out, dev_col_out, t->stream);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int mi355x_shard_gather_col(mi355x_tab *t, int64_t local_col, double *dev_col_out)
+{
+    if (!t || !dev_col_out) return fail(MI_BAD_ARG, "NULL argument");
+    if (local_col < 0 || local_col >= t->v.cols) return fail(MI_BAD_ARG, "local column out of range");
+    int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    launch_gather_col(t->v, local_col, dev_col_out, t->stream);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int mi355x_shard_pivot(mi355x_tab *t, const double *dev_col, int64_t global_col, int64_t col_offset,
+                       int is_owner, double f)
+{
+    if (!t || !dev_col) return fail(MI_BAD_ARG, "NULL argument");
+    int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    launch_shard_prepare(t->v, dev_col, global_col, col_offset, is_owner, f, t->stream);
+    launch_update(t->v, 1.0, 0, t->stream);
+    t->n_part = 0;
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+// tuning hooks, used by bench.py / the microbenchmark only (not part of the reference boundary)
+int         mi355x_tune_variant_count(void) { return update_variant_count(); }
+const char *mi355x_tune_variant_name(int v) { return (v >= 0 && v < update_variant_count()) ? update_variant_name(v) : ""; }
+int         mi355x_tune_set_variant(int v) { set_update_variant(v); return get_update_variant(); }
+int         mi355x_tune_set_select_mode(int mode) { g_select_mode = mode; return g_select_mode; }
+
+}  // extern "C"

@@ -1,0 +1,84 @@
+// simplex_kernels.h -- device-side data structures and launcher prototypes of the
+// MI355X dense-simplex backend (host side of the launchers lives in
+// simplex_kernels.hip, the C ABI in simplex_capi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi355x {
+
+// Common Lisp DOUBLE-FLOAT-EPSILON = 2^-53 (1 + 2^-52)  (src/utils.lisp:84-124)
+constexpr double kClEpsilon = 1.1102230246251568e-16;
+
+// device-side status word; values >= 0 other than kRunning are the MI_* outcomes
+constexpr int32_t kRunning = 100;
+
+// Control block living in device memory: the whole price -> ratio -> pivot loop
+// runs without host round trips, kernels communicate through this struct.
+struct Ctl {
+    int32_t status;       // kRunning, or MI_OPTIMAL / MI_UNBOUNDED / MI_MAX_PIVOTS
+    int32_t _pad;
+    int64_t ec;           // entering column chosen by the last select
+    int64_t cr;           // pivot row chosen by the last select
+    int64_t n_pivots;     // pivots since the last reset
+    int64_t max_pivots;   // 0 = no cap
+    int64_t trace_n;      // pivots recorded in the trace buffers
+};
+
+// One tableau in HBM.  Row-major, leading dimension ld (a multiple of 16 doubles so
+// that every row starts on a 128-byte boundary and 16-byte vector accesses never
+// straddle rows); columns [cols, ld) are padding and hold zeros.
+struct TabView {
+    double  *M;
+    int64_t  ld, rows, cols;
+    int64_t *basis;       // rows-1 entries
+    double  *col;         // snapshot of the entering column before the pivot, rows entries
+    double  *prow;        // normalised pivot row, ld entries (padding zero)
+    Ctl     *ctl;
+    int64_t *trace_ec;    // may be null
+    int64_t *trace_cr;
+    int64_t  trace_cap;
+    double  *part_v;      // per-wave pricing partials left by k_update (key space)
+    int64_t *part_i;
+    int      part_cap;
+};
+
+struct UpdateShape {
+    int strips, strip_pairs, tr, row_chunks, waves_per_block, n_partials;
+};
+
+// select: price -> gather column -> ratio test -> normalise pivot row (one workgroup)
+// n_part > 0: price from the partials the preceding launch_update(..., price=1) left behind
+void launch_select(const TabView &t, int is_max, double fp_factor, int n_part, hipStream_t s);
+// the same select as two multi-workgroup launches (large tableaux)
+void launch_select_split(const TabView &t, int is_max, double fp_factor, int n_part, hipStream_t s);
+bool select_split_supported(const TabView &t);
+// pieces of it, for the step-wise ABI entry points
+void launch_price_only(const TabView &t, int is_max, double fp_factor, hipStream_t s);
+void launch_ratio_only(const TabView &t, int64_t ec, double fp_factor, hipStream_t s);
+void launch_prepare_pivot(const TabView &t, int64_t ec, int64_t cr, hipStream_t s);
+// the bandwidth kernel: M[r][c] -= col[r] * prow[c] (r != cr), M[cr][c] = prow[c]
+// returns the number of pricing partials written (0 if price == 0)
+int  launch_update(const TabView &t, double sgn, int price, hipStream_t s);
+UpdateShape update_shape(const TabView &t);
+// column-partitioned shards (one shard = one handle)
+void launch_shard_price(const TabView &t, int is_max, int64_t col_offset, double *out_val,
+                        int64_t *out_col, hipStream_t s);
+void launch_gather_col(const TabView &t, int64_t local_col, double *out, hipStream_t s);
+void launch_shard_prepare(const TabView &t, const double *col, int64_t global_ec,
+                          int64_t col_offset, int is_owner, double fp_factor, hipStream_t s);
+// two-phase hand-over (src/simplex.lisp:437-451)
+void launch_handover(const TabView &art, const TabView &main_tab, hipStream_t s);
+void launch_ctl_reset(const TabView &t, int64_t max_pivots, int reset_trace, hipStream_t s);
+void launch_ctl_finish(const TabView &t, hipStream_t s);
+// synthetic LP straight into HBM
+void launch_synth_fill(const TabView &t, int64_t n_vars, int64_t n_cons, uint64_t seed,
+                       int64_t col_begin, int64_t col_end, hipStream_t s);
+
+int         update_variant_count();
+const char *update_variant_name(int v);
+void        set_update_variant(int v);      // tuning hook (bench / microbench only)
+int         get_update_variant();
+const char *update_kernel_symbol();
+
+}  // namespace mi355x

@@ -1,0 +1,746 @@
+// simplex_kernels.hip -- hand-written CDNA4 (gfx950) kernels of the dense-simplex hot path.
+//
+// What the reference does per iteration (src/simplex.lisp:453-461):
+//     find-entering-column (362-379) -> find-pivoting-row (382-389) -> n-pivot-row (337-359)
+// as three scalar loops over a boxed (simple-array real 2).  Here the tableau stays
+// resident in HBM and one iteration is two launches:
+//
+//   k_select  (one 1024-thread workgroup, latency-bound, ~R+2C doubles of traffic)
+//       price:  lowest-index strict arg-min (max problems) / arg-max (min problems) of the
+//               objective row, threshold factor/8 * eps
+//       gather: snapshot col[r] = M[r][ec] of the entering column (the only strided access)
+//       ratio:  lowest-index strict arg-min of rhs/col over rows with col > factor/2 * eps
+//       scale:  prow[c] = M[cr][c] / M[cr][ec]   (true division)
+//       writes (ec, cr, status, basis, trace) to the device-side control block
+//
+//   k_update  (the bandwidth kernel: every tableau element is read once and written once)
+//       M[r][c] = M[r][c] - col[r]*prow[c]   for r != cr   (product and difference rounded
+//       M[cr][c] = prow[c]                                   separately: built with
+//                                                            -ffp-contract=off, no FMA)
+//       Each workgroup owns a column strip (its slice of prow lives in registers), streams a
+//       chunk of rows through it with 16-byte-per-lane coalesced loads/stores; col[r] is
+//       wave-uniform and comes through the scalar cache.  k_update reads (cr, status) from
+//       the control block and is a no-op once the solve has terminated, so the host enqueues
+//       iterations blind, with no per-pivot synchronisation.
+//
+// The snapshots col[]/prow[] remove the in-place hazard of the reference's loop order
+// (rows read M[r][ec] and M[cr][c] while other rows are being overwritten) without
+// changing a single rounding: every element sees exactly the operands the sequential
+// loop would have used, so results are bit-identical for any parallel schedule.
+#include "simplex_kernels.h"
+
+namespace mi355x {
+
+// ------------------------------------------------------------------ small helpers
+struct ValIdx {
+    double  v;
+    int64_t i;   // < 0 : empty
+};
+
+// lexicographic (value, index) minimum; an empty slot loses against anything
+__device__ __forceinline__ ValIdx vi_min(ValIdx a, ValIdx b)
+{
+    if (a.i < 0) return b;
+    if (b.i < 0) return a;
+    if (b.v < a.v || (b.v == a.v && b.i < a.i)) return b;
+    return a;
+}
+
+__device__ __forceinline__ ValIdx wave_reduce_min(ValIdx x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        ValIdx y;
+        y.v = __shfl_down(x.v, off, 64);
+        y.i = __shfl_down((long long)x.i, off, 64);
+        x = vi_min(x, y);
+    }
+    return x;
+}
+
+constexpr int kSelThreads = 1024;
+constexpr int kSelWaves   = kSelThreads / 64;
+
+// Block-wide lexicographic arg-min over THREADS threads; result valid in every thread.
+template <int THREADS = kSelThreads>
+__device__ __forceinline__ ValIdx block_reduce_min(ValIdx x, double *s_v, long long *s_i)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    x = wave_reduce_min(x);
+    __syncthreads();                       // protects s_v/s_i reuse across calls
+    if (lane == 0) { s_v[wave] = x.v; s_i[wave] = x.i; }
+    __syncthreads();
+    ValIdx r;
+    r.v = s_v[0]; r.i = s_i[0];
+#pragma unroll
+    for (int w = 1; w < THREADS / 64; ++w) {
+        ValIdx y; y.v = s_v[w]; y.i = s_i[w];
+        r = vi_min(r, y);
+    }
+    return r;
+}
+
+// find-entering-column (src/simplex.lisp:362-379) over columns [0, ncols) of the objective
+// row.  sgn = +1 for max problems (arg-min), -1 for min problems (arg-max of v == arg-min of
+// -v: negation is exact and order reversing).  Returns the lowest-index strict extremum in
+// key space; the caller applies the threshold.
+// All of a thread's loads are issued before the first use (kBatch independent 16-byte loads
+// in flight per thread): this kernel is one workgroup, so its time is the number of
+// serialised memory round trips, not bandwidth.
+constexpr int kBatch = 8;
+
+template <int THREADS = kSelThreads>
+__device__ __forceinline__ ValIdx block_price(const double *__restrict__ obj, int64_t ncols,
+                                              double sgn, double *s_v, long long *s_i)
+{
+    ValIdx best; best.v = 0.0; best.i = -1;
+    const int64_t npair = ncols >> 1;                 // obj is 128-byte aligned (row start)
+    const double2 *obj2 = reinterpret_cast<const double2 *>(obj);
+    for (int64_t base = 0; base < npair; base += (int64_t)kBatch * THREADS) {
+        double2 v[kBatch];
+#pragma unroll
+        for (int g = 0; g < kBatch; ++g) {
+            const int64_t p = base + (int64_t)g * THREADS + threadIdx.x;
+            v[g] = p < npair ? obj2[p] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int g = 0; g < kBatch; ++g) {           // increasing index order within the thread
+            const int64_t p = base + (int64_t)g * THREADS + threadIdx.x;
+            if (p < npair) {
+                const double k0 = v[g].x * sgn, k1 = v[g].y * sgn;
+                if (best.i < 0 || k0 < best.v) { best.v = k0; best.i = 2 * p; }
+                if (k1 < best.v)               { best.v = k1; best.i = 2 * p + 1; }
+            }
+        }
+    }
+    if ((ncols & 1) && threadIdx.x == 0) {          // odd tail element
+        const double k = obj[ncols - 1] * sgn;
+        ValIdx t; t.v = k; t.i = ncols - 1;
+        best = vi_min(best, t);                      // index is the largest, so ties keep `best`
+    }
+    return block_reduce_min<THREADS>(best, s_v, s_i);
+}
+
+// Same result from the per-wave partial winners that k_update left behind when it wrote the
+// objective row (key space already, lowest index per wave): n_part (value, index) pairs.
+template <int THREADS = kSelThreads>
+__device__ __forceinline__ ValIdx block_price_partials(const double *__restrict__ pv,
+                                                       const int64_t *__restrict__ pi,
+                                                       int n_part, double *s_v, long long *s_i)
+{
+    ValIdx best; best.v = 0.0; best.i = -1;
+    for (int k = threadIdx.x; k < n_part; k += THREADS) {
+        ValIdx t; t.v = pv[k]; t.i = pi[k];
+        best = vi_min(best, t);
+    }
+    return block_reduce_min<THREADS>(best, s_v, s_i);
+}
+
+// Gather the entering column and run find-pivoting-row (src/simplex.lisp:382-389).
+// col_src == nullptr: read M[r][ec] (and snapshot it into t.col); otherwise the column was
+// supplied by another shard and is read from col_src (and copied into t.col).
+__device__ __forceinline__ ValIdx block_gather_ratio(const TabView &t, int64_t ec,
+                                                     const double *__restrict__ col_src,
+                                                     double ratio_thr, double *s_v, long long *s_i)
+{
+    const int64_t m = t.rows - 1, vc = t.cols - 1;
+    ValIdx best; best.v = 0.0; best.i = -1;
+    for (int64_t base = 0; base < t.rows; base += (int64_t)kBatch * kSelThreads) {
+        double a[kBatch], b[kBatch];
+#pragma unroll
+        for (int g = 0; g < kBatch; ++g) {           // the strided gathers: all in flight at once
+            const int64_t r = base + (int64_t)g * kSelThreads + threadIdx.x;
+            a[g] = r < t.rows ? (col_src ? col_src[r] : t.M[r * t.ld + ec]) : 0.0;
+            b[g] = r < m ? t.M[r * t.ld + vc] : 0.0;
+        }
+#pragma unroll
+        for (int g = 0; g < kBatch; ++g) {
+            const int64_t r = base + (int64_t)g * kSelThreads + threadIdx.x;
+            if (r < t.rows) t.col[r] = a[g];
+            if (r < m && ratio_thr < a[g]) {         // (fp< 0 a factor/2) -> (< (+ 0 thr) a)
+                const double q = b[g] / a[g];
+                if (best.i < 0 || q < best.v) { best.v = q; best.i = r; }
+            }
+        }
+    }
+    return block_reduce_min(best, s_v, s_i);
+}
+
+// prow[c] = M[cr][c] / M[cr][ec]  (src/simplex.lisp:343-348), padding columns zeroed.
+__device__ __forceinline__ void block_scale_row(const TabView &t, int64_t cr, double row_scale)
+{
+    const double2 *__restrict__ src = reinterpret_cast<const double2 *>(t.M + cr * t.ld);
+    double2 *dst = reinterpret_cast<double2 *>(t.prow);
+    const int64_t npair = t.ld >> 1;
+    for (int64_t base = 0; base < npair; base += (int64_t)kBatch * kSelThreads) {
+        double2 v[kBatch];
+#pragma unroll
+        for (int g = 0; g < kBatch; ++g) {
+            const int64_t p = base + (int64_t)g * kSelThreads + threadIdx.x;
+            v[g] = p < npair ? src[p] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int g = 0; g < kBatch; ++g) {
+            const int64_t p = base + (int64_t)g * kSelThreads + threadIdx.x;
+            if (p < npair) {
+                double2 o;
+                o.x = (2 * p     < t.cols) ? v[g].x / row_scale : 0.0;
+                o.y = (2 * p + 1 < t.cols) ? v[g].y / row_scale : 0.0;
+                dst[p] = o;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void record_pivot(const TabView &t, int64_t ec, int64_t cr)
+{
+    Ctl *ctl = t.ctl;
+    ctl->ec = ec;
+    ctl->cr = cr;
+    if (t.basis) t.basis[cr] = ec;                  // src/simplex.lisp:358
+    if (t.trace_ec && ctl->trace_n < t.trace_cap) {
+        t.trace_ec[ctl->trace_n] = ec;
+        t.trace_cr[ctl->trace_n] = cr;
+    }
+    ctl->trace_n += 1;
+    ctl->n_pivots += 1;
+}
+
+// ------------------------------------------------------------------ select kernels
+__global__ __launch_bounds__(kSelThreads) void k_select(TabView t, double sgn, double price_tol,
+                                                       double ratio_thr, int n_part)
+{
+    __shared__ double    s_v[kSelWaves];
+    __shared__ long long s_i[kSelWaves];
+    Ctl *ctl = t.ctl;
+    if (ctl->status != kRunning) return;
+    const int64_t m = t.rows - 1, vc = t.cols - 1;
+
+    // n_part > 0: the preceding k_update of this tableau priced the new objective row
+    const ValIdx e = n_part > 0 ? block_price_partials(t.part_v, t.part_i, n_part, s_v, s_i)
+                                : block_price(t.M + m * t.ld, vc, sgn, s_v, s_i);
+    // (fp< v 0 factor/8): v < 0 - tol ; min problems: (fp> v 0 factor/8) <=> -v < 0 - tol
+    if (e.i < 0 || !(e.v < 0.0 - price_tol)) {
+        if (threadIdx.x == 0) ctl->status = 0;      // MI_OPTIMAL
+        return;
+    }
+    if (ctl->max_pivots > 0 && ctl->n_pivots >= ctl->max_pivots) {
+        __syncthreads();
+        if (threadIdx.x == 0) ctl->status = 3;      // MI_MAX_PIVOTS
+        return;
+    }
+    const int64_t ec = e.i;
+    const ValIdx q = block_gather_ratio(t, ec, nullptr, ratio_thr, s_v, s_i);
+    if (q.i < 0) {
+        if (threadIdx.x == 0) ctl->status = 1;      // MI_UNBOUNDED
+        return;
+    }
+    const int64_t cr = q.i;
+    block_scale_row(t, cr, t.M[cr * t.ld + ec]);
+    if (threadIdx.x == 0) record_pivot(t, ec, cr);
+}
+
+// ---- the same select, split over many workgroups (large tableaux) -------------------------
+// One workgroup's memory pipeline moves ~10 bytes/cycle; the strided column gather costs a
+// full 64-byte line per useful double, so for thousands of rows a single workgroup needs tens
+// of microseconds.  Split: k_select_gather (ceil(rows/128) workgroups: every workgroup derives
+// the entering column on its own from the same inputs, gathers 128 rows of it and of the RHS
+// column, leaves a ratio-test partial) then k_select_scale (ceil(ld/512) workgroups: every
+// workgroup reduces the partials to the same pivot row and normalises its slice of that row).
+constexpr int kGatherThreads = 128;
+constexpr int kScaleThreads  = 256;
+
+__global__ __launch_bounds__(kGatherThreads) void k_select_gather(TabView t, double sgn,
+                                                                  double price_tol,
+                                                                  double ratio_thr, int n_part,
+                                                                  double *rp_v, int64_t *rp_i)
+{
+    __shared__ double    s_v[kGatherThreads / 64];
+    __shared__ long long s_i[kGatherThreads / 64];
+    Ctl *ctl = t.ctl;
+    if (ctl->status != kRunning) return;
+    const int64_t m = t.rows - 1, vc = t.cols - 1;
+    const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+    const ValIdx e = n_part > 0
+        ? block_price_partials<kGatherThreads>(t.part_v, t.part_i, n_part, s_v, s_i)
+        : block_price<kGatherThreads>(t.M + m * t.ld, vc, sgn, s_v, s_i);
+    if (e.i < 0 || !(e.v < 0.0 - price_tol)) {
+        if (leader) ctl->status = 0;                // MI_OPTIMAL
+        return;
+    }
+    if (ctl->max_pivots > 0 && ctl->n_pivots >= ctl->max_pivots) {
+        if (leader) ctl->status = 3;                // MI_MAX_PIVOTS
+        return;
+    }
+    const int64_t ec = e.i;
+    const int64_t r = (int64_t)blockIdx.x * kGatherThreads + threadIdx.x;
+    ValIdx best; best.v = 0.0; best.i = -1;
+    if (r < t.rows) {
+        const double a = t.M[r * t.ld + ec];
+        const double b = r < m ? t.M[r * t.ld + vc] : 0.0;
+        t.col[r] = a;
+        if (r < m && ratio_thr < a) { best.v = b / a; best.i = r; }
+    }
+    best = block_reduce_min<kGatherThreads>(best, s_v, s_i);
+    if (threadIdx.x == 0) { rp_v[blockIdx.x] = best.v; rp_i[blockIdx.x] = best.i; }
+    if (leader) ctl->ec = ec;
+}
+
+__global__ __launch_bounds__(kScaleThreads) void k_select_scale(TabView t, int n_rp,
+                                                                const double *rp_v,
+                                                                const int64_t *rp_i)
+{
+    __shared__ double    s_v[kScaleThreads / 64];
+    __shared__ long long s_i[kScaleThreads / 64];
+    Ctl *ctl = t.ctl;
+    if (ctl->status != kRunning) return;
+    const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+    const ValIdx q = block_price_partials<kScaleThreads>(rp_v, rp_i, n_rp, s_v, s_i);
+    if (q.i < 0) {
+        if (leader) ctl->status = 1;                // MI_UNBOUNDED
+        return;
+    }
+    const int64_t cr = q.i;
+    const double row_scale = t.col[cr];             // == M[cr][ec], snapshotted by the gather
+    const int64_t npair = t.ld >> 1;
+    const int64_t p = (int64_t)blockIdx.x * kScaleThreads + threadIdx.x;
+    if (p < npair) {
+        const double2 v = reinterpret_cast<const double2 *>(t.M + cr * t.ld)[p];
+        double2 o;
+        o.x = (2 * p     < t.cols) ? v.x / row_scale : 0.0;
+        o.y = (2 * p + 1 < t.cols) ? v.y / row_scale : 0.0;
+        reinterpret_cast<double2 *>(t.prow)[p] = o;
+    }
+    if (leader) record_pivot(t, ctl->ec, cr);
+}
+
+// find-entering-column only: ctl->ec = column or -1.  With out_val/out_col (shard pricing)
+// the local best key and GLOBAL column (col_offset + local) go to device buffers instead,
+// without applying the threshold (the exchange step does that once on the global best).
+__global__ __launch_bounds__(kSelThreads) void k_price_only(TabView t, double sgn, double price_tol,
+                                                           int64_t col_offset, double *out_val,
+                                                           int64_t *out_col)
+{
+    __shared__ double    s_v[kSelWaves];
+    __shared__ long long s_i[kSelWaves];
+    const int64_t m = t.rows - 1, vc = t.cols - 1;
+    const ValIdx e = block_price(t.M + m * t.ld, vc, sgn, s_v, s_i);
+    if (threadIdx.x == 0) {
+        if (out_val) {
+            *out_val = e.i < 0 ? 0.0 : e.v;
+            *out_col = e.i < 0 ? -1 : e.i + col_offset;
+        } else {
+            t.ctl->ec = (e.i >= 0 && e.v < 0.0 - price_tol) ? e.i : -1;
+        }
+    }
+}
+
+// find-pivoting-row only (given ec): ctl->cr = row or -1.  Does not touch the tableau.
+__global__ __launch_bounds__(kSelThreads) void k_ratio_only(TabView t, int64_t ec, double ratio_thr)
+{
+    __shared__ double    s_v[kSelWaves];
+    __shared__ long long s_i[kSelWaves];
+    const ValIdx q = block_gather_ratio(t, ec, nullptr, ratio_thr, s_v, s_i);
+    if (threadIdx.x == 0) t.ctl->cr = q.i;
+}
+
+// Forced pivot (n-pivot-row with caller-chosen ec, cr): snapshot column + scaled row.
+__global__ __launch_bounds__(kSelThreads) void k_prepare_pivot(TabView t, int64_t ec, int64_t cr)
+{
+    for (int64_t r = threadIdx.x; r < t.rows; r += kSelThreads)
+        t.col[r] = t.M[r * t.ld + ec];
+    block_scale_row(t, cr, t.M[cr * t.ld + ec]);
+    if (threadIdx.x == 0) {
+        t.ctl->status = kRunning;
+        record_pivot(t, ec, cr);
+    }
+}
+
+// Shard step 3: copy local column `lc` to a device buffer (rows doubles).
+__global__ __launch_bounds__(kSelThreads) void k_gather_col(TabView t, int64_t lc, double *out)
+{
+    for (int64_t r = blockIdx.x * (int64_t)kSelThreads + threadIdx.x; r < t.rows;
+         r += (int64_t)gridDim.x * kSelThreads)
+        out[r] = t.M[r * t.ld + lc];
+}
+
+// Shard step 5 (prepare): ratio test on the broadcast column against the shard's own RHS copy
+// (identical on every shard => identical cr everywhere, no exchange), row scale from the
+// broadcast column (col[cr] is M[cr][ec] bit for bit), normalise the local slice of row cr.
+// global_ec < 0 (no entering column: optimal) or no eligible row (unbounded) stop the shard.
+__global__ __launch_bounds__(kSelThreads) void k_shard_prepare(TabView t, const double *col_src,
+                                                              int64_t global_ec, int64_t col_offset,
+                                                              int is_owner, double ratio_thr)
+{
+    __shared__ double    s_v[kSelWaves];
+    __shared__ long long s_i[kSelWaves];
+    Ctl *ctl = t.ctl;
+    if (ctl->status != kRunning) return;
+    if (global_ec < 0) {
+        if (threadIdx.x == 0) ctl->status = 0;
+        return;
+    }
+    const ValIdx q = block_gather_ratio(t, 0, col_src, ratio_thr, s_v, s_i);
+    if (q.i < 0) {
+        if (threadIdx.x == 0) ctl->status = 1;
+        return;
+    }
+    const int64_t cr = q.i;
+    block_scale_row(t, cr, col_src[cr]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // basis entries hold GLOBAL column indices on every shard
+        record_pivot(t, global_ec, cr);
+        (void)is_owner; (void)col_offset;
+    }
+}
+
+// ------------------------------------------------------------------ the bandwidth kernel
+typedef double vec2d __attribute__((ext_vector_type(2)));   // one global_load/store_dwordx4
+//
+// Tile = (strip_pairs <= BLOCK 16-byte column pairs) x (tr rows).  A thread owns ONE column pair:
+// its two entries of prow sit in VGPRs for the whole tile; per row it issues one
+// global_load_dwordx4, 2 v_mul_f64 + 2 v_add_f64 (never fused: -ffp-contract=off) and one
+// global_store_dwordx4.  U rows are in flight per thread before the first use.  col[r] is
+// uniform across the workgroup -> scalar loads.  tr and strip_pairs are chosen by the launcher
+// so that the whole grid is resident in ONE balanced round (no tail wave of workgroups).
+// The workgroups that write the objective row also price it for the next iteration: every
+// wave leaves its lowest-index arg-min (in key space v*sgn) in part_v/part_i.
+template <int BLOCK, int U, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_update(double *__restrict__ M, const int64_t ld,
+                                                  const int64_t rows, const int64_t vc,
+                                                  const int tr, const int strip_pairs,
+                                                  const double *__restrict__ col,
+                                                  const double *__restrict__ prow,
+                                                  const Ctl *__restrict__ ctl, const double sgn,
+                                                  double *__restrict__ part_v,
+                                                  int64_t *__restrict__ part_i)
+{
+    if (ctl->status != kRunning) return;
+    const int64_t cr   = ctl->cr;
+    const int64_t ldv  = ld >> 1;                              // row length in 16-byte pairs
+    const int64_t pair = (int64_t)blockIdx.x * strip_pairs + threadIdx.x;
+    const bool active  = (int)threadIdx.x < strip_pairs && pair < ldv;
+    const int64_t r0 = (int64_t)blockIdx.y * tr;
+    const int64_t r1 = (r0 + tr < rows) ? r0 + tr : rows;
+    const bool prices = (r1 == rows) && part_v != nullptr;     // this tile holds the objective row
+    if (!active && !prices) return;                            // no workgroup barrier below
+
+    vec2d *Mp = reinterpret_cast<vec2d *>(M) + pair;
+    vec2d last; last.x = 0.0; last.y = 0.0;
+    if (active) {
+        const vec2d p = reinterpret_cast<const vec2d *>(prow)[pair];
+        auto ld2 = [&](int64_t r) -> vec2d {
+            if constexpr (NT) return __builtin_nontemporal_load(Mp + r * ldv);
+            else              return Mp[r * ldv];
+        };
+        auto st2 = [&](int64_t r, vec2d v) {
+            if constexpr (NT) __builtin_nontemporal_store(v, Mp + r * ldv);
+            else              Mp[r * ldv] = v;
+        };
+        int64_t r = r0;
+        for (; r + U <= r1; r += U) {
+            vec2d v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = ld2(r + u);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double s = col[r + u];
+                const double m0 = s * p.x;                     // rounded product
+                const double m1 = s * p.y;
+                vec2d o;
+                o.x = v[u].x - m0;                             // rounded difference
+                o.y = v[u].y - m1;
+                if (r + u == cr) o = p;                        // the pivot row itself
+                st2(r + u, o);
+                last = o;
+            }
+        }
+        for (; r < r1; ++r) {                                  // row tail of the tile
+            const vec2d x = ld2(r);
+            const double s = col[r];
+            const double m0 = s * p.x;
+            const double m1 = s * p.y;
+            vec2d o;
+            o.x = x.x - m0;
+            o.y = x.y - m1;
+            if (r == cr) o = p;
+            st2(r, o);
+            last = o;
+        }
+    }
+    if (prices) {                                              // `last` = new objective-row entries
+        ValIdx best; best.v = 0.0; best.i = -1;
+        const int64_t c0 = 2 * pair;
+        if (active && c0 < vc)     { best.v = last.x * sgn; best.i = c0; }
+        if (active && c0 + 1 < vc) {
+            const double k1 = last.y * sgn;
+            if (best.i < 0 || k1 < best.v) { best.v = k1; best.i = c0 + 1; }
+        }
+        best = wave_reduce_min(best);
+        if ((threadIdx.x & 63) == 0) {
+            const int slot = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+            part_v[slot] = best.v;
+            part_i[slot] = best.i;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ control block
+__global__ void k_ctl_reset(Ctl *ctl, int64_t max_pivots, int reset_trace)
+{
+    ctl->status     = kRunning;
+    ctl->ec         = -1;
+    ctl->cr         = -1;
+    ctl->n_pivots   = 0;
+    ctl->max_pivots = max_pivots;
+    if (reset_trace) ctl->trace_n = 0;
+}
+
+// After the last enqueued iteration: a tableau that is still "running" has simply used up
+// the pivots it was given.
+__global__ void k_ctl_finish(Ctl *ctl)
+{
+    if (ctl->status == kRunning) ctl->status = 3;              // MI_MAX_PIVOTS
+}
+
+// ------------------------------------------------------------------ two-phase hand-over
+// src/simplex.lisp:437-441: main[r][0..nv) = art[r][0..nv), main[r][nv] = art[r][nav], r < m.
+__global__ __launch_bounds__(256) void k_handover_copy(TabView art, TabView mt)
+{
+    const int64_t nv = mt.cols - 1, nav = art.cols - 1, m = mt.rows - 1;
+    for (int64_t r = blockIdx.y; r < m; r += gridDim.y)
+        for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c <= nv;
+             c += (int64_t)gridDim.x * blockDim.x)
+            mt.M[r * mt.ld + c] = art.M[r * art.ld + (c < nv ? c : nav)];
+}
+
+// src/simplex.lisp:444-451: copy the basis and re-eliminate the objective row, one basic
+// column after the other.  The row-i step reads scale = obj[basis[i]] AFTER steps 0..i-1,
+// exactly as the sequential loop does, hence one workgroup and a barrier per step.
+__global__ __launch_bounds__(kSelThreads) void k_handover_objective(TabView art, TabView mt)
+{
+    const int64_t m = mt.rows - 1, nv = mt.cols - 1;
+    double *obj = mt.M + m * mt.ld;
+    for (int64_t i = 0; i < m; ++i) {
+        const int64_t bc = art.basis[i];
+        if (threadIdx.x == 0) mt.basis[i] = bc;
+        const double scale = obj[bc];
+        __syncthreads();                                   // everyone has read scale
+        if (scale != 0.0) {
+            const double *row = mt.M + i * mt.ld;
+            for (int64_t c = threadIdx.x; c <= nv; c += kSelThreads) {
+                const double prod = scale * row[c];
+                obj[c] = obj[c] - prod;
+            }
+        }
+        __syncthreads();                                   // obj updated before the next scale
+    }
+}
+
+// ------------------------------------------------------------------ synthetic LP generator
+// splitmix64 stream, element k of the stream = mix(seed + (k+1)*gamma); u = (z >> 11) * 2^-53.
+// Stream layout: A row-major (n_cons x n_vars), then b (n_cons), then c (n_vars).
+//   A[i][j] = 0.05 + u     b[i] = n_vars * (0.25 + 0.5 u)     c[j] = 0.5 + u
+// Tableau: [A | I | b ; -c | 0 | 0]  (what build-tableau, src/simplex.lisp:214-283, produces
+// for  max c'x, Ax <= b, x >= 0  with variable order x0..x(n-1)).
+__device__ __forceinline__ double splitmix_u01(uint64_t seed, uint64_t k)
+{
+    uint64_t z = seed + (k + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (double)(z >> 11) * 0x1.0p-53;
+}
+
+__global__ __launch_bounds__(256) void k_synth_fill(TabView t, int64_t n, int64_t m, uint64_t seed,
+                                                    int64_t col_begin, int64_t col_end)
+{
+    const int64_t lcols = t.cols;                              // (col_end - col_begin) + 1
+    for (int64_t i = blockIdx.y; i < t.rows; i += gridDim.y) {
+    for (int64_t jl = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; jl < t.ld;
+         jl += (int64_t)gridDim.x * blockDim.x) {
+        double v = 0.0;
+        if (jl < lcols) {
+            const bool    rhs = (jl == lcols - 1);
+            const int64_t j   = col_begin + jl;                // global column (non-RHS)
+            if (i < m) {
+                if (rhs)            v = (double)n * (0.25 + 0.5 * splitmix_u01(seed, (uint64_t)(n * m + i)));
+                else if (j < n)     v = 0.05 + splitmix_u01(seed, (uint64_t)(i * n + j));
+                else                v = (j - n == i) ? 1.0 : 0.0;
+            } else {
+                if (!rhs && j < n)  v = -(0.5 + splitmix_u01(seed, (uint64_t)(n * m + m + j)));
+            }
+        }
+        t.M[i * t.ld + jl] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && i < m && t.basis) t.basis[i] = n + i;
+    }
+    (void)col_end;
+}
+
+// ------------------------------------------------------------------ host-side launchers
+static inline double sgn_of(int is_max) { return is_max ? 1.0 : -1.0; }
+
+void launch_select(const TabView &t, int is_max, double f, int n_part, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_select, dim3(1), dim3(kSelThreads), 0, s, t, sgn_of(is_max),
+                       (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon, n_part);
+}
+void launch_select_split(const TabView &t, int is_max, double f, int n_part, hipStream_t s)
+{
+    const int g1 = (int)((t.rows + kGatherThreads - 1) / kGatherThreads);
+    const int g2 = (int)(((t.ld >> 1) + kScaleThreads - 1) / kScaleThreads);
+    double  *rp_v = t.part_v + t.part_cap / 2;      // upper half of the partial buffers
+    int64_t *rp_i = t.part_i + t.part_cap / 2;
+    hipLaunchKernelGGL(k_select_gather, dim3(g1), dim3(kGatherThreads), 0, s, t, sgn_of(is_max),
+                       (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon, n_part, rp_v, rp_i);
+    hipLaunchKernelGGL(k_select_scale, dim3(g2), dim3(kScaleThreads), 0, s, t, g1, rp_v, rp_i);
+}
+bool select_split_supported(const TabView &t)
+{
+    return (t.rows + kGatherThreads - 1) / kGatherThreads <= t.part_cap / 2;
+}
+void launch_price_only(const TabView &t, int is_max, double f, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_price_only, dim3(1), dim3(kSelThreads), 0, s, t, sgn_of(is_max),
+                       (f / 8.0) * kClEpsilon, (int64_t)0, (double *)nullptr, (int64_t *)nullptr);
+}
+void launch_ratio_only(const TabView &t, int64_t ec, double f, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_ratio_only, dim3(1), dim3(kSelThreads), 0, s, t, ec,
+                       0.0 + (f / 2.0) * kClEpsilon);
+}
+void launch_prepare_pivot(const TabView &t, int64_t ec, int64_t cr, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_prepare_pivot, dim3(1), dim3(kSelThreads), 0, s, t, ec, cr);
+}
+void launch_shard_price(const TabView &t, int is_max, int64_t col_offset, double *out_val,
+                        int64_t *out_col, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_price_only, dim3(1), dim3(kSelThreads), 0, s, t, sgn_of(is_max), 0.0,
+                       col_offset, out_val, out_col);
+}
+void launch_gather_col(const TabView &t, int64_t lc, double *out, hipStream_t s)
+{
+    int blocks = (int)((t.rows + kSelThreads - 1) / kSelThreads);
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(k_gather_col, dim3(blocks), dim3(kSelThreads), 0, s, t, lc, out);
+}
+void launch_shard_prepare(const TabView &t, const double *col, int64_t global_ec,
+                          int64_t col_offset, int is_owner, double f, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_shard_prepare, dim3(1), dim3(kSelThreads), 0, s, t, col, global_ec,
+                       col_offset, is_owner, 0.0 + (f / 2.0) * kClEpsilon);
+}
+void launch_handover(const TabView &art, const TabView &mt, hipStream_t s)
+{
+    const int64_t m = mt.rows - 1;
+    if (m > 0) {
+        int bx = (int)((mt.cols + 255) / 256);
+        if (bx > 64) bx = 64;
+        hipLaunchKernelGGL(k_handover_copy, dim3(bx, (unsigned)(m < 32768 ? m : 32768)), dim3(256), 0, s, art, mt);
+    }
+    hipLaunchKernelGGL(k_handover_objective, dim3(1), dim3(kSelThreads), 0, s, art, mt);
+}
+void launch_ctl_reset(const TabView &t, int64_t max_pivots, int reset_trace, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_ctl_reset, dim3(1), dim3(1), 0, s, t.ctl, max_pivots, reset_trace);
+}
+void launch_ctl_finish(const TabView &t, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_ctl_finish, dim3(1), dim3(1), 0, s, t.ctl);
+}
+void launch_synth_fill(const TabView &t, int64_t n, int64_t m, uint64_t seed, int64_t cb,
+                       int64_t ce, hipStream_t s)
+{
+    int bx = (int)((t.ld + 255) / 256);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(k_synth_fill, dim3(bx, (unsigned)(t.rows < 32768 ? t.rows : 32768)), dim3(256), 0, s, t, n, m, seed,
+                       cb, ce);
+}
+
+// ---- update-kernel variants (one is the default; the others exist for the tuning sweep)
+struct UpdateVariant {
+    const char *name;
+    int block;            // threads per workgroup = max column pairs per strip
+    int unroll;           // rows in flight per thread; rows per workgroup is a multiple of it
+    int min_tr;           // never fewer rows per workgroup than this
+    int rounds;           // aim for rounds * (resident workgroup slots) workgroups
+    void (*launch)(const TabView &, dim3, int, int, double, int, hipStream_t);
+};
+
+template <int BLOCK, int U, bool NT>
+static void launch_update_t(const TabView &t, dim3 grid, int tr, int strip_pairs, double sgn,
+                            int price, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_update<BLOCK, U, NT>), grid, dim3(BLOCK), 0, s, t.M, t.ld, t.rows,
+                       t.cols - 1, tr, strip_pairs, t.col, t.prow, t.ctl, sgn,
+                       price ? t.part_v : (double *)nullptr, price ? t.part_i : (int64_t *)nullptr);
+}
+
+#define MI_VARIANT(B, U, NT, MINTR, ROUNDS) \
+    { "b" #B "_u" #U "_nt" #NT "_mintr" #MINTR "_x" #ROUNDS, (B), (U), (MINTR), (ROUNDS), &launch_update_t<B, U, NT> }
+
+static const UpdateVariant kVariants[] = {
+    MI_VARIANT(256, 8, true, 8, 4),     // 0: default
+    MI_VARIANT(256, 8, true, 8, 1),
+    MI_VARIANT(256, 8, true, 8, 2),
+    MI_VARIANT(256, 8, true, 8, 8),
+    MI_VARIANT(256, 4, true, 4, 4),
+    MI_VARIANT(256, 4, true, 4, 8),
+    MI_VARIANT(256, 4, true, 4, 16),
+    MI_VARIANT(256, 2, true, 2, 16),
+    MI_VARIANT(256, 16, true, 16, 4),
+    MI_VARIANT(256, 8, false, 8, 4),
+    MI_VARIANT(128, 8, true, 8, 4),
+    MI_VARIANT(128, 4, true, 4, 8),
+    MI_VARIANT(512, 8, true, 8, 4),
+    MI_VARIANT(512, 4, true, 4, 8),
+    MI_VARIANT(64, 4, true, 4, 8),
+    MI_VARIANT(1024, 4, true, 4, 8),
+};
+static int g_variant = 0;
+constexpr int kCUs = 256, kThreadsPerCU = 2048;
+
+int         update_variant_count() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
+const char *update_variant_name(int v) { return kVariants[v].name; }
+void        set_update_variant(int v) { if (v >= 0 && v < update_variant_count()) g_variant = v; }
+int         get_update_variant() { return g_variant; }
+const char *update_kernel_symbol() { return "k_update"; }
+
+UpdateShape update_shape(const TabView &t)
+{
+    const UpdateVariant &v = kVariants[g_variant];
+    const int64_t ldv = t.ld >> 1;
+    UpdateShape g;
+    g.strips = (int)((ldv + v.block - 1) / v.block);
+    // equal-width strips, a multiple of 8 pairs (128 bytes) wide
+    int64_t sp = (ldv + g.strips - 1) / g.strips;
+    sp = (sp + 7) / 8 * 8;
+    if (sp > v.block) sp = v.block;
+    g.strip_pairs = (int)sp;
+    g.strips = (int)((ldv + sp - 1) / sp);
+    const int64_t slots = (int64_t)kCUs * (kThreadsPerCU / v.block) * v.rounds;
+    int64_t by = slots / g.strips;
+    if (by < 1) by = 1;
+    int64_t tr = (t.rows + by - 1) / by;
+    if (tr < v.min_tr) tr = v.min_tr;
+    tr = (tr + v.unroll - 1) / v.unroll * v.unroll;
+    g.tr = (int)tr;
+    g.row_chunks = (int)((t.rows + tr - 1) / tr);
+    g.waves_per_block = v.block / 64;
+    g.n_partials = g.strips * g.waves_per_block;
+    return g;
+}
+
+int launch_update(const TabView &t, double sgn, int price, hipStream_t s)
+{
+    const UpdateVariant &v = kVariants[g_variant];
+    const UpdateShape g = update_shape(t);
+    if (price && g.n_partials > t.part_cap / 2) price = 0;
+    v.launch(t, dim3((unsigned)g.strips, (unsigned)g.row_chunks), g.tr, g.strip_pairs, sgn, price, s);
+    return price ? g.n_partials : 0;
+}
+
+}  // namespace mi355x

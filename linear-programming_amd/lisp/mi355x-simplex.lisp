@@ -1,0 +1,198 @@
+;;;; mi355x-simplex.lisp -- CFFI glue: linear-programming:*solver*  ->  libmi355x_simplex.so
+;;;;
+;;;; Usage (nothing in the reference library changes):
+;;;;
+;;;;   (asdf:load-system "mi355x-simplex")
+;;;;   (let ((linear-programming:*solver* 'mi355x-simplex:mi355x-simplex-solver))
+;;;;     (linear-programming:solve-problem problem))          ; src/solver.lisp:53-56
+;;;;
+;;;; or (setf linear-programming:*solver* 'mi355x-simplex:mi355x-simplex-solver), after which
+;;;; solve-problem / with-solved-problem / with-solution-variables work unchanged.
+;;;;
+;;;; What stays in Lisp: the DSL parser, build-tableau (src/simplex.lisp:142-328, called here
+;;;; through its exported name), the var-mapping based read-back (tableau-variable etc.,
+;;;; src/simplex.lisp:74-120) and the four solution-* generics, which keep working because this
+;;;; backend returns an ordinary `tableau` whose matrix / basis arrays hold the solved values.
+;;;; What moves to the GPU: n-solve-tableau (src/simplex.lisp:399-461) -- pricing, ratio test,
+;;;; rank-1 update and the two-phase hand-over -- in double-float arithmetic.
+;;;;
+;;;; Scope: LP, double-float.  Problems with integer / binary variables are declined with
+;;;; unsupported-constraint-error (src/conditions.lisp:69-77) as the hook's contract expects of
+;;;; a backend (src/solver.lisp:40-45); rational problems are solved in double-float (every
+;;;; entry is coerced), which is the documented behaviour of this backend.
+;;;;
+;;;; NOTE: could not be executed in the build image (no Lisp there); reviewed against
+;;;; include/mi355x_simplex.h and the reference sources cited inline.
+
+(defpackage :mi355x-simplex
+  (:use :cl)
+  (:import-from :linear-programming/simplex
+                #:build-tableau #:tableau-matrix #:tableau-basis-columns
+                #:tableau-var-count #:tableau-constraint-count #:tableau-instance-problem)
+  (:import-from :linear-programming/problem
+                #:problem-type #:problem-integer-vars)
+  (:import-from :linear-programming/conditions
+                #:solver-error #:unbounded-problem-error #:infeasible-problem-error
+                #:unsupported-constraint-error)
+  (:export #:mi355x-simplex-solver
+           #:device-count
+           #:mi355x-error))
+
+(in-package :mi355x-simplex)
+
+;;; ------------------------------------------------------------------ the shared library
+(cffi:define-foreign-library libmi355x-simplex
+  (:unix (:or "libmi355x_simplex.so" "./libmi355x_simplex.so"))
+  (t (:default "libmi355x_simplex")))
+
+(cffi:use-foreign-library libmi355x-simplex)
+
+;; status codes, include/mi355x_simplex.h
+(defconstant +mi-optimal+ 0)
+(defconstant +mi-unbounded+ 1)
+(defconstant +mi-infeasible+ 2)
+(defconstant +mi-max-pivots+ 3)
+(defconstant +mi-art-nonzero+ 4)
+(defconstant +mi-art-stuck+ 5)
+
+(cffi:defcfun ("mi355x_device_count" device-count) :int)
+(cffi:defcfun ("mi355x_last_error" %last-error) :string)
+(cffi:defcfun ("mi355x_tab_create" %tab-create) :int
+  (out :pointer) (rows :int64) (cols :int64) (host-matrix :pointer) (host-basis :pointer)
+  (device :int))
+(cffi:defcfun ("mi355x_tab_destroy" %tab-destroy) :void (tab :pointer))
+(cffi:defcfun ("mi355x_tab_solve" %tab-solve) :int
+  (tab :pointer) (is-max :int) (fp-factor :double) (max-pivots :int64) (n-pivots :pointer))
+(cffi:defcfun ("mi355x_solve_two_phase" %solve-two-phase) :int
+  (art :pointer) (main :pointer) (main-is-max :int) (fp-factor :double) (n-pivots :pointer))
+(cffi:defcfun ("mi355x_tab_download" %tab-download) :int
+  (tab :pointer) (host-matrix :pointer) (host-basis :pointer) (last-row :pointer)
+  (last-col :pointer))
+
+(define-condition mi355x-error (solver-error)
+  ((code :initarg :code :reader mi355x-error-code)
+   (message :initarg :message :reader mi355x-error-message))
+  (:report (lambda (err stream)
+             (format stream "libmi355x_simplex failed with status ~D: ~A"
+                     (mi355x-error-code err) (mi355x-error-message err)))))
+
+(defun check (code)
+  "Negative statuses are library errors (MI_BAD_ARG, MI_HIP_ERROR, MI_NO_DEVICE ...)."
+  (when (minusp code)
+    (error 'mi355x-error :code code :message (%last-error)))
+  code)
+
+(defmacro with-foreign-fp-mode (&body body)
+  "SBCL enables floating point traps; foreign code that produces an inf/nan must not raise
+SIGFPE in the Lisp thread."
+  #+sbcl `(sb-int:with-float-traps-masked (:overflow :invalid :divide-by-zero :inexact)
+            ,@body)
+  #-sbcl `(progn ,@body))
+
+;;; ------------------------------------------------------------------ tableau <-> raw doubles
+(defun tableau->vectors (tableau)
+  "Flatten the boxed (simple-array real 2) of src/simplex.lisp:53 into a row-major
+(simple-array double-float (*)) and the fixnum basis (tagged words: never hand their storage
+to C) into a (signed-byte 64) vector."
+  (let* ((matrix (tableau-matrix tableau))
+         (rows (array-dimension matrix 0))
+         (cols (array-dimension matrix 1))
+         (flat (make-array (* rows cols) :element-type 'double-float))
+         (basis-src (tableau-basis-columns tableau))
+         (basis (make-array (max 1 (length basis-src)) :element-type '(signed-byte 64)
+                                                       :initial-element 0)))
+    (dotimes (r rows)
+      (dotimes (c cols)
+        (setf (aref flat (+ (* r cols) c))
+              (coerce (aref matrix r c) 'double-float))))
+    (dotimes (i (length basis-src))
+      (setf (aref basis i) (aref basis-src i)))
+    (values flat basis rows cols)))
+
+(defun vectors->tableau (tableau flat basis)
+  "Write the solved values back into the tableau's own arrays (the struct slots are read-only,
+the arrays are not), so tableau-variable & co. (src/simplex.lisp:74-120) read GPU results."
+  (let* ((matrix (tableau-matrix tableau))
+         (rows (array-dimension matrix 0))
+         (cols (array-dimension matrix 1))
+         (basis-dst (tableau-basis-columns tableau)))
+    (dotimes (r rows)
+      (dotimes (c cols)
+        (setf (aref matrix r c) (aref flat (+ (* r cols) c)))))
+    (dotimes (i (length basis-dst))
+      (setf (aref basis-dst i) (aref basis i)))
+    tableau))
+
+(defun upload-tableau (tableau device)
+  "Returns (values handle flat basis): a device handle plus the host staging vectors."
+  (multiple-value-bind (flat basis rows cols) (tableau->vectors tableau)
+    (cffi:with-foreign-object (out :pointer)
+      (cffi:with-pointer-to-vector-data (pm flat)
+        (cffi:with-pointer-to-vector-data (pb basis)
+          (check (with-foreign-fp-mode
+                   (%tab-create out rows cols pm pb device)))))
+      (values (cffi:mem-ref out :pointer) flat basis))))
+
+(defun download-tableau (handle tableau flat basis)
+  (cffi:with-pointer-to-vector-data (pm flat)
+    (cffi:with-pointer-to-vector-data (pb basis)
+      (check (%tab-download handle pm pb (cffi:null-pointer) (cffi:null-pointer)))))
+  (vectors->tableau tableau flat basis))
+
+(defun signal-outcome (status)
+  "C outcome -> the reference's conditions (src/conditions.lisp:43-60)."
+  (cond
+    ((= status +mi-optimal+) nil)
+    ((= status +mi-unbounded+) (error 'unbounded-problem-error))     ; src/simplex.lisp:458-459
+    ((= status +mi-infeasible+) (error 'infeasible-problem-error))   ; src/simplex.lisp:405-407
+    ((= status +mi-art-nonzero+) (error "Artificial variable still non-zero"))
+    ((= status +mi-art-stuck+)
+     (error "Artificial variable still in basis and cannot be replaced"))
+    ((= status +mi-max-pivots+) (error 'mi355x-error :code status :message "pivot cap reached"))
+    (t (error 'mi355x-error :code status :message "unknown status"))))
+
+(defun max-problem-p (tableau)
+  (if (eq 'max (problem-type (tableau-instance-problem tableau))) 1 0))
+
+;;; ------------------------------------------------------------------ the *solver* value
+(defun mi355x-simplex-solver (problem &rest args
+                              &key (fp-tolerance 1024) (device 0) (max-pivots 0)
+                              &allow-other-keys)
+  "Solver interface function for the MI355X backend (the value of
+linear-programming:*solver*, src/solver.lisp:39-49).  Takes a problem and backend keyword
+arguments -- :fp-tolerance (as the built-in solver, src/simplex.lisp:506-511), :device,
+:max-pivots -- and returns a solved `tableau`."
+  (declare (ignore args))
+  (when (problem-integer-vars problem)
+    (error 'unsupported-constraint-error
+           :constraint (cons 'integer (problem-integer-vars problem))
+           :solver-name "mi355x-simplex"))
+  (let ((tableaus (build-tableau problem problem :fp-tolerance-factor fp-tolerance))
+        (factor (coerce fp-tolerance 'double-float)))
+    (cffi:with-foreign-object (n-pivots :int64 2)
+      (if (listp tableaus)
+          ;; two-phase: (art-tableau main-tableau), src/simplex.lisp:326-328, 402-452
+          (destructuring-bind (art-tab main-tab) tableaus
+            (multiple-value-bind (art-handle art-flat art-basis) (upload-tableau art-tab device)
+              (declare (ignorable art-flat art-basis))
+              (unwind-protect
+                   (multiple-value-bind (main-handle main-flat main-basis)
+                       (upload-tableau main-tab device)
+                     (unwind-protect
+                          (let ((status (check (with-foreign-fp-mode
+                                                 (%solve-two-phase art-handle main-handle
+                                                                   (max-problem-p main-tab)
+                                                                   factor n-pivots)))))
+                            (signal-outcome status)
+                            (download-tableau main-handle main-tab main-flat main-basis))
+                       (%tab-destroy main-handle)))
+                (%tab-destroy art-handle))))
+          ;; single phase, src/simplex.lisp:453-461
+          (multiple-value-bind (handle flat basis) (upload-tableau tableaus device)
+            (unwind-protect
+                 (let ((status (check (with-foreign-fp-mode
+                                        (%tab-solve handle (max-problem-p tableaus) factor
+                                                    max-pivots n-pivots)))))
+                   (signal-outcome status)
+                   (download-tableau handle tableaus flat basis))
+              (%tab-destroy handle)))))))

@@ -1,0 +1,397 @@
+"""Host-side mirror of the reference's `linear-programming/simplex` package
+(src/simplex.lisp) over the MI355X C ABI.
+
+Same names (Lisp `n-pivot-row` -> `n_pivot_row`), same argument meaning, same error
+behaviour, so the parity tests read like t/simplex.lisp.  Every numeric step of the hot path
+-- pricing, ratio test, rank-1 update, the solve loops, the two-phase hand-over -- runs in
+``libmi355x_simplex.so`` on the GPU; this module only moves arrays across the boundary and
+does the O(n) bookkeeping that stays on the host in the Lisp glue as well
+(`build-tableau` before the boundary, `tableau-variable` read-back after it).
+
+The tableau lives in HBM behind ``Tableau._h``; ``Tableau.matrix`` / ``basis_columns`` are
+host copies refreshed lazily after every device-side mutation.
+"""
+import ctypes
+
+import numpy as np
+
+from . import capi
+from .conditions import (InfeasibleProblemError, ParsingError, SolverError,
+                         UnboundedProblemError, UnsupportedConstraintError)
+from .problem import Problem
+
+_i64p = ctypes.POINTER(ctypes.c_int64)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Tableau:
+    """The `tableau` struct (src/simplex.lisp:48-58): problem, instance-problem, matrix,
+    basis-columns, var-count, constraint-count, var-mapping, fp-tolerance-factor."""
+
+    def __init__(self, problem, instance_problem, matrix, basis_columns, var_count,
+                 constraint_count, var_mapping, fp_tolerance_factor=1024, device=0, _handle=None):
+        self.problem = problem
+        self.instance_problem = instance_problem
+        self.var_count = int(var_count)
+        self.constraint_count = int(constraint_count)
+        self.var_mapping = var_mapping
+        self.fp_tolerance_factor = fp_tolerance_factor
+        self.device = device
+        self._matrix = None
+        self._basis = None
+        self._stale = True
+        self._handle = None
+        if _handle is not None:
+            self._handle = _handle
+        else:
+            matrix = np.ascontiguousarray(matrix, dtype=np.float64)
+            basis = np.ascontiguousarray(basis_columns, dtype=np.int64)
+            if matrix.shape != (self.constraint_count + 1, self.var_count + 1):
+                raise ValueError("matrix shape %r does not match counts" % (matrix.shape,))
+            if basis.shape != (self.constraint_count,):
+                raise ValueError("basis length %r does not match constraint count" % (basis.shape,))
+            # host arrays only; the upload happens at the first device operation
+            self._matrix, self._basis, self._stale = matrix.copy(), basis.copy(), False
+
+    # -- device <-> host
+    @property
+    def _h(self):
+        """The device handle (uploads the host arrays on first use; no CPU fallback)."""
+        if self._handle is None:
+            h = ctypes.c_void_p()
+            capi.check(capi.lib().mi355x_tab_create(
+                ctypes.byref(h), self._matrix.shape[0], self._matrix.shape[1], _ptr(self._matrix),
+                _ptr(self._basis) if self._basis.size else None, self.device), "mi355x_tab_create")
+            self._handle = h
+        return self._handle
+
+    def _refresh(self):
+        if self._stale:
+            R, C = self.constraint_count + 1, self.var_count + 1
+            M = np.empty((R, C), dtype=np.float64)
+            b = np.empty(max(R - 1, 0), dtype=np.int64)
+            capi.check(capi.lib().mi355x_tab_download(self._h, _ptr(M), _ptr(b) if b.size else None,
+                                                      None, None), "mi355x_tab_download")
+            self._matrix, self._basis, self._stale = M, b, False
+
+    def _touch(self):
+        self._stale = True
+
+    @property
+    def matrix(self):
+        """tableau-matrix (host copy of the HBM-resident matrix)."""
+        self._refresh()
+        return self._matrix
+
+    @property
+    def basis_columns(self):
+        """tableau-basis-columns."""
+        self._refresh()
+        return self._basis
+
+    @property
+    def is_max(self):
+        return self.instance_problem.type == "max"
+
+    def pivot_trace(self, cap=1 << 20):
+        """(entering column, row) of every pivot made on this tableau since it was uploaded."""
+        n = ctypes.c_int64(0)
+        ec = np.empty(cap, dtype=np.int64)
+        cr = np.empty(cap, dtype=np.int64)
+        capi.check(capi.lib().mi355x_tab_trace(self._h, _ptr(ec), _ptr(cr), cap, ctypes.byref(n)),
+                   "mi355x_tab_trace")
+        k = min(n.value, cap)
+        return np.stack([ec[:k], cr[:k]], axis=1)
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        self._handle = None
+        if h:
+            try:
+                capi.lib().mi355x_tab_destroy(h)
+            except Exception:
+                pass
+
+
+def copy_tableau(tableau):
+    """copy-tableau (src/simplex.lisp:61-71): deep-copies matrix and basis (device to device),
+    shares everything else."""
+    h = ctypes.c_void_p()
+    capi.check(capi.lib().mi355x_tab_copy(ctypes.byref(h), tableau._h), "mi355x_tab_copy")
+    return Tableau(tableau.problem, tableau.instance_problem, None, None, tableau.var_count,
+                   tableau.constraint_count, tableau.var_mapping, tableau.fp_tolerance_factor,
+                   tableau.device, _handle=h)
+
+
+# ------------------------------------------------------------------ read-back (host, O(n))
+def tableau_objective_value(tableau):
+    """tableau-objective-value (src/simplex.lisp:74-78)."""
+    return float(tableau.matrix[tableau.constraint_count, tableau.var_count])
+
+
+def _basic_value(tableau, col):
+    pos = np.nonzero(tableau.basis_columns == col)[0]       # `position`: first match
+    return float(tableau.matrix[pos[0], tableau.var_count]) if pos.size else 0.0
+
+
+def tableau_variable(tableau, var):
+    """tableau-variable (src/simplex.lisp:81-107)."""
+    if var == tableau.instance_problem.objective_var:
+        return tableau_objective_value(tableau)
+    mapping = tableau.var_mapping.get(var)
+    if mapping is None:
+        raise KeyError("%s is not a variable in the tableau" % (var,))
+    kind = mapping[0]
+    if kind == "positive":
+        return mapping[2] + _basic_value(tableau, mapping[1])
+    if kind == "negative":
+        return mapping[2] + (-_basic_value(tableau, mapping[1]))
+    return _basic_value(tableau, mapping[1]) - _basic_value(tableau, mapping[1] + 1)
+
+
+def tableau_reduced_cost(tableau, var):
+    """tableau-reduced-cost (src/simplex.lisp:111-120)."""
+    mapping = tableau.var_mapping.get(var)
+    if mapping is None:
+        raise KeyError("%s is not a variable in the tableau" % (var,))
+    if mapping[0] != "positive":
+        raise ValueError("%s has no lower bound" % (var,))
+    return float(tableau.matrix[tableau.constraint_count, mapping[1]])
+
+
+# ------------------------------------------------------------------ build-tableau (host)
+def build_tableau(problem, instance_problem=None, fp_tolerance_factor=1024, device=0):
+    """build-tableau (src/simplex.lisp:142-328) in double-float: returns a Tableau, or
+    [art_tableau, main_tableau] when the trivial basis is infeasible.
+
+    This is the producer of what crosses the boundary; in the Lisp deployment the reference's
+    own build-tableau does this job and the glue converts the result to double-float."""
+    if instance_problem is None:
+        instance_problem = problem
+    f = float
+    constraints = [(op, list(expr), rhs) for op, expr, rhs in instance_problem.constraints]
+    pvars = list(problem.vars)
+    n = len(pvars)
+    bounds = dict(problem.var_bounds)
+    mappings = {}
+
+    def mk(matrix, basis, var_count, ccount, inst):
+        return Tableau(problem, inst, matrix, basis, var_count, ccount, mappings,
+                       fp_tolerance_factor, device)
+
+    if not constraints:                                                  # :153-186
+        M = np.zeros((n + 1, n + 1))
+        basis = np.arange(n, dtype=np.int64)
+        objd = dict(problem.objective_func)
+        is_max = problem.type == "max"
+        objective_value = 0.0
+        for i, var in enumerate(pvars):
+            coef = objd[var]
+            lb, ub = bounds.get(var, (None, None))
+            M[i, i] = 1.0
+            if (0 <= coef) == is_max:
+                if ub is None:
+                    raise UnboundedProblemError()
+                mappings[var] = ("positive", i, f(ub))
+                objective_value = objective_value + f(coef) * f(ub)
+            else:
+                if lb is None:
+                    raise UnboundedProblemError()
+                mappings[var] = ("positive", i, f(lb))
+                objective_value = objective_value + f(coef) * f(lb)
+        M[n, n] = objective_value
+        return mk(M, basis, n, n, problem)
+
+    ncv = n                                                              # :189-212
+    column = 0
+    for var in pvars:
+        if var not in bounds:
+            mappings[var] = ("positive", column, 0.0)
+        else:
+            lb, ub = bounds[var]
+            if lb is not None and ub is not None:
+                if 0 <= ub:
+                    constraints.insert(0, ("<=", [(var, 1)], ub))
+                else:
+                    constraints.insert(0, (">=", [(var, 1)], -ub))
+                mappings[var] = ("positive", column, f(lb))
+            elif lb is not None:
+                mappings[var] = ("positive", column, f(lb))
+            elif ub is not None:
+                mappings[var] = ("negative", column, f(ub))
+            else:
+                mappings[var] = ("signed", column)
+                column += 1
+                ncv += 1
+        column += 1
+
+    m = len(constraints)                                                 # :214-221
+    num_slack = sum(1 for c in constraints if c[0] != "=")
+    num_cols = ncv + num_slack + 1
+    M = np.zeros((m + 1, num_cols))
+    basis = np.zeros(m, dtype=np.int64)
+    art_rows = []
+    col_offset = 0
+    for row, (op, expr, rhs) in enumerate(constraints):                  # :223-268
+        M[row, num_cols - 1] = f(rhs)
+        for var, coef in expr:
+            mp = mappings[var]
+            if mp[0] == "positive":
+                M[row, mp[1]] = f(coef)
+                M[row, num_cols - 1] -= f(coef) * mp[2]
+            elif mp[0] == "negative":
+                M[row, mp[1]] = -f(coef)
+                M[row, num_cols - 1] -= f(coef) * mp[2]
+            else:
+                M[row, mp[1]] = f(coef)
+                M[row, mp[1] + 1] = -f(coef)
+        if M[row, num_cols - 1] < 0:                                     # :243-252
+            M[row, :] = -M[row, :]
+            op = {"<=": ">=", ">=": "<=", "=": "="}.get(op, op)
+        if op == "<=":                                                   # :254-265
+            M[row, ncv + col_offset] = 1.0
+            basis[row] = ncv + col_offset
+            col_offset += 1
+        elif op == ">=":
+            art_rows.insert(0, row)
+            M[row, ncv + col_offset] = -1.0
+            basis[row] = num_cols
+            col_offset += 1
+        elif op == "=":
+            art_rows.insert(0, row)
+            basis[row] = num_cols
+        else:
+            raise ParsingError("%r is not a valid constraint equation" % ((op, expr, rhs),))
+    for var, coef in problem.objective_func:                             # :270-283
+        mp = mappings[var]
+        if mp[0] == "positive":
+            M[m, mp[1]] = -f(coef)
+            M[m, num_cols - 1] += f(coef) * mp[2]
+        elif mp[0] == "negative":
+            M[m, mp[1]] = f(coef)
+            M[m, num_cols - 1] += f(coef) * mp[2]
+        else:
+            M[m, mp[1]] = -f(coef)
+            M[m, mp[1] + 1] = f(coef)
+    main = mk(M, basis, num_cols - 1, m, instance_problem)
+    if not art_rows:
+        return main
+    num_art = len(art_rows)                                              # :292-325
+    nac = num_cols + num_art
+    A = np.zeros((m + 1, nac))
+    abasis = basis.copy()
+    for i, row in enumerate(art_rows):
+        abasis[row] = num_cols - 1 + i
+        A[row, num_cols - 1 + i] = 1.0
+    A[:m, :num_cols - 1] = M[:m, :num_cols - 1]
+    A[:m, nac - 1] = M[:m, num_cols - 1]
+    for c in list(range(num_cols - 1)) + [nac - 1]:
+        s = 0.0
+        for r in range(m):                                               # same summation order
+            if r in art_rows:
+                s = s + A[r, c]
+        A[m, c] = s
+    art_problem = Problem(type="min", vars=list(problem.vars))           # artificial problem
+    art = mk(A, abasis, num_cols - 1 + num_art, m, art_problem)
+    return [art, main]
+
+
+# ------------------------------------------------------------------ the hot path (device)
+def find_entering_column(tableau):
+    """find-entering-column (src/simplex.lisp:362-379): column index or None."""
+    col = ctypes.c_int64(-1)
+    capi.check(capi.lib().mi355x_tab_price(tableau._h, int(tableau.is_max),
+                                           float(tableau.fp_tolerance_factor), ctypes.byref(col)),
+               "mi355x_tab_price")
+    return None if col.value < 0 else int(col.value)
+
+
+def find_pivoting_row(tableau, entering_col):
+    """find-pivoting-row (src/simplex.lisp:382-389): row index or None."""
+    row = ctypes.c_int64(-1)
+    capi.check(capi.lib().mi355x_tab_ratio(tableau._h, int(entering_col),
+                                           float(tableau.fp_tolerance_factor), ctypes.byref(row)),
+               "mi355x_tab_ratio")
+    return None if row.value < 0 else int(row.value)
+
+
+def n_pivot_row(tableau, entering_col, changing_row):
+    """n-pivot-row (src/simplex.lisp:337-359): destructively applies a single pivot."""
+    capi.check(capi.lib().mi355x_tab_pivot(tableau._h, int(entering_col), int(changing_row)),
+               "mi355x_tab_pivot")
+    tableau._touch()
+    return tableau
+
+
+def pivot_row(tableau, entering_col, changing_row):
+    """pivot-row (src/simplex.lisp:333-335): non-destructive."""
+    return n_pivot_row(copy_tableau(tableau), entering_col, changing_row)
+
+
+def _raise_for(rc):
+    if rc == capi.MI_UNBOUNDED:
+        raise UnboundedProblemError()
+    if rc == capi.MI_INFEASIBLE:
+        raise InfeasibleProblemError()
+    if rc == capi.MI_ART_NONZERO:
+        raise SolverError("Artificial variable still non-zero")
+    if rc == capi.MI_ART_STUCK:
+        raise SolverError("Artificial variable still in basis and cannot be replaced")
+    if rc == capi.MI_MAX_PIVOTS:
+        raise SolverError("pivot cap reached")
+
+
+def n_solve_tableau(tableau, max_pivots=0):
+    """n-solve-tableau (src/simplex.lisp:399-461): a Tableau (single phase) or a list
+    [art, main] (two-phase).  Returns the solved (main) tableau."""
+    if isinstance(tableau, (list, tuple)):
+        art, main = tableau
+        if not isinstance(art, Tableau) or not isinstance(main, Tableau):
+            raise TypeError("expected tableaus")
+        npv = (ctypes.c_int64 * 2)()
+        rc = capi.check(capi.lib().mi355x_solve_two_phase(
+            art._h, main._h, int(main.is_max), float(main.fp_tolerance_factor), npv),
+            "mi355x_solve_two_phase")
+        art._touch()
+        main._touch()
+        main.n_pivots = (int(npv[0]), int(npv[1]))
+        _raise_for(rc)
+        return main
+    if not isinstance(tableau, Tableau):                    # (check-type tableau tableau) :454
+        raise TypeError("%r is not a tableau" % (tableau,))
+    n = ctypes.c_int64(0)
+    rc = capi.check(capi.lib().mi355x_tab_solve(tableau._h, int(tableau.is_max),
+                                                float(tableau.fp_tolerance_factor),
+                                                int(max_pivots), ctypes.byref(n)),
+                    "mi355x_tab_solve")
+    tableau._touch()
+    tableau.n_pivots = int(n.value)
+    _raise_for(rc)
+    return tableau
+
+
+def solve_tableau(tableau):
+    """solve-tableau (src/simplex.lisp:391-397): leaves the argument(s) untouched."""
+    if isinstance(tableau, (list, tuple)):
+        return n_solve_tableau([copy_tableau(t) for t in tableau])
+    return n_solve_tableau(copy_tableau(tableau))
+
+
+# ------------------------------------------------------------------ the *solver* hook value
+def mi355x_simplex_solver(problem, fp_tolerance=1024, device=0, **_ignored):
+    """What the Lisp glue installs as `*solver*` (src/solver.lisp:39-56): takes a problem and
+    backend keyword arguments, returns a solved tableau answering the four solution-*
+    generics.  LP only: integer/binary variables are declined the way a backend must
+    (unsupported-constraint-error, src/conditions.lisp:69-77); branch-and-bound
+    (src/simplex.lisp:506-542) stays with the reference's own solver."""
+    if problem.integer_vars:
+        raise UnsupportedConstraintError(("integer",) + tuple(problem.integer_vars),
+                                         "mi355x-simplex")
+    tabs = build_tableau(problem, problem, fp_tolerance_factor=fp_tolerance, device=device)
+    return n_solve_tableau(tabs)
+
+
+simplex_solver = mi355x_simplex_solver

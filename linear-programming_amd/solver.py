@@ -1,0 +1,39 @@
+"""Host-side mirror of the reference's `linear-programming/solver` package (src/solver.lisp):
+the `*solver*` hook and the four solution-* generics.
+
+In the Lisp deployment nothing in src/solver.lisp changes: the glue's
+`mi355x-simplex-solver` is simply the value of `linear-programming:*solver*`
+(`(let ((*solver* 'mi355x-simplex-solver)) (solve-problem problem))`) and returns a `tableau`,
+so the reference's own methods at src/solver.lisp:61-80 serve the generics.  This module
+restates that contract for the Python-side tests.
+"""
+from . import simplex
+
+#: `*solver*` (src/solver.lisp:39-49): a function taking a problem and backend-specific keyword
+#: arguments and returning a solution object.  Defaults to the MI355X backend here.
+SOLVER = simplex.mi355x_simplex_solver
+
+
+def solve_problem(problem, **kwargs):
+    """solve-problem (src/solver.lisp:53-56): (apply *solver* problem args)."""
+    return SOLVER(problem, **kwargs)
+
+
+def solution_problem(solution):
+    """solution-problem (src/solver.lisp:59-62)."""
+    return solution.problem
+
+
+def solution_objective_value(solution):
+    """solution-objective-value (src/solver.lisp:64-67)."""
+    return simplex.tableau_objective_value(solution)
+
+
+def solution_variable(solution, variable):
+    """solution-variable (src/solver.lisp:69-72)."""
+    return simplex.tableau_variable(solution, variable)
+
+
+def solution_reduced_cost(solution, variable):
+    """solution-reduced-cost (src/solver.lisp:74-80)."""
+    return simplex.tableau_reduced_cost(solution, variable)

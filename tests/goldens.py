@@ -47,3 +47,10 @@ def to_f64(tab):
     """rational_ref.Tableau -> (float64 matrix, int64 basis)."""
     M = np.array([[float(v) for v in row] for row in tab.matrix], dtype=np.float64)
     return np.ascontiguousarray(M), np.array(tab.basis, dtype=np.int64)
+
+
+def problem_dict(case):
+    """The case's problem in the JSON dict layout but with exact Fractions as numbers."""
+    p = problem(case)
+    return {"type": p["type"], "vars": p["vars"], "objective_var": p["objective_var"],
+            "objective": p["objective"], "bounds": p["bounds"], "constraints": p["constraints"]}

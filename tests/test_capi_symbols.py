@@ -1,0 +1,96 @@
+"""CPU-side checks of the drop-in boundary: libmi355x_simplex.so builds for gfx950, loads, and
+exports every symbol include/mi355x_simplex.h declares; nothing computes without a GPU and
+nothing falls back to the CPU."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.helpers import ROOT, lp_amd
+
+lp = lp_amd()
+HEADER = os.path.join(ROOT, "include", "mi355x_simplex.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi355x_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_is_built_and_loads():
+    import __graft_entry__
+    __graft_entry__.build()
+    assert os.path.exists(lp.capi.LIB_PATH)
+    L = lp.capi.lib()
+    assert L.mi355x_abi_version() == 1
+    assert L.mi355x_epsilon() == 2.0 ** -53 * (1 + 2.0 ** -52)
+    assert L.mi355x_update_kernel_name().decode() == "k_update"
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = declared_functions()
+    assert len(names) >= 25
+    L = ctypes.CDLL(lp.capi.LIB_PATH)
+    for name in names:
+        assert hasattr(L, name), "%s declared in the header but not exported" % name
+    assert sorted(lp.capi.SIGNATURES) == names, "capi.py and the header disagree"
+
+
+def test_exports_are_plain_c_symbols():
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lp.capi.LIB_PATH], text=True)
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    for name in declared_functions():
+        assert name in exported
+
+
+def test_code_object_targets_gfx950():
+    blob = open(lp.capi.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    assert b"k_update" in blob and b"k_select" in blob
+
+
+def test_library_does_not_link_the_oracle_or_torch():
+    out = subprocess.check_output(["ldd", lp.capi.LIB_PATH], text=True)
+    assert "liboracle" not in out and "torch" not in out
+    assert "libamdhip64" in out
+
+
+@pytest.mark.skipif(lp.capi.device_count() > 0, reason="a GPU is present")
+def test_no_device_means_loud_failure_not_fallback():
+    assert lp.capi.device_count() == 0
+    M = np.zeros((3, 4))
+    h = ctypes.c_void_p()
+    rc = lp.capi.lib().mi355x_tab_create(ctypes.byref(h), 3, 4, M.ctypes.data_as(ctypes.c_void_p),
+                                         None, 0)
+    assert rc == lp.capi.MI_NO_DEVICE and not h.value
+    assert b"no HIP device" in lp.capi.lib().mi355x_last_error()
+    t = lp.Tableau(None, lp.Problem(), M, np.zeros(2, dtype=np.int64), 3, 2, {})
+    with pytest.raises(lp.capi.Mi355xError):
+        lp.n_solve_tableau(t)
+    with pytest.raises(lp.capi.Mi355xError):
+        lp.find_entering_column(t)
+
+
+def test_argument_validation_without_device():
+    L = lp.capi.lib()
+    assert L.mi355x_tab_pivot(None, 0, 0) == lp.capi.MI_BAD_ARG
+    assert L.mi355x_tab_solve(None, 1, 1024.0, 0, None) == lp.capi.MI_BAD_ARG
+    assert L.mi355x_tab_download(None, None, None, None, None) == lp.capi.MI_BAD_ARG
+    h = ctypes.c_void_p()
+    assert L.mi355x_tab_create(ctypes.byref(h), 3, 4, None, None, 0) == lp.capi.MI_BAD_ARG
+    assert L.mi355x_tab_create_synthetic(ctypes.byref(h), 0, 4, 1, 0, -1, 0) == lp.capi.MI_BAD_ARG
+    L.mi355x_tab_destroy(None)                       # no-op
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "linear-programming_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".lisp", ".asd")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "liboracle" not in text and "simplex_oracle" not in text, f

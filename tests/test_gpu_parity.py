@@ -1,0 +1,457 @@
+"""Parity tests proper: the HIP path, called through the C ABI (via the host-side mirror of the
+reference's interface), against (a) the reference's own known-answer vectors and (b) the C
+oracle on the same inputs -- bit for bit.  Needs a real MI355X: `pytest -m gpu`."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import rational_ref as rr
+from tests import goldens
+from tests.goldens import fmat, frac
+from tests.helpers import lp_amd, random_mixed_problem
+
+pytestmark = pytest.mark.gpu
+lp = lp_amd()
+
+
+def _problem(case):
+    return lp.Problem.from_dict(goldens.problem_dict(case))
+
+
+def _f64(rows):
+    return np.array(fmat(rows), dtype=np.float64)
+
+
+def _oracle_solve(tabs):
+    """Run the C oracle on the same initial f64 tableau(s).  Returns (status, M, basis, trace)."""
+    if isinstance(tabs, list):
+        art, main = tabs
+        A, ab = art.matrix.copy(), art.basis_columns.copy()
+        Mm, mb = main.matrix.copy(), main.basis_columns.copy()
+        st, npv = oracle.solve_two_phase(A, ab, Mm, mb, main_is_max=main.is_max,
+                                         factor=main.fp_tolerance_factor)
+        return st, Mm, mb, (A, ab, npv)
+    M, b = tabs.matrix.copy(), tabs.basis_columns.copy()
+    st, n, trace = oracle.solve(M, b, is_max=tabs.is_max, factor=tabs.fp_tolerance_factor,
+                                trace_cap=1 << 16)
+    return st, M, b, trace
+
+
+# =========================================================================== t/simplex.lisp
+def test_pivot_row(golden):
+    """t/simplex.lisp:135-159."""
+    case = golden["cases"]["basic"]
+    problem = _problem(case)
+    tableau = lp.build_tableau(problem, problem)
+    exp = case["one_pivot"]
+    tableau2 = lp.pivot_row(tableau, exp["entering_col"], exp["row"])
+    assert tableau is not tableau2
+    assert lp.tableau_objective_value(tableau) == 0                 # original not mutated
+    assert lp.n_pivot_row(tableau, exp["entering_col"], exp["row"]) is tableau
+    assert np.array_equal(tableau.matrix, tableau2.matrix)
+    assert np.array_equal(tableau.basis_columns, tableau2.basis_columns)
+    assert tableau2.var_count == 5 and tableau2.constraint_count == 2
+    assert np.array_equal(tableau.matrix, _f64(exp["matrix"]))
+    assert tableau.basis_columns.tolist() == exp["basis"]
+    assert lp.tableau_objective_value(tableau) == 4
+
+
+def test_errors():
+    """t/simplex.lisp:167-168."""
+    with pytest.raises(TypeError):
+        lp.n_solve_tableau("max x + y st 2x+y <= 5")
+
+
+def test_basic_problem(golden):
+    """t/simplex.lisp:170-194."""
+    case = golden["cases"]["basic"]
+    problem = _problem(case)
+    tableau = lp.build_tableau(problem, problem)
+    tableau2 = lp.solve_tableau(tableau)
+    assert tableau is not tableau2
+    assert lp.tableau_objective_value(tableau) == 0                 # original not solved
+    assert lp.n_solve_tableau(tableau) is tableau
+    assert np.array_equal(tableau.matrix, tableau2.matrix)
+    assert np.array_equal(tableau.basis_columns, tableau2.basis_columns)
+    assert np.array_equal(tableau.matrix, _f64(case["final"]["matrix"]))
+    assert tableau.basis_columns.tolist() == case["final"]["basis"]
+    assert lp.tableau_objective_value(tableau) == 28.5
+    assert tableau.pivot_trace().tolist() == [[1, 1], [0, 0]]
+
+
+def test_equality_constraint(golden):
+    """t/simplex.lisp:196-237 (two-phase; pins first-index-wins on the ratio tie)."""
+    case = golden["cases"]["equality"]
+    problem = _problem(case)
+    tableaus = lp.build_tableau(problem, problem)
+    art_tab, main_tab = tableaus
+    tab2 = lp.solve_tableau(tableaus)
+    assert tab2 is not art_tab and tab2 is not main_tab
+    assert np.array_equal(main_tab.matrix, _f64(case["initial"]["matrix"]))   # untouched
+    assert lp.n_solve_tableau(tableaus) is main_tab
+    assert np.array_equal(main_tab.matrix, tab2.matrix)
+    assert np.array_equal(main_tab.basis_columns, tab2.basis_columns)
+    assert any(np.array_equal(art_tab.matrix, _f64(a["matrix"]))
+               and art_tab.basis_columns.tolist() == a["basis"] for a in case["final_art"])
+    assert lp.tableau_objective_value(art_tab) == 0
+    assert np.array_equal(main_tab.matrix, _f64(case["final"]["matrix"]))
+    assert main_tab.basis_columns.tolist() == case["final"]["basis"]
+    assert lp.tableau_objective_value(main_tab) == 28.5
+
+
+def test_leq_constraint(golden):
+    """t/simplex.lisp:239-275 (values are thirds: f64 agrees to a few ulp)."""
+    case = golden["cases"]["geq"]
+    problem = _problem(case)
+    tableaus = lp.build_tableau(problem, problem)
+    art_tab, main_tab = tableaus
+    assert lp.n_solve_tableau(tableaus) is main_tab
+    assert any(np.allclose(art_tab.matrix, _f64(a["matrix"]), rtol=0, atol=4e-15)
+               and art_tab.basis_columns.tolist() == a["basis"] for a in case["final_art"])
+    assert abs(lp.tableau_objective_value(art_tab)) == 0
+    assert any(np.allclose(main_tab.matrix, _f64(a["matrix"]), rtol=0, atol=4e-15)
+               and main_tab.basis_columns.tolist() == a["basis"]
+               for a in case["final_alternatives"])
+    assert abs(lp.tableau_objective_value(main_tab) - 85 / 3) <= 1e-10 * 85 / 3
+
+
+def test_unsolvable_problems(golden):
+    """t/simplex.lisp:277-289."""
+    p = _problem(golden["cases"]["infeasible"])
+    with pytest.raises(lp.InfeasibleProblemError):
+        lp.solve_tableau(lp.build_tableau(p, p))
+    p = _problem(golden["cases"]["unbounded"])
+    with pytest.raises(lp.UnboundedProblemError):
+        lp.solve_tableau(lp.build_tableau(p, p))
+
+
+def test_copy_tableau(golden):
+    """t/simplex.lisp:293-307."""
+    p = _problem(golden["cases"]["basic"])
+    t1 = lp.build_tableau(p, p)
+    t2 = lp.copy_tableau(t1)
+    assert t1 is not t2 and t1.problem is t2.problem
+    assert t1.matrix is not t2.matrix and np.array_equal(t1.matrix, t2.matrix)
+    assert t1.basis_columns is not t2.basis_columns
+    assert np.array_equal(t1.basis_columns, t2.basis_columns)
+    assert (t1.var_count, t1.constraint_count) == (t2.var_count, t2.constraint_count)
+    lp.n_pivot_row(t2, 0, 0)
+    assert not np.array_equal(t1.matrix, t2.matrix)                 # deep copy
+
+
+ANSWER_CASES = ["basic", "free_x", "free_x_negative", "ub_only_x", "lb_x", "range_y",
+                "free_z_reduced_cost", "widgets", "excessive_constraints", "numerical_issue",
+                "variable_bounds_bug", "variable_bounds_only", "equality", "geq"]
+
+
+@pytest.mark.parametrize("name", ANSWER_CASES)
+def test_golden_answers_and_oracle_bits(golden, name):
+    """tableau-variable / reduced-cost / objective of every LP the reference tests
+    (t/simplex.lisp:309-389, t/solver.lisp:20-32,70-83, t/integration.lisp:18-124), solved
+    through the hook, plus bitwise equality with the C oracle on the same input."""
+    case = golden["cases"][name]
+    problem = _problem(case)
+    f32 = bool(case.get("float32_literals"))
+    st, M_or, b_or, _ = _oracle_solve(lp.build_tableau(problem, problem))
+    assert st == oracle.OPTIMAL
+    solution = lp.solve_problem(problem)
+    assert lp.solution_problem(solution) is problem
+    assert np.array_equal(solution.matrix, M_or), "HIP path differs from the oracle"
+    assert np.array_equal(solution.basis_columns, b_or)
+
+    def close(a, b):
+        return abs(a - float(b)) <= 1e-10 * max(1.0, abs(float(b)))
+    if "objective" in case:
+        assert close(lp.solution_objective_value(solution), frac(case["objective"], f32))
+    for v, e in case.get("variables", {}).items():
+        assert close(lp.solution_variable(solution, v), frac(e, f32)), v
+    for v, e in case.get("reduced_costs", {}).items():
+        assert close(lp.solution_reduced_cost(solution, v), frac(e, f32)), v
+    for v, (lo, hi) in case.get("variable_ranges", {}).items():
+        assert lo <= lp.solution_variable(solution, v) <= hi, v
+    for v in case.get("reduced_cost_errors", []):
+        with pytest.raises((KeyError, ValueError)):
+            lp.solution_reduced_cost(solution, v)
+    for v in case.get("variable_errors", []):
+        with pytest.raises(KeyError):
+            lp.solution_variable(solution, v)
+    if "objective_fp_eq" in case:
+        spec = case["objective_fp_eq"]
+        tol = spec["factor"] * 5.960464477539063e-08 * (1 + 2.0 ** -23)
+        assert abs(lp.solution_objective_value(solution) - float(np.float32(spec["value"]))) <= tol
+
+
+def test_integer_problems_are_declined(golden):
+    """A backend must signal unsupported-constraint-error for what it does not handle
+    (src/conditions.lisp:69-77); B&B stays with the reference's own solver."""
+    p = _problem(golden["cases"]["basic"])
+    p.integer_vars = ["x"]
+    with pytest.raises(lp.UnsupportedConstraintError) as e:
+        lp.solve_problem(p)
+    assert e.value.solver_name == "mi355x-simplex"
+
+
+# =========================================================================== vs the C oracle
+@pytest.mark.parametrize("n,m,seed", [(5, 3, 1), (33, 17, 2), (64, 32, 3), (200, 100, 4),
+                                      (257, 511, 5), (1000, 7, 6), (7, 300, 7)])
+def test_full_solve_bitwise_vs_oracle(n, m, seed):
+    """Same pivot sequence and bit-identical final tableau on random dense LPs of odd shapes
+    (row lengths that are not multiples of the vector width, single tiles, ragged tiles)."""
+    M0, b0 = lp.synth.tableau(n, m, lp.synth.seed_for(9, seed))
+    M, b = M0.copy(), b0.copy()
+    st, npiv, trace = oracle.solve(M, b, trace_cap=1 << 16)
+    t = lp.Tableau(None, lp.Problem(type="max"), M0, b0, n + m, m, {})
+    lp.n_solve_tableau(t)
+    assert st == oracle.OPTIMAL and t.n_pivots == npiv
+    assert np.array_equal(t.pivot_trace(), trace)
+    assert np.array_equal(t.matrix, M)
+    assert np.array_equal(t.basis_columns, b)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("n,m,seed", [(33, 17, 2), (257, 511, 5), (1500, 300, 8)])
+def test_both_select_paths_bitwise_vs_oracle(n, m, seed, mode):
+    """The single-workgroup select and the split (multi-workgroup) select are forced in turn on
+    shapes either side of the automatic switch; both must reproduce the oracle exactly."""
+    L = lp.capi.lib()
+    M0, b0 = lp.synth.tableau(n, m, lp.synth.seed_for(9, seed))
+    M, b = M0.copy(), b0.copy()
+    st, npiv, trace = oracle.solve(M, b, trace_cap=1 << 16)
+    try:
+        L.mi355x_tune_set_select_mode(mode)
+        t = lp.Tableau(None, lp.Problem(type="max"), M0, b0, n + m, m, {})
+        lp.n_solve_tableau(t)
+    finally:
+        L.mi355x_tune_set_select_mode(0)
+    assert t.n_pivots == npiv and np.array_equal(t.pivot_trace(), trace)
+    assert np.array_equal(t.matrix, M) and np.array_equal(t.basis_columns, b)
+
+
+def test_every_update_variant_bitwise_vs_oracle():
+    """All compiled tilings of the rank-1 update kernel give the same bits."""
+    L = lp.capi.lib()
+    n, m = 700, 333
+    M0, b0 = lp.synth.tableau(n, m, lp.synth.seed_for(9, 70))
+    M, b = M0.copy(), b0.copy()
+    st, npiv, trace = oracle.solve(M, b, max_pivots=40, trace_cap=64)
+    try:
+        for v in range(L.mi355x_tune_variant_count()):
+            L.mi355x_tune_set_variant(v)
+            t = lp.Tableau(None, lp.Problem(type="max"), M0, b0, n + m, m, {})
+            with pytest.raises(lp.SolverError):
+                lp.n_solve_tableau(t, max_pivots=40)
+            assert np.array_equal(t.pivot_trace(), trace), v
+            assert np.array_equal(t.matrix, M), v
+    finally:
+        L.mi355x_tune_set_variant(0)
+
+
+def test_config2_full_solve_bitwise_vs_oracle():
+    """BASELINE config 2: dense random LP 1024 vars x 512 constraints, solved to optimality."""
+    n, m = 1024, 512
+    M0, b0 = lp.synth.tableau(n, m, lp.synth.seed_for(2))
+    M, b = M0.copy(), b0.copy()
+    st, npiv, trace = oracle.solve(M, b, trace_cap=1 << 16, omp=True)
+    t = lp.Tableau(None, lp.Problem(type="max"), M0, b0, n + m, m, {})
+    lp.n_solve_tableau(t)
+    assert st == oracle.OPTIMAL and t.n_pivots == npiv and npiv > m // 4
+    assert np.array_equal(t.pivot_trace(), trace)
+    assert np.array_equal(t.matrix, M)
+    assert np.array_equal(t.basis_columns, b)
+
+
+@pytest.mark.parametrize("kind", ["max", "min"])
+def test_min_and_max_problems_bitwise(kind):
+    """min problems price with arg-max / fp> (src/simplex.lisp:373-379)."""
+    rng = np.random.default_rng(11)
+    n, m = 40, 25
+    M0 = np.zeros((m + 1, n + m + 1))
+    M0[:m, :n] = rng.uniform(0.1, 1.0, (m, n))
+    M0[np.arange(m), n + np.arange(m)] = 1.0
+    M0[:m, -1] = rng.uniform(5, 10, m)
+    c = rng.uniform(0.5, 1.5, n)
+    M0[m, :n] = -c if kind == "max" else c       # a min problem improves on positive entries
+    b0 = np.arange(n, n + m, dtype=np.int64)
+    M, b = M0.copy(), b0.copy()
+    st, npiv, trace = oracle.solve(M, b, is_max=(kind == "max"), trace_cap=4096)
+    t = lp.Tableau(None, lp.Problem(type=kind), M0, b0, n + m, m, {})
+    lp.n_solve_tableau(t)
+    assert st == oracle.OPTIMAL and npiv > 0
+    assert np.array_equal(t.pivot_trace(), trace) and np.array_equal(t.matrix, M)
+
+
+@pytest.mark.parametrize("n,mle,mge,meq,seed", [(6, 3, 2, 1, 1), (30, 10, 8, 4, 2),
+                                                (80, 30, 20, 10, 3), (40, 0, 25, 0, 4),
+                                                (300, 100, 60, 30, 5), (12, 4, 4, 4, 6)])
+def test_two_phase_bitwise_vs_oracle(n, mle, mge, meq, seed):
+    """Two-phase branch (src/simplex.lisp:402-452) on random LPs with >= and = rows.  Whatever
+    the reference's algorithm does on the input -- including declaring a feasible problem
+    infeasible because phase 1 ends a few ulp above its 1024-eps test -- the HIP path does
+    the same, bit for bit."""
+    problem = random_mixed_problem(lp, n, mle, mge, meq, seed)
+    tabs = lp.build_tableau(problem, problem)
+    assert isinstance(tabs, list)
+    st, M_or, b_or, (A_or, ab_or, npv) = _oracle_solve(tabs)
+    art, main = tabs
+    if st == oracle.OPTIMAL:
+        lp.n_solve_tableau(tabs)
+        assert main.n_pivots == (int(npv[0]), int(npv[1]))
+    else:
+        assert st == oracle.INFEASIBLE
+        with pytest.raises(lp.InfeasibleProblemError):
+            lp.n_solve_tableau(tabs)
+    assert np.array_equal(art.matrix, A_or) and np.array_equal(art.basis_columns, ab_or)
+    assert np.array_equal(main.matrix, M_or) and np.array_equal(main.basis_columns, b_or)
+
+
+def test_forced_pivot_sequence_bitwise():
+    """n-pivot-row with caller-chosen pivots (not the Dantzig choice), many in a row."""
+    rng = np.random.default_rng(5)
+    R, C = 37, 101
+    M0 = rng.uniform(0.5, 1.5, (R, C))
+    b0 = np.arange(R - 1, dtype=np.int64)
+    M, b = M0.copy(), b0.copy()
+    t = lp.Tableau(None, lp.Problem(), M0, b0, C - 1, R - 1, {})
+    for k in range(60):
+        ec, cr = (7 * k + 3) % C, (5 * k + 1) % (R - 1)
+        oracle.pivot(M, b, ec, cr)
+        lp.n_pivot_row(t, ec, cr)
+    assert np.array_equal(t.matrix, M)
+    assert np.array_equal(t.basis_columns, b)
+    assert np.array_equal(t.pivot_trace(), [[(7 * k + 3) % C, (5 * k + 1) % (R - 1)] for k in range(60)])
+
+
+def test_price_and_ratio_entry_points():
+    """find-entering-column / find-pivoting-row on their own, incl. the exact thresholds."""
+    eps = lp.capi.lib().mi355x_epsilon()
+    assert eps == oracle.EPSILON
+    M0, b0 = lp.synth.tableau(50, 20, 77)
+    t = lp.Tableau(None, lp.Problem(type="max"), M0, b0, 70, 20, {})
+    ec = lp.find_entering_column(t)
+    assert ec == oracle.price(M0)
+    assert lp.find_pivoting_row(t, ec) == oracle.ratio(M0, ec)
+    # exactly -128 eps is NOT below the pricing threshold, the next double is
+    M = np.array([[1.0, 1.0, 1.0], [-128 * eps, 0.0, 0.0]])
+    t = lp.Tableau(None, lp.Problem(type="max"), M, np.array([1], dtype=np.int64), 2, 1, {})
+    assert lp.find_entering_column(t) is None
+    M[1, 0] = np.nextafter(M[1, 0], -1.0)
+    t = lp.Tableau(None, lp.Problem(type="max"), M, np.array([1], dtype=np.int64), 2, 1, {})
+    assert lp.find_entering_column(t) == 0
+    # exactly 512 eps is not an eligible pivot element, the next double is
+    M = np.array([[512 * eps, 0.0, 1.0], [-1.0, 0.0, 0.0]])
+    t = lp.Tableau(None, lp.Problem(type="max"), M, np.array([1], dtype=np.int64), 2, 1, {})
+    assert lp.find_pivoting_row(t, 0) is None
+    M[0, 0] = np.nextafter(M[0, 0], 1.0)
+    t = lp.Tableau(None, lp.Problem(type="max"), M, np.array([1], dtype=np.int64), 2, 1, {})
+    assert lp.find_pivoting_row(t, 0) == 0
+
+
+def test_ties_take_the_lowest_index():
+    """Exact ties in pricing and in the ratio test: first index wins, wherever the tied
+    entries fall relative to wave / thread boundaries."""
+    n, m = 3000, 2500
+    M0 = np.zeros((m + 1, n + m + 1))
+    M0[:m, :n] = 1.0
+    M0[np.arange(m), n + np.arange(m)] = 1.0
+    M0[:m, -1] = 4.0
+    M0[m, :n] = -1.0
+    for cols, rows in [((5, 70, 1029, 2999), (3, 64, 1024, 2047)), ((2998, 2999), (2498, 2499))]:
+        M = M0.copy()
+        M[m, list(cols)] = -2.0                  # tied most-negative reduced costs
+        M[list(rows), -1] = 2.0                  # tied minimum ratios
+        t = lp.Tableau(None, lp.Problem(type="max"), M, np.arange(n, n + m, dtype=np.int64),
+                       n + m, m, {})
+        ec = lp.find_entering_column(t)
+        assert ec == cols[0] == oracle.price(M)
+        assert lp.find_pivoting_row(t, ec) == rows[0] == oracle.ratio(M, ec)
+
+
+def test_max_pivots_and_resume():
+    M0, b0 = lp.synth.tableau(120, 60, 5)
+    M, b = M0.copy(), b0.copy()
+    st, total, trace = oracle.solve(M, b, trace_cap=4096)
+    t = lp.Tableau(None, lp.Problem(type="max"), M0, b0, 180, 60, {})
+    with pytest.raises(lp.SolverError):
+        lp.n_solve_tableau(t, max_pivots=7)
+    assert t.n_pivots == 7
+    Mo, bo = M0.copy(), b0.copy()
+    oracle.solve(Mo, bo, max_pivots=7)
+    assert np.array_equal(t.matrix, Mo)
+    lp.n_solve_tableau(t)                        # resume to optimality
+    assert t.n_pivots == total - 7
+    assert np.array_equal(t.matrix, M) and np.array_equal(t.pivot_trace(), trace)
+
+
+def test_async_enqueue_matches_blocking_solve():
+    """mi355x_tab_solve_async + mi355x_tab_sync (what bench.py times)."""
+    n, m = 300, 150
+    M0, b0 = lp.synth.tableau(n, m, 21)
+    t = lp.Tableau(None, lp.Problem(type="max"), M0, b0, n + m, m, {})
+    L = lp.capi.lib()
+    lp.capi.check(L.mi355x_tab_solve_async(t._h, 1, 1024.0, 25, 1), "solve_async")
+    npv = ctypes.c_int64(0)
+    rc = L.mi355x_tab_sync(t._h, ctypes.byref(npv))
+    assert rc == lp.capi.MI_MAX_PIVOTS and npv.value == 25
+    t._touch()
+    Mo, bo = M0.copy(), b0.copy()
+    oracle.solve(Mo, bo, max_pivots=25)
+    assert np.array_equal(t.matrix, Mo)
+    # enqueue far more iterations than the LP needs: the surplus must be no-ops
+    lp.capi.check(L.mi355x_tab_solve_async(t._h, 1, 1024.0, 3000, 0), "solve_async")
+    rc = L.mi355x_tab_sync(t._h, ctypes.byref(npv))
+    assert rc == lp.capi.MI_OPTIMAL
+    t._touch()
+    st, total, _ = oracle.solve(Mo, bo)
+    assert npv.value == 25 + total and np.array_equal(t.matrix, Mo)
+
+
+# =========================================================================== synthetic inputs
+@pytest.mark.parametrize("n,m", [(8, 4), (130, 70), (1024, 512)])
+def test_device_generator_matches_numpy(n, m):
+    """k_synth_fill writes the same doubles as linear-programming_amd/synth.py."""
+    h = ctypes.c_void_p()
+    seed = lp.synth.seed_for(3, n)
+    lp.capi.check(lp.capi.lib().mi355x_tab_create_synthetic(ctypes.byref(h), n, m, seed, 0, -1, 0),
+                  "create_synthetic")
+    t = lp.Tableau(None, lp.Problem(type="max"), None, None, n + m, m, {}, _handle=h)
+    M, b = lp.synth.tableau(n, m, seed)
+    assert np.array_equal(t.matrix, M) and np.array_equal(t.basis_columns, b)
+
+
+# =========================================================================== full size
+def test_config3_first_pivots_bitwise_and_full_solve_properties():
+    """BASELINE config 3 (8192 vars x 4096 constraints, 4097 x 12289 f64 tableau).
+    (a) the first 24 pivots are bit-identical to the oracle; (b) the full solve terminates
+    optimal and satisfies size-independent properties: dual feasibility of the objective row,
+    primal feasibility, exactly-unit basic columns, objective == c'x from the original data."""
+    n, m = 8192, 4096
+    seed = lp.synth.seed_for(3)
+    h = ctypes.c_void_p()
+    lp.capi.check(lp.capi.lib().mi355x_tab_create_synthetic(ctypes.byref(h), n, m, seed, 0, -1, 0),
+                  "create_synthetic")
+    t = lp.Tableau(None, lp.Problem(type="max"), None, None, n + m, m, {}, _handle=h)
+    K = 24
+    M, b = lp.synth.tableau(n, m, seed)
+    A, rhs, c = M[:m, :n].copy(), M[:m, -1].copy(), -M[m, :n].copy()
+    st, npiv, trace = oracle.solve(M, b, max_pivots=K, trace_cap=K, omp=True)
+    assert (st, npiv) == (oracle.MAX_PIVOTS, K)
+    with pytest.raises(lp.SolverError):
+        lp.n_solve_tableau(t, max_pivots=K)
+    assert np.array_equal(t.pivot_trace(), trace)
+    assert np.array_equal(t.matrix, M)
+    del M
+    lp.n_solve_tableau(t)
+    Mf, bf = t.matrix, t.basis_columns
+    eps = oracle.EPSILON
+    assert Mf[m, :n + m].min() >= -128 * eps                    # nothing left to price
+    assert Mf[:m, -1].min() >= -1e-9                            # primal feasible
+    assert len(set(bf.tolist())) == m
+    cols = Mf[:, bf]                                            # basic columns are unit vectors
+    assert np.array_equal(cols[:m], np.eye(m)) and not cols[m].any()
+    x = np.zeros(n + m)
+    x[bf] = Mf[:m, -1]
+    obj = Mf[m, -1]
+    assert abs(c @ x[:n] - obj) <= 1e-10 * abs(obj)
+    assert (A @ x[:n] - rhs).max() <= 1e-8 * np.abs(rhs).max()

@@ -1,0 +1,144 @@
+"""CPU tests of the host-side logic above the C ABI (no GPU needed): build-tableau,
+read-back, the synthetic generator, status mapping."""
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+from oracle import rational_ref as rr
+from tests import goldens
+from tests.goldens import fmat
+from tests.helpers import lp_amd, random_mixed_problem
+
+lp = lp_amd()
+
+
+def _problem(case):
+    return lp.Problem.from_dict(goldens.problem_dict(case))
+
+
+@pytest.mark.parametrize("name", ["basic", "equality", "geq"])
+def test_build_tableau_golden(golden, name):
+    """t/simplex.lisp:60-133 through the product's host-side build_tableau (f64)."""
+    case = golden["cases"][name]
+    p = _problem(case)
+    tabs = lp.build_tableau(p, p)
+    main = tabs[1] if isinstance(tabs, list) else tabs
+    exp = case["initial"]
+    assert isinstance(main, lp.Tableau) and main.problem is p and main.instance_problem is p
+    assert np.array_equal(main.matrix, np.array(fmat(exp["matrix"]), dtype=float))
+    assert main.basis_columns.tolist() == exp["basis"]
+    assert (main.var_count, main.constraint_count) == (exp["var_count"], exp["constraint_count"])
+    assert lp.tableau_objective_value(main) == exp["objective"]
+    if "initial_art" in case:
+        art, exp = tabs[0], case["initial_art"]
+        assert art.instance_problem.type == "min" and art.problem is p
+        assert np.array_equal(art.matrix, np.array(fmat(exp["matrix"]), dtype=float))
+        assert art.basis_columns.tolist() == exp["basis"]
+        assert art.var_count == exp["var_count"]
+        assert lp.tableau_objective_value(art) == exp["objective"]
+
+
+def test_build_tableau_rejects_bad_operator(golden):
+    """t/simplex.lisp:49-58: a /= constraint signals parsing-error."""
+    p = lp.Problem(type="max", vars=["x", "y"], objective_func=[("x", 1), ("y", 2)],
+                   constraints=[("<=", [("x", 5), ("y", 1)], 10), ("/=", [("x", 1), ("y", 1)], 5)])
+    with pytest.raises(lp.ParsingError):
+        lp.build_tableau(p, p)
+
+
+@pytest.mark.parametrize("name", ["free_x", "free_x_negative", "ub_only_x", "lb_x", "range_y",
+                                  "free_z_reduced_cost", "widgets", "excessive_constraints",
+                                  "numerical_issue", "variable_bounds_bug", "variable_bounds_only"])
+def test_build_tableau_matches_rational_restatement(golden, name):
+    """Bounds handling (free / negative / shifted / ranged variables, the no-constraint special
+    case): the product's f64 build_tableau equals the exact-rational restatement, entry by entry
+    (the golden answers pin the latter in test_oracle_golden.py)."""
+    case = golden["cases"][name]
+    got = lp.build_tableau(_problem(case))
+    exp = rr.build_tableau(goldens.problem(case))
+    got = got if isinstance(got, list) else [got]
+    exp = list(exp) if isinstance(exp, tuple) else [exp]
+    assert len(got) == len(exp)
+    for g, e in zip(got, exp):
+        Me, be = goldens.to_f64(e)
+        assert g.matrix.shape == Me.shape
+        assert np.allclose(g.matrix, Me, rtol=1e-15, atol=0)
+        assert g.basis_columns.tolist() == be.tolist()
+        assert (g.var_count, g.constraint_count) == (e.var_count, e.constraint_count)
+        assert g.is_max == e.is_max
+        for var, mp in e.var_mapping.items():
+            gm = g.var_mapping[var]
+            assert gm[:2] == mp[:2]
+            if len(mp) > 2:
+                assert gm[2] == pytest.approx(float(mp[2]), rel=1e-15)
+
+
+def test_random_mixed_problems_build_like_the_restatement():
+    for seed in range(4):
+        p = random_mixed_problem(lp, 12, 5, 4, 3, seed)
+        d = {"type": p.type, "vars": p.vars, "objective_var": p.objective_var,
+             "objective": [[v, Fraction(c)] for v, c in p.objective_func], "bounds": [],
+             "constraints": [[op, [[v, Fraction(c)] for v, c in e], Fraction(r)]
+                             for op, e, r in p.constraints]}
+        art_e, main_e = rr.build_tableau(d)
+        art, main = lp.build_tableau(p)
+        assert np.allclose(art.matrix, goldens.to_f64(art_e)[0], rtol=1e-13, atol=0)
+        assert np.array_equal(main.matrix, goldens.to_f64(main_e)[0])
+        assert art.basis_columns.tolist() == art_e.basis
+        assert main.basis_columns.tolist() == main_e.basis
+
+
+def test_readback_on_host_arrays(golden):
+    """tableau-variable / -reduced-cost / -objective-value (src/simplex.lisp:74-120) on a solved
+    tableau supplied as host arrays (the golden final tableau), no device involved."""
+    case = golden["cases"]["basic"]
+    p = _problem(case)
+    t0 = lp.build_tableau(p, p)
+    t = lp.Tableau(p, p, np.array(fmat(case["final"]["matrix"]), dtype=float),
+                   np.array(case["final"]["basis"]), t0.var_count, t0.constraint_count,
+                   t0.var_mapping)
+    assert lp.tableau_objective_value(t) == 28.5
+    assert [lp.tableau_variable(t, v) for v in "wxyz"] == [28.5, 0.5, 7.0, 0.0]
+    assert [lp.tableau_reduced_cost(t, v) for v in "xyz"] == [0.0, 0.0, 0.5]
+    with pytest.raises(KeyError):
+        lp.tableau_variable(t, "foo")
+    with pytest.raises(KeyError):
+        lp.tableau_reduced_cost(t, "w")
+    assert lp.solution_problem(t) is p and lp.solution_objective_value(t) == 28.5
+
+
+def test_synthetic_generator_is_the_documented_splitmix64():
+    """First outputs of splitmix64 for seed 0 are the published test vector."""
+    z = []
+    s = 0
+    for _ in range(3):
+        s = (s + 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
+        x = s
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & (2 ** 64 - 1)
+        z.append(x ^ (x >> 31))
+    assert z[0] == 0xE220A8397B1DCDAF and z[1] == 0x6E789E6AA1B965F4
+    u = lp.synth.splitmix_u01(0, 0, 3)
+    assert u.tolist() == [(v >> 11) * 2.0 ** -53 for v in z]
+    assert lp.synth.splitmix_u01(0, 2, 1)[0] == u[2]            # random access == sequential
+
+
+def test_synthetic_tableau_layout():
+    n, m = 6, 4
+    seed = lp.synth.seed_for(3)
+    assert seed == (0x9E3779B97F4A7C15 ^ (20260928 + 3000))
+    M, b = lp.synth.tableau(n, m, seed)
+    A, rhs, c = lp.synth.lp_data(n, m, seed)
+    assert M.shape == (m + 1, n + m + 1) and b.tolist() == [6, 7, 8, 9]
+    assert np.array_equal(M[:m, :n], A) and np.array_equal(M[:m, n:n + m], np.eye(m))
+    assert np.array_equal(M[:m, -1], rhs) and np.array_equal(M[m, :n], -c)
+    assert not M[m, n:].any()
+    assert (A >= 0.05).all() and (A < 1.05).all() and (rhs >= 0.25 * n).all() and (c >= 0.5).all()
+
+
+def test_integer_problems_are_declined_before_any_device_work(golden):
+    p = _problem(golden["cases"]["basic"])
+    p.integer_vars = ["x", "y"]
+    with pytest.raises(lp.UnsupportedConstraintError):
+        lp.solve_problem(p)
