@@ -45,11 +45,17 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS) + ["colpart"])
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS) + ["cfg4", "colpart"])
+    ap.add_argument("--batch-lps", type=int, default=128,
+                    help="cfg4: LPs per GPU (BASELINE config 4 = 1024 LPs over 8 GPUs)")
+    ap.add_argument("--colpart-vars", type=int, default=0,
+                    help="colpart: override the number of variables (constraints = vars/2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pivots", type=int, default=24)
     ap.add_argument("--no-events", action="store_true",
                     help="do not bracket the update launches with HIP events (roofline = null)")
+    ap.add_argument("--event-stride", type=int, default=8,
+                    help="bracket every k-th update launch of the timed region with a HIP event pair")
     return ap.parse_args()
 
 
@@ -73,6 +79,68 @@ def cpu_baseline(lp, n, m, seed, pivots):
                   "%.3f pivots/s over the next %d pivots" % (npiv, n, m, npiv1 / t_one, npiv1),
         "single_thread_value": npiv1 / t_one,
         "GBps": 2.0 * (m + 1) * (n + m + 1) * 8 * npiv / t_omp / 1e9,
+    }
+
+
+def pmc_traffic(workload):
+    """HBM bytes per k_update launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE in separate runs, FETCH doubled per the gfx950 correction, calibrated on a copy of
+    the same buffer -- profiles/r01_cfg3_pmc_traffic.json).  PMC counters cannot be collected
+    from inside this process, so the number is the last profiled one for this workload, or None."""
+    path = os.path.join(ROOT, "profiles", "r01_%s_pmc_traffic.json" % workload)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return d["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+    except Exception:
+        return None, None
+
+
+def bench_batch(args, lp, rank, local_rank, N, barrier, torch, dist):
+    """BASELINE config 4: a batch of independent 512 x 256 LPs per GPU (1024 over 8 GPUs),
+    solved to optimality; value = total pivots of all LPs / time.  No collective."""
+    import numpy as np
+    n, m = 512, 256
+    nl = args.batch_lps
+    seeds = np.array([lp.synth.seed_for(4, rank * nl + k) for k in range(nl)], dtype=np.uint64)
+    warm = lp.TableauBatch.synthetic(min(nl, 8), n, m, seeds[:min(nl, 8)], device=local_rank)
+    warm.solve(max_pivots=max(args.warmup, 1))           # untimed warm-up on a throw-away batch
+    del warm
+    batch = lp.TableauBatch.synthetic(nl, n, m, seeds, device=local_rank)
+    L = lp.capi.lib()
+    L.mi355x_batch_timing_enable(batch._h, 1)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st, npv = batch.solve()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    nlch, sm, mn = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+    L.mi355x_batch_timing_read(batch._h, ctypes.byref(nlch), ctypes.byref(sm), ctypes.byref(mn))
+    assert (st == 0).all(), "not every LP reached optimality"
+    tot = torch.tensor([float(npv.sum()), elapsed], dtype=torch.float64, device="cuda")
+    if N > 1:
+        piv = tot[:1].clone()
+        dist.all_reduce(piv, op=dist.ReduceOp.SUM)
+        tmax = tot[1:].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        total_pivots, elapsed = float(piv.item()), float(tmax.item())
+    else:
+        total_pivots = float(npv.sum())
+    R, C = m + 1, n + m + 1
+    return {
+        "metric": "simplex pivots/sec, batch of independent 512x256 f64 LPs",
+        "value": total_pivots / elapsed, "unit": "pivots/s", "n_gpus": N,
+        "steps": int(npv.max()), "warmup": args.warmup,
+        "ms_per_step": elapsed / max(int(npv.max()), 1) * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE config 4: %d independent LPs per GPU, 512 vars x 256 "
+                               "<=-constraints each (257x769 f64 tableau), solved to optimality"
+                               % nl, "lps_total": nl * N, "pivots_total": total_pivots,
+                   "pivots_per_lp_min_mean_max": [int(npv.min()), float(npv.mean()), int(npv.max())]},
+        "aggregate_GBps": 2.0 * R * C * 8 * total_pivots / elapsed / 1e9,
+        "update_launches": int(nlch.value), "update_ms_total": sm.value,
     }
 
 
@@ -102,6 +170,14 @@ def main():
         if N > 1:
             dist.barrier()
 
+    if args.workload == "cfg4":
+        rec = bench_batch(args, lp, rank, local_rank, N, barrier, torch, dist)
+        if rank == 0:
+            print(json.dumps(rec), flush=True)
+        if N > 1:
+            dist.destroy_process_group()
+        return
+
     if args.workload == "colpart":
         from importlib import import_module
         colpart = import_module("linear-programming_amd.colpart")
@@ -126,7 +202,7 @@ def main():
     lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, args.warmup, 1), "warmup")
     L.mi355x_tab_sync(h, ctypes.byref(npv))
     if not args.no_events:
-        L.mi355x_tab_timing_enable(h, 1)
+        L.mi355x_tab_timing_enable(h, max(1, args.event_stride))
 
     barrier()
     torch.cuda.synchronize()
@@ -138,7 +214,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     done = npv.value - args.warmup
-    if rc != lp.capi.MI_MAX_PIVOTS or done != args.steps:
+    if rc != lp.capi.MI_RUNNING or done != args.steps:
         sys.exit("rank %d: the LP terminated (status %d) after %d of %d timed pivots -- "
                  "use fewer steps" % (rank, rc, done, args.steps))
 
@@ -159,8 +235,10 @@ def main():
         roofline = None
         if upd_avg_ms:
             ach = bytes_per_pivot / (upd_avg_ms * 1e-3) / 1e9
+            traffic, traffic_src = pmc_traffic(args.workload)
             roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                        "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
+                        "traffic_source": traffic_src,
                         "kernel": L.mi355x_update_kernel_name().decode(),
                         "kernel_avg_us": upd_avg_ms * 1e3,
                         "algorithmic_bytes_per_launch": bytes_per_pivot,

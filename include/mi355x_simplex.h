@@ -46,6 +46,8 @@ extern "C" {
 #define MI_MAX_PIVOTS    3   /* pivot cap reached (backend-specific; the reference has no cap) */
 #define MI_ART_NONZERO   4   /* "Artificial variable ~S still non-zero"       simplex.lisp:423-424 */
 #define MI_ART_STUCK     5   /* "Artificial variable still in basis and ..."  simplex.lisp:432-433 */
+#define MI_RUNNING     100   /* asynchronous use only: the iterations enqueued so far have not
+                                terminated the solve (mi355x_tab_sync) */
 /* errors */
 #define MI_BAD_ARG      -1
 #define MI_HIP_ERROR    -2
@@ -54,6 +56,7 @@ extern "C" {
 #define MI_NO_MEMORY    -5
 
 typedef struct mi355x_tab   mi355x_tab;     /* one tableau resident in HBM              */
+typedef struct mi355x_batch mi355x_batch;   /* a batch of same-shape tableaux in HBM    */
 
 /* ---- library / device ------------------------------------------------------------- */
 int         mi355x_abi_version(void);
@@ -115,20 +118,24 @@ int  mi355x_tab_trace(mi355x_tab *t, int64_t *entering_cols, int64_t *pivot_rows
 
 /* ---- asynchronous / measurement plumbing ------------------------------------------- */
 /* Run the handle's kernels on an existing HIP stream (hipStream_t as void*), e.g.
- * torch.cuda.current_stream().cuda_stream.  NULL = the handle's own stream. */
-int  mi355x_tab_set_stream(mi355x_tab *t, void *hip_stream);
+ * torch.cuda.current_stream().cuda_stream -- NULL is HIP's default (null) stream, which is what
+ * torch uses unless told otherwise.  use_own != 0: back to the handle's private stream. */
+int  mi355x_tab_set_stream(mi355x_tab *t, void *hip_stream, int use_own);
 /* Enqueue up to n_pivots iterations of price -> ratio -> pivot without any host
  * synchronisation (kernels turn into no-ops once the tableau is optimal/unbounded).
  * reset != 0 restarts the device-side pivot counter/status first. */
 int  mi355x_tab_solve_async(mi355x_tab *t, int is_max, double fp_factor, int64_t n_pivots,
                             int reset);
+/* Restart the device-side status / pivot counter of a handle and set its pivot cap
+ * (0 = none) without touching the tableau. */
+int  mi355x_tab_reset(mi355x_tab *t, int64_t max_pivots);
 /* Wait for the stream; returns the device-side status (MI_OPTIMAL, MI_UNBOUNDED,
- * MI_MAX_PIVOTS = still running when the enqueued pivots ran out) and the number of
- * pivots done since the last reset. */
+ * MI_MAX_PIVOTS, or MI_RUNNING when the enqueued iterations ran out first) and the number
+ * of pivots done since the last reset. */
 int  mi355x_tab_sync(mi355x_tab *t, int64_t *n_pivots);
 /* Per-launch HIP-event timing of the rank-1 update kernel (the bandwidth kernel):
- * enable != 0 brackets every update launch with an event pair on the launch stream
- * (up to 4096 launches kept).  mi355x_tab_timing_read waits for the stream and returns
+ * enable = k > 0 brackets every k-th update launch with an event pair on the launch stream
+ * (up to 4096 timed launches kept); 0 switches it off.  mi355x_tab_timing_read waits for the stream and returns
  * the number of timed launches, their summed and minimum duration in milliseconds,
  * then clears the record. */
 int  mi355x_tab_timing_enable(mi355x_tab *t, int enable);
@@ -136,23 +143,51 @@ int  mi355x_tab_timing_read(mi355x_tab *t, int64_t *n_launches, double *sum_ms, 
 /* Name of the rank-1 update kernel as it appears in rocprofv3 kernel traces. */
 const char *mi355x_update_kernel_name(void);
 
+/* ---- batches of independent LPs (BASELINE config 4) -------------------------------- */
+/* n_lps same-shape LPs stacked in one allocation; one (select, update) launch pair advances
+ * every unfinished LP by one pivot.  host_matrices: n_lps * rows * cols doubles,
+ * host_bases: n_lps * (rows-1) (may be NULL). */
+int  mi355x_batch_create(mi355x_batch **out, int64_t n_lps, int64_t rows, int64_t cols,
+                         const double *host_matrices, const int64_t *host_bases, int device);
+/* The synthetic LP of mi355x_tab_create_synthetic, one per seed (seeds: n_lps host values). */
+int  mi355x_batch_create_synthetic(mi355x_batch **out, int64_t n_lps, int64_t n_vars,
+                                   int64_t n_cons, const uint64_t *seeds, int device);
+/* n-solve-tableau (single phase) on every LP of the batch; status[i] (MI_OPTIMAL /
+ * MI_UNBOUNDED / MI_MAX_PIVOTS) and n_pivots[i] per LP (host arrays, may be NULL).
+ * max_pivots = 0: no cap.  Returns MI_OK or an error. */
+int  mi355x_batch_solve(mi355x_batch *b, int is_max, double fp_factor, int64_t max_pivots,
+                        int32_t *status, int64_t *n_pivots);
+int  mi355x_batch_download(mi355x_batch *b, int64_t lp_index, double *host_matrix,
+                           int64_t *host_basis, double *last_row, double *last_col);
+/* HIP-event timing of the batched update launches (see mi355x_tab_timing_*). */
+int  mi355x_batch_timing_enable(mi355x_batch *b, int enable);
+int  mi355x_batch_timing_read(mi355x_batch *b, int64_t *n_launches, double *sum_ms, double *min_ms);
+void mi355x_batch_destroy(mi355x_batch *b);
+
 /* ---- column-partitioned tableau: per-shard steps (BASELINE config 5) --------------- */
-/* One pivot of a tableau whose non-RHS columns are split across shards (one shard =
- * one handle = one GPU / rank; every shard keeps its own copy of the RHS column as its
- * last column):
- *   1. every shard: mi355x_shard_price      -> local best (value, GLOBAL column)
- *   2. exchange (all-gather 16 B per shard), pick the lexicographic (value, column) best
- *   3. owner shard: mi355x_shard_gather_col -> the entering column (rows doubles, device)
- *   4. exchange (broadcast of that column from the owner)
- *   5. every shard: mi355x_shard_pivot      -> ratio test on (column, own RHS copy),
- *      normalise own slice of the pivot row, rank-1 update of own slice.
- * col_offset = global index of the shard's first column.  Device pointers are raw
- * device addresses (e.g. torch tensors' data_ptr()). */
-int  mi355x_shard_price(mi355x_tab *t, int is_max, int64_t col_offset,
-                        double *dev_value_out, int64_t *dev_col_out);
-int  mi355x_shard_gather_col(mi355x_tab *t, int64_t local_col, double *dev_col_out);
-int  mi355x_shard_pivot(mi355x_tab *t, const double *dev_col, int64_t global_col,
-                        int64_t col_offset, int is_owner, double fp_factor);
+/* One tableau whose non-RHS columns are split across shards (one shard = one handle = one
+ * GPU / rank; every shard keeps its own copy of the RHS column as its last column and updates
+ * it redundantly).  One pivot = three local steps and two exchanges, all asynchronous on the
+ * handle's stream (see mi355x_tab_set_stream), none needing the host to know who owns the
+ * entering column:
+ *   1. mi355x_shard_price       local pricing winner -> dev_out2 = {key, global column}
+ *      -- exchange A: all-gather of the 2 doubles of every shard
+ *   2. mi355x_shard_contribute  every shard derives the same global winner (lexicographic
+ *      (key, column) minimum == lowest-index strict minimum) and applies the threshold;
+ *      the owner writes the entering column's bit patterns (rows int64) to dev_col_bits,
+ *      everyone else zeros; dev_ec = global entering column or -1
+ *      -- exchange B: integer SUM all-reduce of dev_col_bits (= broadcast from the owner)
+ *   3. mi355x_shard_pivot       ratio test on the exchanged column against the own RHS copy
+ *      (same result on every shard), normalise own slice of the pivot row, rank-1 update
+ *      of own slice, basis[cr] = global column.
+ * col_offset = global index of the shard's first column.  dev_* are raw device addresses
+ * (e.g. torch tensors' data_ptr()).  Status/pivot count: mi355x_tab_sync. */
+int  mi355x_shard_price(mi355x_tab *t, int is_max, int64_t col_offset, double *dev_out2);
+int  mi355x_shard_contribute(mi355x_tab *t, const double *dev_gathered, int n_shards,
+                             int64_t col_offset, double fp_factor, int64_t *dev_col_bits,
+                             int64_t *dev_ec);
+int  mi355x_shard_pivot(mi355x_tab *t, const int64_t *dev_col_bits, const int64_t *dev_ec,
+                        double fp_factor);
 
 #ifdef __cplusplus
 }

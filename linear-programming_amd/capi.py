@@ -8,6 +8,7 @@ LIB_PATH = os.path.join(HERE, "libmi355x_simplex.so")
 
 MI_OK = MI_OPTIMAL = 0
 MI_UNBOUNDED, MI_INFEASIBLE, MI_MAX_PIVOTS, MI_ART_NONZERO, MI_ART_STUCK = 1, 2, 3, 4, 5
+MI_RUNNING = 100
 MI_BAD_ARG, MI_HIP_ERROR, MI_RCCL_ERROR, MI_NO_DEVICE, MI_NO_MEMORY = -1, -2, -3, -4, -5
 
 _i64, _dbl, _p, _int = ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, ctypes.c_int
@@ -32,15 +33,23 @@ SIGNATURES = {
     "mi355x_solve_two_phase": (_int, [_p, _p, _int, _dbl, _p]),
     "mi355x_tab_download": (_int, [_p, _p, _p, _p, _p]),
     "mi355x_tab_trace": (_int, [_p, _p, _p, _i64, _p]),
-    "mi355x_tab_set_stream": (_int, [_p, _p]),
+    "mi355x_tab_set_stream": (_int, [_p, _p, _int]),
     "mi355x_tab_solve_async": (_int, [_p, _int, _dbl, _i64, _int]),
+    "mi355x_tab_reset": (_int, [_p, _i64]),
     "mi355x_tab_sync": (_int, [_p, _p]),
     "mi355x_tab_timing_enable": (_int, [_p, _int]),
     "mi355x_tab_timing_read": (_int, [_p, _p, _p, _p]),
     "mi355x_update_kernel_name": (ctypes.c_char_p, []),
-    "mi355x_shard_price": (_int, [_p, _int, _i64, _p, _p]),
-    "mi355x_shard_gather_col": (_int, [_p, _i64, _p]),
-    "mi355x_shard_pivot": (_int, [_p, _p, _i64, _i64, _int, _dbl]),
+    "mi355x_batch_create": (_int, [_pp, _i64, _i64, _i64, _p, _p, _int]),
+    "mi355x_batch_create_synthetic": (_int, [_pp, _i64, _i64, _i64, _p, _int]),
+    "mi355x_batch_solve": (_int, [_p, _int, _dbl, _i64, _p, _p]),
+    "mi355x_batch_download": (_int, [_p, _i64, _p, _p, _p, _p]),
+    "mi355x_batch_timing_enable": (_int, [_p, _int]),
+    "mi355x_batch_timing_read": (_int, [_p, _p, _p, _p]),
+    "mi355x_batch_destroy": (None, [_p]),
+    "mi355x_shard_price": (_int, [_p, _int, _i64, _p]),
+    "mi355x_shard_contribute": (_int, [_p, _p, _int, _i64, _dbl, _p, _p]),
+    "mi355x_shard_pivot": (_int, [_p, _p, _p, _dbl]),
 }
 # tuning hooks exported by the library but not part of include/mi355x_simplex.h
 _EXTRA = {
@@ -57,6 +66,26 @@ class ExtensionMissing(RuntimeError):
     pass
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7, but NEEDED by
+    libtorch_hip.so under its file name), so a process that loads /opt/rocm's copy first (through
+    this library) and torch's copy later ends up with TWO HIP runtimes, and the second one sees
+    no GPU.  When torch is installed, load ITS runtime first: libmi355x_simplex.so's NEEDED
+    entry `libamdhip64.so.7` then resolves to that already-loaded copy and the process has one
+    runtime whichever of the two gets used first.  Without torch (e.g. under the Lisp glue) the
+    system runtime is used as usual."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     """The loaded shared library.  Raises if it has not been built -- there is no fallback."""
     global _lib
@@ -65,6 +94,7 @@ def lib():
             raise ExtensionMissing(
                 "%s is missing: build it with `python linear-programming_amd/build.py` "
                 "(there is no CPU fallback)" % LIB_PATH)
+        _share_hip_runtime_with_torch()
         L = ctypes.CDLL(LIB_PATH)
         for table in (SIGNATURES, _EXTRA):
             for name, (res, args) in table.items():

@@ -47,7 +47,8 @@ int fail(int code, const char *fmt, ...)
 constexpr int64_t kTraceCap   = 1 << 20;
 constexpr int     kTimingCap  = 4096;
 constexpr int64_t kLdAlign    = 16;       // doubles: rows start on 128-byte boundaries
-constexpr int     kPartCap    = 16384;
+constexpr int     kPartCap    = 16384;    // single tableau: 8192 pricing + 8192 ratio partials
+constexpr int     kBatchPartCap = 512;    // per LP of a batch
 
 int64_t padded_ld(int64_t cols) { return (cols + kLdAlign - 1) / kLdAlign * kLdAlign; }
 
@@ -70,9 +71,15 @@ struct mi355x_tab {
     int64_t     pivots_before = 0;        // (unused by the ABI; kept for debugging)
     int         n_part = 0;               // pricing partials left by the last update (0 = none)
     int         part_is_max = -1;         // ... and the problem sense they were computed for
-    bool        timing = false;
+    int         shard_is_max = 1;         // sense last given to mi355x_shard_price
+    int         timing_stride = 0;        // 0 = off, k = bracket every k-th update launch
+    int64_t     update_launches = 0;
     int         n_timed = 0;
     std::vector<hipEvent_t> ev0, ev1;
+};
+
+struct mi355x_batch {
+    mi355x_tab *t = nullptr;              // same machinery, TabView::n_lps > 1
 };
 
 namespace {
@@ -94,6 +101,7 @@ void free_tab(mi355x_tab *t)
     (void)hipFree(t->v.basis);
     (void)hipFree(t->v.col);
     (void)hipFree(t->v.prow);
+    (void)hipFree(t->v.rhs);
     (void)hipFree(t->v.ctl);
     (void)hipFree(t->v.trace_ec);
     (void)hipFree(t->v.trace_cr);
@@ -105,7 +113,7 @@ void free_tab(mi355x_tab *t)
 }
 
 // allocate an empty handle of the given shape on `device`
-int alloc_tab(mi355x_tab **out, int64_t rows, int64_t cols, int device)
+int alloc_tab(mi355x_tab **out, int64_t rows, int64_t cols, int device, int64_t n_lps = 1)
 {
     if (!out) return fail(MI_BAD_ARG, "out is NULL");
     *out = nullptr;
@@ -113,6 +121,7 @@ int alloc_tab(mi355x_tab **out, int64_t rows, int64_t cols, int device)
                                           (long long)rows, (long long)cols);
     if (rows > 65535LL * 16) return fail(MI_BAD_ARG, "rows=%lld exceeds the supported 1048560",
                                          (long long)rows);
+    if (n_lps < 1 || n_lps > 65535) return fail(MI_BAD_ARG, "n_lps=%lld outside [1,65535]", (long long)n_lps);
     const int ndev = device_count_checked();
     if (ndev <= 0) return fail(MI_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
     if (device < 0 || device >= ndev) return fail(MI_BAD_ARG, "device %d out of range [0,%d)", device, ndev);
@@ -123,8 +132,18 @@ int alloc_tab(mi355x_tab **out, int64_t rows, int64_t cols, int device)
     t->v.rows = rows;
     t->v.cols = cols;
     t->v.ld = padded_ld(cols);
-    t->v.trace_cap = kTraceCap;
-    const size_t mbytes = (size_t)rows * (size_t)t->v.ld * sizeof(double);
+    t->v.n_lps = n_lps;
+    const int part_cap = n_lps == 1 ? kPartCap : kBatchPartCap;
+    const int64_t nb = std::max<int64_t>(rows - 1, 1);
+    if (n_lps > 1) {
+        t->v.zs_M = rows * t->v.ld;
+        t->v.zs_basis = nb;
+        t->v.zs_col = rows;
+        t->v.zs_prow = t->v.ld;
+        t->v.zs_part = part_cap;
+    }
+    t->v.trace_cap = n_lps == 1 ? kTraceCap : 0;
+    const size_t mbytes = (size_t)n_lps * (size_t)rows * (size_t)t->v.ld * sizeof(double);
     hipError_t e;
 #define ALLOC(ptr, bytes)                                                                  \
     if ((e = hipMalloc((void **)&(ptr), (bytes))) != hipSuccess) {                         \
@@ -133,26 +152,28 @@ int alloc_tab(mi355x_tab **out, int64_t rows, int64_t cols, int device)
                     "hipMalloc(%zu bytes) failed: %s", (size_t)(bytes), hipGetErrorString(e)); \
     }
     ALLOC(t->v.M, mbytes);
-    ALLOC(t->v.basis, std::max<int64_t>(rows - 1, 1) * sizeof(int64_t));
-    ALLOC(t->v.col, rows * sizeof(double));
-    ALLOC(t->v.prow, t->v.ld * sizeof(double));
-    ALLOC(t->v.ctl, sizeof(Ctl));
-    ALLOC(t->v.trace_ec, kTraceCap * sizeof(int64_t));
-    ALLOC(t->v.trace_cr, kTraceCap * sizeof(int64_t));
-    ALLOC(t->v.part_v, kPartCap * sizeof(double));
-    ALLOC(t->v.part_i, kPartCap * sizeof(int64_t));
-    t->v.part_cap = kPartCap;
+    ALLOC(t->v.basis, n_lps * nb * sizeof(int64_t));
+    ALLOC(t->v.col, n_lps * rows * sizeof(double));
+    ALLOC(t->v.prow, n_lps * t->v.ld * sizeof(double));
+    if (n_lps == 1) ALLOC(t->v.rhs, rows * sizeof(double));
+    ALLOC(t->v.ctl, n_lps * sizeof(Ctl));
+    if (n_lps == 1) {
+        ALLOC(t->v.trace_ec, kTraceCap * sizeof(int64_t));
+        ALLOC(t->v.trace_cr, kTraceCap * sizeof(int64_t));
+    }
+    ALLOC(t->v.part_v, n_lps * part_cap * sizeof(double));
+    ALLOC(t->v.part_i, n_lps * part_cap * sizeof(int64_t));
+    t->v.part_cap = part_cap;
 #undef ALLOC
-    if ((e = hipHostMalloc((void **)&t->h_ctl, sizeof(Ctl))) != hipSuccess ||
+    if ((e = hipHostMalloc((void **)&t->h_ctl, n_lps * sizeof(Ctl))) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&t->own_stream, hipStreamNonBlocking)) != hipSuccess) {
         free_tab(t);
         return fail(MI_HIP_ERROR, "stream/pinned allocation failed: %s", hipGetErrorString(e));
     }
     t->stream = t->own_stream;
-    memset(t->h_ctl, 0, sizeof(Ctl));
-    if ((e = hipMemsetAsync(t->v.ctl, 0, sizeof(Ctl), t->stream)) != hipSuccess ||
-        (e = hipMemsetAsync(t->v.basis, 0, std::max<int64_t>(rows - 1, 1) * sizeof(int64_t),
-                            t->stream)) != hipSuccess) {
+    memset(t->h_ctl, 0, n_lps * sizeof(Ctl));
+    if ((e = hipMemsetAsync(t->v.ctl, 0, n_lps * sizeof(Ctl), t->stream)) != hipSuccess ||
+        (e = hipMemsetAsync(t->v.basis, 0, n_lps * nb * sizeof(int64_t), t->stream)) != hipSuccess) {
         free_tab(t);
         return fail(MI_HIP_ERROR, "memset failed: %s", hipGetErrorString(e));
     }
@@ -165,14 +186,15 @@ int upload(mi355x_tab *t, const double *hm, const int64_t *hb)
     const TabView &v = t->v;
     t->n_part = 0;
     if (hm) {
+        const size_t all_rows = (size_t)v.rows * v.n_lps;     // LPs of a batch are stacked
         if (v.ld != v.cols)    // zero the padding columns once per upload
-            HIP_TRY(hipMemsetAsync(v.M, 0, (size_t)v.rows * v.ld * sizeof(double), t->stream));
+            HIP_TRY(hipMemsetAsync(v.M, 0, all_rows * v.ld * sizeof(double), t->stream));
         HIP_TRY(hipMemcpy2DAsync(v.M, v.ld * sizeof(double), hm, v.cols * sizeof(double),
-                                 v.cols * sizeof(double), v.rows, hipMemcpyHostToDevice, t->stream));
+                                 v.cols * sizeof(double), all_rows, hipMemcpyHostToDevice, t->stream));
     }
     if (hb && v.rows > 1)
-        HIP_TRY(hipMemcpyAsync(v.basis, hb, (v.rows - 1) * sizeof(int64_t), hipMemcpyHostToDevice,
-                               t->stream));
+        HIP_TRY(hipMemcpyAsync(v.basis, hb, v.n_lps * (v.rows - 1) * sizeof(int64_t),
+                               hipMemcpyHostToDevice, t->stream));
     launch_ctl_reset(v, 0, /*reset_trace=*/1, t->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(t->stream));   // host buffers may be released by the caller
@@ -202,7 +224,8 @@ void enqueue_select(mi355x_tab *t, int is_max, double f)
 // update of one iteration (+ optional event pair around it); prices the new objective row
 int enqueue_update(mi355x_tab *t, int is_max)
 {
-    const bool timed = t->timing && t->n_timed < kTimingCap;
+    const bool timed = t->timing_stride > 0 && t->n_timed < kTimingCap &&
+                       (t->update_launches++ % t->timing_stride) == 0;
     if (timed) {
         if ((int)t->ev0.size() <= t->n_timed) {
             hipEvent_t a, b;
@@ -228,7 +251,7 @@ int enqueue_iteration(mi355x_tab *t, int is_max, double f)
     return enqueue_update(t, is_max);
 }
 
-int status_to_rc(int32_t st) { return st == kRunning ? MI_MAX_PIVOTS : (int)st; }
+int status_to_rc(int32_t st) { return st == kRunning ? MI_RUNNING : (int)st; }
 
 }  // namespace
 
@@ -293,7 +316,7 @@ int mi355x_tab_create_synthetic(mi355x_tab **out, int64_t n_vars, int64_t n_cons
     mi355x_tab *t = nullptr;
     int rc = alloc_tab(&t, n_cons + 1, (col_end - col_begin) + 1, device);
     if (rc != MI_OK) return rc;
-    launch_synth_fill(t->v, n_vars, n_cons, seed, col_begin, col_end, t->stream);
+    launch_synth_fill(t->v, n_vars, n_cons, seed, nullptr, col_begin, col_end, t->stream);
     launch_ctl_reset(t->v, 0, 1, t->stream);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
@@ -371,6 +394,17 @@ int mi355x_tab_solve_async(mi355x_tab *t, int is_max, double f, int64_t n_pivots
     return MI_OK;
 }
 
+int mi355x_tab_reset(mi355x_tab *t, int64_t max_pivots)
+{
+    if (!t) return fail(MI_BAD_ARG, "handle is NULL");
+    if (max_pivots < 0) return fail(MI_BAD_ARG, "max_pivots < 0");
+    int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    launch_ctl_reset(t->v, max_pivots, 0, t->stream);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
 int mi355x_tab_sync(mi355x_tab *t, int64_t *n_pivots)
 {
     if (!t) return fail(MI_BAD_ARG, "handle is NULL");
@@ -389,24 +423,22 @@ int mi355x_tab_solve(mi355x_tab *t, int is_max, double f, int64_t max_pivots, in
     int rc = use_device(t);
     if (rc != MI_OK) return rc;
     launch_ctl_reset(t->v, max_pivots, 0, t->stream);
-    // Blind enqueue in growing chunks; one status read-back per chunk.  Iterations enqueued
-    // past termination are no-ops on the device (kernels test ctl->status first).
+    // Blind enqueue in growing chunks, one status read-back per chunk.  The stream always
+    // ends on a select (it is the select that detects optimality / unboundedness / the cap);
+    // an update is a no-op unless the preceding select chose a pivot, so iterations enqueued
+    // past termination cost a few empty launches and nothing else.
+    enqueue_select(t, is_max, f);
     int64_t chunk = 16;
     for (;;) {
         for (int64_t i = 0; i < chunk; ++i) {
-            rc = enqueue_iteration(t, is_max, f);
+            rc = enqueue_update(t, is_max);
             if (rc != MI_OK) return rc;
+            enqueue_select(t, is_max, f);
         }
-        // the select of the NEXT iteration is what detects optimality / the cap
-        enqueue_select(t, is_max, f);
         HIP_TRY(hipGetLastError());
         rc = read_ctl(t);
         if (rc != MI_OK) return rc;
         if (t->h_ctl->status != kRunning) break;
-        // the extra select above already chose the next pivot (ctl->ec/cr, col, prow are
-        // set and it was counted): apply its update before continuing
-        rc = enqueue_update(t, is_max);
-        if (rc != MI_OK) return rc;
         if (chunk < 512) chunk *= 2;
     }
     if (n_pivots) *n_pivots = t->h_ctl->n_pivots;
@@ -509,20 +541,21 @@ int mi355x_tab_trace(mi355x_tab *t, int64_t *ecs, int64_t *crs, int64_t cap, int
     return MI_OK;
 }
 
-int mi355x_tab_set_stream(mi355x_tab *t, void *hip_stream)
+int mi355x_tab_set_stream(mi355x_tab *t, void *hip_stream, int use_own)
 {
     if (!t) return fail(MI_BAD_ARG, "handle is NULL");
     int rc = use_device(t);
     if (rc != MI_OK) return rc;
     HIP_TRY(hipStreamSynchronize(t->stream));
-    t->stream = hip_stream ? (hipStream_t)hip_stream : t->own_stream;
+    t->stream = use_own ? t->own_stream : (hipStream_t)hip_stream;   // NULL = HIP's null stream
     return MI_OK;
 }
 
 int mi355x_tab_timing_enable(mi355x_tab *t, int enable)
 {
     if (!t) return fail(MI_BAD_ARG, "handle is NULL");
-    t->timing = enable != 0;
+    t->timing_stride = enable > 0 ? enable : 0;
+    t->update_launches = 0;
     return MI_OK;
 }
 
@@ -546,38 +579,167 @@ int mi355x_tab_timing_read(mi355x_tab *t, int64_t *n_launches, double *sum_ms, d
     return MI_OK;
 }
 
+// ---- batches of independent LPs ---------------------------------------------------------
+// The LPs of a batch share one shape and live stacked in one allocation; every kernel of the
+// single-tableau path runs unchanged with grid.z = LP index, so the whole batch advances one
+// simplex iteration per (select, update) launch pair and finished LPs simply stop.
+int mi355x_batch_create(mi355x_batch **out, int64_t n_lps, int64_t rows, int64_t cols,
+                        const double *host_matrices, const int64_t *host_bases, int device)
+{
+    if (!out) return fail(MI_BAD_ARG, "out is NULL");
+    *out = nullptr;
+    if (!host_matrices) return fail(MI_BAD_ARG, "host_matrices is NULL");
+    mi355x_tab *t = nullptr;
+    int rc = alloc_tab(&t, rows, cols, device, n_lps);
+    if (rc != MI_OK) return rc;
+    rc = upload(t, host_matrices, host_bases);
+    if (rc != MI_OK) { free_tab(t); return rc; }
+    mi355x_batch *b = new (std::nothrow) mi355x_batch;
+    if (!b) { free_tab(t); return fail(MI_NO_MEMORY, "host allocation failed"); }
+    b->t = t;
+    *out = b;
+    return MI_OK;
+}
+
+int mi355x_batch_create_synthetic(mi355x_batch **out, int64_t n_lps, int64_t n_vars, int64_t n_cons,
+                                  const uint64_t *seeds, int device)
+{
+    if (!out) return fail(MI_BAD_ARG, "out is NULL");
+    *out = nullptr;
+    if (!seeds || n_vars < 1 || n_cons < 1) return fail(MI_BAD_ARG, "bad arguments");
+    mi355x_tab *t = nullptr;
+    int rc = alloc_tab(&t, n_cons + 1, n_vars + n_cons + 1, device, n_lps);
+    if (rc != MI_OK) return rc;
+    uint64_t *dseeds = nullptr;
+    hipError_t e = hipMalloc((void **)&dseeds, n_lps * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(dseeds, seeds, n_lps * sizeof(uint64_t), hipMemcpyHostToDevice, t->stream);
+    if (e == hipSuccess) {
+        launch_synth_fill(t->v, n_vars, n_cons, 0, dseeds, 0, n_vars + n_cons, t->stream);
+        launch_ctl_reset(t->v, 0, 1, t->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    (void)hipFree(dseeds);
+    if (e != hipSuccess) { free_tab(t); return fail(MI_HIP_ERROR, "synthetic batch fill failed: %s", hipGetErrorString(e)); }
+    mi355x_batch *b = new (std::nothrow) mi355x_batch;
+    if (!b) { free_tab(t); return fail(MI_NO_MEMORY, "host allocation failed"); }
+    b->t = t;
+    *out = b;
+    return MI_OK;
+}
+
+int mi355x_batch_solve(mi355x_batch *b, int is_max, double f, int64_t max_pivots, int32_t *status,
+                       int64_t *n_pivots)
+{
+    if (!b || !b->t) return fail(MI_BAD_ARG, "batch is NULL");
+    if (max_pivots < 0) return fail(MI_BAD_ARG, "max_pivots < 0");
+    mi355x_tab *t = b->t;
+    int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    const int64_t n = t->v.n_lps;
+    launch_ctl_reset(t->v, max_pivots, 0, t->stream);
+    enqueue_select(t, is_max, f);
+    int64_t chunk = 16;
+    for (;;) {
+        for (int64_t i = 0; i < chunk; ++i) {
+            rc = enqueue_update(t, is_max);
+            if (rc != MI_OK) return rc;
+            enqueue_select(t, is_max, f);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(t->h_ctl, t->v.ctl, n * sizeof(Ctl), hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        bool running = false;
+        for (int64_t i = 0; i < n && !running; ++i) running = t->h_ctl[i].status == kRunning;
+        if (!running) break;
+        if (chunk < 256) chunk *= 2;
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        if (status) status[i] = t->h_ctl[i].status;
+        if (n_pivots) n_pivots[i] = t->h_ctl[i].n_pivots;
+    }
+    return MI_OK;
+}
+
+int mi355x_batch_download(mi355x_batch *b, int64_t k, double *hm, int64_t *hb, double *last_row,
+                          double *last_col)
+{
+    if (!b || !b->t) return fail(MI_BAD_ARG, "batch is NULL");
+    mi355x_tab *t = b->t;
+    const TabView &v = t->v;
+    if (k < 0 || k >= v.n_lps) return fail(MI_BAD_ARG, "lp_index %lld out of range", (long long)k);
+    int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    const double *M = v.M + k * v.rows * v.ld;
+    if (hm)
+        HIP_TRY(hipMemcpy2DAsync(hm, v.cols * sizeof(double), M, v.ld * sizeof(double),
+                                 v.cols * sizeof(double), v.rows, hipMemcpyDeviceToHost, t->stream));
+    if (hb && v.rows > 1)
+        HIP_TRY(hipMemcpyAsync(hb, v.basis + k * std::max<int64_t>(v.rows - 1, 1),
+                               (v.rows - 1) * sizeof(int64_t), hipMemcpyDeviceToHost, t->stream));
+    if (last_row)
+        HIP_TRY(hipMemcpyAsync(last_row, M + (v.rows - 1) * v.ld, v.cols * sizeof(double),
+                               hipMemcpyDeviceToHost, t->stream));
+    if (last_col)
+        HIP_TRY(hipMemcpy2DAsync(last_col, sizeof(double), M + (v.cols - 1), v.ld * sizeof(double),
+                                 sizeof(double), v.rows, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    return MI_OK;
+}
+
+int mi355x_batch_timing_enable(mi355x_batch *b, int enable)
+{
+    if (!b || !b->t) return fail(MI_BAD_ARG, "batch is NULL");
+    return mi355x_tab_timing_enable(b->t, enable);
+}
+
+int mi355x_batch_timing_read(mi355x_batch *b, int64_t *n_launches, double *sum_ms, double *min_ms)
+{
+    if (!b || !b->t) return fail(MI_BAD_ARG, "batch is NULL");
+    return mi355x_tab_timing_read(b->t, n_launches, sum_ms, min_ms);
+}
+
+void mi355x_batch_destroy(mi355x_batch *b)
+{
+    if (!b) return;
+    free_tab(b->t);
+    delete b;
+}
+
 // ---- column-partitioned shards ------------------------------------------------------
-int mi355x_shard_price(mi355x_tab *t, int is_max, int64_t col_offset, double *dev_value_out,
-                       int64_t *dev_col_out)
+int mi355x_shard_price(mi355x_tab *t, int is_max, int64_t col_offset, double *dev_out2)
 {
-    if (!t || !dev_value_out || !dev_col_out) return fail(MI_BAD_ARG, "NULL argument");
+    if (!t || !dev_out2) return fail(MI_BAD_ARG, "NULL argument");
     int rc = use_device(t);
     if (rc != MI_OK) return rc;
-    launch_shard_price(t->v, is_max, col_offset, dev_value_out, dev_col_out, t->stream);
+    t->shard_is_max = is_max ? 1 : 0;
+    const int np = (t->n_part > 0 && t->part_is_max == (is_max ? 1 : 0)) ? t->n_part : 0;
+    launch_shard_price(t->v, is_max, col_offset, dev_out2, np, t->stream);
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }
 
-int mi355x_shard_gather_col(mi355x_tab *t, int64_t local_col, double *dev_col_out)
+int mi355x_shard_contribute(mi355x_tab *t, const double *dev_gathered, int n_shards,
+                            int64_t col_offset, double f, int64_t *dev_col_bits, int64_t *dev_ec)
 {
-    if (!t || !dev_col_out) return fail(MI_BAD_ARG, "NULL argument");
-    if (local_col < 0 || local_col >= t->v.cols) return fail(MI_BAD_ARG, "local column out of range");
+    if (!t || !dev_gathered || !dev_col_bits || !dev_ec) return fail(MI_BAD_ARG, "NULL argument");
+    if (n_shards < 1) return fail(MI_BAD_ARG, "n_shards < 1");
     int rc = use_device(t);
     if (rc != MI_OK) return rc;
-    launch_gather_col(t->v, local_col, dev_col_out, t->stream);
+    launch_shard_contribute(t->v, dev_gathered, n_shards, col_offset, f, dev_col_bits, dev_ec, t->stream);
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }
 
-int mi355x_shard_pivot(mi355x_tab *t, const double *dev_col, int64_t global_col, int64_t col_offset,
-                       int is_owner, double f)
+int mi355x_shard_pivot(mi355x_tab *t, const int64_t *dev_col_bits, const int64_t *dev_ec, double f)
 {
-    if (!t || !dev_col) return fail(MI_BAD_ARG, "NULL argument");
+    if (!t || !dev_col_bits || !dev_ec) return fail(MI_BAD_ARG, "NULL argument");
     int rc = use_device(t);
     if (rc != MI_OK) return rc;
-    launch_shard_prepare(t->v, dev_col, global_col, col_offset, is_owner, f, t->stream);
-    launch_update(t->v, 1.0, 0, t->stream);
-    t->n_part = 0;
+    launch_shard_prepare(t->v, reinterpret_cast<const double *>(dev_col_bits), dev_ec, f, t->stream);
+    // the update prices the new local objective-row slice for the next mi355x_shard_price
+    t->n_part = launch_update(t->v, t->shard_is_max ? 1.0 : -1.0, 1, t->stream);
+    t->part_is_max = t->shard_is_max;
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }

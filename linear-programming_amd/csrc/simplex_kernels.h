@@ -34,13 +34,17 @@ struct TabView {
     int64_t *basis;       // rows-1 entries
     double  *col;         // snapshot of the entering column before the pivot, rows entries
     double  *prow;        // normalised pivot row, ld entries (padding zero)
+    double  *rhs;         // contiguous snapshot of the RHS column (column shards only), rows entries
     Ctl     *ctl;
     int64_t *trace_ec;    // may be null
     int64_t *trace_cr;
     int64_t  trace_cap;
-    double  *part_v;      // per-wave pricing partials left by k_update (key space)
-    int64_t *part_i;
+    double  *part_v;      // per-wave pricing partials left by k_update (key space); the
+    int64_t *part_i;      // upper half holds the ratio-test partials of the split select
     int      part_cap;
+    // batch of n_lps same-shape LPs: per-LP element strides (all zero for a single tableau)
+    int64_t  n_lps;
+    int64_t  zs_M, zs_basis, zs_col, zs_prow, zs_part;
 };
 
 struct UpdateShape {
@@ -62,18 +66,20 @@ void launch_prepare_pivot(const TabView &t, int64_t ec, int64_t cr, hipStream_t 
 int  launch_update(const TabView &t, double sgn, int price, hipStream_t s);
 UpdateShape update_shape(const TabView &t);
 // column-partitioned shards (one shard = one handle)
-void launch_shard_price(const TabView &t, int is_max, int64_t col_offset, double *out_val,
-                        int64_t *out_col, hipStream_t s);
-void launch_gather_col(const TabView &t, int64_t local_col, double *out, hipStream_t s);
-void launch_shard_prepare(const TabView &t, const double *col, int64_t global_ec,
-                          int64_t col_offset, int is_owner, double fp_factor, hipStream_t s);
+void launch_shard_price(const TabView &t, int is_max, int64_t col_offset, double *out2, int n_part,
+                        hipStream_t s);
+void launch_shard_contribute(const TabView &t, const double *gathered, int n_shards,
+                             int64_t col_offset, double fp_factor, int64_t *bits_out,
+                             int64_t *ec_out, hipStream_t s);
+void launch_shard_prepare(const TabView &t, const double *col, const int64_t *ec_dev,
+                          double fp_factor, hipStream_t s);
 // two-phase hand-over (src/simplex.lisp:437-451)
 void launch_handover(const TabView &art, const TabView &main_tab, hipStream_t s);
 void launch_ctl_reset(const TabView &t, int64_t max_pivots, int reset_trace, hipStream_t s);
 void launch_ctl_finish(const TabView &t, hipStream_t s);
 // synthetic LP straight into HBM
 void launch_synth_fill(const TabView &t, int64_t n_vars, int64_t n_cons, uint64_t seed,
-                       int64_t col_begin, int64_t col_end, hipStream_t s);
+                       const uint64_t *dev_seeds, int64_t col_begin, int64_t col_end, hipStream_t s);
 
 int         update_variant_count();
 const char *update_variant_name(int v);

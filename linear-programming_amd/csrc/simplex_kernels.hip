@@ -141,7 +141,8 @@ __device__ __forceinline__ ValIdx block_price_partials(const double *__restrict_
 // supplied by another shard and is read from col_src (and copied into t.col).
 __device__ __forceinline__ ValIdx block_gather_ratio(const TabView &t, int64_t ec,
                                                      const double *__restrict__ col_src,
-                                                     double ratio_thr, double *s_v, long long *s_i)
+                                                     double ratio_thr, double *s_v, long long *s_i,
+                                                     const double *__restrict__ rhs_src = nullptr)
 {
     const int64_t m = t.rows - 1, vc = t.cols - 1;
     ValIdx best; best.v = 0.0; best.i = -1;
@@ -151,7 +152,7 @@ __device__ __forceinline__ ValIdx block_gather_ratio(const TabView &t, int64_t e
         for (int g = 0; g < kBatch; ++g) {           // the strided gathers: all in flight at once
             const int64_t r = base + (int64_t)g * kSelThreads + threadIdx.x;
             a[g] = r < t.rows ? (col_src ? col_src[r] : t.M[r * t.ld + ec]) : 0.0;
-            b[g] = r < m ? t.M[r * t.ld + vc] : 0.0;
+            b[g] = r < m ? (rhs_src ? rhs_src[r] : t.M[r * t.ld + vc]) : 0.0;
         }
 #pragma unroll
         for (int g = 0; g < kBatch; ++g) {
@@ -206,12 +207,28 @@ __device__ __forceinline__ void record_pivot(const TabView &t, int64_t ec, int64
     ctl->n_pivots += 1;
 }
 
+// A batch of same-shape LPs is one TabView plus per-LP element strides; grid.z = LP index
+// (all strides are zero for a single tableau, where grid.z == 1).
+__device__ __forceinline__ TabView lp_slice(TabView t)
+{
+    const int64_t z = blockIdx.z;
+    t.M      += z * t.zs_M;
+    t.basis  += z * t.zs_basis;
+    t.col    += z * t.zs_col;
+    t.prow   += z * t.zs_prow;
+    t.part_v += z * t.zs_part;
+    t.part_i += z * t.zs_part;
+    t.ctl    += z;
+    return t;
+}
+
 // ------------------------------------------------------------------ select kernels
 __global__ __launch_bounds__(kSelThreads) void k_select(TabView t, double sgn, double price_tol,
                                                        double ratio_thr, int n_part)
 {
     __shared__ double    s_v[kSelWaves];
     __shared__ long long s_i[kSelWaves];
+    t = lp_slice(t);
     Ctl *ctl = t.ctl;
     if (ctl->status != kRunning) return;
     const int64_t m = t.rows - 1, vc = t.cols - 1;
@@ -252,11 +269,13 @@ constexpr int kScaleThreads  = 256;
 
 __global__ __launch_bounds__(kGatherThreads) void k_select_gather(TabView t, double sgn,
                                                                   double price_tol,
-                                                                  double ratio_thr, int n_part,
-                                                                  double *rp_v, int64_t *rp_i)
+                                                                  double ratio_thr, int n_part)
 {
     __shared__ double    s_v[kGatherThreads / 64];
     __shared__ long long s_i[kGatherThreads / 64];
+    t = lp_slice(t);
+    double  *rp_v = t.part_v + t.part_cap / 2;      // ratio partials: upper half of the buffers
+    int64_t *rp_i = t.part_i + t.part_cap / 2;
     Ctl *ctl = t.ctl;
     if (ctl->status != kRunning) return;
     const int64_t m = t.rows - 1, vc = t.cols - 1;
@@ -286,12 +305,13 @@ __global__ __launch_bounds__(kGatherThreads) void k_select_gather(TabView t, dou
     if (leader) ctl->ec = ec;
 }
 
-__global__ __launch_bounds__(kScaleThreads) void k_select_scale(TabView t, int n_rp,
-                                                                const double *rp_v,
-                                                                const int64_t *rp_i)
+__global__ __launch_bounds__(kScaleThreads) void k_select_scale(TabView t, int n_rp)
 {
     __shared__ double    s_v[kScaleThreads / 64];
     __shared__ long long s_i[kScaleThreads / 64];
+    t = lp_slice(t);
+    const double  *rp_v = t.part_v + t.part_cap / 2;
+    const int64_t *rp_i = t.part_i + t.part_cap / 2;
     Ctl *ctl = t.ctl;
     if (ctl->status != kRunning) return;
     const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
@@ -314,21 +334,22 @@ __global__ __launch_bounds__(kScaleThreads) void k_select_scale(TabView t, int n
     if (leader) record_pivot(t, ctl->ec, cr);
 }
 
-// find-entering-column only: ctl->ec = column or -1.  With out_val/out_col (shard pricing)
-// the local best key and GLOBAL column (col_offset + local) go to device buffers instead,
-// without applying the threshold (the exchange step does that once on the global best).
+// find-entering-column only: ctl->ec = column or -1.  With out2 (shard pricing) the local
+// best key (v*sgn) and its GLOBAL column (col_offset + local, as a double; -1 = none) go to a
+// device buffer instead, without the threshold (applied once on the global best later).
 __global__ __launch_bounds__(kSelThreads) void k_price_only(TabView t, double sgn, double price_tol,
-                                                           int64_t col_offset, double *out_val,
-                                                           int64_t *out_col)
+                                                           int64_t col_offset, double *out2,
+                                                           int n_part)
 {
     __shared__ double    s_v[kSelWaves];
     __shared__ long long s_i[kSelWaves];
     const int64_t m = t.rows - 1, vc = t.cols - 1;
-    const ValIdx e = block_price(t.M + m * t.ld, vc, sgn, s_v, s_i);
+    const ValIdx e = n_part > 0 ? block_price_partials(t.part_v, t.part_i, n_part, s_v, s_i)
+                                : block_price(t.M + m * t.ld, vc, sgn, s_v, s_i);
     if (threadIdx.x == 0) {
-        if (out_val) {
-            *out_val = e.i < 0 ? 0.0 : e.v;
-            *out_col = e.i < 0 ? -1 : e.i + col_offset;
+        if (out2) {
+            out2[0] = e.i < 0 ? 0.0 : e.v;
+            out2[1] = e.i < 0 ? -1.0 : (double)(e.i + col_offset);
         } else {
             t.ctl->ec = (e.i >= 0 && e.v < 0.0 - price_tol) ? e.i : -1;
         }
@@ -356,43 +377,65 @@ __global__ __launch_bounds__(kSelThreads) void k_prepare_pivot(TabView t, int64_
     }
 }
 
-// Shard step 3: copy local column `lc` to a device buffer (rows doubles).
-__global__ __launch_bounds__(kSelThreads) void k_gather_col(TabView t, int64_t lc, double *out)
+// Column-partitioned tableau, exchange step.  `gathered` holds (key, global column) of every
+// shard's local pricing winner (all-gathered, 2 doubles per shard).  Every shard derives the
+// same global winner -- lexicographic (key, column) minimum = the sequential lowest-index strict
+// minimum -- applies the pricing threshold, and contributes to the column exchange: the owner
+// of the entering column writes the BIT PATTERNS of its entries, everyone else zeros, so an
+// integer sum all-reduce delivers the owner's column to every shard exactly (no float addition,
+// signed zeros preserved) without any shard needing to know the owner on the host.
+__global__ __launch_bounds__(kSelThreads) void k_shard_contribute(TabView t, const double *gathered,
+                                                                 int n_shards, int64_t col_offset,
+                                                                 double price_tol,
+                                                                 long long *bits_out, int64_t *ec_out)
 {
+    ValIdx best; best.v = 0.0; best.i = -1;
+    for (int k = 0; k < n_shards; ++k) {
+        ValIdx c; c.v = gathered[2 * k]; c.i = (int64_t)gathered[2 * k + 1];
+        best = vi_min(best, c);
+    }
+    const int64_t ec = (best.i >= 0 && best.v < 0.0 - price_tol) ? best.i : -1;
+    const int64_t lc = ec - col_offset;
+    const bool mine = ec >= 0 && lc >= 0 && lc < t.cols - 1;
+    // The strided gathers (entering column on the owner, RHS column on everyone: snapshotted
+    // contiguously for the ratio test of k_shard_prepare) run here, spread over many workgroups.
     for (int64_t r = blockIdx.x * (int64_t)kSelThreads + threadIdx.x; r < t.rows;
-         r += (int64_t)gridDim.x * kSelThreads)
-        out[r] = t.M[r * t.ld + lc];
+         r += (int64_t)gridDim.x * kSelThreads) {
+        bits_out[r] = mine ? __double_as_longlong(t.M[r * t.ld + lc]) : 0ll;
+        if (ec >= 0) t.rhs[r] = t.M[r * t.ld + (t.cols - 1)];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *ec_out = ec;
 }
 
-// Shard step 5 (prepare): ratio test on the broadcast column against the shard's own RHS copy
-// (identical on every shard => identical cr everywhere, no exchange), row scale from the
-// broadcast column (col[cr] is M[cr][ec] bit for bit), normalise the local slice of row cr.
-// global_ec < 0 (no entering column: optimal) or no eligible row (unbounded) stop the shard.
+// Column-partitioned tableau, local step after the exchange: ratio test on the (now global)
+// entering column against the shard's own RHS copy (identical on every shard => identical
+// pivot row everywhere, no further exchange), row scale = col[cr] (== M[cr][ec] bit for bit),
+// normalise the local slice of row cr.  *ec_dev < 0: the tableau is optimal.
 __global__ __launch_bounds__(kSelThreads) void k_shard_prepare(TabView t, const double *col_src,
-                                                              int64_t global_ec, int64_t col_offset,
-                                                              int is_owner, double ratio_thr)
+                                                              const int64_t *ec_dev,
+                                                              double ratio_thr)
 {
     __shared__ double    s_v[kSelWaves];
     __shared__ long long s_i[kSelWaves];
     Ctl *ctl = t.ctl;
     if (ctl->status != kRunning) return;
+    const int64_t global_ec = *ec_dev;
     if (global_ec < 0) {
-        if (threadIdx.x == 0) ctl->status = 0;
+        if (threadIdx.x == 0) ctl->status = 0;      // MI_OPTIMAL
         return;
     }
-    const ValIdx q = block_gather_ratio(t, 0, col_src, ratio_thr, s_v, s_i);
+    if (ctl->max_pivots > 0 && ctl->n_pivots >= ctl->max_pivots) {
+        if (threadIdx.x == 0) ctl->status = 3;      // MI_MAX_PIVOTS
+        return;
+    }
+    const ValIdx q = block_gather_ratio(t, 0, col_src, ratio_thr, s_v, s_i, t.rhs);
     if (q.i < 0) {
-        if (threadIdx.x == 0) ctl->status = 1;
+        if (threadIdx.x == 0) ctl->status = 1;      // MI_UNBOUNDED
         return;
     }
     const int64_t cr = q.i;
     block_scale_row(t, cr, col_src[cr]);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // basis entries hold GLOBAL column indices on every shard
-        record_pivot(t, global_ec, cr);
-        (void)is_owner; (void)col_offset;
-    }
+    if (threadIdx.x == 0) record_pivot(t, global_ec, cr);   // basis holds GLOBAL column indices
 }
 
 // ------------------------------------------------------------------ the bandwidth kernel
@@ -407,15 +450,17 @@ typedef double vec2d __attribute__((ext_vector_type(2)));   // one global_load/s
 // The workgroups that write the objective row also price it for the next iteration: every
 // wave leaves its lowest-index arg-min (in key space v*sgn) in part_v/part_i.
 template <int BLOCK, int U, bool NT>
-__global__ __launch_bounds__(BLOCK) void k_update(double *__restrict__ M, const int64_t ld,
-                                                  const int64_t rows, const int64_t vc,
-                                                  const int tr, const int strip_pairs,
-                                                  const double *__restrict__ col,
-                                                  const double *__restrict__ prow,
-                                                  const Ctl *__restrict__ ctl, const double sgn,
-                                                  double *__restrict__ part_v,
-                                                  int64_t *__restrict__ part_i)
+__global__ __launch_bounds__(BLOCK) void k_update(TabView t, const int tr, const int strip_pairs,
+                                                  const double sgn, const int price)
 {
+    t = lp_slice(t);
+    double *__restrict__ M = t.M;
+    const int64_t ld = t.ld, rows = t.rows, vc = t.cols - 1;
+    const double *__restrict__ col  = t.col;
+    const double *__restrict__ prow = t.prow;
+    const Ctl *__restrict__ ctl = t.ctl;
+    double  *__restrict__ part_v = price ? t.part_v : nullptr;
+    int64_t *__restrict__ part_i = t.part_i;
     if (ctl->status != kRunning) return;
     const int64_t cr   = ctl->cr;
     const int64_t ldv  = ld >> 1;                              // row length in 16-byte pairs
@@ -489,6 +534,7 @@ __global__ __launch_bounds__(BLOCK) void k_update(double *__restrict__ M, const 
 // ------------------------------------------------------------------ control block
 __global__ void k_ctl_reset(Ctl *ctl, int64_t max_pivots, int reset_trace)
 {
+    ctl += blockIdx.x;                                         // one block per LP of a batch
     ctl->status     = kRunning;
     ctl->ec         = -1;
     ctl->cr         = -1;
@@ -501,6 +547,7 @@ __global__ void k_ctl_reset(Ctl *ctl, int64_t max_pivots, int reset_trace)
 // the pivots it was given.
 __global__ void k_ctl_finish(Ctl *ctl)
 {
+    ctl += blockIdx.x;
     if (ctl->status == kRunning) ctl->status = 3;              // MI_MAX_PIVOTS
 }
 
@@ -554,8 +601,11 @@ __device__ __forceinline__ double splitmix_u01(uint64_t seed, uint64_t k)
 }
 
 __global__ __launch_bounds__(256) void k_synth_fill(TabView t, int64_t n, int64_t m, uint64_t seed,
-                                                    int64_t col_begin, int64_t col_end)
+                                                    const uint64_t *seeds, int64_t col_begin,
+                                                    int64_t col_end)
 {
+    if (seeds) seed = seeds[blockIdx.z];                       // batch: one seed per LP
+    t = lp_slice(t);
     const int64_t lcols = t.cols;                              // (col_end - col_begin) + 1
     for (int64_t i = blockIdx.y; i < t.rows; i += gridDim.y) {
     for (int64_t jl = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; jl < t.ld;
@@ -584,18 +634,16 @@ static inline double sgn_of(int is_max) { return is_max ? 1.0 : -1.0; }
 
 void launch_select(const TabView &t, int is_max, double f, int n_part, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_select, dim3(1), dim3(kSelThreads), 0, s, t, sgn_of(is_max),
+    hipLaunchKernelGGL(k_select, dim3(1, 1, (unsigned)t.n_lps), dim3(kSelThreads), 0, s, t, sgn_of(is_max),
                        (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon, n_part);
 }
 void launch_select_split(const TabView &t, int is_max, double f, int n_part, hipStream_t s)
 {
     const int g1 = (int)((t.rows + kGatherThreads - 1) / kGatherThreads);
     const int g2 = (int)(((t.ld >> 1) + kScaleThreads - 1) / kScaleThreads);
-    double  *rp_v = t.part_v + t.part_cap / 2;      // upper half of the partial buffers
-    int64_t *rp_i = t.part_i + t.part_cap / 2;
-    hipLaunchKernelGGL(k_select_gather, dim3(g1), dim3(kGatherThreads), 0, s, t, sgn_of(is_max),
-                       (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon, n_part, rp_v, rp_i);
-    hipLaunchKernelGGL(k_select_scale, dim3(g2), dim3(kScaleThreads), 0, s, t, g1, rp_v, rp_i);
+    hipLaunchKernelGGL(k_select_gather, dim3(g1, 1, (unsigned)t.n_lps), dim3(kGatherThreads), 0, s, t,
+                       sgn_of(is_max), (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon, n_part);
+    hipLaunchKernelGGL(k_select_scale, dim3(g2, 1, (unsigned)t.n_lps), dim3(kScaleThreads), 0, s, t, g1);
 }
 bool select_split_supported(const TabView &t)
 {
@@ -604,7 +652,7 @@ bool select_split_supported(const TabView &t)
 void launch_price_only(const TabView &t, int is_max, double f, hipStream_t s)
 {
     hipLaunchKernelGGL(k_price_only, dim3(1), dim3(kSelThreads), 0, s, t, sgn_of(is_max),
-                       (f / 8.0) * kClEpsilon, (int64_t)0, (double *)nullptr, (int64_t *)nullptr);
+                       (f / 8.0) * kClEpsilon, (int64_t)0, (double *)nullptr, 0);
 }
 void launch_ratio_only(const TabView &t, int64_t ec, double f, hipStream_t s)
 {
@@ -615,23 +663,26 @@ void launch_prepare_pivot(const TabView &t, int64_t ec, int64_t cr, hipStream_t 
 {
     hipLaunchKernelGGL(k_prepare_pivot, dim3(1), dim3(kSelThreads), 0, s, t, ec, cr);
 }
-void launch_shard_price(const TabView &t, int is_max, int64_t col_offset, double *out_val,
-                        int64_t *out_col, hipStream_t s)
+void launch_shard_price(const TabView &t, int is_max, int64_t col_offset, double *out2, int n_part,
+                        hipStream_t s)
 {
     hipLaunchKernelGGL(k_price_only, dim3(1), dim3(kSelThreads), 0, s, t, sgn_of(is_max), 0.0,
-                       col_offset, out_val, out_col);
+                       col_offset, out2, n_part);
 }
-void launch_gather_col(const TabView &t, int64_t lc, double *out, hipStream_t s)
+void launch_shard_contribute(const TabView &t, const double *gathered, int n_shards,
+                             int64_t col_offset, double f, int64_t *bits_out, int64_t *ec_out,
+                             hipStream_t s)
 {
     int blocks = (int)((t.rows + kSelThreads - 1) / kSelThreads);
-    if (blocks > 64) blocks = 64;
-    hipLaunchKernelGGL(k_gather_col, dim3(blocks), dim3(kSelThreads), 0, s, t, lc, out);
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(k_shard_contribute, dim3(blocks), dim3(kSelThreads), 0, s, t, gathered,
+                       n_shards, col_offset, (f / 8.0) * kClEpsilon, (long long *)bits_out, ec_out);
 }
-void launch_shard_prepare(const TabView &t, const double *col, int64_t global_ec,
-                          int64_t col_offset, int is_owner, double f, hipStream_t s)
+void launch_shard_prepare(const TabView &t, const double *col, const int64_t *ec_dev, double f,
+                          hipStream_t s)
 {
-    hipLaunchKernelGGL(k_shard_prepare, dim3(1), dim3(kSelThreads), 0, s, t, col, global_ec,
-                       col_offset, is_owner, 0.0 + (f / 2.0) * kClEpsilon);
+    hipLaunchKernelGGL(k_shard_prepare, dim3(1), dim3(kSelThreads), 0, s, t, col, ec_dev,
+                       0.0 + (f / 2.0) * kClEpsilon);
 }
 void launch_handover(const TabView &art, const TabView &mt, hipStream_t s)
 {
@@ -645,19 +696,19 @@ void launch_handover(const TabView &art, const TabView &mt, hipStream_t s)
 }
 void launch_ctl_reset(const TabView &t, int64_t max_pivots, int reset_trace, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_ctl_reset, dim3(1), dim3(1), 0, s, t.ctl, max_pivots, reset_trace);
+    hipLaunchKernelGGL(k_ctl_reset, dim3((unsigned)t.n_lps), dim3(1), 0, s, t.ctl, max_pivots, reset_trace);
 }
 void launch_ctl_finish(const TabView &t, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_ctl_finish, dim3(1), dim3(1), 0, s, t.ctl);
+    hipLaunchKernelGGL(k_ctl_finish, dim3((unsigned)t.n_lps), dim3(1), 0, s, t.ctl);
 }
-void launch_synth_fill(const TabView &t, int64_t n, int64_t m, uint64_t seed, int64_t cb,
-                       int64_t ce, hipStream_t s)
+void launch_synth_fill(const TabView &t, int64_t n, int64_t m, uint64_t seed,
+                       const uint64_t *dev_seeds, int64_t cb, int64_t ce, hipStream_t s)
 {
     int bx = (int)((t.ld + 255) / 256);
     if (bx > 64) bx = 64;
-    hipLaunchKernelGGL(k_synth_fill, dim3(bx, (unsigned)(t.rows < 32768 ? t.rows : 32768)), dim3(256), 0, s, t, n, m, seed,
-                       cb, ce);
+    hipLaunchKernelGGL(k_synth_fill, dim3(bx, (unsigned)(t.rows < 32768 ? t.rows : 32768), (unsigned)t.n_lps),
+                       dim3(256), 0, s, t, n, m, seed, dev_seeds, cb, ce);
 }
 
 // ---- update-kernel variants (one is the default; the others exist for the tuning sweep)
@@ -674,31 +725,29 @@ template <int BLOCK, int U, bool NT>
 static void launch_update_t(const TabView &t, dim3 grid, int tr, int strip_pairs, double sgn,
                             int price, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_update<BLOCK, U, NT>), grid, dim3(BLOCK), 0, s, t.M, t.ld, t.rows,
-                       t.cols - 1, tr, strip_pairs, t.col, t.prow, t.ctl, sgn,
-                       price ? t.part_v : (double *)nullptr, price ? t.part_i : (int64_t *)nullptr);
+    hipLaunchKernelGGL((k_update<BLOCK, U, NT>), grid, dim3(BLOCK), 0, s, t, tr, strip_pairs, sgn,
+                       price);
 }
 
 #define MI_VARIANT(B, U, NT, MINTR, ROUNDS) \
     { "b" #B "_u" #U "_nt" #NT "_mintr" #MINTR "_x" #ROUNDS, (B), (U), (MINTR), (ROUNDS), &launch_update_t<B, U, NT> }
 
 static const UpdateVariant kVariants[] = {
-    MI_VARIANT(256, 8, true, 8, 4),     // 0: default
-    MI_VARIANT(256, 8, true, 8, 1),
-    MI_VARIANT(256, 8, true, 8, 2),
-    MI_VARIANT(256, 8, true, 8, 8),
-    MI_VARIANT(256, 4, true, 4, 4),
-    MI_VARIANT(256, 4, true, 4, 8),
+    MI_VARIANT(256, 4, true, 4, 0),     // 0: default -- 4-row tiles whatever the size
     MI_VARIANT(256, 4, true, 4, 16),
-    MI_VARIANT(256, 2, true, 2, 16),
-    MI_VARIANT(256, 16, true, 16, 4),
-    MI_VARIANT(256, 8, false, 8, 4),
-    MI_VARIANT(128, 8, true, 8, 4),
-    MI_VARIANT(128, 4, true, 4, 8),
-    MI_VARIANT(512, 8, true, 8, 4),
-    MI_VARIANT(512, 4, true, 4, 8),
-    MI_VARIANT(64, 4, true, 4, 8),
-    MI_VARIANT(1024, 4, true, 4, 8),
+    MI_VARIANT(256, 4, true, 4, 8),
+    MI_VARIANT(256, 4, false, 4, 0),
+    MI_VARIANT(256, 2, true, 2, 0),
+    MI_VARIANT(256, 8, true, 8, 0),
+    MI_VARIANT(256, 8, true, 8, 4),
+    MI_VARIANT(256, 8, true, 8, 1),
+    MI_VARIANT(128, 8, true, 8, 0),
+    MI_VARIANT(512, 4, true, 4, 0),
+    MI_VARIANT(512, 2, true, 2, 0),
+    MI_VARIANT(64, 4, true, 4, 0),
+    MI_VARIANT(1024, 4, true, 4, 0),
+    MI_VARIANT(256, 4, true, 8, 0),
+    MI_VARIANT(256, 4, true, 12, 0),
 };
 static int g_variant = 0;
 constexpr int kCUs = 256, kThreadsPerCU = 2048;
@@ -721,12 +770,20 @@ UpdateShape update_shape(const TabView &t)
     if (sp > v.block) sp = v.block;
     g.strip_pairs = (int)sp;
     g.strips = (int)((ldv + sp - 1) / sp);
-    const int64_t slots = (int64_t)kCUs * (kThreadsPerCU / v.block) * v.rounds;
-    int64_t by = slots / g.strips;
-    if (by < 1) by = 1;
-    int64_t tr = (t.rows + by - 1) / by;
-    if (tr < v.min_tr) tr = v.min_tr;
+    // Rows per workgroup.  Measured on config 3: SMALL tiles win -- with 4-row
+    // tiles dispatched x-fastest the resident workgroups cover one contiguous window of the
+    // tableau that sweeps through memory once.  rounds == 0 selects that fixed small tile;
+    // rounds > 0 is the older "rounds x resident slots" sizing kept for the tuning sweep.
+    int64_t tr = v.min_tr;
+    if (v.rounds > 0) {
+        const int64_t slots = (int64_t)kCUs * (kThreadsPerCU / v.block) * v.rounds;
+        int64_t by = slots / ((int64_t)g.strips * t.n_lps);
+        if (by < 1) by = 1;
+        tr = (t.rows + by - 1) / by;
+        if (tr < v.min_tr) tr = v.min_tr;
+    }
     tr = (tr + v.unroll - 1) / v.unroll * v.unroll;
+    while ((t.rows + tr - 1) / tr > 65535) tr *= 2;            // grid.y limit
     g.tr = (int)tr;
     g.row_chunks = (int)((t.rows + tr - 1) / tr);
     g.waves_per_block = v.block / 64;
@@ -739,7 +796,8 @@ int launch_update(const TabView &t, double sgn, int price, hipStream_t s)
     const UpdateVariant &v = kVariants[g_variant];
     const UpdateShape g = update_shape(t);
     if (price && g.n_partials > t.part_cap / 2) price = 0;
-    v.launch(t, dim3((unsigned)g.strips, (unsigned)g.row_chunks), g.tr, g.strip_pairs, sgn, price, s);
+    v.launch(t, dim3((unsigned)g.strips, (unsigned)g.row_chunks, (unsigned)t.n_lps), g.tr,
+             g.strip_pairs, sgn, price, s);
     return price ? g.n_partials : 0;
 }
 

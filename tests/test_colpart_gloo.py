@@ -1,0 +1,60 @@
+"""The N>1 path on CPU: world_size-2 (and 3) gloo jobs run the column-partition exchange
+protocol of linear-programming_amd/colpart.py -- the same driver code the GPUs use, with a
+test-supplied numpy compute backend -- and must reproduce the single-tableau oracle exactly."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+from tests.helpers import ROOT, lp_amd
+
+lp = lp_amd()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(world, n, m, seed, max_pivots, tmp_path):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "tests", "_colpart_gloo_worker.py"), str(tmp_path),
+             str(n), str(m), str(seed), str(max_pivots)], env=env, cwd=ROOT))
+    for p in procs:
+        assert p.wait(timeout=240) == 0
+    return [np.load(os.path.join(tmp_path, "rank%d.npz" % r)) for r in range(world)]
+
+
+@pytest.mark.parametrize("world,n,m,max_pivots", [(2, 40, 24, 0), (3, 50, 31, 0), (2, 64, 32, 9)])
+def test_column_partition_protocol_matches_oracle(world, n, m, max_pivots, tmp_path):
+    seed = lp.synth.seed_for(5, world)
+    res = _run(world, n, m, seed, max_pivots, tmp_path)
+    M, b = lp.synth.tableau(n, m, seed)
+    st, npiv, trace = oracle.solve(M, b, max_pivots=max_pivots, trace_cap=4096)
+    got = np.concatenate([r["M"][:, :-1] for r in res], axis=1)
+    for r in res:
+        assert int(r["status"]) == st and int(r["npiv"]) == npiv
+        assert np.array_equal(r["trace"], trace)
+        assert np.array_equal(r["basis"], b)                  # global column indices everywhere
+        assert np.array_equal(r["M"][:, -1], M[:, -1])        # every shard's RHS copy
+    assert np.array_equal(got, M[:, :-1])
+
+
+def test_partition_helper():
+    cp = __import__("importlib").import_module("linear-programming_amd.colpart")
+    assert cp.partition(98304, 8) == [(i * 12288, (i + 1) * 12288) for i in range(8)]
+    assert cp.partition(10, 3) == [(0, 4), (4, 8), (8, 10)]
+    with pytest.raises(ValueError):
+        cp.partition(4, 8)

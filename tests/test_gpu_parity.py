@@ -393,7 +393,7 @@ def test_async_enqueue_matches_blocking_solve():
     lp.capi.check(L.mi355x_tab_solve_async(t._h, 1, 1024.0, 25, 1), "solve_async")
     npv = ctypes.c_int64(0)
     rc = L.mi355x_tab_sync(t._h, ctypes.byref(npv))
-    assert rc == lp.capi.MI_MAX_PIVOTS and npv.value == 25
+    assert rc == lp.capi.MI_RUNNING and npv.value == 25
     t._touch()
     Mo, bo = M0.copy(), b0.copy()
     oracle.solve(Mo, bo, max_pivots=25)
@@ -405,6 +405,107 @@ def test_async_enqueue_matches_blocking_solve():
     t._touch()
     st, total, _ = oracle.solve(Mo, bo)
     assert npv.value == 25 + total and np.array_equal(t.matrix, Mo)
+
+
+# =========================================================================== batches (config 4)
+def test_batch_bitwise_vs_oracle():
+    """Every LP of a batch ends bit-identical to the oracle run on it alone (LPs of different
+    pivot counts, so finished LPs idle while others continue)."""
+    n, m, nl = 60, 30, 37
+    seeds = [lp.synth.seed_for(4, k) for k in range(nl)]
+    tabs = [lp.synth.tableau(n, m, s) for s in seeds]
+    Ms = np.stack([t[0] for t in tabs])
+    Bs = np.stack([t[1] for t in tabs])
+    batch = lp.TableauBatch.from_arrays(Ms, Bs)
+    st, npv = batch.solve()
+    pivots = []
+    for k in range(nl):
+        M, b = Ms[k].copy(), Bs[k].copy()
+        so, no, _ = oracle.solve(M, b)
+        pivots.append(no)
+        Mg, bg = batch.download(k)
+        assert st[k] == so == oracle.OPTIMAL and npv[k] == no, k
+        assert np.array_equal(Mg, M) and np.array_equal(bg, b), k
+    assert len(set(pivots)) > 3
+
+
+def test_batch_synthetic_config4_shape_and_statuses():
+    """BASELINE config 4 shape (512 vars x 256 constraints) on a sub-batch: device generator ==
+    numpy generator per LP, mixed outcomes (an unbounded LP in the batch), pivot cap."""
+    n, m, nl = 512, 256, 8
+    seeds = np.array([lp.synth.seed_for(4, k) for k in range(nl)], dtype=np.uint64)
+    batch = lp.TableauBatch.synthetic(nl, n, m, seeds)
+    for k in (0, nl - 1):
+        M, b = lp.synth.tableau(n, m, int(seeds[k]))
+        Mg, bg = batch.download(k)
+        assert np.array_equal(Mg, M) and np.array_equal(bg, b)
+    st, npv = batch.solve(max_pivots=50)
+    assert (st == lp.capi.MI_MAX_PIVOTS).all() and (npv == 50).all()
+    M, b = lp.synth.tableau(n, m, int(seeds[3]))
+    oracle.solve(M, b, max_pivots=50)
+    assert np.array_equal(batch.download(3)[0], M)
+    st, npv = batch.solve()                       # resume to optimality
+    M, b = lp.synth.tableau(n, m, int(seeds[3]))
+    so, no, _ = oracle.solve(M, b, omp=True)
+    assert st[3] == so == oracle.OPTIMAL and npv[3] == no - 50
+    assert np.array_equal(batch.download(3)[0], M)
+    # an unbounded member does not disturb the others
+    tabs = [lp.synth.tableau(20, 10, 100 + k) for k in range(5)]
+    Ms = np.stack([t[0] for t in tabs]); Bs = np.stack([t[1] for t in tabs])
+    Ms[2, :10, 4] = -1.0                          # column 4 of LP 2 can grow without bound
+    batch = lp.TableauBatch.from_arrays(Ms, Bs)
+    st, npv = batch.solve()
+    for k in range(5):
+        M, b = Ms[k].copy(), Bs[k].copy()
+        so, no, _ = oracle.solve(M, b)
+        assert st[k] == so and npv[k] == no
+        assert np.array_equal(batch.download(k)[0], M)
+    assert st[2] == lp.capi.MI_UNBOUNDED
+
+
+# =========================================================================== column partition (config 5)
+@pytest.mark.parametrize("n_shards,n,m", [(1, 60, 40), (2, 96, 64), (3, 100, 50), (8, 512, 256)])
+def test_column_partition_logical_shards_bitwise(n_shards, n, m):
+    """One tableau as N column shards on ONE device (exchanges = local tensor ops with the
+    collectives' semantics): same pivot sequence and same bits as the unpartitioned solve."""
+    import importlib
+    import torch
+    cp = importlib.import_module("linear-programming_amd.colpart")
+    seed = lp.synth.seed_for(5, n_shards)
+    shards = cp.synthetic_shards(torch, n, m, seed, list(range(n_shards)), n_shards, 0)
+    tab = cp.ColumnPartitionedTableau(shards, cp.LocalComm(torch), cp.HipBackend())
+    st, npiv = tab.solve(check_every=32)
+    M, b = lp.synth.tableau(n, m, seed)
+    so, no, trace = oracle.solve(M, b, trace_cap=1 << 16)
+    assert (st, npiv) == (so, no) == (oracle.OPTIMAL, no)
+    parts = [cp.download_shard(sh) for sh in shards]
+    got = np.concatenate([p[0][:, :-1] for p in parts], axis=1)
+    assert np.array_equal(got, M[:, :-1])
+    for Ms, bs in parts:
+        assert np.array_equal(Ms[:, -1], M[:, -1])            # every RHS copy
+        assert np.array_equal(bs, b)                          # global column indices
+    ec = np.empty(no, dtype=np.int64); cr = np.empty(no, dtype=np.int64); k = ctypes.c_int64(0)
+    lp.capi.check(lp.capi.lib().mi355x_tab_trace(shards[-1].handle, ec.ctypes.data_as(ctypes.c_void_p),
+                                                 cr.ctypes.data_as(ctypes.c_void_p), no, ctypes.byref(k)),
+                  "trace")
+    assert k.value == no and np.array_equal(np.stack([ec, cr], axis=1), trace)
+    cp.destroy_shards(shards)
+
+
+def test_column_partition_pivot_cap_and_unbounded():
+    import importlib
+    import torch
+    cp = importlib.import_module("linear-programming_amd.colpart")
+    n, m, seed = 80, 40, lp.synth.seed_for(5, 99)
+    shards = cp.synthetic_shards(torch, n, m, seed, [0, 1, 2], 3, 0)
+    tab = cp.ColumnPartitionedTableau(shards, cp.LocalComm(torch), cp.HipBackend())
+    st, npiv = tab.solve(max_pivots=11, check_every=4)
+    assert (st, npiv) == (lp.capi.MI_MAX_PIVOTS, 11)
+    M, b = lp.synth.tableau(n, m, seed)
+    oracle.solve(M, b, max_pivots=11)
+    got = np.concatenate([cp.download_shard(sh)[0][:, :-1] for sh in shards], axis=1)
+    assert np.array_equal(got, M[:, :-1])
+    cp.destroy_shards(shards)
 
 
 # =========================================================================== synthetic inputs

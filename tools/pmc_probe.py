@@ -1,0 +1,14 @@
+"""HBM-traffic probe for rocprofv3 --pmc runs: a device-to-device copy of the tableau (known
+bytes: calibrates FETCH_SIZE / WRITE_SIZE), then N pivots of config 3."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.helpers import lp_amd
+lp = lp_amd(); L = lp.capi.lib()
+n, m = 8192, 4096
+h = ctypes.c_void_p()
+lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h), n, m, lp.synth.seed_for(3), 0, -1, 0), "create")
+h2 = ctypes.c_void_p()
+lp.capi.check(L.mi355x_tab_copy(ctypes.byref(h2), h), "copy")      # reads + writes rows*ld*8 bytes
+lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, int(sys.argv[1]) if len(sys.argv) > 1 else 30, 1), "run")
+npv = ctypes.c_int64(0)
+print("rc", L.mi355x_tab_sync(h, ctypes.byref(npv)), "pivots", npv.value)
