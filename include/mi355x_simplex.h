@@ -54,9 +54,12 @@ extern "C" {
 #define MI_RCCL_ERROR   -3
 #define MI_NO_DEVICE    -4
 #define MI_NO_MEMORY    -5
+#define MI_UNSUPPORTED  -6   /* -> unsupported-constraint-error (integer / binary variables) */
 
 typedef struct mi355x_tab   mi355x_tab;     /* one tableau resident in HBM              */
 typedef struct mi355x_batch mi355x_batch;   /* a batch of same-shape tableaux in HBM    */
+typedef struct mi355x_problem  mi355x_problem;   /* a parsed LP, src/problem.lisp:45-53 (host)  */
+typedef struct mi355x_solution mi355x_solution;  /* what the read-back needs of a solved tableau */
 
 /* ---- library / device ------------------------------------------------------------- */
 int         mi355x_abi_version(void);
@@ -142,6 +145,44 @@ int  mi355x_tab_timing_enable(mi355x_tab *t, int enable);
 int  mi355x_tab_timing_read(mi355x_tab *t, int64_t *n_launches, double *sum_ms, double *min_ms);
 /* Name of the rank-1 update kernel as it appears in rocprofv3 kernel traces. */
 const char *mi355x_update_kernel_name(void);
+
+/* ---- native host side of the hook: problem -> tableau -> solution ------------------- */
+/* The reference's parsed `problem` struct (src/problem.lisp:45-53), variables identified by
+ * their index in problem-vars.  A variable without a bounds entry is >= 0 (`positive`
+ * mapping with offset 0); set_bounds(var, 0,_, 0,_) makes it free (`signed`, two columns).
+ * op: 0 `<=`, 1 `>=`, 2 `=`; as after parsing, `<=` / `>=` rows carry rhs >= 0. */
+int  mi355x_problem_create(mi355x_problem **out, int is_max, int64_t n_vars);
+int  mi355x_problem_set_objective(mi355x_problem *p, const int64_t *var, const double *coef,
+                                  int64_t nnz);
+int  mi355x_problem_set_bounds(mi355x_problem *p, int64_t var, int has_lb, double lb, int has_ub,
+                               double ub);
+int  mi355x_problem_set_integer(mi355x_problem *p, int64_t var);
+int  mi355x_problem_add_constraint(mi355x_problem *p, int op, const int64_t *var,
+                                   const double *coef, int64_t nnz, double rhs);
+void mi355x_problem_destroy(mi355x_problem *p);
+/* build-tableau (src/simplex.lisp:142-328) in double-float, on the host.  which = 0: the main
+ * tableau, 1: the artificial tableau (two-phase problems only).  Call once with NULL arrays for
+ * the shape, again to fill matrix (rows*cols) and basis (rows-1).  Returns MI_UNBOUNDED for the
+ * unbounded no-constraint special case (:170,:174). */
+int  mi355x_build_tableau(const mi355x_problem *p, int which, int64_t *rows, int64_t *cols,
+                          double *matrix, int64_t *basis, int *two_phase);
+/* var-mapping entry of a variable (src/simplex.lisp:44-46): kind 0 positive, 1 negative,
+ * 2 signed; first column; offset. */
+int  mi355x_var_mapping(const mi355x_problem *p, int64_t var, int *kind, int64_t *col,
+                        double *offset);
+/* simplex-solver for LPs (src/simplex.lisp:506-542 without branch-and-bound): build-tableau,
+ * upload, n-solve-tableau on the device (single- or two-phase), read back the objective row,
+ * the RHS column and the basis only.  Returns MI_OPTIMAL and a solution, or MI_UNBOUNDED /
+ * MI_INFEASIBLE / MI_UNSUPPORTED (integer variables) / an error. */
+int  mi355x_simplex_solver(const mi355x_problem *p, double fp_tolerance, int device,
+                           mi355x_solution **out);
+/* tableau-objective-value / tableau-variable / tableau-reduced-cost (src/simplex.lisp:74-120).
+ * reduced_cost fails with MI_BAD_ARG for a variable without a lower bound, as the reference. */
+int  mi355x_solution_objective_value(const mi355x_solution *s, double *out);
+int  mi355x_solution_variable(const mi355x_solution *s, int64_t var, double *out);
+int  mi355x_solution_reduced_cost(const mi355x_solution *s, int64_t var, double *out);
+int  mi355x_solution_pivots(const mi355x_solution *s, int64_t *phase1, int64_t *phase2);
+void mi355x_solution_destroy(mi355x_solution *s);
 
 /* ---- batches of independent LPs (BASELINE config 4) -------------------------------- */
 /* n_lps same-shape LPs stacked in one allocation; one (select, update) launch pair advances

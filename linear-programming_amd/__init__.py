@@ -13,7 +13,8 @@ GPU, and fails loudly otherwise.
 (The directory name contains a hyphen; import it with
 ``importlib.import_module("linear-programming_amd")``.)
 """
-from . import batch, capi, simplex, solver, synth               # noqa: F401
+from . import batch, capi, native, simplex, solver, synth       # noqa: F401
+from .native import NativeProblem, NativeSolution               # noqa: F401
 from .batch import TableauBatch                                 # noqa: F401
 from .conditions import (SolverError, UnboundedProblemError, InfeasibleProblemError,   # noqa: F401
                          UnsupportedConstraintError, ParsingError)

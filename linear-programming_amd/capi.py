@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(HERE, "libmi355x_simplex.so")
 MI_OK = MI_OPTIMAL = 0
 MI_UNBOUNDED, MI_INFEASIBLE, MI_MAX_PIVOTS, MI_ART_NONZERO, MI_ART_STUCK = 1, 2, 3, 4, 5
 MI_RUNNING = 100
-MI_BAD_ARG, MI_HIP_ERROR, MI_RCCL_ERROR, MI_NO_DEVICE, MI_NO_MEMORY = -1, -2, -3, -4, -5
+MI_BAD_ARG, MI_HIP_ERROR, MI_RCCL_ERROR, MI_NO_DEVICE, MI_NO_MEMORY, MI_UNSUPPORTED = -1, -2, -3, -4, -5, -6
 
 _i64, _dbl, _p, _int = ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, ctypes.c_int
 _pp = ctypes.POINTER(ctypes.c_void_p)
@@ -40,6 +40,20 @@ SIGNATURES = {
     "mi355x_tab_timing_enable": (_int, [_p, _int]),
     "mi355x_tab_timing_read": (_int, [_p, _p, _p, _p]),
     "mi355x_update_kernel_name": (ctypes.c_char_p, []),
+    "mi355x_problem_create": (_int, [_pp, _int, _i64]),
+    "mi355x_problem_set_objective": (_int, [_p, _p, _p, _i64]),
+    "mi355x_problem_set_bounds": (_int, [_p, _i64, _int, _dbl, _int, _dbl]),
+    "mi355x_problem_set_integer": (_int, [_p, _i64]),
+    "mi355x_problem_add_constraint": (_int, [_p, _int, _p, _p, _i64, _dbl]),
+    "mi355x_problem_destroy": (None, [_p]),
+    "mi355x_build_tableau": (_int, [_p, _int, _p, _p, _p, _p, _p]),
+    "mi355x_var_mapping": (_int, [_p, _i64, _p, _p, _p]),
+    "mi355x_simplex_solver": (_int, [_p, _dbl, _int, _pp]),
+    "mi355x_solution_objective_value": (_int, [_p, _p]),
+    "mi355x_solution_variable": (_int, [_p, _i64, _p]),
+    "mi355x_solution_reduced_cost": (_int, [_p, _i64, _p]),
+    "mi355x_solution_pivots": (_int, [_p, _p, _p]),
+    "mi355x_solution_destroy": (None, [_p]),
     "mi355x_batch_create": (_int, [_pp, _i64, _i64, _i64, _p, _p, _int]),
     "mi355x_batch_create_synthetic": (_int, [_pp, _i64, _i64, _i64, _p, _int]),
     "mi355x_batch_solve": (_int, [_p, _int, _dbl, _i64, _p, _p]),

@@ -1,0 +1,415 @@
+// host_problem.cpp -- native host side of the solver hook: problem -> tableau(s) -> solution.
+//
+// C++ restatement (double-float) of what surrounds the hot path in the reference's default
+// backend, so that a caller can hand over a parsed `problem` (src/problem.lisp:45-53) and get
+// back what `simplex-solver` (src/simplex.lisp:506-542) returns for an LP, without any Lisp or
+// Python in between:
+//   mi355x_build_tableau      = build-tableau            (src/simplex.lisp:142-328), host only
+//   mi355x_simplex_solver     = simplex-solver for LPs   (build -> n-solve-tableau on the GPU)
+//   mi355x_solution_*         = tableau-objective-value / tableau-variable /
+//                               tableau-reduced-cost      (src/simplex.lisp:74-120)
+// The solution object keeps only what the read-back needs -- objective row, RHS column, basis,
+// var-mapping -- so a 400 MB tableau is never downloaded.
+// Variables are identified by their index in problem-vars.  Integer variables are declined
+// (MI_UNSUPPORTED -> unsupported-constraint-error): branch-and-bound stays with the reference.
+#include "../../include/mi355x_simplex.h"
+
+extern "C" void mi355x_set_last_error_(const char *msg);   // simplex_capi.hip (thread-local message)
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+enum MapKind { kPositive = 0, kNegative = 1, kSigned = 2 };   // var-mapping-entry, simplex.lisp:44-46
+
+struct Mapping {
+    int     kind = kPositive;
+    int64_t col = 0;
+    double  offset = 0.0;
+};
+
+struct Constraint {
+    int op;                                   // 0: <=   1: >=   2: =
+    std::vector<int64_t> var;
+    std::vector<double>  coef;
+    double rhs;
+};
+
+struct Bound {
+    bool present = false;                     // an entry exists in problem-var-bounds
+    bool has_lb = false, has_ub = false;
+    double lb = 0.0, ub = 0.0;
+};
+
+}  // namespace
+
+struct mi355x_problem {
+    bool    is_max = true;
+    int64_t n_vars = 0;
+    std::vector<int64_t> obj_var;             // objective-func alist, in insertion order
+    std::vector<double>  obj_coef;
+    std::vector<Bound>   bounds;
+    std::vector<char>    is_integer;
+    std::vector<Constraint> constraints;
+};
+
+namespace {
+
+struct HostTableau {
+    int64_t rows = 0, cols = 0;               // rows = constraint-count + 1, cols = var-count + 1
+    std::vector<double>  M;                   // row-major, tight
+    std::vector<int64_t> basis;
+    double &at(int64_t r, int64_t c) { return M[(size_t)r * cols + c]; }
+};
+
+struct Built {
+    bool two_phase = false;
+    HostTableau main_tab, art;
+    std::vector<Mapping> map;
+    int status = MI_OK;                       // MI_UNBOUNDED from the no-constraint special case
+};
+
+// build-tableau, src/simplex.lisp:142-328 (line numbers in the comments below)
+Built build(const mi355x_problem &p)
+{
+    Built b;
+    const int64_t n = p.n_vars;
+    b.map.resize((size_t)n);
+    std::vector<Constraint> cons = p.constraints;
+
+    if (cons.empty()) {                                                   // :153-186
+        HostTableau &t = b.main_tab;
+        t.rows = n + 1; t.cols = n + 1;
+        t.M.assign((size_t)t.rows * t.cols, 0.0);
+        t.basis.resize((size_t)n);
+        std::vector<double> coef((size_t)n, 0.0);
+        std::vector<char> has_coef((size_t)n, 0);
+        for (size_t k = 0; k < p.obj_var.size(); ++k)
+            if (!has_coef[(size_t)p.obj_var[k]]) { coef[(size_t)p.obj_var[k]] = p.obj_coef[k]; has_coef[(size_t)p.obj_var[k]] = 1; }
+        double objective = 0.0;
+        for (int64_t i = 0; i < n; ++i) {
+            const Bound &bd = p.bounds[(size_t)i];
+            t.basis[(size_t)i] = i;
+            t.at(i, i) = 1.0;
+            const bool use_ub = ((0.0 <= coef[(size_t)i]) == p.is_max);
+            if (use_ub) {
+                if (!(bd.present && bd.has_ub)) { b.status = MI_UNBOUNDED; return b; }
+                b.map[(size_t)i] = {kPositive, i, bd.ub};
+                objective = objective + coef[(size_t)i] * bd.ub;
+            } else {
+                if (!(bd.present && bd.has_lb)) { b.status = MI_UNBOUNDED; return b; }
+                b.map[(size_t)i] = {kPositive, i, bd.lb};
+                objective = objective + coef[(size_t)i] * bd.lb;
+            }
+        }
+        t.at(n, n) = objective;
+        return b;
+    }
+
+    int64_t ncv = n, column = 0;                                           // :189-212
+    for (int64_t v = 0; v < n; ++v) {
+        const Bound &bd = p.bounds[(size_t)v];
+        if (!bd.present) {
+            b.map[(size_t)v] = {kPositive, column, 0.0};
+        } else if (bd.has_lb && bd.has_ub) {
+            Constraint c;
+            if (0.0 <= bd.ub) { c.op = 0; c.rhs = bd.ub; } else { c.op = 1; c.rhs = -bd.ub; }
+            c.var = {v}; c.coef = {1.0};
+            cons.insert(cons.begin(), c);                                  // (push ... constraints)
+            b.map[(size_t)v] = {kPositive, column, bd.lb};
+        } else if (bd.has_lb) {
+            b.map[(size_t)v] = {kPositive, column, bd.lb};
+        } else if (bd.has_ub) {
+            b.map[(size_t)v] = {kNegative, column, bd.ub};
+        } else {
+            b.map[(size_t)v] = {kSigned, column, 0.0};
+            ++column; ++ncv;
+        }
+        ++column;
+    }
+
+    const int64_t m = (int64_t)cons.size();                                // :214-221
+    int64_t num_slack = 0;
+    for (const auto &c : cons) if (c.op != 2) ++num_slack;
+    const int64_t num_cols = ncv + num_slack + 1;
+    HostTableau &t = b.main_tab;
+    t.rows = m + 1; t.cols = num_cols;
+    t.M.assign((size_t)t.rows * t.cols, 0.0);
+    t.basis.assign((size_t)m, 0);
+    std::vector<int64_t> art_rows;                                         // most recent first
+    int64_t col_offset = 0;
+    for (int64_t row = 0; row < m; ++row) {                                // :223-268
+        const Constraint &c = cons[(size_t)row];
+        int op = c.op;
+        t.at(row, num_cols - 1) = c.rhs;
+        for (size_t k = 0; k < c.var.size(); ++k) {
+            const Mapping &mp = b.map[(size_t)c.var[k]];
+            const double coef = c.coef[k];
+            if (mp.kind == kPositive) {
+                t.at(row, mp.col) = coef;
+                t.at(row, num_cols - 1) = t.at(row, num_cols - 1) - coef * mp.offset;
+            } else if (mp.kind == kNegative) {
+                t.at(row, mp.col) = -coef;
+                t.at(row, num_cols - 1) = t.at(row, num_cols - 1) - coef * mp.offset;
+            } else {
+                t.at(row, mp.col) = coef;
+                t.at(row, mp.col + 1) = -coef;
+            }
+        }
+        if (t.at(row, num_cols - 1) < 0.0) {                               // :243-252
+            for (int64_t cc = 0; cc < num_cols; ++cc) t.at(row, cc) = -t.at(row, cc);
+            op = (op == 0) ? 1 : (op == 1) ? 0 : 2;
+        }
+        if (op == 0) {                                                     // :254-265
+            t.at(row, ncv + col_offset) = 1.0;
+            t.basis[(size_t)row] = ncv + col_offset;
+            ++col_offset;
+        } else if (op == 1) {
+            art_rows.insert(art_rows.begin(), row);
+            t.at(row, ncv + col_offset) = -1.0;
+            t.basis[(size_t)row] = num_cols;
+            ++col_offset;
+        } else {
+            art_rows.insert(art_rows.begin(), row);
+            t.basis[(size_t)row] = num_cols;
+        }
+    }
+    for (size_t k = 0; k < p.obj_var.size(); ++k) {                        // :270-283
+        const Mapping &mp = b.map[(size_t)p.obj_var[k]];
+        const double coef = p.obj_coef[k];
+        if (mp.kind == kPositive) {
+            t.at(m, mp.col) = -coef;
+            t.at(m, num_cols - 1) = t.at(m, num_cols - 1) + coef * mp.offset;
+        } else if (mp.kind == kNegative) {
+            t.at(m, mp.col) = coef;
+            t.at(m, num_cols - 1) = t.at(m, num_cols - 1) + coef * mp.offset;
+        } else {
+            t.at(m, mp.col) = -coef;
+            t.at(m, mp.col + 1) = coef;
+        }
+    }
+    if (art_rows.empty()) return b;
+
+    b.two_phase = true;                                                    // :292-325
+    const int64_t num_art = (int64_t)art_rows.size();
+    const int64_t nac = num_cols + num_art;
+    HostTableau &a = b.art;
+    a.rows = m + 1; a.cols = nac;
+    a.M.assign((size_t)a.rows * a.cols, 0.0);
+    a.basis = t.basis;
+    std::vector<char> is_art((size_t)m, 0);
+    for (int64_t i = 0; i < num_art; ++i) {
+        const int64_t row = art_rows[(size_t)i];
+        is_art[(size_t)row] = 1;
+        a.basis[(size_t)row] = num_cols - 1 + i;
+        a.at(row, num_cols - 1 + i) = 1.0;
+    }
+    for (int64_t c = 0; c < num_cols - 1; ++c) {
+        double s = 0.0;
+        for (int64_t r = 0; r < m; ++r) {
+            a.at(r, c) = t.at(r, c);
+            if (is_art[(size_t)r]) s = s + a.at(r, c);
+        }
+        a.at(m, c) = s;
+    }
+    {
+        double s = 0.0;
+        for (int64_t r = 0; r < m; ++r) {
+            a.at(r, nac - 1) = t.at(r, num_cols - 1);
+            if (is_art[(size_t)r]) s = s + a.at(r, nac - 1);
+        }
+        a.at(m, nac - 1) = s;
+    }
+    return b;
+}
+
+int hfail(int code, const char *msg) { mi355x_set_last_error_(msg); return code; }
+
+}  // namespace
+
+struct mi355x_solution {
+    int64_t rows = 0, cols = 0;
+    std::vector<double>  last_row;            // objective row
+    std::vector<double>  last_col;            // RHS column
+    std::vector<int64_t> basis;
+    std::vector<Mapping> map;
+    int64_t n_pivots[2] = {0, 0};
+};
+
+extern "C" {
+
+int mi355x_problem_create(mi355x_problem **out, int is_max, int64_t n_vars)
+{
+    if (!out || n_vars < 1) return hfail(MI_BAD_ARG, "bad arguments");
+    mi355x_problem *p = new (std::nothrow) mi355x_problem;
+    if (!p) return hfail(MI_NO_MEMORY, "host allocation failed");
+    p->is_max = is_max != 0;
+    p->n_vars = n_vars;
+    p->bounds.resize((size_t)n_vars);
+    p->is_integer.assign((size_t)n_vars, 0);
+    *out = p;
+    return MI_OK;
+}
+
+void mi355x_problem_destroy(mi355x_problem *p) { delete p; }
+
+static int check_vars(const mi355x_problem *p, const int64_t *var, int64_t nnz)
+{
+    for (int64_t k = 0; k < nnz; ++k)
+        if (var[k] < 0 || var[k] >= p->n_vars) return 0;
+    return 1;
+}
+
+int mi355x_problem_set_objective(mi355x_problem *p, const int64_t *var, const double *coef, int64_t nnz)
+{
+    if (!p || nnz < 0 || (nnz && (!var || !coef)) || !check_vars(p, var, nnz))
+        return hfail(MI_BAD_ARG, "bad objective");
+    p->obj_var.assign(var, var + nnz);
+    p->obj_coef.assign(coef, coef + nnz);
+    return MI_OK;
+}
+
+int mi355x_problem_set_bounds(mi355x_problem *p, int64_t var, int has_lb, double lb, int has_ub, double ub)
+{
+    if (!p || var < 0 || var >= p->n_vars) return hfail(MI_BAD_ARG, "bad variable index");
+    if (has_lb && has_ub && ub < lb) return hfail(MI_BAD_ARG, "invalid bounds: upper < lower");   // invalid-bounds-error
+    Bound &b = p->bounds[(size_t)var];
+    b.present = true; b.has_lb = has_lb != 0; b.has_ub = has_ub != 0; b.lb = lb; b.ub = ub;
+    return MI_OK;
+}
+
+int mi355x_problem_set_integer(mi355x_problem *p, int64_t var)
+{
+    if (!p || var < 0 || var >= p->n_vars) return hfail(MI_BAD_ARG, "bad variable index");
+    p->is_integer[(size_t)var] = 1;
+    return MI_OK;
+}
+
+int mi355x_problem_add_constraint(mi355x_problem *p, int op, const int64_t *var, const double *coef,
+                                  int64_t nnz, double rhs)
+{
+    if (!p || nnz < 0 || (nnz && (!var || !coef)) || !check_vars(p, var, nnz))
+        return hfail(MI_BAD_ARG, "bad constraint");
+    if (op < 0 || op > 2) return hfail(MI_BAD_ARG, "not a valid constraint equation");   // parsing-error, :266
+    Constraint c;
+    c.op = op; c.rhs = rhs;
+    c.var.assign(var, var + nnz);
+    c.coef.assign(coef, coef + nnz);
+    p->constraints.push_back(std::move(c));
+    return MI_OK;
+}
+
+int mi355x_build_tableau(const mi355x_problem *p, int which, int64_t *rows, int64_t *cols,
+                         double *matrix, int64_t *basis, int *two_phase)
+{
+    if (!p) return hfail(MI_BAD_ARG, "problem is NULL");
+    const Built b = build(*p);
+    if (b.status != MI_OK) return b.status;
+    if (two_phase) *two_phase = b.two_phase ? 1 : 0;
+    if (which != 0 && !b.two_phase) return hfail(MI_BAD_ARG, "no artificial tableau for this problem");
+    const HostTableau &t = which ? b.art : b.main_tab;
+    if (rows) *rows = t.rows;
+    if (cols) *cols = t.cols;
+    if (matrix) std::memcpy(matrix, t.M.data(), t.M.size() * sizeof(double));
+    if (basis && !t.basis.empty()) std::memcpy(basis, t.basis.data(), t.basis.size() * sizeof(int64_t));
+    return MI_OK;
+}
+
+int mi355x_var_mapping(const mi355x_problem *p, int64_t var, int *kind, int64_t *col, double *offset)
+{
+    if (!p || var < 0 || var >= p->n_vars) return hfail(MI_BAD_ARG, "bad variable index");
+    const Built b = build(*p);
+    if (b.status != MI_OK) return b.status;
+    if (kind) *kind = b.map[(size_t)var].kind;
+    if (col) *col = b.map[(size_t)var].col;
+    if (offset) *offset = b.map[(size_t)var].offset;
+    return MI_OK;
+}
+
+int mi355x_simplex_solver(const mi355x_problem *p, double fp_tolerance, int device,
+                          mi355x_solution **out)
+{
+    if (!p || !out) return hfail(MI_BAD_ARG, "NULL argument");
+    *out = nullptr;
+    for (char f : p->is_integer)
+        if (f) return hfail(MI_UNSUPPORTED, "integer constraints cannot be handled by the mi355x-simplex solver");
+    Built b = build(*p);
+    if (b.status != MI_OK) return b.status;
+    mi355x_solution *s = new (std::nothrow) mi355x_solution;
+    if (!s) return hfail(MI_NO_MEMORY, "host allocation failed");
+    HostTableau &t = b.main_tab;
+    s->rows = t.rows; s->cols = t.cols;
+    s->map = b.map;
+    s->last_row.resize((size_t)t.cols);
+    s->last_col.resize((size_t)t.rows);
+    s->basis.resize((size_t)std::max<int64_t>(t.rows - 1, 0));
+    mi355x_tab *mt = nullptr, *at = nullptr;
+    int rc = mi355x_tab_create(&mt, t.rows, t.cols, t.M.data(), t.basis.empty() ? nullptr : t.basis.data(), device);
+    if (rc == MI_OK && b.two_phase)
+        rc = mi355x_tab_create(&at, b.art.rows, b.art.cols, b.art.M.data(), b.art.basis.data(), device);
+    if (rc == MI_OK) {
+        if (b.two_phase) rc = mi355x_solve_two_phase(at, mt, p->is_max ? 1 : 0, fp_tolerance, s->n_pivots);
+        else             rc = mi355x_tab_solve(mt, p->is_max ? 1 : 0, fp_tolerance, 0, &s->n_pivots[1]);
+    }
+    int drc = MI_OK;
+    if (rc == MI_OPTIMAL)
+        drc = mi355x_tab_download(mt, nullptr, s->basis.empty() ? nullptr : s->basis.data(),
+                                  s->last_row.data(), s->last_col.data());
+    mi355x_tab_destroy(at);
+    mi355x_tab_destroy(mt);
+    if (rc != MI_OPTIMAL || drc != MI_OK) { delete s; return rc != MI_OPTIMAL ? rc : drc; }
+    *out = s;
+    return MI_OPTIMAL;
+}
+
+void mi355x_solution_destroy(mi355x_solution *s) { delete s; }
+
+int mi355x_solution_objective_value(const mi355x_solution *s, double *out)
+{
+    if (!s || !out) return hfail(MI_BAD_ARG, "NULL argument");
+    *out = s->last_row[(size_t)s->cols - 1];                                // simplex.lisp:74-78
+    return MI_OK;
+}
+
+static double basic_value(const mi355x_solution *s, int64_t col)
+{
+    for (size_t i = 0; i < s->basis.size(); ++i)                            // `position`: first match
+        if (s->basis[i] == col) return s->last_col[i];
+    return 0.0;
+}
+
+int mi355x_solution_variable(const mi355x_solution *s, int64_t var, double *out)
+{
+    if (!s || !out) return hfail(MI_BAD_ARG, "NULL argument");
+    if (var < 0 || var >= (int64_t)s->map.size()) return hfail(MI_BAD_ARG, "not a variable in the tableau");
+    const Mapping &mp = s->map[(size_t)var];                                // simplex.lisp:81-107
+    if (mp.kind == kPositive)      *out = mp.offset + basic_value(s, mp.col);
+    else if (mp.kind == kNegative) *out = mp.offset + (-basic_value(s, mp.col));
+    else                           *out = basic_value(s, mp.col) - basic_value(s, mp.col + 1);
+    return MI_OK;
+}
+
+int mi355x_solution_reduced_cost(const mi355x_solution *s, int64_t var, double *out)
+{
+    if (!s || !out) return hfail(MI_BAD_ARG, "NULL argument");
+    if (var < 0 || var >= (int64_t)s->map.size()) return hfail(MI_BAD_ARG, "not a variable in the tableau");
+    const Mapping &mp = s->map[(size_t)var];                                // simplex.lisp:111-120
+    if (mp.kind != kPositive) return hfail(MI_BAD_ARG, "variable has no lower bound");
+    *out = s->last_row[(size_t)mp.col];
+    return MI_OK;
+}
+
+int mi355x_solution_pivots(const mi355x_solution *s, int64_t *phase1, int64_t *phase2)
+{
+    if (!s) return hfail(MI_BAD_ARG, "NULL argument");
+    if (phase1) *phase1 = s->n_pivots[0];
+    if (phase2) *phase2 = s->n_pivots[1];
+    return MI_OK;
+}
+
+}  // extern "C"

@@ -260,6 +260,7 @@ extern "C" {
 int mi355x_abi_version(void) { return MI355X_SIMPLEX_ABI_VERSION; }
 int mi355x_device_count(void) { return device_count_checked(); }
 const char *mi355x_last_error(void) { return g_err.c_str(); }
+void mi355x_set_last_error_(const char *msg) { g_err = msg ? msg : ""; }   // for host_problem.cpp
 double mi355x_epsilon(void) { return kClEpsilon; }
 const char *mi355x_update_kernel_name(void) { return update_kernel_symbol(); }
 

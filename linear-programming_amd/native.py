@@ -1,0 +1,136 @@
+"""ctypes view of the NATIVE host side of the hook (csrc/host_problem.cpp): problem ->
+build-tableau -> n-solve-tableau on the GPU -> light solution object, all in C++ behind the C
+ABI (mi355x_problem_*, mi355x_build_tableau, mi355x_simplex_solver, mi355x_solution_*).  This
+is what a non-Lisp, non-Python caller links against; simplex.py keeps the reference-named Python
+mirror used by most tests."""
+import ctypes
+
+import numpy as np
+
+from . import capi
+from .conditions import (InfeasibleProblemError, SolverError, UnboundedProblemError,
+                         UnsupportedConstraintError)
+
+_OPS = {"<=": 0, ">=": 1, "=": 2}
+
+
+def _arr(xs, dt):
+    a = np.ascontiguousarray(xs, dtype=dt)
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+class NativeProblem:
+    """A mi355x_problem built from a `Problem` (src/problem.lisp:45-53 in parsed form)."""
+
+    def __init__(self, problem):
+        L = capi.lib()
+        self.problem = problem
+        self.index = {v: i for i, v in enumerate(problem.vars)}
+        h = ctypes.c_void_p()
+        capi.check(L.mi355x_problem_create(ctypes.byref(h), int(problem.type == "max"),
+                                           len(problem.vars)), "mi355x_problem_create")
+        self._h = h
+        v, vp = _arr([self.index[x] for x, _ in problem.objective_func], np.int64)
+        c, cp = _arr([float(k) for _, k in problem.objective_func], np.float64)
+        capi.check(L.mi355x_problem_set_objective(h, vp, cp, len(v)), "set_objective")
+        for var, (lb, ub) in problem.var_bounds:
+            capi.check(L.mi355x_problem_set_bounds(h, self.index[var], int(lb is not None),
+                                                   float(lb or 0), int(ub is not None),
+                                                   float(ub or 0)), "set_bounds")
+        for var in problem.integer_vars:
+            capi.check(L.mi355x_problem_set_integer(h, self.index[var]), "set_integer")
+        for op, expr, rhs in problem.constraints:
+            v, vp = _arr([self.index[x] for x, _ in expr], np.int64)
+            c, cp = _arr([float(k) for _, k in expr], np.float64)
+            capi.check(L.mi355x_problem_add_constraint(h, _OPS.get(op, -1), vp, cp, len(v),
+                                                       float(rhs)), "add_constraint")
+
+    def build_tableau(self):
+        """[(matrix, basis)] for a single-phase problem, [(art...), (main...)] for two-phase."""
+        L = capi.lib()
+        two = ctypes.c_int(0)
+        out = []
+        rc = L.mi355x_build_tableau(self._h, 0, None, None, None, None, ctypes.byref(two))
+        if rc == capi.MI_UNBOUNDED:
+            raise UnboundedProblemError()
+        capi.check(rc, "mi355x_build_tableau")
+        for which in ([1, 0] if two.value else [0]):
+            r, c = ctypes.c_int64(0), ctypes.c_int64(0)
+            capi.check(L.mi355x_build_tableau(self._h, which, ctypes.byref(r), ctypes.byref(c), None,
+                                              None, None), "mi355x_build_tableau")
+            M = np.empty((r.value, c.value))
+            b = np.empty(r.value - 1, dtype=np.int64)
+            capi.check(L.mi355x_build_tableau(self._h, which, None, None,
+                                              M.ctypes.data_as(ctypes.c_void_p),
+                                              b.ctypes.data_as(ctypes.c_void_p) if b.size else None,
+                                              None), "mi355x_build_tableau")
+            out.append((M, b))
+        return out
+
+    def var_mapping(self, var):
+        k, c, o = ctypes.c_int(0), ctypes.c_int64(0), ctypes.c_double(0)
+        capi.check(capi.lib().mi355x_var_mapping(self._h, self.index[var], ctypes.byref(k),
+                                                 ctypes.byref(c), ctypes.byref(o)), "var_mapping")
+        kind = ("positive", "negative", "signed")[k.value]
+        return (kind, c.value) if kind == "signed" else (kind, c.value, o.value)
+
+    def solve(self, fp_tolerance=1024, device=0):
+        """mi355x_simplex_solver: returns a NativeSolution or raises the reference's errors."""
+        s = ctypes.c_void_p()
+        rc = capi.lib().mi355x_simplex_solver(self._h, float(fp_tolerance), device, ctypes.byref(s))
+        if rc == capi.MI_UNBOUNDED:
+            raise UnboundedProblemError()
+        if rc == capi.MI_INFEASIBLE:
+            raise InfeasibleProblemError()
+        if rc == capi.MI_UNSUPPORTED:
+            raise UnsupportedConstraintError(("integer",) + tuple(self.problem.integer_vars),
+                                             "mi355x-simplex")
+        if rc in (capi.MI_ART_NONZERO, capi.MI_ART_STUCK):
+            raise SolverError("artificial variable could not be removed from the basis")
+        capi.check(rc, "mi355x_simplex_solver")
+        return NativeSolution(self, s)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            capi.lib().mi355x_problem_destroy(h)
+
+
+class NativeSolution:
+    def __init__(self, nproblem, handle):
+        self.nproblem, self._h = nproblem, handle
+
+    def objective_value(self):
+        x = ctypes.c_double(0)
+        capi.check(capi.lib().mi355x_solution_objective_value(self._h, ctypes.byref(x)), "objective")
+        return x.value
+
+    def variable(self, var):
+        if var == self.nproblem.problem.objective_var:
+            return self.objective_value()
+        if var not in self.nproblem.index:
+            raise KeyError("%s is not a variable in the tableau" % (var,))
+        x = ctypes.c_double(0)
+        capi.check(capi.lib().mi355x_solution_variable(self._h, self.nproblem.index[var],
+                                                       ctypes.byref(x)), "variable")
+        return x.value
+
+    def reduced_cost(self, var):
+        if var not in self.nproblem.index:
+            raise KeyError("%s is not a variable in the tableau" % (var,))
+        x = ctypes.c_double(0)
+        rc = capi.lib().mi355x_solution_reduced_cost(self._h, self.nproblem.index[var], ctypes.byref(x))
+        if rc == capi.MI_BAD_ARG:
+            raise ValueError("%s has no lower bound" % (var,))
+        capi.check(rc, "reduced_cost")
+        return x.value
+
+    def pivots(self):
+        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+        capi.check(capi.lib().mi355x_solution_pivots(self._h, ctypes.byref(a), ctypes.byref(b)), "pivots")
+        return a.value, b.value
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            capi.lib().mi355x_solution_destroy(h)

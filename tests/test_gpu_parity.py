@@ -183,6 +183,38 @@ def test_golden_answers_and_oracle_bits(golden, name):
         assert abs(lp.solution_objective_value(solution) - float(np.float32(spec["value"]))) <= tol
 
 
+@pytest.mark.parametrize("name", ANSWER_CASES)
+def test_native_solver_golden_answers(golden, name):
+    """The all-C++ path (mi355x_simplex_solver + light solution object) on the same goldens."""
+    case = golden["cases"][name]
+    problem = _problem(case)
+    f32 = bool(case.get("float32_literals"))
+    sol = lp.NativeProblem(problem).solve()
+    ref = lp.solve_problem(problem)
+    assert sol.objective_value() == lp.solution_objective_value(ref)
+    for v in problem.vars:
+        assert sol.variable(v) == lp.solution_variable(ref, v)
+
+    def close(a, b):
+        return abs(a - float(b)) <= 1e-10 * max(1.0, abs(float(b)))
+    if "objective" in case:
+        assert close(sol.objective_value(), frac(case["objective"], f32))
+    for v, e in case.get("variables", {}).items():
+        assert close(sol.variable(v), frac(e, f32)), v
+    for v, e in case.get("reduced_costs", {}).items():
+        assert close(sol.reduced_cost(v), frac(e, f32)), v
+    for v in case.get("reduced_cost_errors", []):
+        with pytest.raises((KeyError, ValueError)):
+            sol.reduced_cost(v)
+
+
+def test_native_solver_errors(golden):
+    with pytest.raises(lp.InfeasibleProblemError):
+        lp.NativeProblem(_problem(golden["cases"]["infeasible"])).solve()
+    with pytest.raises(lp.UnboundedProblemError):
+        lp.NativeProblem(_problem(golden["cases"]["unbounded"])).solve()
+
+
 def test_integer_problems_are_declined(golden):
     """A backend must signal unsupported-constraint-error for what it does not handle
     (src/conditions.lisp:69-77); B&B stays with the reference's own solver."""
@@ -304,6 +336,33 @@ def test_two_phase_bitwise_vs_oracle(n, mle, mge, meq, seed):
             lp.n_solve_tableau(tabs)
     assert np.array_equal(art.matrix, A_or) and np.array_equal(art.basis_columns, ab_or)
     assert np.array_equal(main.matrix, M_or) and np.array_equal(main.basis_columns, b_or)
+
+
+def test_degenerate_shapes():
+    """Edge shapes: no constraint rows at all, a single column, one row x many columns, many
+    rows x few columns, a 1 x 1 tableau -- same outcome and bits as the oracle."""
+    def both(M0, b0, is_max=True):
+        M, b = M0.copy(), b0.copy()
+        st, n, tr = oracle.solve(M, b, is_max=is_max, trace_cap=4096)
+        t = lp.Tableau(None, lp.Problem(type="max" if is_max else "min"), M0, b0,
+                       M0.shape[1] - 1, M0.shape[0] - 1, {})
+        rc = lp.capi.lib().mi355x_tab_solve(t._h, int(is_max), 1024.0, 0, None)
+        t._touch()
+        assert rc == st
+        assert np.array_equal(t.matrix, M) and np.array_equal(t.basis_columns, b)
+        assert np.array_equal(t.pivot_trace(), tr)
+        return st
+    e = np.zeros(0, dtype=np.int64)
+    assert both(np.array([[3.0]]), e) == oracle.OPTIMAL                       # 1 x 1: nothing to price
+    assert both(np.array([[0.5, -1.0, 2.0, 7.0]]), e) == oracle.UNBOUNDED     # objective row only
+    assert both(np.array([[0.5, 1.0, 2.0, 7.0]]), e) == oracle.OPTIMAL
+    assert both(np.array([[0.5, -1.0, 2.0, 7.0]]), e, is_max=False) == oracle.UNBOUNDED
+    M0, b0 = lp.synth.tableau(20000, 1, 3)                                     # one constraint
+    assert both(M0, b0) == oracle.OPTIMAL
+    M0, b0 = lp.synth.tableau(3, 5000, 4)                                      # tall and thin
+    assert both(M0, b0) == oracle.OPTIMAL
+    M0 = np.array([[1.0, 4.0], [-1.0, 0.0]])                                   # one variable column
+    assert both(M0, np.array([0], dtype=np.int64)) == oracle.OPTIMAL
 
 
 def test_forced_pivot_sequence_bitwise():

@@ -142,3 +142,59 @@ def test_integer_problems_are_declined_before_any_device_work(golden):
     p.integer_vars = ["x", "y"]
     with pytest.raises(lp.UnsupportedConstraintError):
         lp.solve_problem(p)
+
+
+# ------------------------------------------------------------------ native (C++) host side
+ALL_LP = ["basic", "equality", "geq", "free_x", "free_x_negative", "ub_only_x", "lb_x", "range_y",
+          "free_z_reduced_cost", "widgets", "excessive_constraints", "numerical_issue",
+          "variable_bounds_bug", "variable_bounds_only"]
+
+
+@pytest.mark.parametrize("name", ALL_LP)
+def test_native_build_tableau_equals_python_mirror(golden, name):
+    """csrc/host_problem.cpp's build-tableau (C++) and simplex.py's (Python) produce the same
+    tableaux bit for bit, and both match the goldens / the rational restatement above."""
+    p = _problem(golden["cases"][name])
+    py = lp.build_tableau(p, p)
+    py = py if isinstance(py, list) else [py]
+    nat = lp.NativeProblem(p)
+    got = nat.build_tableau()
+    assert len(got) == len(py)
+    for (M, b), t in zip(got, py):
+        assert np.array_equal(M, t.matrix) and np.array_equal(b, t.basis_columns)
+    for var in p.vars:
+        exp = py[-1].var_mapping[var]
+        assert nat.var_mapping(var) == tuple(exp)
+
+
+def test_native_build_tableau_golden_matrices(golden):
+    for name in ["basic", "equality", "geq"]:
+        case = golden["cases"][name]
+        got = lp.NativeProblem(_problem(case)).build_tableau()
+        assert np.array_equal(got[-1][0], np.array(fmat(case["initial"]["matrix"]), dtype=float))
+        assert got[-1][1].tolist() == case["initial"]["basis"]
+        if "initial_art" in case:
+            assert np.array_equal(got[0][0], np.array(fmat(case["initial_art"]["matrix"]), dtype=float))
+            assert got[0][1].tolist() == case["initial_art"]["basis"]
+
+
+def test_native_problem_validation():
+    L = lp.capi.lib()
+    import ctypes
+    h = ctypes.c_void_p()
+    assert L.mi355x_problem_create(ctypes.byref(h), 1, 0) == lp.capi.MI_BAD_ARG
+    assert L.mi355x_problem_create(ctypes.byref(h), 1, 2) == 0
+    v = np.array([0, 5], dtype=np.int64)
+    c = np.array([1.0, 1.0])
+    vp, cp = v.ctypes.data_as(ctypes.c_void_p), c.ctypes.data_as(ctypes.c_void_p)
+    assert L.mi355x_problem_set_objective(h, vp, cp, 2) == lp.capi.MI_BAD_ARG      # var 5 of 2
+    assert L.mi355x_problem_add_constraint(h, 3, vp, cp, 1, 1.0) == lp.capi.MI_BAD_ARG  # bad op
+    assert L.mi355x_problem_set_bounds(h, 0, 1, 2.0, 1, 1.0) == lp.capi.MI_BAD_ARG  # ub < lb
+    assert L.mi355x_problem_set_bounds(h, 0, 1, 1.0, 1, 2.0) == 0
+    L.mi355x_problem_destroy(h)
+    p = lp.Problem(type="max", vars=["x"], objective_func=[("x", 1)])               # unbounded, no rows
+    with pytest.raises(lp.UnboundedProblemError):
+        lp.NativeProblem(p).build_tableau()
+    p.integer_vars = ["x"]
+    with pytest.raises(lp.UnsupportedConstraintError):
+        lp.NativeProblem(p).solve()
