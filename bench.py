@@ -218,6 +218,13 @@ def main():
         sys.exit("rank %d: the LP terminated (status %d) after %d of %d timed pivots -- "
                  "use fewer steps" % (rank, rc, done, args.steps))
 
+    compact, stored_cols, stored_ld = ctypes.c_int(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    L.mi355x_tab_layout(h, ctypes.byref(compact), ctypes.byref(stored_cols), ctypes.byref(stored_ld))
+    # bytes the update kernel has to move per launch in the representation it runs on: every
+    # STORED element read once + written once.  Dense: C = n+m+1 columns (SURVEY 8d's figure);
+    # compact: only the n non-basic columns + RHS carry information.
+    kernel_bytes = 2 * R * stored_cols.value * 8
+
     upd_avg_ms = None
     if not args.no_events:
         nl, sm, mn = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
@@ -234,14 +241,17 @@ def main():
         value = N * args.steps / elapsed
         roofline = None
         if upd_avg_ms:
-            ach = bytes_per_pivot / (upd_avg_ms * 1e-3) / 1e9
+            ach = kernel_bytes / (upd_avg_ms * 1e-3) / 1e9
             traffic, traffic_src = pmc_traffic(args.workload)
             roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
                         "traffic_source": traffic_src,
                         "kernel": L.mi355x_update_kernel_name().decode(),
                         "kernel_avg_us": upd_avg_ms * 1e3,
-                        "algorithmic_bytes_per_launch": bytes_per_pivot,
+                        "algorithmic_bytes_per_launch": kernel_bytes,
+                        "representation": "compact [non-basic columns | RHS], %d of %d columns stored"
+                                          % (stored_cols.value, C) if compact.value else "dense",
+                        "dense_tableau_bytes_per_pivot": bytes_per_pivot,
                         "launches_timed": int(nl.value)}
         rec = {
             "metric": "simplex pivots/sec + achieved HBM GB/s, dense 8192x4096 f64 tableau"
@@ -254,7 +264,8 @@ def main():
                                    "%dx%d f64 tableau, one independent LP per GPU" % (cfg, n, m, R, C),
                        "tableau_bytes": R * C * 8, "fp_tolerance": 1024,
                        "parallelism": "independent LPs, %d rank(s), no collective" % N},
-            "whole_pivot_GBps": bytes_per_pivot * value / N / 1e9,
+            "whole_pivot_GBps": kernel_bytes * value / N / 1e9,
+            "dense_equivalent_GBps": bytes_per_pivot * value / N / 1e9,
             "roofline": roofline,
         }
         if N == 1 and not args.no_cpu_baseline:

@@ -86,6 +86,15 @@ int  mi355x_tab_create_synthetic(mi355x_tab **out, int64_t n_vars, int64_t n_con
 void mi355x_tab_destroy(mi355x_tab *t);
 int  mi355x_tab_shape(const mi355x_tab *t, int64_t *rows, int64_t *cols, int64_t *ld);
 
+/* Which representation currently holds the tableau in HBM.  The solve entry points run on the
+ * COMPACT representation [non-basic columns | RHS] (rows x (var_count - constraint_count + 1))
+ * whenever the basis columns are exact unit vectors -- they are for every tableau
+ * build-tableau produces, and pivoting keeps them so -- because basic columns never change
+ * under a pivot; every other entry point sees the dense logical tableau (rebuilt on demand),
+ * so the representation is invisible except through this query.  *stored_cols includes the
+ * RHS column. */
+int  mi355x_tab_layout(const mi355x_tab *t, int *compact, int64_t *stored_cols, int64_t *stored_ld);
+
 /* ---- the hot path ------------------------------------------------------------------ */
 /* n-pivot-row (src/simplex.lisp:337-359): normalise row `pivot_row` by its entry in
  * `entering_col`, eliminate that column from every other row (objective row included),

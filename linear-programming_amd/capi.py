@@ -26,6 +26,7 @@ SIGNATURES = {
     "mi355x_tab_create_synthetic": (_int, [_pp, _i64, _i64, ctypes.c_uint64, _i64, _i64, _int]),
     "mi355x_tab_destroy": (None, [_p]),
     "mi355x_tab_shape": (_int, [_p, _p, _p, _p]),
+    "mi355x_tab_layout": (_int, [_p, _p, _p, _p]),
     "mi355x_tab_pivot": (_int, [_p, _i64, _i64]),
     "mi355x_tab_price": (_int, [_p, _int, _dbl, _p]),
     "mi355x_tab_ratio": (_int, [_p, _i64, _dbl, _p]),
@@ -71,6 +72,7 @@ _EXTRA = {
     "mi355x_tune_variant_name": (ctypes.c_char_p, [_int]),
     "mi355x_tune_set_variant": (_int, [_int]),
     "mi355x_tune_set_select_mode": (_int, [_int]),
+    "mi355x_tune_set_compact": (_int, [_int]),
 }
 
 _lib = None

@@ -23,6 +23,7 @@ namespace {
 
 thread_local std::string g_err;
 int g_select_mode = 0;                    // 0 auto, 1 single workgroup, 2 split (tuning/test hook)
+int g_compact_enabled = 1;                // solve loops run on the compact representation
 
 int fail(int code, const char *fmt, ...)
 {
@@ -69,6 +70,12 @@ struct mi355x_tab {
     hipStream_t stream = nullptr;
     Ctl        *h_ctl = nullptr;          // pinned host mirror of the control block
     int64_t     pivots_before = 0;        // (unused by the ABI; kept for debugging)
+    TabView     c{};                      // compact view [non-basic columns | RHS]; shares
+                                          // basis / col / prow / ctl / trace / partials with v
+    bool        compact = false;          // which representation currently holds the tableau
+    bool        compact_failed = false;   // basis is not a set of unit columns: stay dense
+    int64_t    *brow = nullptr;           // scratch for k_expand (var_count entries)
+    int        *flag = nullptr;           // verification flag
     int         n_part = 0;               // pricing partials left by the last update (0 = none)
     int         part_is_max = -1;         // ... and the problem sense they were computed for
     int         shard_is_max = 1;         // sense last given to mi355x_shard_price
@@ -107,6 +114,11 @@ void free_tab(mi355x_tab *t)
     (void)hipFree(t->v.trace_cr);
     (void)hipFree(t->v.part_v);
     (void)hipFree(t->v.part_i);
+    (void)hipFree(t->c.M);
+    (void)hipFree(t->c.p2l);
+    (void)hipFree(t->c.l2p);
+    (void)hipFree(t->brow);
+    (void)hipFree(t->flag);
     if (t->h_ctl) (void)hipHostFree(t->h_ctl);
     if (t->own_stream) (void)hipStreamDestroy(t->own_stream);
     delete t;
@@ -185,6 +197,8 @@ int upload(mi355x_tab *t, const double *hm, const int64_t *hb)
 {
     const TabView &v = t->v;
     t->n_part = 0;
+    t->compact = false;                   // the dense logical tableau is (re)defined by the caller
+    t->compact_failed = false;
     if (hm) {
         const size_t all_rows = (size_t)v.rows * v.n_lps;     // LPs of a batch are stacked
         if (v.ld != v.cols)    // zero the padding columns once per upload
@@ -208,17 +222,81 @@ int read_ctl(mi355x_tab *t)
     return MI_OK;
 }
 
+// ---- representation changes -------------------------------------------
+TabView &cur(mi355x_tab *t) { return t->compact ? t->c : t->v; }
+
+// Rebuild the dense logical tableau from the compact representation (no-op when dense).
+int ensure_dense(mi355x_tab *t)
+{
+    if (!t->compact) return MI_OK;
+    launch_expand(t->v, t->c, t->brow, t->stream);
+    HIP_TRY(hipGetLastError());
+    t->compact = false;
+    t->n_part = 0;
+    return MI_OK;
+}
+
+// Switch to [non-basic columns | RHS] if the basis columns are exactly unit vectors (they are
+// for everything build-tableau produces and stay so under pivoting); otherwise stay dense.
+int ensure_compact(mi355x_tab *t)
+{
+    TabView &v = t->v;
+    const int64_t m = v.rows - 1, vc = v.cols - 1, n_nb = vc - m;
+    if (t->compact || !g_compact_enabled || t->compact_failed || v.n_lps != 1 || m < 1 || n_nb < 1)
+        return MI_OK;
+    t->compact_failed = true;                         // until proven otherwise
+    std::vector<int64_t> basis((size_t)m);
+    HIP_TRY(hipMemcpyAsync(basis.data(), v.basis, m * sizeof(int64_t), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    std::vector<int64_t> l2p((size_t)vc, 0), p2l;
+    for (int64_t i = 0; i < m; ++i) {
+        const int64_t b = basis[(size_t)i];
+        if (b < 0 || b >= vc || l2p[(size_t)b] == -1) return MI_OK;     // out of range / repeated
+        l2p[(size_t)b] = -1;
+    }
+    if (!t->flag) HIP_TRY(hipMalloc((void **)&t->flag, sizeof(int)));
+    HIP_TRY(hipMemsetAsync(t->flag, 0, sizeof(int), t->stream));
+    launch_verify_basis(v, t->flag, t->stream);
+    int bad = 1;
+    HIP_TRY(hipMemcpyAsync(&bad, t->flag, sizeof(int), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    if (bad) return MI_OK;
+    p2l.reserve((size_t)n_nb);
+    for (int64_t cidx = 0; cidx < vc; ++cidx)
+        if (l2p[(size_t)cidx] != -1) { l2p[(size_t)cidx] = (int64_t)p2l.size(); p2l.push_back(cidx); }
+    if (!t->c.M) {
+        t->c = v;                                     // shares every auxiliary buffer
+        t->c.M = nullptr; t->c.p2l = nullptr; t->c.l2p = nullptr;
+        t->c.cols = n_nb + 1;
+        t->c.ld = padded_ld(n_nb + 1);
+        HIP_TRY(hipMalloc((void **)&t->c.M, (size_t)v.rows * t->c.ld * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&t->c.p2l, n_nb * sizeof(int64_t)));
+        HIP_TRY(hipMalloc((void **)&t->c.l2p, vc * sizeof(int64_t)));
+        HIP_TRY(hipMalloc((void **)&t->brow, vc * sizeof(int64_t)));
+    }
+    HIP_TRY(hipMemcpyAsync(t->c.p2l, p2l.data(), n_nb * sizeof(int64_t), hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(hipMemcpyAsync(t->c.l2p, l2p.data(), vc * sizeof(int64_t), hipMemcpyHostToDevice, t->stream));
+    launch_compact(v, t->c, t->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(t->stream));         // p2l / l2p host vectors go out of scope
+    t->compact = true;
+    t->compact_failed = false;
+    t->n_part = 0;
+    return MI_OK;
+}
+
 // select of one iteration; prices from the partials of the preceding update when they exist
 void enqueue_select(mi355x_tab *t, int is_max, double f)
 {
     const int np = (t->n_part > 0 && t->part_is_max == (is_max ? 1 : 0)) ? t->n_part : 0;
     // single-workgroup select for small tableaux (fewest launches), split select for large
     // ones (the strided column gather needs many workgroups' memory pipelines)
-    bool split = (t->v.rows > 1024 || t->v.ld > 4096);
+    const TabView &v = cur(t);
+    bool split = (v.rows > 1024 || v.ld > 4096);
     if (g_select_mode == 1) split = false;
     if (g_select_mode == 2) split = true;
-    if (split && select_split_supported(t->v)) launch_select_split(t->v, is_max, f, np, t->stream);
-    else                                       launch_select(t->v, is_max, f, np, t->stream);
+    if (split && select_split_supported(v)) launch_select_split(v, is_max, f, np, t->stream);
+    else                                    launch_select(v, is_max, f, np, t->stream);
 }
 
 // update of one iteration (+ optional event pair around it); prices the new objective row
@@ -236,7 +314,7 @@ int enqueue_update(mi355x_tab *t, int is_max)
         }
         HIP_TRY(hipEventRecord(t->ev0[t->n_timed], t->stream));
     }
-    t->n_part = launch_update(t->v, is_max ? 1.0 : -1.0, 1, t->stream);
+    t->n_part = launch_update(cur(t), is_max ? 1.0 : -1.0, 1, t->stream);
     t->part_is_max = is_max ? 1 : 0;
     if (timed) {
         HIP_TRY(hipEventRecord(t->ev1[t->n_timed], t->stream));
@@ -289,7 +367,9 @@ int mi355x_tab_copy(mi355x_tab **out, const mi355x_tab *src)
 {
     if (!src) return fail(MI_BAD_ARG, "src is NULL");
     mi355x_tab *t = nullptr;
-    int rc = alloc_tab(&t, src->v.rows, src->v.cols, src->device);
+    int rc = ensure_dense(const_cast<mi355x_tab *>(src));
+    if (rc != MI_OK) return rc;
+    rc = alloc_tab(&t, src->v.rows, src->v.cols, src->device);
     if (rc != MI_OK) return rc;
     hipError_t e = hipStreamSynchronize(src->stream);
     if (e == hipSuccess)
@@ -337,6 +417,16 @@ int mi355x_tab_shape(const mi355x_tab *t, int64_t *rows, int64_t *cols, int64_t 
     return MI_OK;
 }
 
+int mi355x_tab_layout(const mi355x_tab *t, int *compact, int64_t *stored_cols, int64_t *stored_ld)
+{
+    if (!t) return fail(MI_BAD_ARG, "handle is NULL");
+    const TabView &v = t->compact ? t->c : t->v;
+    if (compact) *compact = t->compact ? 1 : 0;
+    if (stored_cols) *stored_cols = v.cols;
+    if (stored_ld) *stored_ld = v.ld;
+    return MI_OK;
+}
+
 int mi355x_tab_pivot(mi355x_tab *t, int64_t ec, int64_t cr)
 {
     if (!t) return fail(MI_BAD_ARG, "handle is NULL");
@@ -344,6 +434,8 @@ int mi355x_tab_pivot(mi355x_tab *t, int64_t ec, int64_t cr)
         return fail(MI_BAD_ARG, "pivot (col %lld, row %lld) outside %lldx%lld", (long long)ec,
                     (long long)cr, (long long)t->v.rows, (long long)t->v.cols);
     int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    rc = ensure_dense(t);
     if (rc != MI_OK) return rc;
     launch_prepare_pivot(t->v, ec, cr, t->stream);
     launch_update(t->v, 1.0, 0, t->stream);
@@ -357,6 +449,8 @@ int mi355x_tab_price(mi355x_tab *t, int is_max, double f, int64_t *col)
 {
     if (!t || !col) return fail(MI_BAD_ARG, "NULL argument");
     int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    rc = ensure_dense(t);
     if (rc != MI_OK) return rc;
     launch_price_only(t->v, is_max, f, t->stream);
     HIP_TRY(hipGetLastError());
@@ -372,6 +466,8 @@ int mi355x_tab_ratio(mi355x_tab *t, int64_t ec, double f, int64_t *row)
     if (ec < 0 || ec >= t->v.cols) return fail(MI_BAD_ARG, "entering column %lld out of range", (long long)ec);
     int rc = use_device(t);
     if (rc != MI_OK) return rc;
+    rc = ensure_dense(t);
+    if (rc != MI_OK) return rc;
     launch_ratio_only(t->v, ec, f, t->stream);
     HIP_TRY(hipGetLastError());
     rc = read_ctl(t);
@@ -385,6 +481,8 @@ int mi355x_tab_solve_async(mi355x_tab *t, int is_max, double f, int64_t n_pivots
     if (!t) return fail(MI_BAD_ARG, "handle is NULL");
     if (n_pivots < 0) return fail(MI_BAD_ARG, "n_pivots < 0");
     int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    rc = ensure_compact(t);
     if (rc != MI_OK) return rc;
     if (reset) launch_ctl_reset(t->v, 0, 0, t->stream);
     for (int64_t i = 0; i < n_pivots; ++i) {
@@ -423,6 +521,8 @@ int mi355x_tab_solve(mi355x_tab *t, int is_max, double f, int64_t max_pivots, in
     if (max_pivots < 0) return fail(MI_BAD_ARG, "max_pivots < 0");
     int rc = use_device(t);
     if (rc != MI_OK) return rc;
+    rc = ensure_compact(t);
+    if (rc != MI_OK) return rc;
     launch_ctl_reset(t->v, max_pivots, 0, t->stream);
     // Blind enqueue in growing chunks, one status read-back per chunk.  The stream always
     // ends on a select (it is the select that detects optimality / unboundedness / the cap);
@@ -458,6 +558,10 @@ int mi355x_solve_two_phase(mi355x_tab *art, mi355x_tab *mt, int main_is_max, dou
     int rc = mi355x_tab_solve(art, /*is_max=*/0, f, 0, &n1);             // simplex.lisp:403
     if (n_pivots) n_pivots[0] = n1;
     if (rc != MI_OPTIMAL) return rc;
+    rc = ensure_dense(art);                // the hand-over works on the logical tableaux
+    if (rc != MI_OK) return rc;
+    rc = ensure_dense(mt);
+    if (rc != MI_OK) return rc;
     // (fp= 0 objective factor)                                             simplex.lisp:405-407
     double art_obj = 0.0;
     HIP_TRY(hipMemcpyAsync(&art_obj, art->v.M + m * art->v.ld + num_art_vars, sizeof(double),
@@ -509,6 +613,8 @@ int mi355x_tab_download(mi355x_tab *t, double *hm, int64_t *hb, double *last_row
 {
     if (!t) return fail(MI_BAD_ARG, "handle is NULL");
     int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    rc = ensure_dense(t);
     if (rc != MI_OK) return rc;
     const TabView &v = t->v;
     if (hm)
@@ -713,6 +819,8 @@ int mi355x_shard_price(mi355x_tab *t, int is_max, int64_t col_offset, double *de
     if (!t || !dev_out2) return fail(MI_BAD_ARG, "NULL argument");
     int rc = use_device(t);
     if (rc != MI_OK) return rc;
+    rc = ensure_dense(t);
+    if (rc != MI_OK) return rc;
     t->shard_is_max = is_max ? 1 : 0;
     const int np = (t->n_part > 0 && t->part_is_max == (is_max ? 1 : 0)) ? t->n_part : 0;
     launch_shard_price(t->v, is_max, col_offset, dev_out2, np, t->stream);
@@ -727,6 +835,8 @@ int mi355x_shard_contribute(mi355x_tab *t, const double *dev_gathered, int n_sha
     if (n_shards < 1) return fail(MI_BAD_ARG, "n_shards < 1");
     int rc = use_device(t);
     if (rc != MI_OK) return rc;
+    rc = ensure_dense(t);
+    if (rc != MI_OK) return rc;
     launch_shard_contribute(t->v, dev_gathered, n_shards, col_offset, f, dev_col_bits, dev_ec, t->stream);
     HIP_TRY(hipGetLastError());
     return MI_OK;
@@ -736,6 +846,8 @@ int mi355x_shard_pivot(mi355x_tab *t, const int64_t *dev_col_bits, const int64_t
 {
     if (!t || !dev_col_bits || !dev_ec) return fail(MI_BAD_ARG, "NULL argument");
     int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    rc = ensure_dense(t);
     if (rc != MI_OK) return rc;
     launch_shard_prepare(t->v, reinterpret_cast<const double *>(dev_col_bits), dev_ec, f, t->stream);
     // the update prices the new local objective-row slice for the next mi355x_shard_price
@@ -750,5 +862,6 @@ int         mi355x_tune_variant_count(void) { return update_variant_count(); }
 const char *mi355x_tune_variant_name(int v) { return (v >= 0 && v < update_variant_count()) ? update_variant_name(v) : ""; }
 int         mi355x_tune_set_variant(int v) { set_update_variant(v); return get_update_variant(); }
 int         mi355x_tune_set_select_mode(int mode) { g_select_mode = mode; return g_select_mode; }
+int         mi355x_tune_set_compact(int on) { g_compact_enabled = on ? 1 : 0; return g_compact_enabled; }
 
 }  // extern "C"

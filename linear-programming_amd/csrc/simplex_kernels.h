@@ -23,6 +23,7 @@ struct Ctl {
     int64_t n_pivots;     // pivots since the last reset
     int64_t max_pivots;   // 0 = no cap
     int64_t trace_n;      // pivots recorded in the trace buffers
+    int64_t slot;         // physical column of `ec` (== ec unless the representation is compact)
 };
 
 // One tableau in HBM.  Row-major, leading dimension ld (a multiple of 16 doubles so
@@ -42,6 +43,10 @@ struct TabView {
     double  *part_v;      // per-wave pricing partials left by k_update (key space); the
     int64_t *part_i;      // upper half holds the ratio-test partials of the split select
     int      part_cap;
+    // compact representation (non-basic columns + RHS only): physical slot <-> logical column
+    // maps; both null for the dense logical layout
+    int64_t *p2l;         // cols-1 entries: logical column stored in physical slot j
+    int64_t *l2p;         // logical var_count entries: slot of a logical column, -1 if basic
     // batch of n_lps same-shape LPs: per-LP element strides (all zero for a single tableau)
     int64_t  n_lps;
     int64_t  zs_M, zs_basis, zs_col, zs_prow, zs_part;
@@ -75,6 +80,10 @@ void launch_shard_prepare(const TabView &t, const double *col, const int64_t *ec
                           double fp_factor, hipStream_t s);
 // two-phase hand-over (src/simplex.lisp:437-451)
 void launch_handover(const TabView &art, const TabView &main_tab, hipStream_t s);
+// dense logical tableau <-> compact representation
+void launch_verify_basis(const TabView &t, int *flag, hipStream_t s);
+void launch_compact(const TabView &dense, const TabView &compact, hipStream_t s);
+void launch_expand(const TabView &dense, const TabView &compact, int64_t *brow, hipStream_t s);
 void launch_ctl_reset(const TabView &t, int64_t max_pivots, int reset_trace, hipStream_t s);
 void launch_ctl_finish(const TabView &t, hipStream_t s);
 // synthetic LP straight into HBM

@@ -91,8 +91,12 @@ constexpr int kBatch = 8;
 
 template <int THREADS = kSelThreads>
 __device__ __forceinline__ ValIdx block_price(const double *__restrict__ obj, int64_t ncols,
-                                              double sgn, double *s_v, long long *s_i)
+                                              double sgn, double *s_v, long long *s_i,
+                                              const int64_t *__restrict__ p2l = nullptr)
 {
+    // p2l != nullptr (compact representation): physical slot -> logical column; the winner is
+    // the lexicographic (key, LOGICAL column) minimum, i.e. still the reference's lowest-index
+    // strict minimum, whatever order the columns are stored in.
     ValIdx best; best.v = 0.0; best.i = -1;
     const int64_t npair = ncols >> 1;                 // obj is 128-byte aligned (row start)
     const double2 *obj2 = reinterpret_cast<const double2 *>(obj);
@@ -104,19 +108,19 @@ __device__ __forceinline__ ValIdx block_price(const double *__restrict__ obj, in
             v[g] = p < npair ? obj2[p] : make_double2(0.0, 0.0);
         }
 #pragma unroll
-        for (int g = 0; g < kBatch; ++g) {           // increasing index order within the thread
+        for (int g = 0; g < kBatch; ++g) {
             const int64_t p = base + (int64_t)g * THREADS + threadIdx.x;
             if (p < npair) {
-                const double k0 = v[g].x * sgn, k1 = v[g].y * sgn;
-                if (best.i < 0 || k0 < best.v) { best.v = k0; best.i = 2 * p; }
-                if (k1 < best.v)               { best.v = k1; best.i = 2 * p + 1; }
+                ValIdx c0, c1;
+                c0.v = v[g].x * sgn; c0.i = p2l ? p2l[2 * p] : 2 * p;
+                c1.v = v[g].y * sgn; c1.i = p2l ? p2l[2 * p + 1] : 2 * p + 1;
+                best = vi_min(vi_min(best, c0), c1);
             }
         }
     }
     if ((ncols & 1) && threadIdx.x == 0) {          // odd tail element
-        const double k = obj[ncols - 1] * sgn;
-        ValIdx t; t.v = k; t.i = ncols - 1;
-        best = vi_min(best, t);                      // index is the largest, so ties keep `best`
+        ValIdx t; t.v = obj[ncols - 1] * sgn; t.i = p2l ? p2l[ncols - 1] : ncols - 1;
+        best = vi_min(best, t);
     }
     return block_reduce_min<THREADS>(best, s_v, s_i);
 }
@@ -168,7 +172,21 @@ __device__ __forceinline__ ValIdx block_gather_ratio(const TabView &t, int64_t e
 }
 
 // prow[c] = M[cr][c] / M[cr][ec]  (src/simplex.lisp:343-348), padding columns zeroed.
-__device__ __forceinline__ void block_scale_row(const TabView &t, int64_t cr, double row_scale)
+// unit_slot >= 0 (compact representation): that physical column is about to hold the LEAVING
+// basic column, whose pre-pivot content is the unit vector e_cr, so its pivot-row entry is 1.0.
+__device__ __forceinline__ double2 scale_pair(const TabView &t, int64_t p, double2 v,
+                                              double row_scale, int64_t unit_slot)
+{
+    if (2 * p == unit_slot)     v.x = 1.0;
+    if (2 * p + 1 == unit_slot) v.y = 1.0;
+    double2 o;
+    o.x = (2 * p     < t.cols) ? v.x / row_scale : 0.0;
+    o.y = (2 * p + 1 < t.cols) ? v.y / row_scale : 0.0;
+    return o;
+}
+
+__device__ __forceinline__ void block_scale_row(const TabView &t, int64_t cr, double row_scale,
+                                                int64_t unit_slot = -1)
 {
     const double2 *__restrict__ src = reinterpret_cast<const double2 *>(t.M + cr * t.ld);
     double2 *dst = reinterpret_cast<double2 *>(t.prow);
@@ -183,14 +201,20 @@ __device__ __forceinline__ void block_scale_row(const TabView &t, int64_t cr, do
 #pragma unroll
         for (int g = 0; g < kBatch; ++g) {
             const int64_t p = base + (int64_t)g * kSelThreads + threadIdx.x;
-            if (p < npair) {
-                double2 o;
-                o.x = (2 * p     < t.cols) ? v[g].x / row_scale : 0.0;
-                o.y = (2 * p + 1 < t.cols) ? v[g].y / row_scale : 0.0;
-                dst[p] = o;
-            }
+            if (p < npair) dst[p] = scale_pair(t, p, v[g], row_scale, unit_slot);
         }
     }
+}
+
+// Compact representation, bookkeeping of one pivot (ONE thread): the entering logical column
+// becomes basic in row cr and gives up its physical slot to the leaving basic column.
+__device__ __forceinline__ void swap_columns(const TabView &t, int64_t ec_log, int64_t cr)
+{
+    const int64_t slot    = t.l2p[ec_log];
+    const int64_t leaving = t.basis[cr];            // read BEFORE record_pivot overwrites it
+    t.p2l[slot]    = leaving;
+    t.l2p[leaving] = slot;
+    t.l2p[ec_log]  = -1;
 }
 
 __device__ __forceinline__ void record_pivot(const TabView &t, int64_t ec, int64_t cr)
@@ -235,7 +259,7 @@ __global__ __launch_bounds__(kSelThreads) void k_select(TabView t, double sgn, d
 
     // n_part > 0: the preceding k_update of this tableau priced the new objective row
     const ValIdx e = n_part > 0 ? block_price_partials(t.part_v, t.part_i, n_part, s_v, s_i)
-                                : block_price(t.M + m * t.ld, vc, sgn, s_v, s_i);
+                                : block_price(t.M + m * t.ld, vc, sgn, s_v, s_i, t.p2l);
     // (fp< v 0 factor/8): v < 0 - tol ; min problems: (fp> v 0 factor/8) <=> -v < 0 - tol
     if (e.i < 0 || !(e.v < 0.0 - price_tol)) {
         if (threadIdx.x == 0) ctl->status = 0;      // MI_OPTIMAL
@@ -246,14 +270,22 @@ __global__ __launch_bounds__(kSelThreads) void k_select(TabView t, double sgn, d
         if (threadIdx.x == 0) ctl->status = 3;      // MI_MAX_PIVOTS
         return;
     }
-    const int64_t ec = e.i;
-    const ValIdx q = block_gather_ratio(t, ec, nullptr, ratio_thr, s_v, s_i);
+    const int64_t ec   = e.i;                       // LOGICAL column
+    const int64_t slot = t.l2p ? t.l2p[ec] : ec;    // where it is stored
+    const ValIdx q = block_gather_ratio(t, slot, nullptr, ratio_thr, s_v, s_i);
     if (q.i < 0) {
         if (threadIdx.x == 0) ctl->status = 1;      // MI_UNBOUNDED
         return;
     }
     const int64_t cr = q.i;
-    block_scale_row(t, cr, t.M[cr * t.ld + ec]);
+    const double row_scale = t.M[cr * t.ld + slot];
+    __syncthreads();                                // everyone has row_scale before the overwrite
+    block_scale_row(t, cr, row_scale, t.p2l ? slot : -1);
+    if (t.p2l) {                                    // the slot now holds the leaving column: e_cr
+        for (int64_t r = threadIdx.x; r < t.rows; r += kSelThreads)
+            t.M[r * t.ld + slot] = (r == cr) ? 1.0 : 0.0;
+        if (threadIdx.x == 0) swap_columns(t, ec, cr);
+    }
     if (threadIdx.x == 0) record_pivot(t, ec, cr);
 }
 
@@ -282,7 +314,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_select_gather(TabView t, dou
     const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
     const ValIdx e = n_part > 0
         ? block_price_partials<kGatherThreads>(t.part_v, t.part_i, n_part, s_v, s_i)
-        : block_price<kGatherThreads>(t.M + m * t.ld, vc, sgn, s_v, s_i);
+        : block_price<kGatherThreads>(t.M + m * t.ld, vc, sgn, s_v, s_i, t.p2l);
     if (e.i < 0 || !(e.v < 0.0 - price_tol)) {
         if (leader) ctl->status = 0;                // MI_OPTIMAL
         return;
@@ -291,18 +323,19 @@ __global__ __launch_bounds__(kGatherThreads) void k_select_gather(TabView t, dou
         if (leader) ctl->status = 3;                // MI_MAX_PIVOTS
         return;
     }
-    const int64_t ec = e.i;
+    const int64_t ec   = e.i;                       // LOGICAL column
+    const int64_t slot = t.l2p ? t.l2p[ec] : ec;
     const int64_t r = (int64_t)blockIdx.x * kGatherThreads + threadIdx.x;
     ValIdx best; best.v = 0.0; best.i = -1;
     if (r < t.rows) {
-        const double a = t.M[r * t.ld + ec];
+        const double a = t.M[r * t.ld + slot];
         const double b = r < m ? t.M[r * t.ld + vc] : 0.0;
         t.col[r] = a;
         if (r < m && ratio_thr < a) { best.v = b / a; best.i = r; }
     }
     best = block_reduce_min<kGatherThreads>(best, s_v, s_i);
     if (threadIdx.x == 0) { rp_v[blockIdx.x] = best.v; rp_i[blockIdx.x] = best.i; }
-    if (leader) ctl->ec = ec;
+    if (leader) { ctl->ec = ec; ctl->slot = slot; }
 }
 
 __global__ __launch_bounds__(kScaleThreads) void k_select_scale(TabView t, int n_rp)
@@ -322,16 +355,24 @@ __global__ __launch_bounds__(kScaleThreads) void k_select_scale(TabView t, int n
     }
     const int64_t cr = q.i;
     const double row_scale = t.col[cr];             // == M[cr][ec], snapshotted by the gather
+    const int64_t ec   = ctl->ec;                   // LOGICAL column (written by the gather)
+    const int64_t slot = t.p2l ? ctl->slot : -1;    // compact: the slot the leaving column takes
     const int64_t npair = t.ld >> 1;
     const int64_t p = (int64_t)blockIdx.x * kScaleThreads + threadIdx.x;
     if (p < npair) {
         const double2 v = reinterpret_cast<const double2 *>(t.M + cr * t.ld)[p];
-        double2 o;
-        o.x = (2 * p     < t.cols) ? v.x / row_scale : 0.0;
-        o.y = (2 * p + 1 < t.cols) ? v.y / row_scale : 0.0;
-        reinterpret_cast<double2 *>(t.prow)[p] = o;
+        reinterpret_cast<double2 *>(t.prow)[p] = scale_pair(t, p, v, row_scale, slot);
     }
-    if (leader) record_pivot(t, ctl->ec, cr);
+    if (t.p2l) {
+        // the slot now holds the leaving basic column, whose pre-pivot content is e_cr; the
+        // only reader of M[cr][slot] above substitutes 1.0, so the overwrite cannot race
+        for (int64_t r = p; r < t.rows; r += (int64_t)gridDim.x * kScaleThreads)
+            t.M[r * t.ld + slot] = (r == cr) ? 1.0 : 0.0;
+    }
+    if (leader) {
+        if (t.p2l) swap_columns(t, ec, cr);
+        record_pivot(t, ec, cr);
+    }
 }
 
 // find-entering-column only: ctl->ec = column or -1.  With out2 (shard pricing) the local
@@ -517,10 +558,13 @@ __global__ __launch_bounds__(BLOCK) void k_update(TabView t, const int tr, const
     if (prices) {                                              // `last` = new objective-row entries
         ValIdx best; best.v = 0.0; best.i = -1;
         const int64_t c0 = 2 * pair;
-        if (active && c0 < vc)     { best.v = last.x * sgn; best.i = c0; }
+        if (active && c0 < vc) {
+            ValIdx c; c.v = last.x * sgn; c.i = t.p2l ? t.p2l[c0] : c0;
+            best = vi_min(best, c);
+        }
         if (active && c0 + 1 < vc) {
-            const double k1 = last.y * sgn;
-            if (best.i < 0 || k1 < best.v) { best.v = k1; best.i = c0 + 1; }
+            ValIdx c; c.v = last.y * sgn; c.i = t.p2l ? t.p2l[c0 + 1] : c0 + 1;
+            best = vi_min(best, c);
         }
         best = wave_reduce_min(best);
         if ((threadIdx.x & 63) == 0) {
@@ -529,6 +573,74 @@ __global__ __launch_bounds__(BLOCK) void k_update(TabView t, const int tr, const
             part_i[slot] = best.i;
         }
     }
+}
+
+// ------------------------------------------------------------------ compact representation
+// Basic columns of a consistent tableau are unit vectors and stay bit-for-bit unchanged under
+// every pivot (x - s*(+0) == x, and a column that becomes basic is produced as x - x = +0 /
+// rs/rs = 1 exactly), so only the var_count - m NON-basic columns and the RHS column carry
+// information.  The solve loop therefore runs on P = [non-basic columns | RHS]
+// (rows x (var_count - m + 1)): a pivot snapshots the entering column, overwrites its slot with
+// e_cr (= the pre-pivot content of the leaving basic column, which takes the slot over) and runs
+// the SAME rank-1 update on P.  One third less traffic at n = 2m, identical results.  The
+// dense logical tableau is rebuilt by k_expand whenever an entry point needs it.
+
+// flag[0] |= 1 unless column basis[i] is exactly e_i (bit patterns: +0.0 and 1.0) for every i,
+// including a +0.0 in the objective row.  One workgroup per row.
+__global__ __launch_bounds__(256) void k_verify_basis(TabView t, int *flag)
+{
+    const int64_t m = t.rows - 1;
+    const unsigned long long one = 0x3FF0000000000000ull;
+    for (int64_t r = blockIdx.x; r < t.rows; r += gridDim.x) {
+        bool bad = false;
+        for (int64_t i = threadIdx.x; i < m; i += blockDim.x) {
+            const unsigned long long bits =
+                (unsigned long long)__double_as_longlong(t.M[r * t.ld + t.basis[i]]);
+            bad |= bits != ((r == i) ? one : 0ull);
+        }
+        if (bad) atomicOr(flag, 1);
+    }
+}
+
+// P[r][j] = M[r][p2l[j]] (j < n_nb), P[r][n_nb] = M[r][vc]; padding zero.
+__global__ __launch_bounds__(256) void k_compact(TabView d, TabView c)
+{
+    const int64_t n_nb = c.cols - 1, vc = d.cols - 1;
+    for (int64_t r = blockIdx.y; r < d.rows; r += gridDim.y)
+        for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < c.ld;
+             j += (int64_t)gridDim.x * blockDim.x) {
+            double v = 0.0;
+            if (j < n_nb)       v = d.M[r * d.ld + c.p2l[j]];
+            else if (j == n_nb) v = d.M[r * d.ld + vc];
+            c.M[r * c.ld + j] = v;
+        }
+}
+
+// brow[col] = row in which logical column `col` is basic, -1 otherwise.
+__global__ __launch_bounds__(256) void k_basis_rows(TabView d, int64_t *brow, int phase)
+{
+    const int64_t vc = d.cols - 1, m = d.rows - 1;
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (phase == 0) { if (i < vc) brow[i] = -1; }
+    else            { if (i < m && d.basis[i] >= 0 && d.basis[i] < vc) brow[d.basis[i]] = i; }
+}
+
+// The inverse: rebuild the dense logical tableau from P, the maps and the basis.
+__global__ __launch_bounds__(256) void k_expand(TabView d, TabView c, const int64_t *brow)
+{
+    const int64_t n_nb = c.cols - 1, vc = d.cols - 1;
+    for (int64_t r = blockIdx.y; r < d.rows; r += gridDim.y)
+        for (int64_t col = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; col < d.ld;
+             col += (int64_t)gridDim.x * blockDim.x) {
+            double v = 0.0;
+            if (col < vc) {
+                const int64_t slot = c.l2p[col];
+                v = slot >= 0 ? c.M[r * c.ld + slot] : (brow[col] == r ? 1.0 : 0.0);
+            } else if (col == vc) {
+                v = c.M[r * c.ld + n_nb];
+            }
+            d.M[r * d.ld + col] = v;
+        }
 }
 
 // ------------------------------------------------------------------ control block
@@ -694,6 +806,29 @@ void launch_handover(const TabView &art, const TabView &mt, hipStream_t s)
     }
     hipLaunchKernelGGL(k_handover_objective, dim3(1), dim3(kSelThreads), 0, s, art, mt);
 }
+void launch_verify_basis(const TabView &t, int *flag, hipStream_t s)
+{
+    const unsigned g = (unsigned)(t.rows < 16384 ? t.rows : 16384);
+    hipLaunchKernelGGL(k_verify_basis, dim3(g), dim3(256), 0, s, t, flag);
+}
+void launch_compact(const TabView &d, const TabView &c, hipStream_t s)
+{
+    int bx = (int)((c.ld + 255) / 256);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(k_compact, dim3(bx, (unsigned)(d.rows < 32768 ? d.rows : 32768)), dim3(256),
+                       0, s, d, c);
+}
+void launch_expand(const TabView &d, const TabView &c, int64_t *brow, hipStream_t s)
+{
+    const int64_t n = (d.cols > d.rows ? d.cols : d.rows);
+    const unsigned g = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_basis_rows, dim3(g), dim3(256), 0, s, d, brow, 0);
+    hipLaunchKernelGGL(k_basis_rows, dim3(g), dim3(256), 0, s, d, brow, 1);
+    int bx = (int)((d.ld + 255) / 256);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(k_expand, dim3(bx, (unsigned)(d.rows < 32768 ? d.rows : 32768)), dim3(256),
+                       0, s, d, c, brow);
+}
 void launch_ctl_reset(const TabView &t, int64_t max_pivots, int reset_trace, hipStream_t s)
 {
     hipLaunchKernelGGL(k_ctl_reset, dim3((unsigned)t.n_lps), dim3(1), 0, s, t.ctl, max_pivots, reset_trace);
@@ -733,11 +868,14 @@ static void launch_update_t(const TabView &t, dim3 grid, int tr, int strip_pairs
     { "b" #B "_u" #U "_nt" #NT "_mintr" #MINTR "_x" #ROUNDS, (B), (U), (MINTR), (ROUNDS), &launch_update_t<B, U, NT> }
 
 static const UpdateVariant kVariants[] = {
-    MI_VARIANT(256, 4, true, 4, 0),     // 0: default -- 4-row tiles whatever the size
+    MI_VARIANT(256, 4, true, 4, 0),     // 0: default -- 4-row tiles whatever the size; the
+                                        //    launcher swaps in variant 1 (plain loads/stores)
+                                        //    when the stored tableau fits the Infinity Cache
+    MI_VARIANT(256, 4, false, 4, 0),
     MI_VARIANT(256, 4, true, 4, 16),
     MI_VARIANT(256, 4, true, 4, 8),
-    MI_VARIANT(256, 4, false, 4, 0),
     MI_VARIANT(256, 2, true, 2, 0),
+    MI_VARIANT(256, 2, false, 2, 0),
     MI_VARIANT(256, 8, true, 8, 0),
     MI_VARIANT(256, 8, true, 8, 4),
     MI_VARIANT(256, 8, true, 8, 1),
@@ -758,9 +896,21 @@ void        set_update_variant(int v) { if (v >= 0 && v < update_variant_count()
 int         get_update_variant() { return g_variant; }
 const char *update_kernel_symbol() { return "k_update"; }
 
+// Non-temporal accesses pay off when the stored tableau is streamed from HBM every pivot
+// (config 3 dense, 403 MB: 125 vs 145 us); when it (mostly) fits the 256 MiB Infinity Cache
+// plain accesses are faster (config 3 compact, 269 MB: 82 vs 90 us).
+constexpr double kNtThresholdBytes = 320.0 * 1024 * 1024;
+
+static int effective_variant(const TabView &t)
+{
+    if (g_variant != 0) return g_variant;
+    const double bytes = (double)t.rows * (double)t.ld * 8.0 * (double)t.n_lps;
+    return bytes > kNtThresholdBytes ? 0 : 1;
+}
+
 UpdateShape update_shape(const TabView &t)
 {
-    const UpdateVariant &v = kVariants[g_variant];
+    const UpdateVariant &v = kVariants[effective_variant(t)];
     const int64_t ldv = t.ld >> 1;
     UpdateShape g;
     g.strips = (int)((ldv + v.block - 1) / v.block);
@@ -793,7 +943,7 @@ UpdateShape update_shape(const TabView &t)
 
 int launch_update(const TabView &t, double sgn, int price, hipStream_t s)
 {
-    const UpdateVariant &v = kVariants[g_variant];
+    const UpdateVariant &v = kVariants[effective_variant(t)];
     const UpdateShape g = update_shape(t);
     if (price && g.n_partials > t.part_cap / 2) price = 0;
     v.launch(t, dim3((unsigned)g.strips, (unsigned)g.row_chunks, (unsigned)t.n_lps), g.tr,

@@ -261,6 +261,76 @@ def test_both_select_paths_bitwise_vs_oracle(n, m, seed, mode):
     assert np.array_equal(t.matrix, M) and np.array_equal(t.basis_columns, b)
 
 
+def _layout(t):
+    c, cols, ld = ctypes.c_int(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    lp.capi.check(lp.capi.lib().mi355x_tab_layout(t._h, ctypes.byref(c), ctypes.byref(cols),
+                                                  ctypes.byref(ld)), "layout")
+    return c.value, cols.value, ld.value
+
+
+@pytest.mark.parametrize("compact", [0, 1])
+@pytest.mark.parametrize("n,m,seed", [(33, 17, 2), (257, 511, 5), (1500, 300, 8), (2000, 1100, 9)])
+def test_dense_and_compact_representations_bitwise(n, m, seed, compact):
+    """The solve loop on the dense logical tableau and on the compact [non-basic | RHS]
+    representation: same pivots, same bits, and the representation is invisible to every
+    other entry point (download / price / ratio / pivot / copy in between)."""
+    L = lp.capi.lib()
+    M0, b0 = lp.synth.tableau(n, m, lp.synth.seed_for(9, seed))
+    M, b = M0.copy(), b0.copy()
+    try:
+        L.mi355x_tune_set_compact(compact)
+        t = lp.Tableau(None, lp.Problem(type="max"), M0, b0, n + m, m, {})
+        rc = L.mi355x_tab_solve(t._h, 1, 1024.0, 3, None)
+        t._touch()
+        assert _layout(t) == ((1, n + 1, (n + 1 + 15) // 16 * 16) if compact
+                              else (0, n + m + 1, (n + m + 1 + 15) // 16 * 16))
+        st, _, _ = oracle.solve(M, b, max_pivots=3)
+        assert rc == st == oracle.MAX_PIVOTS
+        ec = lp.find_entering_column(t)                  # dense entry points in the middle
+        assert _layout(t)[0] == 0
+        assert ec == oracle.price(M) and lp.find_pivoting_row(t, ec) == oracle.ratio(M, ec)
+        assert np.array_equal(t.matrix, M) and np.array_equal(t.basis_columns, b)
+        t2 = lp.copy_tableau(t)
+        cr = oracle.ratio(M, ec)
+        lp.n_pivot_row(t, ec, cr)
+        oracle.pivot(M, b, ec, cr)
+        lp.n_solve_tableau(t)                            # back to compact, to optimality
+        st, npiv, _ = oracle.solve(M, b)
+        assert st == oracle.OPTIMAL and t.n_pivots == npiv
+        assert np.array_equal(t.matrix, M) and np.array_equal(t.basis_columns, b)
+        lp.n_solve_tableau(t2)                           # the copy, solved independently
+        assert np.array_equal(t2.matrix, M)
+    finally:
+        L.mi355x_tune_set_compact(1)
+
+
+def test_inconsistent_basis_falls_back_to_dense():
+    """A caller-supplied basis whose columns are NOT unit vectors (nothing in the reference
+    forbids it): the compact representation is refused and the dense path reproduces the
+    oracle; same for repeated and out-of-range basis entries."""
+    rng = np.random.default_rng(3)
+    n, m = 50, 20
+    for kind in ["dense_columns", "repeated", "out_of_range", "minus_zero"]:
+        M0, b0 = lp.synth.tableau(n, m, 77)
+        if kind == "dense_columns":
+            M0[:m, n:n + m] += rng.uniform(0.0, 0.1, (m, m))
+        elif kind == "repeated":
+            b0[3] = b0[2]
+        elif kind == "out_of_range":
+            b0[5] = n + m + 3                       # like build-tableau's marker for art rows
+        else:
+            M0[4, n + 2] = -0.0                     # a -0.0 inside a basic column
+        M, b = M0.copy(), b0.copy()
+        st, npiv, trace = oracle.solve(M, b, max_pivots=60, trace_cap=64)
+        t = lp.Tableau(None, lp.Problem(type="max"), M0, b0, n + m, m, {})
+        rc = lp.capi.lib().mi355x_tab_solve(t._h, 1, 1024.0, 60, None)
+        assert _layout(t)[0] == 0, kind
+        t._touch()
+        assert rc == st and np.array_equal(t.pivot_trace(), trace), kind
+        assert np.array_equal(t.matrix.view(np.int64), M.view(np.int64)), kind
+        assert np.array_equal(t.basis_columns, b), kind
+
+
 def test_every_update_variant_bitwise_vs_oracle():
     """All compiled tilings of the rank-1 update kernel give the same bits."""
     L = lp.capi.lib()

@@ -12,3 +12,6 @@ lp.capi.check(L.mi355x_tab_copy(ctypes.byref(h2), h), "copy")      # reads + wri
 lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, int(sys.argv[1]) if len(sys.argv) > 1 else 30, 1), "run")
 npv = ctypes.c_int64(0)
 print("rc", L.mi355x_tab_sync(h, ctypes.byref(npv)), "pivots", npv.value)
+c, cols, ld = ctypes.c_int(0), ctypes.c_int64(0), ctypes.c_int64(0)
+L.mi355x_tab_layout(h, ctypes.byref(c), ctypes.byref(cols), ctypes.byref(ld))
+print("layout compact=%d stored_cols=%d stored_ld=%d rows=%d" % (c.value, cols.value, ld.value, m + 1))

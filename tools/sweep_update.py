@@ -37,7 +37,10 @@ def run(n, m, pivots, variants):
         L.mi355x_tab_timing_read(h, ctypes.byref(nl), ctypes.byref(sm), ctypes.byref(mn))
         L.mi355x_tab_timing_enable(h, 0)
         avg = sm.value / max(nl.value, 1)
-        rec = {"variant": v, "name": name, "n": n, "m": m, "rc": rc, "pivots_per_s": pivots / wall,
+        c, cols, ld = ctypes.c_int(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        L.mi355x_tab_layout(h, ctypes.byref(c), ctypes.byref(cols), ctypes.byref(ld))
+        bytes_per = 2 * R * cols.value * 8
+        rec = {"variant": v, "name": name, "compact": c.value, "stored_cols": cols.value, "n": n, "m": m, "rc": rc, "pivots_per_s": pivots / wall,
                "wall_us_per_pivot": wall / pivots * 1e6, "update_avg_us": avg * 1e3,
                "update_min_us": mn.value * 1e3, "update_GBps": bytes_per / (avg * 1e-3) / 1e9,
                "update_GBps_best": bytes_per / (mn.value * 1e-3) / 1e9}
