@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS) + ["cfg4", "colpart"])
     ap.add_argument("--batch-lps", type=int, default=128,
                     help="cfg4: LPs per GPU (BASELINE config 4 = 1024 LPs over 8 GPUs)")
+    ap.add_argument("--batch-mode", type=int, default=0,
+                    help="cfg4: 0 auto, 1 lockstep launch pairs, 2 one workgroup per LP")
     ap.add_argument("--colpart-vars", type=int, default=0,
                     help="colpart: override the number of variables (constraints = vars/2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -108,6 +110,7 @@ def bench_batch(args, lp, rank, local_rank, N, barrier, torch, dist):
     del warm
     batch = lp.TableauBatch.synthetic(nl, n, m, seeds, device=local_rank)
     L = lp.capi.lib()
+    L.mi355x_tune_set_batch_mode(args.batch_mode)
     L.mi355x_batch_timing_enable(batch._h, 1)
     barrier()
     torch.cuda.synchronize()

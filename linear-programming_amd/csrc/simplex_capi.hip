@@ -24,6 +24,7 @@ namespace {
 thread_local std::string g_err;
 int g_select_mode = 0;                    // 0 auto, 1 single workgroup, 2 split (tuning/test hook)
 int g_compact_enabled = 1;                // solve loops run on the compact representation
+int g_batch_mode = 0;                     // 0 auto, 1 lockstep launch pairs, 2 one workgroup per LP
 
 int fail(int code, const char *fmt, ...)
 {
@@ -745,9 +746,22 @@ int mi355x_batch_solve(mi355x_batch *b, int is_max, double f, int64_t max_pivots
     if (rc != MI_OK) return rc;
     const int64_t n = t->v.n_lps;
     launch_ctl_reset(t->v, max_pivots, 0, t->stream);
-    enqueue_select(t, is_max, f);
+    // preferred: one launch, one workgroup per LP (k_batch_solve); lockstep launch pairs when
+    // an LP is too large for the LDS budget (or when forced by the tuning hook)
+    // measured (257x769 LPs): lockstep 1.38 M pivots/s at 128 LPs, one-workgroup-per-LP
+    // 1.30 M at 128 and 1.32 M at 1024 LPs (no lockstep tail); auto = per-LP from 256 LPs up
+    const bool want_persistent = g_batch_mode == 2 || (g_batch_mode == 0 && n >= 256);
+    bool persistent = want_persistent && launch_batch_solve(t->v, is_max, f, t->stream);
+    if (persistent) t->n_part = 0;
+    if (!persistent) enqueue_select(t, is_max, f);
     int64_t chunk = 16;
     for (;;) {
+        if (persistent) {
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(t->h_ctl, t->v.ctl, n * sizeof(Ctl), hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            break;
+        }
         for (int64_t i = 0; i < chunk; ++i) {
             rc = enqueue_update(t, is_max);
             if (rc != MI_OK) return rc;
@@ -862,6 +876,7 @@ int         mi355x_tune_variant_count(void) { return update_variant_count(); }
 const char *mi355x_tune_variant_name(int v) { return (v >= 0 && v < update_variant_count()) ? update_variant_name(v) : ""; }
 int         mi355x_tune_set_variant(int v) { set_update_variant(v); return get_update_variant(); }
 int         mi355x_tune_set_select_mode(int mode) { g_select_mode = mode; return g_select_mode; }
+int         mi355x_tune_set_batch_mode(int mode) { g_batch_mode = mode; return g_batch_mode; }
 int         mi355x_tune_set_compact(int on) { g_compact_enabled = on ? 1 : 0; return g_compact_enabled; }
 
 }  // extern "C"

@@ -575,6 +575,113 @@ __global__ __launch_bounds__(BLOCK) void k_update(TabView t, const int tr, const
     }
 }
 
+// ------------------------------------------------------------------ batch: one workgroup per LP
+// BASELINE config 4 is many SMALL independent LPs (257 x 769 doubles = 1.6 MB each).  Advancing
+// them in lockstep with the launch pairs above makes every LP wait for the slowest one (78..199
+// pivots per LP in the benchmark batch) and pays 2-3 launch boundaries per pivot.  Here ONE
+// 1024-thread workgroup owns one LP and runs its whole n-solve-tableau loop
+// (src/simplex.lisp:453-461) inside a single launch: the snapshot of the entering column and
+// the normalised pivot row live in LDS, the phases are separated by workgroup barriers only,
+// LPs progress independently and the hardware schedules waiting LPs onto free CUs.  Same
+// arithmetic, same lexicographic reductions => same bits as the lockstep path and the oracle.
+constexpr int kLpThreads = 1024;
+
+__global__ __launch_bounds__(kLpThreads) void k_batch_solve(TabView t, double sgn, double price_tol,
+                                                           double ratio_thr)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double    s_v[kLpThreads / 64];
+    __shared__ long long s_i[kLpThreads / 64];
+    t = lp_slice(t);
+    Ctl *ctl = t.ctl;
+    if (ctl->status != kRunning) return;
+    const int64_t rows = t.rows, m = rows - 1, vc = t.cols - 1, ld = t.ld, ldv = ld >> 1;
+    double  *s_prow = lds;                          // ld doubles (16-byte aligned)
+    double  *s_col  = lds + ld;                     // rows doubles
+    vec2d   *M2 = reinterpret_cast<vec2d *>(t.M);
+    const int64_t total = rows * ldv;               // tableau size in 16-byte pairs
+    const int64_t dr = kLpThreads / ldv, dp = kLpThreads % ldv;   // flat-index stride as (row, pair)
+    int64_t n_pivots = ctl->n_pivots;
+    const int64_t max_pivots = ctl->max_pivots;
+
+    ValIdx e = block_price(t.M + m * ld, vc, sgn, s_v, s_i);
+    for (;;) {
+        if (e.i < 0 || !(e.v < 0.0 - price_tol)) {
+            if (threadIdx.x == 0) ctl->status = 0;  // MI_OPTIMAL
+            break;
+        }
+        if (max_pivots > 0 && n_pivots >= max_pivots) {
+            if (threadIdx.x == 0) ctl->status = 3;  // MI_MAX_PIVOTS
+            break;
+        }
+        const int64_t ec = e.i;
+        // gather the entering column into LDS + ratio test
+        ValIdx best; best.v = 0.0; best.i = -1;
+        for (int64_t r = threadIdx.x; r < rows; r += kLpThreads) {
+            const double a = t.M[r * ld + ec];
+            s_col[r] = a;
+            if (r < m && ratio_thr < a) {
+                ValIdx c; c.v = t.M[r * ld + vc] / a; c.i = r;
+                best = vi_min(best, c);
+            }
+        }
+        const ValIdx q = block_reduce_min(best, s_v, s_i);     // barriers: s_col complete
+        if (q.i < 0) {
+            if (threadIdx.x == 0) ctl->status = 1;  // MI_UNBOUNDED
+            break;
+        }
+        const int64_t cr = q.i;
+        const double row_scale = s_col[cr];
+        // normalised pivot row into LDS
+        for (int64_t p = threadIdx.x; p < ldv; p += kLpThreads) {
+            const double2 v = reinterpret_cast<const double2 *>(t.M + cr * ld)[p];
+            reinterpret_cast<double2 *>(s_prow)[p] = scale_pair(t, p, v, row_scale, -1);
+        }
+        __syncthreads();
+        // rank-1 update of the whole tableau, 4 independent 16-byte accesses in flight per thread;
+        // the threads that write the objective row price it for the next iteration
+        best.v = 0.0; best.i = -1;
+        int64_t idx = threadIdx.x, r = threadIdx.x / ldv, p = threadIdx.x % ldv;
+        while (idx < total) {
+            vec2d   v[4];
+            int64_t ri[4], pi[4], ii[4];
+            int     n = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (idx < total) {
+                    ri[u] = r; pi[u] = p; ii[u] = idx;
+                    v[u] = M2[idx];
+                    n = u + 1;
+                    idx += kLpThreads; r += dr; p += dp;
+                    if (p >= ldv) { p -= ldv; r += 1; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u < n) {
+                    const double s = s_col[ri[u]];
+                    const double2 pp = reinterpret_cast<const double2 *>(s_prow)[pi[u]];
+                    const double m0 = s * pp.x;
+                    const double m1 = s * pp.y;
+                    vec2d o;
+                    o.x = v[u].x - m0;
+                    o.y = v[u].y - m1;
+                    if (ri[u] == cr) { o.x = pp.x; o.y = pp.y; }
+                    M2[ii[u]] = o;
+                    if (ri[u] == m) {
+                        const int64_t c0 = 2 * pi[u];
+                        if (c0 < vc)     { ValIdx c; c.v = o.x * sgn; c.i = c0;     best = vi_min(best, c); }
+                        if (c0 + 1 < vc) { ValIdx c; c.v = o.y * sgn; c.i = c0 + 1; best = vi_min(best, c); }
+                    }
+                }
+            }
+        }
+        if (threadIdx.x == 0) record_pivot(t, ec, cr);
+        n_pivots += 1;
+        e = block_reduce_min(best, s_v, s_i);       // barrier: the update is complete and visible
+    }
+}
+
 // ------------------------------------------------------------------ compact representation
 // Basic columns of a consistent tableau are unit vectors and stay bit-for-bit unchanged under
 // every pivot (x - s*(+0) == x, and a column that becomes basic is produced as x - x = +0 /
@@ -805,6 +912,15 @@ void launch_handover(const TabView &art, const TabView &mt, hipStream_t s)
         hipLaunchKernelGGL(k_handover_copy, dim3(bx, (unsigned)(m < 32768 ? m : 32768)), dim3(256), 0, s, art, mt);
     }
     hipLaunchKernelGGL(k_handover_objective, dim3(1), dim3(kSelThreads), 0, s, art, mt);
+}
+// one launch solves the whole batch; returns false if an LP does not fit the LDS budget
+bool launch_batch_solve(const TabView &t, int is_max, double f, hipStream_t s)
+{
+    const size_t lds = (size_t)(t.ld + t.rows) * sizeof(double);
+    if (lds > 96 * 1024 || t.ld / 2 < 1) return false;
+    hipLaunchKernelGGL(k_batch_solve, dim3(1, 1, (unsigned)t.n_lps), dim3(kLpThreads), lds, s, t,
+                       sgn_of(is_max), (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon);
+    return true;
 }
 void launch_verify_basis(const TabView &t, int *flag, hipStream_t s)
 {

@@ -22,7 +22,7 @@ def one(pattern):
     g = glob.glob(os.path.join(EV, pattern))
     if not g:
         raise SystemExit("missing " + pattern)
-    return g[0]
+    return max(g, key=os.path.getmtime)       # gpurun merges runs: take the newest
 
 
 def counter(path, kernel_sub):
