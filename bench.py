@@ -53,7 +53,8 @@ def parse():
     ap.add_argument("--colpart-vars", type=int, default=0,
                     help="colpart: override the number of variables (constraints = vars/2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pivots", type=int, default=24)
+    ap.add_argument("--cpu-pivots", type=int, default=400,
+                    help="cpu_baseline: pivots timed with all host threads (a quarter of it single-threaded)")
     ap.add_argument("--no-events", action="store_true",
                     help="do not bracket the update launches with HIP events (roofline = null)")
     ap.add_argument("--event-stride", type=int, default=8,
@@ -70,7 +71,7 @@ def cpu_baseline(lp, n, m, seed, pivots):
     t0 = time.perf_counter()
     st, npiv, _ = oracle.solve(M, b, max_pivots=pivots, omp=True)
     t_omp = time.perf_counter() - t0
-    single = max(2, pivots // 6)
+    single = max(2, pivots // 4)
     t0 = time.perf_counter()
     st1, npiv1, _ = oracle.solve(M, b, max_pivots=single, omp=False)
     t_one = time.perf_counter() - t0
@@ -193,47 +194,72 @@ def main():
 
     n, m, cfg = WORKLOADS[args.workload]
     R, C = m + 1, n + m + 1
-    bytes_per_pivot = 2 * R * C * 8            # every element read once + written once
+    bytes_per_pivot = 2 * R * C * 8            # dense tableau: every element read once + written once
     L = lp.capi.lib()
-    seed = lp.synth.seed_for(cfg, rank)
-    h = ctypes.c_void_p()
-    lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h), n, m, seed, 0, -1, local_rank),
-                  "mi355x_tab_create_synthetic")
+    # One LP supports only so many pivots before it is optimal (config 3: 5 700-6 100, config 2:
+    # ~290 with these seeds).  If more timed steps are asked for than one LP safely provides,
+    # further LPs of the same shape are generated in HBM BEFORE the timed region and the timed
+    # steps simply continue on the next one.
+    capacity = {"cfg3": 4500, "cfg2": 220}[args.workload]
+    per_lp = max(capacity - args.warmup, 1)
+    n_lps = -(-args.steps // per_lp)
+    handles = []
     npv = ctypes.c_int64(0)
-
-    # warm-up (untimed)
-    lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, args.warmup, 1), "warmup")
-    L.mi355x_tab_sync(h, ctypes.byref(npv))
-    if not args.no_events:
-        L.mi355x_tab_timing_enable(h, max(1, args.event_stride))
+    for k in range(n_lps):
+        h = ctypes.c_void_p()
+        seed = lp.synth.seed_for(cfg, rank + 1000 * k)
+        lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h), n, m, seed, 0, -1, local_rank),
+                      "mi355x_tab_create_synthetic")
+        # every handle launches on torch's current stream, so chained LPs run back to back
+        lp.capi.check(L.mi355x_tab_set_stream(
+            h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), 0), "set_stream")
+        # warm-up (untimed): also moves the handle onto the representation the loop runs on
+        lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, args.warmup, 1), "warmup")
+        L.mi355x_tab_sync(h, ctypes.byref(npv))
+        if not args.no_events:
+            L.mi355x_tab_timing_enable(h, max(1, args.event_stride))
+        handles.append(h)
+    seed = lp.synth.seed_for(cfg, rank)
+    h = handles[0]
 
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, args.steps, 0), "timed steps")
-    rc = L.mi355x_tab_sync(h, ctypes.byref(npv))       # waits for the launch stream
+    left, done = args.steps, 0
+    for hk in handles:
+        k = min(left, per_lp)
+        lp.capi.check(L.mi355x_tab_solve_async(hk, 1, 1024.0, k, 0), "timed steps")
+        left -= k
+    for hk in handles:
+        rc = L.mi355x_tab_sync(hk, ctypes.byref(npv))  # waits for the launch stream
+        if rc != lp.capi.MI_RUNNING:
+            sys.exit("rank %d: an LP terminated (status %d) inside the timed region" % (rank, rc))
+        done += npv.value - args.warmup
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-
-    done = npv.value - args.warmup
-    if rc != lp.capi.MI_RUNNING or done != args.steps:
-        sys.exit("rank %d: the LP terminated (status %d) after %d of %d timed pivots -- "
-                 "use fewer steps" % (rank, rc, done, args.steps))
+    if done != args.steps:
+        sys.exit("rank %d: %d of %d timed pivots were performed" % (rank, done, args.steps))
 
     compact, stored_cols, stored_ld = ctypes.c_int(0), ctypes.c_int64(0), ctypes.c_int64(0)
     L.mi355x_tab_layout(h, ctypes.byref(compact), ctypes.byref(stored_cols), ctypes.byref(stored_ld))
     # bytes the update kernel has to move per launch in the representation it runs on: every
     # STORED element read once + written once.  Dense: C = n+m+1 columns (SURVEY 8d's figure);
-    # compact: only the n non-basic columns + RHS carry information (DESIGN.md 4.6).
+    # compact: only the n non-basic columns + RHS carry information (DESIGN.md 4.5).
     kernel_bytes = 2 * R * stored_cols.value * 8
 
     upd_avg_ms = None
+    nl = ctypes.c_int64(0)
     if not args.no_events:
-        nl, sm, mn = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
-        L.mi355x_tab_timing_read(h, ctypes.byref(nl), ctypes.byref(sm), ctypes.byref(mn))
-        if nl.value > 0:
-            upd_avg_ms = sm.value / nl.value
+        tot_n, tot_ms = 0, 0.0
+        for hk in handles:
+            sm, mn = ctypes.c_double(0), ctypes.c_double(0)
+            L.mi355x_tab_timing_read(hk, ctypes.byref(nl), ctypes.byref(sm), ctypes.byref(mn))
+            tot_n += nl.value
+            tot_ms += sm.value
+        nl = ctypes.c_int64(tot_n)
+        if tot_n > 0:
+            upd_avg_ms = tot_ms / tot_n
 
     if N > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -274,7 +300,8 @@ def main():
         if N == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(lp, n, m, seed, args.cpu_pivots)
         print(json.dumps(rec), flush=True)
-    L.mi355x_tab_destroy(h)
+    for hk in handles:
+        L.mi355x_tab_destroy(hk)
     if N > 1:
         dist.destroy_process_group()
 

@@ -223,7 +223,7 @@ int read_ctl(mi355x_tab *t)
     return MI_OK;
 }
 
-// ---- representation changes (DESIGN.md 4.6) -------------------------------------------
+// ---- representation changes (DESIGN.md 4.5) -------------------------------------------
 TabView &cur(mi355x_tab *t) { return t->compact ? t->c : t->v; }
 
 // Rebuild the dense logical tableau from the compact representation (no-op when dense).
