@@ -242,18 +242,23 @@ int ensure_dense(mi355x_tab *t)
 int ensure_compact(mi355x_tab *t)
 {
     TabView &v = t->v;
-    const int64_t m = v.rows - 1, vc = v.cols - 1, n_nb = vc - m;
-    if (t->compact || !g_compact_enabled || t->compact_failed || v.n_lps != 1 || m < 1 || n_nb < 1)
-        return MI_OK;
+    const int64_t m = v.rows - 1, vc = v.cols - 1, n_nb = vc - m, nl = v.n_lps;
+    if (t->compact || !g_compact_enabled || t->compact_failed || m < 1 || n_nb < 1) return MI_OK;
     t->compact_failed = true;                         // until proven otherwise
-    std::vector<int64_t> basis((size_t)m);
-    HIP_TRY(hipMemcpyAsync(basis.data(), v.basis, m * sizeof(int64_t), hipMemcpyDeviceToHost, t->stream));
+    std::vector<int64_t> basis((size_t)(nl * m));
+    HIP_TRY(hipMemcpyAsync(basis.data(), v.basis, nl * m * sizeof(int64_t), hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
-    std::vector<int64_t> l2p((size_t)vc, 0), p2l;
-    for (int64_t i = 0; i < m; ++i) {
-        const int64_t b = basis[(size_t)i];
-        if (b < 0 || b >= vc || l2p[(size_t)b] == -1) return MI_OK;     // out of range / repeated
-        l2p[(size_t)b] = -1;
+    std::vector<int64_t> l2p((size_t)(nl * vc), 0), p2l((size_t)(nl * n_nb), 0);
+    for (int64_t k = 0; k < nl; ++k) {                // every LP of a batch must qualify
+        int64_t *l = l2p.data() + k * vc, *p = p2l.data() + k * n_nb;
+        for (int64_t i = 0; i < m; ++i) {
+            const int64_t b = basis[(size_t)(k * m + i)];
+            if (b < 0 || b >= vc || l[b] == -1) return MI_OK;           // out of range / repeated
+            l[b] = -1;
+        }
+        int64_t slot = 0;
+        for (int64_t cidx = 0; cidx < vc; ++cidx)
+            if (l[cidx] != -1) { l[cidx] = slot; p[slot++] = cidx; }
     }
     if (!t->flag) HIP_TRY(hipMalloc((void **)&t->flag, sizeof(int)));
     HIP_TRY(hipMemsetAsync(t->flag, 0, sizeof(int), t->stream));
@@ -262,21 +267,19 @@ int ensure_compact(mi355x_tab *t)
     HIP_TRY(hipMemcpyAsync(&bad, t->flag, sizeof(int), hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
     if (bad) return MI_OK;
-    p2l.reserve((size_t)n_nb);
-    for (int64_t cidx = 0; cidx < vc; ++cidx)
-        if (l2p[(size_t)cidx] != -1) { l2p[(size_t)cidx] = (int64_t)p2l.size(); p2l.push_back(cidx); }
     if (!t->c.M) {
         t->c = v;                                     // shares every auxiliary buffer
         t->c.M = nullptr; t->c.p2l = nullptr; t->c.l2p = nullptr;
         t->c.cols = n_nb + 1;
         t->c.ld = padded_ld(n_nb + 1);
-        HIP_TRY(hipMalloc((void **)&t->c.M, (size_t)v.rows * t->c.ld * sizeof(double)));
-        HIP_TRY(hipMalloc((void **)&t->c.p2l, n_nb * sizeof(int64_t)));
-        HIP_TRY(hipMalloc((void **)&t->c.l2p, vc * sizeof(int64_t)));
-        HIP_TRY(hipMalloc((void **)&t->brow, vc * sizeof(int64_t)));
+        if (nl > 1) { t->c.zs_M = v.rows * t->c.ld; t->c.zs_p2l = n_nb; t->c.zs_l2p = vc; }
+        HIP_TRY(hipMalloc((void **)&t->c.M, (size_t)nl * v.rows * t->c.ld * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&t->c.p2l, nl * n_nb * sizeof(int64_t)));
+        HIP_TRY(hipMalloc((void **)&t->c.l2p, nl * vc * sizeof(int64_t)));
+        HIP_TRY(hipMalloc((void **)&t->brow, nl * vc * sizeof(int64_t)));
     }
-    HIP_TRY(hipMemcpyAsync(t->c.p2l, p2l.data(), n_nb * sizeof(int64_t), hipMemcpyHostToDevice, t->stream));
-    HIP_TRY(hipMemcpyAsync(t->c.l2p, l2p.data(), vc * sizeof(int64_t), hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(hipMemcpyAsync(t->c.p2l, p2l.data(), nl * n_nb * sizeof(int64_t), hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(hipMemcpyAsync(t->c.l2p, l2p.data(), nl * vc * sizeof(int64_t), hipMemcpyHostToDevice, t->stream));
     launch_compact(v, t->c, t->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(t->stream));         // p2l / l2p host vectors go out of scope
@@ -745,13 +748,15 @@ int mi355x_batch_solve(mi355x_batch *b, int is_max, double f, int64_t max_pivots
     int rc = use_device(t);
     if (rc != MI_OK) return rc;
     const int64_t n = t->v.n_lps;
+    rc = ensure_compact(t);
+    if (rc != MI_OK) return rc;
     launch_ctl_reset(t->v, max_pivots, 0, t->stream);
     // preferred: one launch, one workgroup per LP (k_batch_solve); lockstep launch pairs when
     // an LP is too large for the LDS budget (or when forced by the tuning hook)
-    // measured (257x769 LPs): lockstep 1.38 M pivots/s at 128 LPs, one-workgroup-per-LP
-    // 1.30 M at 128 and 1.32 M at 1024 LPs (no lockstep tail); auto = per-LP from 256 LPs up
-    const bool want_persistent = g_batch_mode == 2 || (g_batch_mode == 0 && n >= 256);
-    bool persistent = want_persistent && launch_batch_solve(t->v, is_max, f, t->stream);
+    // measured (257x769 LPs, compact representation): one workgroup per LP 1.76 M pivots/s at
+    // 128 LPs and 2.13 M at 1024 LPs; lockstep launch pairs 1.62 M and 1.25 M
+    const bool want_persistent = g_batch_mode != 1;
+    bool persistent = want_persistent && launch_batch_solve(cur(t), is_max, f, t->stream);
     if (persistent) t->n_part = 0;
     if (!persistent) enqueue_select(t, is_max, f);
     int64_t chunk = 16;
@@ -790,6 +795,8 @@ int mi355x_batch_download(mi355x_batch *b, int64_t k, double *hm, int64_t *hb, d
     const TabView &v = t->v;
     if (k < 0 || k >= v.n_lps) return fail(MI_BAD_ARG, "lp_index %lld out of range", (long long)k);
     int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    rc = ensure_dense(t);
     if (rc != MI_OK) return rc;
     const double *M = v.M + k * v.rows * v.ld;
     if (hm)

@@ -49,7 +49,7 @@ struct TabView {
     int64_t *l2p;         // logical var_count entries: slot of a logical column, -1 if basic
     // batch of n_lps same-shape LPs: per-LP element strides (all zero for a single tableau)
     int64_t  n_lps;
-    int64_t  zs_M, zs_basis, zs_col, zs_prow, zs_part;
+    int64_t  zs_M, zs_basis, zs_col, zs_prow, zs_part, zs_p2l, zs_l2p;
 };
 
 struct UpdateShape {

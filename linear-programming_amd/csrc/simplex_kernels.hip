@@ -243,6 +243,7 @@ __device__ __forceinline__ TabView lp_slice(TabView t)
     t.part_v += z * t.zs_part;
     t.part_i += z * t.zs_part;
     t.ctl    += z;
+    if (t.p2l) { t.p2l += z * t.zs_p2l; t.l2p += z * t.zs_l2p; }
     return t;
 }
 
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_solve(TabView t, double sg
     int64_t n_pivots = ctl->n_pivots;
     const int64_t max_pivots = ctl->max_pivots;
 
-    ValIdx e = block_price(t.M + m * ld, vc, sgn, s_v, s_i);
+    ValIdx e = block_price(t.M + m * ld, vc, sgn, s_v, s_i, t.p2l);
     for (;;) {
         if (e.i < 0 || !(e.v < 0.0 - price_tol)) {
             if (threadIdx.x == 0) ctl->status = 0;  // MI_OPTIMAL
@@ -614,11 +615,12 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_solve(TabView t, double sg
             if (threadIdx.x == 0) ctl->status = 3;  // MI_MAX_PIVOTS
             break;
         }
-        const int64_t ec = e.i;
+        const int64_t ec   = e.i;                   // LOGICAL column
+        const int64_t slot = t.l2p ? t.l2p[ec] : ec;
         // gather the entering column into LDS + ratio test
         ValIdx best; best.v = 0.0; best.i = -1;
         for (int64_t r = threadIdx.x; r < rows; r += kLpThreads) {
-            const double a = t.M[r * ld + ec];
+            const double a = t.M[r * ld + slot];
             s_col[r] = a;
             if (r < m && ratio_thr < a) {
                 ValIdx c; c.v = t.M[r * ld + vc] / a; c.i = r;
@@ -635,7 +637,13 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_solve(TabView t, double sg
         // normalised pivot row into LDS
         for (int64_t p = threadIdx.x; p < ldv; p += kLpThreads) {
             const double2 v = reinterpret_cast<const double2 *>(t.M + cr * ld)[p];
-            reinterpret_cast<double2 *>(s_prow)[p] = scale_pair(t, p, v, row_scale, -1);
+            reinterpret_cast<double2 *>(s_prow)[p] = scale_pair(t, p, v, row_scale, t.p2l ? slot : -1);
+        }
+        if (t.p2l) {                                // compact: the slot takes over the leaving column
+            __syncthreads();                        // row cr has been read
+            for (int64_t r = threadIdx.x; r < rows; r += kLpThreads)
+                t.M[r * ld + slot] = (r == cr) ? 1.0 : 0.0;
+            if (threadIdx.x == 0) swap_columns(t, ec, cr);
         }
         __syncthreads();
         // rank-1 update of the whole tableau, 4 independent 16-byte accesses in flight per thread;
@@ -670,8 +678,8 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_solve(TabView t, double sg
                     M2[ii[u]] = o;
                     if (ri[u] == m) {
                         const int64_t c0 = 2 * pi[u];
-                        if (c0 < vc)     { ValIdx c; c.v = o.x * sgn; c.i = c0;     best = vi_min(best, c); }
-                        if (c0 + 1 < vc) { ValIdx c; c.v = o.y * sgn; c.i = c0 + 1; best = vi_min(best, c); }
+                        if (c0 < vc)     { ValIdx c; c.v = o.x * sgn; c.i = t.p2l ? t.p2l[c0] : c0;         best = vi_min(best, c); }
+                        if (c0 + 1 < vc) { ValIdx c; c.v = o.y * sgn; c.i = t.p2l ? t.p2l[c0 + 1] : c0 + 1; best = vi_min(best, c); }
                     }
                 }
             }
@@ -696,6 +704,7 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_solve(TabView t, double sg
 // including a +0.0 in the objective row.  One workgroup per row.
 __global__ __launch_bounds__(256) void k_verify_basis(TabView t, int *flag)
 {
+    t = lp_slice(t);
     const int64_t m = t.rows - 1;
     const unsigned long long one = 0x3FF0000000000000ull;
     for (int64_t r = blockIdx.x; r < t.rows; r += gridDim.x) {
@@ -712,6 +721,8 @@ __global__ __launch_bounds__(256) void k_verify_basis(TabView t, int *flag)
 // P[r][j] = M[r][p2l[j]] (j < n_nb), P[r][n_nb] = M[r][vc]; padding zero.
 __global__ __launch_bounds__(256) void k_compact(TabView d, TabView c)
 {
+    d = lp_slice(d);
+    c = lp_slice(c);
     const int64_t n_nb = c.cols - 1, vc = d.cols - 1;
     for (int64_t r = blockIdx.y; r < d.rows; r += gridDim.y)
         for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < c.ld;
@@ -726,6 +737,8 @@ __global__ __launch_bounds__(256) void k_compact(TabView d, TabView c)
 // brow[col] = row in which logical column `col` is basic, -1 otherwise.
 __global__ __launch_bounds__(256) void k_basis_rows(TabView d, int64_t *brow, int phase)
 {
+    d = lp_slice(d);
+    brow += (int64_t)blockIdx.z * (d.cols - 1);
     const int64_t vc = d.cols - 1, m = d.rows - 1;
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (phase == 0) { if (i < vc) brow[i] = -1; }
@@ -735,6 +748,9 @@ __global__ __launch_bounds__(256) void k_basis_rows(TabView d, int64_t *brow, in
 // The inverse: rebuild the dense logical tableau from P, the maps and the basis.
 __global__ __launch_bounds__(256) void k_expand(TabView d, TabView c, const int64_t *brow)
 {
+    d = lp_slice(d);
+    c = lp_slice(c);
+    brow += (int64_t)blockIdx.z * (d.cols - 1);
     const int64_t n_nb = c.cols - 1, vc = d.cols - 1;
     for (int64_t r = blockIdx.y; r < d.rows; r += gridDim.y)
         for (int64_t col = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; col < d.ld;
@@ -925,25 +941,25 @@ bool launch_batch_solve(const TabView &t, int is_max, double f, hipStream_t s)
 void launch_verify_basis(const TabView &t, int *flag, hipStream_t s)
 {
     const unsigned g = (unsigned)(t.rows < 16384 ? t.rows : 16384);
-    hipLaunchKernelGGL(k_verify_basis, dim3(g), dim3(256), 0, s, t, flag);
+    hipLaunchKernelGGL(k_verify_basis, dim3(g, 1, (unsigned)t.n_lps), dim3(256), 0, s, t, flag);
 }
 void launch_compact(const TabView &d, const TabView &c, hipStream_t s)
 {
     int bx = (int)((c.ld + 255) / 256);
     if (bx > 64) bx = 64;
-    hipLaunchKernelGGL(k_compact, dim3(bx, (unsigned)(d.rows < 32768 ? d.rows : 32768)), dim3(256),
-                       0, s, d, c);
+    hipLaunchKernelGGL(k_compact, dim3(bx, (unsigned)(d.rows < 32768 ? d.rows : 32768), (unsigned)d.n_lps),
+                       dim3(256), 0, s, d, c);
 }
 void launch_expand(const TabView &d, const TabView &c, int64_t *brow, hipStream_t s)
 {
     const int64_t n = (d.cols > d.rows ? d.cols : d.rows);
     const unsigned g = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_basis_rows, dim3(g), dim3(256), 0, s, d, brow, 0);
-    hipLaunchKernelGGL(k_basis_rows, dim3(g), dim3(256), 0, s, d, brow, 1);
+    hipLaunchKernelGGL(k_basis_rows, dim3(g, 1, (unsigned)d.n_lps), dim3(256), 0, s, d, brow, 0);
+    hipLaunchKernelGGL(k_basis_rows, dim3(g, 1, (unsigned)d.n_lps), dim3(256), 0, s, d, brow, 1);
     int bx = (int)((d.ld + 255) / 256);
     if (bx > 64) bx = 64;
-    hipLaunchKernelGGL(k_expand, dim3(bx, (unsigned)(d.rows < 32768 ? d.rows : 32768)), dim3(256),
-                       0, s, d, c, brow);
+    hipLaunchKernelGGL(k_expand, dim3(bx, (unsigned)(d.rows < 32768 ? d.rows : 32768), (unsigned)d.n_lps),
+                       dim3(256), 0, s, d, c, brow);
 }
 void launch_ctl_reset(const TabView &t, int64_t max_pivots, int reset_trace, hipStream_t s)
 {

@@ -545,10 +545,19 @@ def batch_mode(request):
     L.mi355x_tune_set_batch_mode(0)
 
 
+@pytest.fixture(params=[1, 0], ids=["compact", "dense"])
+def representation(request):
+    L = lp.capi.lib()
+    L.mi355x_tune_set_compact(request.param)
+    yield request.param
+    L.mi355x_tune_set_compact(1)
+
+
 @pytest.mark.parametrize("n,m,nl", [(60, 30, 37), (7, 3, 5), (300, 40, 9), (33, 200, 6)])
-def test_batch_bitwise_vs_oracle(batch_mode, n, m, nl):
+def test_batch_bitwise_vs_oracle(batch_mode, representation, n, m, nl):
     """Every LP of a batch ends bit-identical to the oracle run on it alone (LPs of different
-    pivot counts, so finished LPs idle while others continue), with both batch drivers."""
+    pivot counts, so finished LPs idle while others continue), with both batch drivers and both
+    tableau representations."""
     seeds = [lp.synth.seed_for(4, k) for k in range(nl)]
     tabs = [lp.synth.tableau(n, m, s) for s in seeds]
     Ms = np.stack([t[0] for t in tabs])
