@@ -123,7 +123,8 @@ def bench_batch(args, lp, rank, local_rank, N, barrier, torch, dist):
     nlch, sm, mn = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
     L.mi355x_batch_timing_read(batch._h, ctypes.byref(nlch), ctypes.byref(sm), ctypes.byref(mn))
     assert (st == 0).all(), "not every LP reached optimality"
-    tot = torch.tensor([float(npv.sum()), elapsed], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(npv.sum()), elapsed], dtype=torch.float64,
+                       device="cuda" if dist.get_backend() == "nccl" else "cpu") if N > 1 else None
     if N > 1:
         piv = tot[:1].clone()
         dist.all_reduce(piv, op=dist.ReduceOp.SUM)
@@ -165,10 +166,20 @@ def main():
     lp = importlib.import_module("linear-programming_amd")
     if not torch.cuda.is_available() or lp.capi.device_count() < 1:
         sys.exit("bench.py needs a GPU (no CPU fallback exists)")
+    # Test hooks (used to exercise the multi-rank code path on a 1-GPU box, never by the driver):
+    # BENCH_SHARE_DEVICE=1 puts every rank on cuda:0, BENCH_DIST_BACKEND=gloo replaces RCCL
+    # (which refuses two ranks on one device) for the few scalar reductions bench.py does.
+    if os.environ.get("BENCH_SHARE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local_rank)
     if N > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     def barrier():
         if N > 1:
@@ -262,7 +273,7 @@ def main():
             upd_avg_ms = tot_ms / tot_n
 
     if N > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -90,18 +90,31 @@ class HipBackend:
 
 
 class DistComm:
-    """Exchanges over torch.distributed (nccl == RCCL on ROCm, or gloo on CPU): one local shard."""
+    """Exchanges over torch.distributed (nccl == RCCL on ROCm, or gloo on CPU): one local shard.
 
-    def __init__(self, dist, group=None):
-        self.dist, self.group = dist, group
+    stage_through_host=True is a test set-up only (several ranks sharing one GPU, where RCCL
+    refuses to run): device buffers are copied to the host, exchanged with gloo and copied back."""
+
+    def __init__(self, dist, group=None, stage_through_host=False):
+        self.dist, self.group, self.stage = dist, group, stage_through_host
 
     def gather(self, shards):
         (sh,) = shards
-        self.dist.all_gather_into_tensor(sh.gathered, sh.send, group=self.group)
+        if self.stage:
+            out = sh.gathered.cpu()
+            self.dist.all_gather_into_tensor(out, sh.send.cpu(), group=self.group)
+            sh.gathered.copy_(out)
+        else:
+            self.dist.all_gather_into_tensor(sh.gathered, sh.send, group=self.group)
 
     def reduce(self, shards):
         (sh,) = shards
-        self.dist.all_reduce(sh.bits, op=self.dist.ReduceOp.SUM, group=self.group)
+        if self.stage:
+            buf = sh.bits.cpu()
+            self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group)
+            sh.bits.copy_(buf)
+        else:
+            self.dist.all_reduce(sh.bits, op=self.dist.ReduceOp.SUM, group=self.group)
 
 
 class LocalComm:
@@ -214,7 +227,8 @@ def bench(args, rank, local_rank, world):
         n, m = args.colpart_vars, args.colpart_vars // 2
     seed = synth.seed_for(5)
     shards = synthetic_shards(torch, n, m, seed, [rank], world, local_rank)
-    comm = DistComm(dist) if world > 1 else LocalComm(torch)
+    staged = world > 1 and dist.get_backend() != "nccl"          # test hook: ranks share one GPU
+    comm = DistComm(dist, stage_through_host=staged) if world > 1 else LocalComm(torch)
     tab = ColumnPartitionedTableau(shards, comm, HipBackend())
     tab.reset()
     tab.run(args.warmup)
@@ -232,7 +246,7 @@ def bench(args, rank, local_rank, world):
     if st != capi.MI_RUNNING or done != args.warmup + args.steps:
         raise SystemExit("colpart: LP terminated early (status %d after %d pivots)" % (st, done))
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if staged else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     R, C = m + 1, n + m + 1

@@ -1,0 +1,32 @@
+"""Worker for the multi-PROCESS column-partition GPU test: several ranks share cuda:0 (RCCL
+refuses that, so the two exchanges are staged through the host with gloo -- a test set-up), each
+rank drives its own shard through the real C ABI (mi355x_shard_*)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.helpers import lp_amd  # noqa: E402
+
+
+def main():
+    out_dir, n, m, seed, max_pivots = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    lp = lp_amd()
+    cp = __import__("importlib").import_module("linear-programming_amd.colpart")
+    shards = cp.synthetic_shards(torch, n, m, seed, [rank], world, 0)
+    tab = cp.ColumnPartitionedTableau(shards, cp.DistComm(dist, stage_through_host=True), cp.HipBackend())
+    st, npiv = tab.solve(max_pivots=max_pivots, check_every=8)
+    M, b = cp.download_shard(shards[0])
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), M=M, basis=b, status=st, npiv=npiv)
+    cp.destroy_shards(shards)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

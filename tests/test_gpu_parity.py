@@ -638,6 +638,35 @@ def test_column_partition_logical_shards_bitwise(n_shards, n, m):
     cp.destroy_shards(shards)
 
 
+@pytest.mark.parametrize("world,n,m", [(2, 96, 64), (3, 200, 90)])
+def test_column_partition_multi_process(world, n, m, tmp_path):
+    """One OS process per shard, as in production (torch.distributed rendezvous, one handle per
+    rank, real kernels); the ranks have to share the single GPU of the test box, so the two
+    exchanges are staged through the host with gloo instead of RCCL."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from tests.helpers import ROOT
+    seed = lp.synth.seed_for(5, 40 + world)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_colpart_gpu_worker.py"),
+                                       str(tmp_path), str(n), str(m), str(seed), "0"], env=env, cwd=ROOT))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    M, b = lp.synth.tableau(n, m, seed)
+    so, no, _ = oracle.solve(M, b)
+    res = [np.load(os.path.join(tmp_path, "rank%d.npz" % r)) for r in range(world)]
+    for r in res:
+        assert (int(r["status"]), int(r["npiv"])) == (so, no)
+        assert np.array_equal(r["basis"], b) and np.array_equal(r["M"][:, -1], M[:, -1])
+    assert np.array_equal(np.concatenate([r["M"][:, :-1] for r in res], axis=1), M[:, :-1])
+
+
 def test_column_partition_pivot_cap_and_unbounded():
     import importlib
     import torch
