@@ -70,7 +70,6 @@ struct mi355x_tab {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     Ctl        *h_ctl = nullptr;          // pinned host mirror of the control block
-    int64_t     pivots_before = 0;        // (unused by the ABI; kept for debugging)
     TabView     c{};                      // compact view [non-basic columns | RHS]; shares
                                           // basis / col / prow / ctl / trace / partials with v
     bool        compact = false;          // which representation currently holds the tableau
@@ -267,17 +266,18 @@ int ensure_compact(mi355x_tab *t)
     HIP_TRY(hipMemcpyAsync(&bad, t->flag, sizeof(int), hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
     if (bad) return MI_OK;
-    if (!t->c.M) {
+    if (t->c.cols != n_nb + 1) {                      // first time: describe the compact view
         t->c = v;                                     // shares every auxiliary buffer
         t->c.M = nullptr; t->c.p2l = nullptr; t->c.l2p = nullptr;
         t->c.cols = n_nb + 1;
         t->c.ld = padded_ld(n_nb + 1);
         if (nl > 1) { t->c.zs_M = v.rows * t->c.ld; t->c.zs_p2l = n_nb; t->c.zs_l2p = vc; }
-        HIP_TRY(hipMalloc((void **)&t->c.M, (size_t)nl * v.rows * t->c.ld * sizeof(double)));
-        HIP_TRY(hipMalloc((void **)&t->c.p2l, nl * n_nb * sizeof(int64_t)));
-        HIP_TRY(hipMalloc((void **)&t->c.l2p, nl * vc * sizeof(int64_t)));
-        HIP_TRY(hipMalloc((void **)&t->brow, nl * vc * sizeof(int64_t)));
     }
+    // allocate whatever is still missing (a failed attempt must not leave a half-built view)
+    if (!t->c.M)   HIP_TRY(hipMalloc((void **)&t->c.M, (size_t)nl * v.rows * t->c.ld * sizeof(double)));
+    if (!t->c.p2l) HIP_TRY(hipMalloc((void **)&t->c.p2l, nl * n_nb * sizeof(int64_t)));
+    if (!t->c.l2p) HIP_TRY(hipMalloc((void **)&t->c.l2p, nl * vc * sizeof(int64_t)));
+    if (!t->brow)  HIP_TRY(hipMalloc((void **)&t->brow, nl * vc * sizeof(int64_t)));
     HIP_TRY(hipMemcpyAsync(t->c.p2l, p2l.data(), nl * n_nb * sizeof(int64_t), hipMemcpyHostToDevice, t->stream));
     HIP_TRY(hipMemcpyAsync(t->c.l2p, l2p.data(), nl * vc * sizeof(int64_t), hipMemcpyHostToDevice, t->stream));
     launch_compact(v, t->c, t->stream);
