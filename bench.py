@@ -50,6 +50,8 @@ def parse():
                     help="cfg4: LPs per GPU (BASELINE config 4 = 1024 LPs over 8 GPUs)")
     ap.add_argument("--batch-mode", type=int, default=0,
                     help="cfg4: 0 auto, 1 lockstep launch pairs, 2 one workgroup per LP")
+    ap.add_argument("--colpart-dense", action="store_true",
+                    help="colpart: shards hold all logical columns instead of the non-basic ones only")
     ap.add_argument("--colpart-vars", type=int, default=0,
                     help="colpart: override the number of variables (constraints = vars/2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

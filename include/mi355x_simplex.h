@@ -232,6 +232,14 @@ void mi355x_batch_destroy(mi355x_batch *b);
  *      of own slice, basis[cr] = global column.
  * col_offset = global index of the shard's first column.  dev_* are raw device addresses
  * (e.g. torch tensors' data_ptr()).  Status/pivot count: mi355x_tab_sync. */
+/* A COMPACT shard stores only non-basic columns (plus the RHS copy): global_cols[j] is the
+ * global logical column held in local slot j (cols-1 entries, host array).  The shard that
+ * owns the entering column hands its slot over to the leaving basic column at every pivot
+ * (DESIGN.md 4.5), so ownership of logical columns moves between slots but a shard's size never
+ * changes and basic columns are stored nowhere.  basis[] holds global column indices.
+ * mi355x_shard_columns reads the current slot -> global column map back. */
+int  mi355x_shard_set_compact(mi355x_tab *t, int64_t global_var_count, const int64_t *global_cols);
+int  mi355x_shard_columns(mi355x_tab *t, int64_t *global_cols);
 int  mi355x_shard_price(mi355x_tab *t, int is_max, int64_t col_offset, double *dev_out2);
 int  mi355x_shard_contribute(mi355x_tab *t, const double *dev_gathered, int n_shards,
                              int64_t col_offset, double fp_factor, int64_t *dev_col_bits,

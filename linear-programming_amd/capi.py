@@ -62,6 +62,8 @@ SIGNATURES = {
     "mi355x_batch_timing_enable": (_int, [_p, _int]),
     "mi355x_batch_timing_read": (_int, [_p, _p, _p, _p]),
     "mi355x_batch_destroy": (None, [_p]),
+    "mi355x_shard_set_compact": (_int, [_p, _i64, _p]),
+    "mi355x_shard_columns": (_int, [_p, _p]),
     "mi355x_shard_price": (_int, [_p, _int, _i64, _p]),
     "mi355x_shard_contribute": (_int, [_p, _p, _int, _i64, _dbl, _p, _p]),
     "mi355x_shard_pivot": (_int, [_p, _p, _p, _dbl]),

@@ -117,6 +117,8 @@ void free_tab(mi355x_tab *t)
     (void)hipFree(t->c.M);
     (void)hipFree(t->c.p2l);
     (void)hipFree(t->c.l2p);
+    (void)hipFree(t->v.p2l);
+    (void)hipFree(t->v.l2p);
     (void)hipFree(t->brow);
     (void)hipFree(t->flag);
     if (t->h_ctl) (void)hipHostFree(t->h_ctl);
@@ -243,6 +245,7 @@ int ensure_compact(mi355x_tab *t)
     TabView &v = t->v;
     const int64_t m = v.rows - 1, vc = v.cols - 1, n_nb = vc - m, nl = v.n_lps;
     if (t->compact || !g_compact_enabled || t->compact_failed || m < 1 || n_nb < 1) return MI_OK;
+    if (v.p2l) return MI_OK;                          // a compact column shard stays as it is
     t->compact_failed = true;                         // until proven otherwise
     std::vector<int64_t> basis((size_t)(nl * m));
     HIP_TRY(hipMemcpyAsync(basis.data(), v.basis, nl * m * sizeof(int64_t), hipMemcpyDeviceToHost, t->stream));
@@ -875,6 +878,45 @@ int mi355x_shard_pivot(mi355x_tab *t, const int64_t *dev_col_bits, const int64_t
     t->n_part = launch_update(t->v, t->shard_is_max ? 1.0 : -1.0, 1, t->stream);
     t->part_is_max = t->shard_is_max;
     HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int mi355x_shard_set_compact(mi355x_tab *t, int64_t global_var_count, const int64_t *global_cols)
+{
+    if (!t || !global_cols) return fail(MI_BAD_ARG, "NULL argument");
+    const int64_t n_local = t->v.cols - 1;
+    if (t->v.n_lps != 1 || n_local < 1 || global_var_count < n_local)
+        return fail(MI_BAD_ARG, "bad shard shape");
+    int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    rc = ensure_dense(t);
+    if (rc != MI_OK) return rc;
+    std::vector<int64_t> l2p((size_t)global_var_count, -1);
+    for (int64_t j = 0; j < n_local; ++j) {
+        const int64_t g = global_cols[j];
+        if (g < 0 || g >= global_var_count || l2p[(size_t)g] != -1)
+            return fail(MI_BAD_ARG, "global column %lld out of range or repeated", (long long)g);
+        l2p[(size_t)g] = j;
+    }
+    if (!t->v.p2l) HIP_TRY(hipMalloc((void **)&t->v.p2l, n_local * sizeof(int64_t)));
+    (void)hipFree(t->v.l2p);
+    t->v.l2p = nullptr;
+    HIP_TRY(hipMalloc((void **)&t->v.l2p, global_var_count * sizeof(int64_t)));
+    HIP_TRY(hipMemcpyAsync(t->v.p2l, global_cols, n_local * sizeof(int64_t), hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(hipMemcpyAsync(t->v.l2p, l2p.data(), global_var_count * sizeof(int64_t), hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    t->n_part = 0;
+    return MI_OK;
+}
+
+int mi355x_shard_columns(mi355x_tab *t, int64_t *global_cols)
+{
+    if (!t || !global_cols) return fail(MI_BAD_ARG, "NULL argument");
+    if (!t->v.p2l) return fail(MI_BAD_ARG, "not a compact shard");
+    int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(global_cols, t->v.p2l, (t->v.cols - 1) * sizeof(int64_t), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
     return MI_OK;
 }
 

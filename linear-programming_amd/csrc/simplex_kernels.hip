@@ -387,11 +387,11 @@ __global__ __launch_bounds__(kSelThreads) void k_price_only(TabView t, double sg
     __shared__ long long s_i[kSelWaves];
     const int64_t m = t.rows - 1, vc = t.cols - 1;
     const ValIdx e = n_part > 0 ? block_price_partials(t.part_v, t.part_i, n_part, s_v, s_i)
-                                : block_price(t.M + m * t.ld, vc, sgn, s_v, s_i);
+                                : block_price(t.M + m * t.ld, vc, sgn, s_v, s_i, t.p2l);
     if (threadIdx.x == 0) {
-        if (out2) {
+        if (out2) {                                 // compact shards price GLOBAL columns already
             out2[0] = e.i < 0 ? 0.0 : e.v;
-            out2[1] = e.i < 0 ? -1.0 : (double)(e.i + col_offset);
+            out2[1] = e.i < 0 ? -1.0 : (double)(e.i + (t.p2l ? 0 : col_offset));
         } else {
             t.ctl->ec = (e.i >= 0 && e.v < 0.0 - price_tol) ? e.i : -1;
         }
@@ -437,7 +437,9 @@ __global__ __launch_bounds__(kSelThreads) void k_shard_contribute(TabView t, con
         best = vi_min(best, c);
     }
     const int64_t ec = (best.i >= 0 && best.v < 0.0 - price_tol) ? best.i : -1;
-    const int64_t lc = ec - col_offset;
+    // dense shard: a fixed block of logical columns; compact shard: whatever non-basic columns
+    // currently live in its slots (l2p: global logical column -> local slot, -1 = not here)
+    const int64_t lc = ec < 0 ? -1 : (t.l2p ? t.l2p[ec] : ec - col_offset);
     const bool mine = ec >= 0 && lc >= 0 && lc < t.cols - 1;
     // The strided gathers (entering column on the owner, RHS column on everyone: snapshotted
     // contiguously for the ratio test of k_shard_prepare) run here, spread over many workgroups.
@@ -476,7 +478,15 @@ __global__ __launch_bounds__(kSelThreads) void k_shard_prepare(TabView t, const 
         return;
     }
     const int64_t cr = q.i;
-    block_scale_row(t, cr, col_src[cr]);
+    // compact shard that owns the entering column: its slot is taken over by the leaving basic
+    // column (pre-pivot content e_cr); the other shards only update what they store
+    const int64_t slot = t.p2l ? t.l2p[global_ec] : -1;
+    block_scale_row(t, cr, col_src[cr], slot);
+    if (slot >= 0) {
+        for (int64_t r = threadIdx.x; r < t.rows; r += kSelThreads)
+            t.M[r * t.ld + slot] = (r == cr) ? 1.0 : 0.0;
+        if (threadIdx.x == 0) swap_columns(t, global_ec, cr);
+    }
     if (threadIdx.x == 0) record_pivot(t, global_ec, cr);   // basis holds GLOBAL column indices
 }
 

@@ -18,11 +18,13 @@ def main():
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     lp = lp_amd()
     cp = __import__("importlib").import_module("linear-programming_amd.colpart")
-    shards = cp.synthetic_shards(torch, n, m, seed, [rank], world, 0)
+    compact = len(sys.argv) > 6 and sys.argv[6] == "compact"
+    shards = cp.synthetic_shards(torch, n, m, seed, [rank], world, 0, compact=compact)
     tab = cp.ColumnPartitionedTableau(shards, cp.DistComm(dist, stage_through_host=True), cp.HipBackend())
     st, npiv = tab.solve(max_pivots=max_pivots, check_every=8)
     M, b = cp.download_shard(shards[0])
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), M=M, basis=b, status=st, npiv=npiv)
+    cols = cp.shard_columns(shards[0]) if compact else np.arange(shards[0].col_begin, shards[0].col_end)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), M=M, basis=b, status=st, npiv=npiv, cols=cols)
     cp.destroy_shards(shards)
     dist.barrier()
     dist.destroy_process_group()

@@ -610,23 +610,31 @@ def test_batch_synthetic_config4_shape_and_statuses(batch_mode):
 
 
 # =========================================================================== column partition (config 5)
+@pytest.mark.parametrize("compact", [False, True], ids=["dense-shards", "compact-shards"])
 @pytest.mark.parametrize("n_shards,n,m", [(1, 60, 40), (2, 96, 64), (3, 100, 50), (8, 512, 256)])
-def test_column_partition_logical_shards_bitwise(n_shards, n, m):
+def test_column_partition_logical_shards_bitwise(n_shards, n, m, compact):
     """One tableau as N column shards on ONE device (exchanges = local tensor ops with the
-    collectives' semantics): same pivot sequence and same bits as the unpartitioned solve."""
+    collectives' semantics): same pivot sequence and same bits as the unpartitioned solve, with
+    shards that hold fixed blocks of all columns and with compact shards (non-basic columns
+    only, slots handed over at every pivot)."""
     import importlib
     import torch
     cp = importlib.import_module("linear-programming_amd.colpart")
     seed = lp.synth.seed_for(5, n_shards)
-    shards = cp.synthetic_shards(torch, n, m, seed, list(range(n_shards)), n_shards, 0)
+    shards = cp.synthetic_shards(torch, n, m, seed, list(range(n_shards)), n_shards, 0, compact=compact)
     tab = cp.ColumnPartitionedTableau(shards, cp.LocalComm(torch), cp.HipBackend())
     st, npiv = tab.solve(check_every=32)
     M, b = lp.synth.tableau(n, m, seed)
     so, no, trace = oracle.solve(M, b, trace_cap=1 << 16)
     assert (st, npiv) == (so, no) == (oracle.OPTIMAL, no)
     parts = [cp.download_shard(sh) for sh in shards]
-    got = np.concatenate([p[0][:, :-1] for p in parts], axis=1)
-    assert np.array_equal(got, M[:, :-1])
+    if compact:
+        got, bs = cp.assemble_compact(shards, n + m)
+        assert np.array_equal(got.view(np.int64), M.view(np.int64)) and np.array_equal(bs, b)
+        assert sum(p[0].shape[1] - 1 for p in parts) == n     # only non-basic columns are stored
+    else:
+        got = np.concatenate([p[0][:, :-1] for p in parts], axis=1)
+        assert np.array_equal(got, M[:, :-1])
     for Ms, bs in parts:
         assert np.array_equal(Ms[:, -1], M[:, -1])            # every RHS copy
         assert np.array_equal(bs, b)                          # global column indices
@@ -638,8 +646,9 @@ def test_column_partition_logical_shards_bitwise(n_shards, n, m):
     cp.destroy_shards(shards)
 
 
-@pytest.mark.parametrize("world,n,m", [(2, 96, 64), (3, 200, 90)])
-def test_column_partition_multi_process(world, n, m, tmp_path):
+@pytest.mark.parametrize("world,n,m,kind", [(2, 96, 64, "dense"), (3, 200, 90, "compact"),
+                                            (2, 300, 120, "compact")])
+def test_column_partition_multi_process(world, n, m, kind, tmp_path):
     """One OS process per shard, as in production (torch.distributed rendezvous, one handle per
     rank, real kernels); the ranks have to share the single GPU of the test box, so the two
     exchanges are staged through the host with gloo instead of RCCL."""
@@ -655,16 +664,21 @@ def test_column_partition_multi_process(world, n, m, tmp_path):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_colpart_gpu_worker.py"),
-                                       str(tmp_path), str(n), str(m), str(seed), "0"], env=env, cwd=ROOT))
+                                       str(tmp_path), str(n), str(m), str(seed), "0", kind], env=env, cwd=ROOT))
     for p in procs:
         assert p.wait(timeout=600) == 0
     M, b = lp.synth.tableau(n, m, seed)
     so, no, _ = oracle.solve(M, b)
     res = [np.load(os.path.join(tmp_path, "rank%d.npz" % r)) for r in range(world)]
+    got = np.zeros_like(M)
+    for i, bc in enumerate(b):
+        got[i, bc] = 1.0                                      # basic columns (stored nowhere if compact)
     for r in res:
         assert (int(r["status"]), int(r["npiv"])) == (so, no)
         assert np.array_equal(r["basis"], b) and np.array_equal(r["M"][:, -1], M[:, -1])
-    assert np.array_equal(np.concatenate([r["M"][:, :-1] for r in res], axis=1), M[:, :-1])
+        got[:, r["cols"]] = r["M"][:, :-1]
+    got[:, -1] = M[:, -1]
+    assert np.array_equal(got, M)
 
 
 def test_column_partition_pivot_cap_and_unbounded():

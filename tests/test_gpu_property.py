@@ -1,0 +1,87 @@
+"""Property-based parity: random shapes, senses, degeneracy patterns and internal code paths --
+the HIP path must always take the oracle's pivots and end with the oracle's bits."""
+import ctypes
+
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+import oracle
+from tests.helpers import lp_amd
+
+pytestmark = pytest.mark.gpu
+lp = lp_amd()
+
+
+def _random_tableau(rng, n, m, kind, density, degenerate):
+    """[A | I | b ; -+c | 0 | 0] with optional sparsity and exact ties (integer data)."""
+    if degenerate:
+        A = rng.integers(0, 4, (m, n)).astype(np.float64)
+        b = rng.integers(0, 5, m).astype(np.float64)            # zeros => degenerate pivots
+        c = rng.integers(-2, 5, n).astype(np.float64)
+    else:
+        A = rng.uniform(-0.5, 1.5, (m, n))
+        A[rng.uniform(size=(m, n)) > density] = 0.0
+        b = rng.uniform(0.5, 5.0, m)
+        c = rng.uniform(-0.5, 2.0, n)
+    M = np.zeros((m + 1, n + m + 1))
+    M[:m, :n] = A
+    M[np.arange(m), n + np.arange(m)] = 1.0
+    M[:m, -1] = b
+    M[m, :n] = -c if kind == "max" else c
+    return M, np.arange(n, n + m, dtype=np.int64)
+
+
+@settings(max_examples=200, deadline=None, suppress_health_check=list(HealthCheck))
+@given(n=st.integers(1, 700), m=st.integers(1, 400), seed=st.integers(0, 2 ** 31 - 1),
+       kind=st.sampled_from(["max", "min"]), density=st.sampled_from([1.0, 0.5, 0.1]),
+       degenerate=st.booleans(), select_mode=st.sampled_from([0, 1, 2]),
+       compact=st.sampled_from([0, 1]), variant=st.integers(0, 15))
+def test_random_lps_bitwise(n, m, seed, kind, density, degenerate, select_mode, compact, variant):
+    L = lp.capi.lib()
+    rng = np.random.default_rng(seed)
+    M0, b0 = _random_tableau(rng, n, m, kind, density, degenerate)
+    M, b = M0.copy(), b0.copy()
+    cap = 400                                        # degenerate LPs may cycle: no anti-cycling rule
+    st_o, npiv, trace = oracle.solve(M, b, is_max=(kind == "max"), max_pivots=cap, trace_cap=cap)
+    try:
+        L.mi355x_tune_set_select_mode(select_mode)
+        L.mi355x_tune_set_compact(compact)
+        L.mi355x_tune_set_variant(variant % L.mi355x_tune_variant_count())
+        t = lp.Tableau(None, lp.Problem(type=kind), M0, b0, n + m, m, {})
+        k = ctypes.c_int64(0)
+        rc = L.mi355x_tab_solve(t._h, int(kind == "max"), 1024.0, cap, ctypes.byref(k))
+        t._touch()
+    finally:
+        L.mi355x_tune_set_select_mode(0)
+        L.mi355x_tune_set_compact(1)
+        L.mi355x_tune_set_variant(0)
+    assert rc == st_o and k.value == npiv
+    assert np.array_equal(t.pivot_trace(), trace)
+    assert np.array_equal(t.matrix.view(np.int64), M.view(np.int64))      # bits, incl. signed zeros
+    assert np.array_equal(t.basis_columns, b)
+
+
+@settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+@given(n=st.integers(2, 60), mle=st.integers(0, 20), mge=st.integers(0, 15), meq=st.integers(0, 10),
+       seed=st.integers(0, 2 ** 31 - 1), kind=st.sampled_from(["max", "min"]))
+def test_random_two_phase_bitwise(n, mle, mge, meq, seed, kind):
+    from tests.helpers import random_mixed_problem
+    if mge + meq == 0:
+        mge = 1
+    problem = random_mixed_problem(lp, n, mle, mge, meq, seed, kind=kind)
+    tabs = lp.build_tableau(problem, problem)
+    art, main = tabs
+    A, ab = art.matrix.copy(), art.basis_columns.copy()
+    Mm, mb = main.matrix.copy(), main.basis_columns.copy()
+    st_o, npv = oracle.solve_two_phase(A, ab, Mm, mb, main_is_max=main.is_max)
+    npiv = (ctypes.c_int64 * 2)()
+    rc = lp.capi.lib().mi355x_solve_two_phase(art._h, main._h, int(main.is_max), 1024.0, npiv)
+    art._touch(); main._touch()
+    assert rc == st_o
+    assert np.array_equal(art.matrix.view(np.int64), A.view(np.int64))
+    if st_o == oracle.OPTIMAL:
+        assert (npiv[0], npiv[1]) == (npv[0], npv[1])
+    if st_o in (oracle.OPTIMAL, oracle.UNBOUNDED):
+        assert np.array_equal(main.matrix.view(np.int64), Mm.view(np.int64))
+        assert np.array_equal(main.basis_columns, mb)
