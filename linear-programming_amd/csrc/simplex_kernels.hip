@@ -1019,15 +1019,17 @@ static const UpdateVariant kVariants[] = {
     MI_VARIANT(256, 2, true, 2, 0),
     MI_VARIANT(256, 2, false, 2, 0),
     MI_VARIANT(256, 8, true, 8, 0),
+    MI_VARIANT(256, 8, false, 8, 0),
     MI_VARIANT(256, 8, true, 8, 4),
-    MI_VARIANT(256, 8, true, 8, 1),
+    MI_VARIANT(128, 4, false, 4, 0),
     MI_VARIANT(128, 8, true, 8, 0),
     MI_VARIANT(512, 4, true, 4, 0),
-    MI_VARIANT(512, 2, true, 2, 0),
-    MI_VARIANT(64, 4, true, 4, 0),
-    MI_VARIANT(1024, 4, true, 4, 0),
-    MI_VARIANT(256, 4, true, 8, 0),
-    MI_VARIANT(256, 4, true, 12, 0),
+    MI_VARIANT(512, 4, false, 4, 0),
+    MI_VARIANT(512, 2, false, 2, 0),
+    MI_VARIANT(64, 4, false, 4, 0),
+    MI_VARIANT(1024, 4, false, 4, 0),
+    MI_VARIANT(256, 4, false, 8, 0),
+    MI_VARIANT(256, 1, false, 1, 0),
 };
 static int g_variant = 0;
 constexpr int kCUs = 256, kThreadsPerCU = 2048;

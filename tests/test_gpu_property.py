@@ -36,7 +36,7 @@ def _random_tableau(rng, n, m, kind, density, degenerate):
 @given(n=st.integers(1, 700), m=st.integers(1, 400), seed=st.integers(0, 2 ** 31 - 1),
        kind=st.sampled_from(["max", "min"]), density=st.sampled_from([1.0, 0.5, 0.1]),
        degenerate=st.booleans(), select_mode=st.sampled_from([0, 1, 2]),
-       compact=st.sampled_from([0, 1]), variant=st.integers(0, 15))
+       compact=st.sampled_from([0, 1]), variant=st.integers(0, 17))
 def test_random_lps_bitwise(n, m, seed, kind, density, degenerate, select_mode, compact, variant):
     L = lp.capi.lib()
     rng = np.random.default_rng(seed)
