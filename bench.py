@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS) + ["cfg4", "colpart"])
     ap.add_argument("--batch-lps", type=int, default=128,
                     help="cfg4: LPs per GPU (BASELINE config 4 = 1024 LPs over 8 GPUs)")
+    ap.add_argument("--alternate-sweep", action="store_true",
+                    help="tuning: consecutive update launches sweep the tableau in opposite directions")
+    ap.add_argument("--force-dense", action="store_true",
+                    help="tuning: run the solve loop on the dense tableau (no compact representation)")
     ap.add_argument("--batch-mode", type=int, default=0,
                     help="cfg4: 0 auto, 1 lockstep launch pairs, 2 one workgroup per LP")
     ap.add_argument("--colpart-dense", action="store_true",
@@ -209,6 +213,10 @@ def main():
     R, C = m + 1, n + m + 1
     bytes_per_pivot = 2 * R * C * 8            # dense tableau: every element read once + written once
     L = lp.capi.lib()
+    if args.alternate_sweep:
+        L.mi355x_tune_set_alternate_sweep(1)
+    if args.force_dense:
+        L.mi355x_tune_set_compact(0)
     # One LP supports only so many pivots before it is optimal (config 3: 5 700-6 100, config 2:
     # ~290 with these seeds).  If more timed steps are asked for than one LP safely provides,
     # further LPs of the same shape are generated in HBM BEFORE the timed region and the timed

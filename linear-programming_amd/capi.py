@@ -75,6 +75,7 @@ _EXTRA = {
     "mi355x_tune_set_variant": (_int, [_int]),
     "mi355x_tune_set_select_mode": (_int, [_int]),
     "mi355x_tune_set_compact": (_int, [_int]),
+    "mi355x_tune_set_alternate_sweep": (_int, [_int]),
     "mi355x_tune_set_batch_mode": (_int, [_int]),
 }
 

@@ -81,6 +81,7 @@ struct mi355x_tab {
     int         shard_is_max = 1;         // sense last given to mi355x_shard_price
     int         timing_stride = 0;        // 0 = off, k = bracket every k-th update launch
     int64_t     update_launches = 0;
+    int64_t     sweeps = 0;               // update launches so far: odd ones sweep bottom-up
     int         n_timed = 0;
     std::vector<hipEvent_t> ev0, ev1;
 };
@@ -321,7 +322,7 @@ int enqueue_update(mi355x_tab *t, int is_max)
         }
         HIP_TRY(hipEventRecord(t->ev0[t->n_timed], t->stream));
     }
-    t->n_part = launch_update(cur(t), is_max ? 1.0 : -1.0, 1, t->stream);
+    t->n_part = launch_update(cur(t), is_max ? 1.0 : -1.0, 1, t->stream, t->sweeps++);
     t->part_is_max = is_max ? 1 : 0;
     if (timed) {
         HIP_TRY(hipEventRecord(t->ev1[t->n_timed], t->stream));
@@ -926,6 +927,7 @@ const char *mi355x_tune_variant_name(int v) { return (v >= 0 && v < update_varia
 int         mi355x_tune_set_variant(int v) { set_update_variant(v); return get_update_variant(); }
 int         mi355x_tune_set_select_mode(int mode) { g_select_mode = mode; return g_select_mode; }
 int         mi355x_tune_set_batch_mode(int mode) { g_batch_mode = mode; return g_batch_mode; }
+int         mi355x_tune_set_alternate_sweep(int on) { set_alternate_sweep(on); return on; }
 int         mi355x_tune_set_compact(int on) { g_compact_enabled = on ? 1 : 0; return g_compact_enabled; }
 
 }  // extern "C"

@@ -68,7 +68,8 @@ void launch_ratio_only(const TabView &t, int64_t ec, double fp_factor, hipStream
 void launch_prepare_pivot(const TabView &t, int64_t ec, int64_t cr, hipStream_t s);
 // the bandwidth kernel: M[r][c] -= col[r] * prow[c] (r != cr), M[cr][c] = prow[c]
 // returns the number of pricing partials written (0 if price == 0)
-int  launch_update(const TabView &t, double sgn, int price, hipStream_t s);
+int  launch_update(const TabView &t, double sgn, int price, hipStream_t s, int64_t launch_index = 0);
+void set_alternate_sweep(int on);
 UpdateShape update_shape(const TabView &t);
 // column-partitioned shards (one shard = one handle)
 void launch_shard_price(const TabView &t, int is_max, int64_t col_offset, double *out2, int n_part,
