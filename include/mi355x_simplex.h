@@ -169,6 +169,19 @@ int  mi355x_problem_set_integer(mi355x_problem *p, int64_t var);
 int  mi355x_problem_add_constraint(mi355x_problem *p, int op, const int64_t *var,
                                    const double *coef, int64_t nnz, double rhs);
 void mi355x_problem_destroy(mi355x_problem *p);
+/* The parsed problem as JSON text (inspection / tests).  Returns the length needed, writes at
+ * most cap-1 characters plus a NUL. */
+int64_t mi355x_problem_to_json(const mi355x_problem *p, char *buf, int64_t cap);
+/* read-mps (src/external-formats.lisp:78-348): fixed-width MPS text -> problem.
+ * default_is_max: 1 max, 0 min, -1 = the file's OBJSENSE section must say; rhs_id: name of the
+ * RHS vector to use, NULL = the first one in the file; read_case: 0 upcase, 1 downcase,
+ * 2 preserve, 3 invert (the reference's :read-case).  Variable names of the problem most
+ * recently read by the calling thread, in problem-vars order: mi355x_mps_var_name. */
+int  mi355x_problem_read_mps(const char *text, int64_t len, int default_is_max, const char *rhs_id,
+                             int read_case, mi355x_problem **out);
+int64_t     mi355x_mps_var_count(void);
+const char *mi355x_mps_var_name(int64_t i);
+const char *mi355x_mps_objective_name(void);
 /* build-tableau (src/simplex.lisp:142-328) in double-float, on the host.  which = 0: the main
  * tableau, 1: the artificial tableau (two-phase problems only).  Call once with NULL arrays for
  * the shape, again to fill matrix (rows*cols) and basis (rows-1).  Returns MI_UNBOUNDED for the

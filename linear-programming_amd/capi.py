@@ -47,6 +47,11 @@ SIGNATURES = {
     "mi355x_problem_set_integer": (_int, [_p, _i64]),
     "mi355x_problem_add_constraint": (_int, [_p, _int, _p, _p, _i64, _dbl]),
     "mi355x_problem_destroy": (None, [_p]),
+    "mi355x_problem_to_json": (_i64, [_p, ctypes.c_char_p, _i64]),
+    "mi355x_problem_read_mps": (_int, [ctypes.c_char_p, _i64, _int, ctypes.c_char_p, _int, _pp]),
+    "mi355x_mps_var_count": (_i64, []),
+    "mi355x_mps_var_name": (ctypes.c_char_p, [_i64]),
+    "mi355x_mps_objective_name": (ctypes.c_char_p, []),
     "mi355x_build_tableau": (_int, [_p, _int, _p, _p, _p, _p, _p]),
     "mi355x_var_mapping": (_int, [_p, _i64, _p, _p, _p]),
     "mi355x_simplex_solver": (_int, [_p, _dbl, _int, _pp]),

@@ -18,6 +18,7 @@ extern "C" void mi355x_set_last_error_(const char *msg);   // simplex_capi.hip (
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <new>
 #include <string>
@@ -302,6 +303,49 @@ int mi355x_problem_add_constraint(mi355x_problem *p, int op, const int64_t *var,
     c.coef.assign(coef, coef + nnz);
     p->constraints.push_back(std::move(c));
     return MI_OK;
+}
+
+// The parsed problem as JSON (for inspection / tests): returns the length needed (excluding the
+// terminating NUL); writes at most cap-1 characters.
+int64_t mi355x_problem_to_json(const mi355x_problem *p, char *buf, int64_t cap)
+{
+    if (!p) return hfail(MI_BAD_ARG, "problem is NULL");
+    std::string s = "{\"type\": \"";
+    s += p->is_max ? "max" : "min";
+    s += "\", \"n_vars\": " + std::to_string(p->n_vars) + ", \"objective\": [";
+    char num[64];
+    auto fmt = [&](double x) { snprintf(num, sizeof num, "%.17g", x); return std::string(num); };
+    for (size_t k = 0; k < p->obj_var.size(); ++k)
+        s += (k ? ", [" : "[") + std::to_string(p->obj_var[k]) + ", " + fmt(p->obj_coef[k]) + "]";
+    s += "], \"integer\": [";
+    bool first = true;
+    for (int64_t v = 0; v < p->n_vars; ++v)
+        if (p->is_integer[(size_t)v]) { s += (first ? "" : ", ") + std::to_string(v); first = false; }
+    s += "], \"bounds\": [";
+    first = true;
+    for (int64_t v = 0; v < p->n_vars; ++v) {
+        const Bound &b = p->bounds[(size_t)v];
+        if (!b.present) continue;
+        s += std::string(first ? "" : ", ") + "[" + std::to_string(v) + ", " +
+             (b.has_lb ? fmt(b.lb) : "null") + ", " + (b.has_ub ? fmt(b.ub) : "null") + "]";
+        first = false;
+    }
+    s += "], \"constraints\": [";
+    static const char *ops[] = {"<=", ">=", "="};
+    for (size_t k = 0; k < p->constraints.size(); ++k) {
+        const Constraint &c = p->constraints[k];
+        s += std::string(k ? ", " : "") + "[\"" + ops[c.op] + "\", [";
+        for (size_t j = 0; j < c.var.size(); ++j)
+            s += (j ? ", [" : "[") + std::to_string(c.var[j]) + ", " + fmt(c.coef[j]) + "]";
+        s += "], " + fmt(c.rhs) + "]";
+    }
+    s += "]}";
+    if (buf && cap > 0) {
+        const size_t n = std::min<size_t>(s.size(), (size_t)cap - 1);
+        std::memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)s.size();
 }
 
 int mi355x_build_tableau(const mi355x_problem *p, int which, int64_t *rows, int64_t *cols,

@@ -134,3 +134,40 @@ class NativeSolution:
         h, self._h = getattr(self, "_h", None), None
         if h:
             capi.lib().mi355x_solution_destroy(h)
+
+
+_READ_CASE = {"upcase": 0, "downcase": 1, "preserve": 2, "invert": 3}
+
+
+def read_mps(text, problem_type=None, rhs_id=None, read_case="upcase"):
+    """read-mps (src/external-formats.lisp:78-348) through the native reader
+    (csrc/mps_reader.cpp): fixed-width MPS text -> `Problem`.  problem_type: 'max' / 'min' /
+    None (the file's OBJSENSE section decides)."""
+    import json
+    from .conditions import ParsingError
+    from .problem import Problem
+    L = capi.lib()
+    data = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+    h = ctypes.c_void_p()
+    rc = L.mi355x_problem_read_mps(data, len(data),
+                                   {None: -1, "max": 1, "min": 0}[problem_type],
+                                   None if rhs_id is None else rhs_id.encode("utf-8"),
+                                   _READ_CASE[read_case], ctypes.byref(h))
+    if rc == capi.MI_BAD_ARG:
+        raise ParsingError(L.mi355x_last_error().decode("utf-8", "replace"))
+    capi.check(rc, "mi355x_problem_read_mps")
+    try:
+        n = L.mi355x_problem_to_json(h, None, 0)
+        buf = ctypes.create_string_buffer(n + 1)
+        L.mi355x_problem_to_json(h, buf, n + 1)
+        d = json.loads(buf.value.decode("utf-8"))
+        names = [L.mi355x_mps_var_name(i).decode("utf-8") for i in range(L.mi355x_mps_var_count())]
+        objective_var = L.mi355x_mps_objective_name().decode("utf-8")
+    finally:
+        L.mi355x_problem_destroy(h)
+    return Problem(type=d["type"], vars=names, objective_var=objective_var,
+                   objective_func=[(names[v], c) for v, c in d["objective"]],
+                   integer_vars=[names[v] for v in d["integer"]],
+                   var_bounds=[(names[v], (lb, ub)) for v, lb, ub in d["bounds"]],
+                   constraints=[(op, [(names[v], c) for v, c in e], rhs)
+                                for op, e, rhs in d["constraints"]])

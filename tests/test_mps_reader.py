@@ -1,0 +1,116 @@
+"""The native fixed-width MPS reader (csrc/mps_reader.cpp) against the expectations of the
+reference's own read-mps test (t/external-formats.lisp:212-291) on the reference's own data
+files (tests/golden/mps/, copied from t/data/).  CPU only."""
+import os
+
+import pytest
+
+from tests.helpers import ROOT, lp_amd
+
+lp = lp_amd()
+read_mps = lp.native.read_mps
+DATA = os.path.join(ROOT, "tests", "golden", "mps")
+
+
+def _text(name):
+    with open(os.path.join(DATA, name), newline="") as f:      # keep CRLF as it is
+        return f.read()
+
+
+def _cset(constraints):
+    return {(op, frozenset(e), rhs) for op, e, rhs in constraints}
+
+
+@pytest.mark.parametrize("name", ["simple-problem.mps", "simple-problem-crlf.mps"])
+def test_simple_problem(name):
+    """t/external-formats.lisp:213-230 and 274-291 (the CRLF copy parses identically)."""
+    p = read_mps(_text(name), "max")
+    assert p.type == "max"
+    assert set(p.vars) == {"X", "Y", "Z"}
+    assert set(p.objective_func) == {("X", 1.0), ("Y", 4.0), ("Z", 8.0)}
+    assert p.integer_vars == [] and p.var_bounds == []
+    assert _cset(p.constraints) == _cset([("<=", [("X", 3.0), ("Y", 1.0)], 8.0),
+                                          ("<=", [("Y", 1.0), ("Z", 2.0)], 7.0)])
+
+
+def test_advanced_problem():
+    """t/external-formats.lisp:231-248: lower-case headers, OBJSENSE min, the named RHS vector,
+    a G row with negative right-hand side (flipped), BV / LO / UP / FR bounds, decimal 4.5."""
+    p = read_mps(_text("advanced-problem.mps"), None, rhs_id="rhs1", read_case="preserve")
+    assert p.type == "min"
+    assert set(p.vars) == {"w", "X", "Y", "Z"}
+    assert set(p.objective_func) == {("w", -1.0), ("X", 1.0), ("Y", 4.5), ("Z", 8.0)}
+    assert set(p.integer_vars) == {"w"}
+    assert set(p.var_bounds) == {("Z", (0.0, 4.0)), ("w", (0.0, 1.0)), ("X", (None, None))}
+    assert _cset(p.constraints) == _cset([("<=", [("X", 3.0), ("Y", 1.0)], 8.0),
+                                          ("<=", [("Y", 1.0), ("Z", 2.0)], 10.0),
+                                          ("<=", [("w", -1.0), ("X", -2.0), ("Z", 1.0)], 1.0)])
+
+
+@pytest.mark.parametrize("mode,expect", [("upcase", {"W", "X", "Y", "Z"}),
+                                         ("downcase", {"w", "x", "y", "z"}),
+                                         ("invert", {"W", "x", "y", "z"})])
+def test_read_case_modes(mode, expect):
+    """t/external-formats.lisp:250-271."""
+    p = read_mps(_text("advanced-problem.mps"), None, rhs_id="rhs1", read_case=mode)
+    assert set(p.vars) == expect
+
+
+def test_first_rhs_vector_is_the_default_and_type_is_required():
+    p = read_mps(_text("advanced-problem.mps"), None, read_case="preserve")     # first: testrhs
+    rhs = sorted(c[2] for c in p.constraints)
+    assert rhs == [6.0, 10.0, 18.0]
+    text = _text("simple-problem.mps")
+    with pytest.raises(lp.ParsingError):
+        read_mps(text, None)                                  # "No valid problem type was specified"
+    with pytest.raises(lp.ParsingError):
+        read_mps(text.replace(" L  row2", " Q  row2"), "max")  # unknown row type
+
+
+def test_extras_bounds_ranges_single_variable_rows_and_embedding():
+    text = """NAME          t
+ROWS
+ N  cost
+ L  lim1
+ G  lim2
+ E  eq1
+ L  onlyx
+COLUMNS
+    x         cost      1.5             lim1      1
+    x         lim2      1               onlyx     2
+    y         cost      2               lim1      1
+    y         eq1       -1
+    z         cost      -1              eq1       1
+    z         lim2      1
+RHS
+    r         lim1      4               lim2      1
+    r         eq1       -7              onlyx     6
+RANGES
+    r         lim1      2.5
+BOUNDS
+ UP b         y         10
+ MI b         z
+ LI b         x         1
+ENDATA
+this text after ENDATA is not part of the problem
+"""
+    p = read_mps(text, "max", read_case="preserve")
+    assert p.vars == ["x", "y", "z"] and p.integer_vars == ["x"]
+    b = dict(p.var_bounds)
+    assert b["x"] == (1.0, 3.0)            # LI 1, and the single-variable row 2x <= 6
+    assert b["y"] == (0.0, 10.0) and b["z"] == (None, None)
+    assert _cset(p.constraints) == _cset([("<=", [("x", 1.0), ("y", 1.0)], 4.0),
+                                          (">=", [("x", 1.0), ("y", 1.0)], 1.5),     # range 2.5
+                                          (">=", [("x", 1.0), ("z", 1.0)], 1.0),
+                                          ("=", [("y", 1.0), ("z", -1.0)], 7.0)])     # flipped
+
+
+@pytest.mark.gpu
+def test_mps_to_solution_on_gpu():
+    """MPS text -> native problem -> GPU solve: the simple problem's LP optimum."""
+    p = read_mps(_text("simple-problem.mps"), "max")
+    sol = lp.NativeProblem(p).solve()
+    # max x + 4y + 8z, 3x + y <= 8, y + 2z <= 7  ->  x = 8/3, y = 0, z = 7/2: 92/3
+    assert abs(sol.objective_value() - 92.0 / 3.0) < 1e-12
+    assert abs(sol.variable("X") - 8.0 / 3.0) < 1e-12 and sol.variable("Y") == 0.0
+    assert abs(sol.variable("Z") - 3.5) < 1e-12
