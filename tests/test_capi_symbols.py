@@ -94,3 +94,15 @@ def test_product_package_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
                 assert "liboracle" not in text and "simplex_oracle" not in text, f
+
+
+def test_header_is_plain_c_and_a_c_program_links(tmp_path):
+    """gcc -std=c11 -Wall -Werror on a C client of the header, linked against the library."""
+    exe = str(tmp_path / "c_abi_check")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror",
+                           "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_abi_check.c"), "-o", exe,
+                           "-L", os.path.dirname(lp.capi.LIB_PATH), "-lmi355x_simplex",
+                           "-Wl,-rpath," + os.path.dirname(lp.capi.LIB_PATH)])
+    out = subprocess.check_output([exe], text=True)
+    assert "c abi ok" in out
