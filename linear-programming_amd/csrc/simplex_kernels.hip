@@ -157,6 +157,7 @@ __device__ __forceinline__ ValIdx block_price_partials(const double *__restrict_
 // Gather the entering column and run find-pivoting-row (src/simplex.lisp:382-389).
 // col_src == nullptr: read M[r][ec] (and snapshot it into t.col); otherwise the column was
 // supplied by another shard and is read from col_src (and copied into t.col).
+template <int THREADS = kSelThreads>
 __device__ __forceinline__ ValIdx block_gather_ratio(const TabView &t, int64_t ec,
                                                      const double *__restrict__ col_src,
                                                      double ratio_thr, double *s_v, long long *s_i,
@@ -164,17 +165,17 @@ __device__ __forceinline__ ValIdx block_gather_ratio(const TabView &t, int64_t e
 {
     const int64_t m = t.rows - 1, vc = t.cols - 1;
     ValIdx best; best.v = 0.0; best.i = -1;
-    for (int64_t base = 0; base < t.rows; base += (int64_t)kBatch * kSelThreads) {
+    for (int64_t base = 0; base < t.rows; base += (int64_t)kBatch * THREADS) {
         double a[kBatch], b[kBatch];
 #pragma unroll
         for (int g = 0; g < kBatch; ++g) {           // the strided gathers: all in flight at once
-            const int64_t r = base + (int64_t)g * kSelThreads + threadIdx.x;
+            const int64_t r = base + (int64_t)g * THREADS + threadIdx.x;
             a[g] = r < t.rows ? (col_src ? col_src[r] : t.M[r * t.ld + ec]) : 0.0;
             b[g] = r < m ? (rhs_src ? rhs_src[r] : t.M[r * t.ld + vc]) : 0.0;
         }
 #pragma unroll
         for (int g = 0; g < kBatch; ++g) {
-            const int64_t r = base + (int64_t)g * kSelThreads + threadIdx.x;
+            const int64_t r = base + (int64_t)g * THREADS + threadIdx.x;
             if (r < t.rows) t.col[r] = a[g];
             if (r < m && ratio_thr < a[g]) {         // (fp< 0 a factor/2) -> (< (+ 0 thr) a)
                 const double q = b[g] / a[g];
@@ -182,7 +183,7 @@ __device__ __forceinline__ ValIdx block_gather_ratio(const TabView &t, int64_t e
             }
         }
     }
-    return block_reduce_min(best, s_v, s_i);
+    return block_reduce_min<THREADS>(best, s_v, s_i);
 }
 
 // prow[c] = M[cr][c] / M[cr][ec]  (src/simplex.lisp:343-348), padding columns zeroed.
@@ -199,22 +200,23 @@ __device__ __forceinline__ double2 scale_pair(const TabView &t, int64_t p, doubl
     return o;
 }
 
+template <int THREADS = kSelThreads>
 __device__ __forceinline__ void block_scale_row(const TabView &t, int64_t cr, double row_scale,
                                                 int64_t unit_slot = -1)
 {
     const double2 *__restrict__ src = reinterpret_cast<const double2 *>(t.M + cr * t.ld);
     double2 *dst = reinterpret_cast<double2 *>(t.prow);
     const int64_t npair = t.ld >> 1;
-    for (int64_t base = 0; base < npair; base += (int64_t)kBatch * kSelThreads) {
+    for (int64_t base = 0; base < npair; base += (int64_t)kBatch * THREADS) {
         double2 v[kBatch];
 #pragma unroll
         for (int g = 0; g < kBatch; ++g) {
-            const int64_t p = base + (int64_t)g * kSelThreads + threadIdx.x;
+            const int64_t p = base + (int64_t)g * THREADS + threadIdx.x;
             v[g] = p < npair ? src[p] : make_double2(0.0, 0.0);
         }
 #pragma unroll
         for (int g = 0; g < kBatch; ++g) {
-            const int64_t p = base + (int64_t)g * kSelThreads + threadIdx.x;
+            const int64_t p = base + (int64_t)g * THREADS + threadIdx.x;
             if (p < npair) dst[p] = scale_pair(t, p, v[g], row_scale, unit_slot);
         }
     }
@@ -262,19 +264,20 @@ __device__ __forceinline__ TabView lp_slice(TabView t)
 }
 
 // ------------------------------------------------------------------ select kernels
-__global__ __launch_bounds__(kSelThreads) void k_select(TabView t, double sgn, double price_tol,
-                                                       double ratio_thr, int n_part)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_select(TabView t, double sgn, double price_tol,
+                                                   double ratio_thr, int n_part)
 {
-    __shared__ double    s_v[kSelWaves];
-    __shared__ long long s_i[kSelWaves];
+    __shared__ double    s_v[THREADS / 64];
+    __shared__ long long s_i[THREADS / 64];
     t = lp_slice(t);
     Ctl *ctl = t.ctl;
     if (ctl->status != kRunning) return;
     const int64_t m = t.rows - 1, vc = t.cols - 1;
 
     // n_part > 0: the preceding k_update of this tableau priced the new objective row
-    const ValIdx e = n_part > 0 ? block_price_partials(t.part_v, t.part_i, n_part, s_v, s_i)
-                                : block_price(t.M + m * t.ld, vc, sgn, s_v, s_i, t.p2l);
+    const ValIdx e = n_part > 0 ? block_price_partials<THREADS>(t.part_v, t.part_i, n_part, s_v, s_i)
+                                : block_price<THREADS>(t.M + m * t.ld, vc, sgn, s_v, s_i, t.p2l);
     // (fp< v 0 factor/8): v < 0 - tol ; min problems: (fp> v 0 factor/8) <=> -v < 0 - tol
     if (e.i < 0 || !(e.v < 0.0 - price_tol)) {
         if (threadIdx.x == 0) ctl->status = 0;      // MI_OPTIMAL
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(kSelThreads) void k_select(TabView t, double sgn, d
     }
     const int64_t ec   = e.i;                       // LOGICAL column
     const int64_t slot = t.l2p ? t.l2p[ec] : ec;    // where it is stored
-    const ValIdx q = block_gather_ratio(t, slot, nullptr, ratio_thr, s_v, s_i);
+    const ValIdx q = block_gather_ratio<THREADS>(t, slot, nullptr, ratio_thr, s_v, s_i);
     if (q.i < 0) {
         if (threadIdx.x == 0) ctl->status = 1;      // MI_UNBOUNDED
         return;
@@ -295,9 +298,9 @@ __global__ __launch_bounds__(kSelThreads) void k_select(TabView t, double sgn, d
     const int64_t cr = q.i;
     const double row_scale = t.M[cr * t.ld + slot];
     __syncthreads();                                // everyone has row_scale before the overwrite
-    block_scale_row(t, cr, row_scale, t.p2l ? slot : -1);
+    block_scale_row<THREADS>(t, cr, row_scale, t.p2l ? slot : -1);
     if (t.p2l) {                                    // the slot now holds the leaving column: e_cr
-        for (int64_t r = threadIdx.x; r < t.rows; r += kSelThreads)
+        for (int64_t r = threadIdx.x; r < t.rows; r += THREADS)
             t.M[r * t.ld + slot] = (r == cr) ? 1.0 : 0.0;
         if (threadIdx.x == 0) swap_columns(t, ec, cr);
     }
@@ -898,8 +901,15 @@ static inline double sgn_of(int is_max) { return is_max ? 1.0 : -1.0; }
 
 void launch_select(const TabView &t, int is_max, double f, int n_part, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_select, dim3(1, 1, (unsigned)t.n_lps), dim3(kSelThreads), 0, s, t, sgn_of(is_max),
-                       (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon, n_part);
+    // one workgroup per tableau; a narrow workgroup when there is little to do per phase (its
+    // barriers and reductions are the cost): measured on config 2, 10.3 us with 1024 threads
+    const dim3 grid(1, 1, (unsigned)t.n_lps);
+    const double ptol = (f / 8.0) * kClEpsilon, rthr = 0.0 + (f / 2.0) * kClEpsilon;
+    if (t.rows <= 2048 && t.ld <= 4096)
+        hipLaunchKernelGGL(k_select<256>, grid, dim3(256), 0, s, t, sgn_of(is_max), ptol, rthr, n_part);
+    else
+        hipLaunchKernelGGL(k_select<kSelThreads>, grid, dim3(kSelThreads), 0, s, t, sgn_of(is_max),
+                           ptol, rthr, n_part);
 }
 void launch_select_split(const TabView &t, int is_max, double f, int n_part, hipStream_t s)
 {
