@@ -115,6 +115,7 @@ void free_tab(mi355x_tab *t)
     (void)hipFree(t->v.trace_cr);
     (void)hipFree(t->v.part_v);
     (void)hipFree(t->v.part_i);
+    (void)hipFree(t->v.part_s);
     (void)hipFree(t->c.M);
     (void)hipFree(t->c.p2l);
     (void)hipFree(t->c.l2p);
@@ -178,6 +179,7 @@ int alloc_tab(mi355x_tab **out, int64_t rows, int64_t cols, int device, int64_t 
     }
     ALLOC(t->v.part_v, n_lps * part_cap * sizeof(double));
     ALLOC(t->v.part_i, n_lps * part_cap * sizeof(int64_t));
+    ALLOC(t->v.part_s, n_lps * part_cap * sizeof(int64_t));
     t->v.part_cap = part_cap;
 #undef ALLOC
     if ((e = hipHostMalloc((void **)&t->h_ctl, n_lps * sizeof(Ctl))) != hipSuccess ||

@@ -42,6 +42,7 @@ struct TabView {
     int64_t  trace_cap;
     double  *part_v;      // per-wave pricing partials left by k_update (key space); the
     int64_t *part_i;      // upper half holds the ratio-test partials of the split select
+    int64_t *part_s;      // payload of each partial (physical slot / pivot-element bits)
     int      part_cap;
     // compact representation (non-basic columns + RHS only): physical slot <-> logical column
     // maps; both null for the dense logical layout

@@ -49,6 +49,8 @@ namespace mi355x {
 struct ValIdx {
     double  v;
     int64_t i;   // < 0 : empty
+    int64_t s;   // payload that travels with the winner (never compared): the physical slot of a
+                 // pricing candidate / the bit pattern of the pivot element of a ratio candidate
 };
 
 // lexicographic (value, index) minimum; an empty slot loses against anything
@@ -67,6 +69,7 @@ __device__ __forceinline__ ValIdx wave_reduce_min(ValIdx x)
         ValIdx y;
         y.v = __shfl_down(x.v, off, 64);
         y.i = __shfl_down((long long)x.i, off, 64);
+        y.s = __shfl_down((long long)x.s, off, 64);
         x = vi_min(x, y);
     }
     return x;
@@ -79,16 +82,17 @@ constexpr int kSelWaves   = kSelThreads / 64;
 template <int THREADS = kSelThreads>
 __device__ __forceinline__ ValIdx block_reduce_min(ValIdx x, double *s_v, long long *s_i)
 {
+    __shared__ long long s_s[THREADS / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     x = wave_reduce_min(x);
-    __syncthreads();                       // protects s_v/s_i reuse across calls
-    if (lane == 0) { s_v[wave] = x.v; s_i[wave] = x.i; }
+    __syncthreads();                       // protects s_v/s_i/s_s reuse across calls
+    if (lane == 0) { s_v[wave] = x.v; s_i[wave] = x.i; s_s[wave] = x.s; }
     __syncthreads();
     ValIdx r;
-    r.v = s_v[0]; r.i = s_i[0];
+    r.v = s_v[0]; r.i = s_i[0]; r.s = s_s[0];
 #pragma unroll
     for (int w = 1; w < THREADS / 64; ++w) {
-        ValIdx y; y.v = s_v[w]; y.i = s_i[w];
+        ValIdx y; y.v = s_v[w]; y.i = s_i[w]; y.s = s_s[w];
         r = vi_min(r, y);
     }
     return r;
@@ -111,7 +115,7 @@ __device__ __forceinline__ ValIdx block_price(const double *__restrict__ obj, in
     // p2l != nullptr (compact representation): physical slot -> logical column; the winner is
     // the lexicographic (key, LOGICAL column) minimum, i.e. still the reference's lowest-index
     // strict minimum, whatever order the columns are stored in.
-    ValIdx best; best.v = 0.0; best.i = -1;
+    ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
     const int64_t npair = ncols >> 1;                 // obj is 128-byte aligned (row start)
     const double2 *obj2 = reinterpret_cast<const double2 *>(obj);
     for (int64_t base = 0; base < npair; base += (int64_t)kBatch * THREADS) {
@@ -126,14 +130,14 @@ __device__ __forceinline__ ValIdx block_price(const double *__restrict__ obj, in
             const int64_t p = base + (int64_t)g * THREADS + threadIdx.x;
             if (p < npair) {
                 ValIdx c0, c1;
-                c0.v = v[g].x * sgn; c0.i = p2l ? p2l[2 * p] : 2 * p;
-                c1.v = v[g].y * sgn; c1.i = p2l ? p2l[2 * p + 1] : 2 * p + 1;
+                c0.v = v[g].x * sgn; c0.i = p2l ? p2l[2 * p] : 2 * p;         c0.s = 2 * p;
+                c1.v = v[g].y * sgn; c1.i = p2l ? p2l[2 * p + 1] : 2 * p + 1; c1.s = 2 * p + 1;
                 best = vi_min(vi_min(best, c0), c1);
             }
         }
     }
     if ((ncols & 1) && threadIdx.x == 0) {          // odd tail element
-        ValIdx t; t.v = obj[ncols - 1] * sgn; t.i = p2l ? p2l[ncols - 1] : ncols - 1;
+        ValIdx t; t.v = obj[ncols - 1] * sgn; t.i = p2l ? p2l[ncols - 1] : ncols - 1; t.s = ncols - 1;
         best = vi_min(best, t);
     }
     return block_reduce_min<THREADS>(best, s_v, s_i);
@@ -144,11 +148,12 @@ __device__ __forceinline__ ValIdx block_price(const double *__restrict__ obj, in
 template <int THREADS = kSelThreads>
 __device__ __forceinline__ ValIdx block_price_partials(const double *__restrict__ pv,
                                                        const int64_t *__restrict__ pi,
+                                                       const int64_t *__restrict__ ps,
                                                        int n_part, double *s_v, long long *s_i)
 {
-    ValIdx best; best.v = 0.0; best.i = -1;
+    ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
     for (int k = threadIdx.x; k < n_part; k += THREADS) {
-        ValIdx t; t.v = pv[k]; t.i = pi[k];
+        ValIdx t; t.v = pv[k]; t.i = pi[k]; t.s = ps[k];
         best = vi_min(best, t);
     }
     return block_reduce_min<THREADS>(best, s_v, s_i);
@@ -164,7 +169,7 @@ __device__ __forceinline__ ValIdx block_gather_ratio(const TabView &t, int64_t e
                                                      const double *__restrict__ rhs_src = nullptr)
 {
     const int64_t m = t.rows - 1, vc = t.cols - 1;
-    ValIdx best; best.v = 0.0; best.i = -1;
+    ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
     for (int64_t base = 0; base < t.rows; base += (int64_t)kBatch * THREADS) {
         double a[kBatch], b[kBatch];
 #pragma unroll
@@ -179,7 +184,7 @@ __device__ __forceinline__ ValIdx block_gather_ratio(const TabView &t, int64_t e
             if (r < t.rows) t.col[r] = a[g];
             if (r < m && ratio_thr < a[g]) {         // (fp< 0 a factor/2) -> (< (+ 0 thr) a)
                 const double q = b[g] / a[g];
-                if (best.i < 0 || q < best.v) { best.v = q; best.i = r; }
+                if (best.i < 0 || q < best.v) { best.v = q; best.i = r; best.s = __double_as_longlong(a[g]); }
             }
         }
     }
@@ -224,27 +229,30 @@ __device__ __forceinline__ void block_scale_row(const TabView &t, int64_t cr, do
 
 // Compact representation, bookkeeping of one pivot (ONE thread): the entering logical column
 // becomes basic in row cr and gives up its physical slot to the leaving basic column.
-__device__ __forceinline__ void swap_columns(const TabView &t, int64_t ec_log, int64_t cr)
+__device__ __forceinline__ void swap_columns(const TabView &t, int64_t ec_log, int64_t cr,
+                                             int64_t slot)
 {
-    const int64_t slot    = t.l2p[ec_log];
     const int64_t leaving = t.basis[cr];            // read BEFORE record_pivot overwrites it
     t.p2l[slot]    = leaving;
     t.l2p[leaving] = slot;
     t.l2p[ec_log]  = -1;
 }
 
-__device__ __forceinline__ void record_pivot(const TabView &t, int64_t ec, int64_t cr)
+// `c0` is the control block as loaded at kernel entry: the bookkeeping at the END of a select
+// kernel is then a handful of independent stores instead of a chain of dependent
+// load-modify-store round trips on one thread (which used to be the kernel's tail).
+__device__ __forceinline__ void record_pivot(const TabView &t, const Ctl &c0, int64_t ec, int64_t cr)
 {
     Ctl *ctl = t.ctl;
     ctl->ec = ec;
     ctl->cr = cr;
     if (t.basis) t.basis[cr] = ec;                  // src/simplex.lisp:358
-    if (t.trace_ec && ctl->trace_n < t.trace_cap) {
-        t.trace_ec[ctl->trace_n] = ec;
-        t.trace_cr[ctl->trace_n] = cr;
+    if (t.trace_ec && c0.trace_n < t.trace_cap) {
+        t.trace_ec[c0.trace_n] = ec;
+        t.trace_cr[c0.trace_n] = cr;
     }
-    ctl->trace_n += 1;
-    ctl->n_pivots += 1;
+    ctl->trace_n  = c0.trace_n + 1;
+    ctl->n_pivots = c0.n_pivots + 1;
 }
 
 // A batch of same-shape LPs is one TabView plus per-LP element strides; grid.z = LP index
@@ -258,6 +266,7 @@ __device__ __forceinline__ TabView lp_slice(TabView t)
     t.prow   += z * t.zs_prow;
     t.part_v += z * t.zs_part;
     t.part_i += z * t.zs_part;
+    t.part_s += z * t.zs_part;
     t.ctl    += z;
     if (t.p2l) { t.p2l += z * t.zs_p2l; t.l2p += z * t.zs_l2p; }
     return t;
@@ -272,39 +281,39 @@ __global__ __launch_bounds__(THREADS) void k_select(TabView t, double sgn, doubl
     __shared__ long long s_i[THREADS / 64];
     t = lp_slice(t);
     Ctl *ctl = t.ctl;
-    if (ctl->status != kRunning) return;
+    const Ctl c0 = *ctl;                            // one load of the whole control block
+    if (c0.status != kRunning) return;
     const int64_t m = t.rows - 1, vc = t.cols - 1;
 
     // n_part > 0: the preceding k_update of this tableau priced the new objective row
-    const ValIdx e = n_part > 0 ? block_price_partials<THREADS>(t.part_v, t.part_i, n_part, s_v, s_i)
+    const ValIdx e = n_part > 0 ? block_price_partials<THREADS>(t.part_v, t.part_i, t.part_s, n_part, s_v, s_i)
                                 : block_price<THREADS>(t.M + m * t.ld, vc, sgn, s_v, s_i, t.p2l);
     // (fp< v 0 factor/8): v < 0 - tol ; min problems: (fp> v 0 factor/8) <=> -v < 0 - tol
     if (e.i < 0 || !(e.v < 0.0 - price_tol)) {
         if (threadIdx.x == 0) ctl->status = 0;      // MI_OPTIMAL
         return;
     }
-    if (ctl->max_pivots > 0 && ctl->n_pivots >= ctl->max_pivots) {
+    if (c0.max_pivots > 0 && c0.n_pivots >= c0.max_pivots) {
         __syncthreads();
         if (threadIdx.x == 0) ctl->status = 3;      // MI_MAX_PIVOTS
         return;
     }
     const int64_t ec   = e.i;                       // LOGICAL column
-    const int64_t slot = t.l2p ? t.l2p[ec] : ec;    // where it is stored
+    const int64_t slot = e.s;                       // where it is stored (travels with the winner)
     const ValIdx q = block_gather_ratio<THREADS>(t, slot, nullptr, ratio_thr, s_v, s_i);
     if (q.i < 0) {
         if (threadIdx.x == 0) ctl->status = 1;      // MI_UNBOUNDED
         return;
     }
     const int64_t cr = q.i;
-    const double row_scale = t.M[cr * t.ld + slot];
-    __syncthreads();                                // everyone has row_scale before the overwrite
+    const double row_scale = __longlong_as_double(q.s);   // M[cr][slot], carried by the winner
     block_scale_row<THREADS>(t, cr, row_scale, t.p2l ? slot : -1);
     if (t.p2l) {                                    // the slot now holds the leaving column: e_cr
         for (int64_t r = threadIdx.x; r < t.rows; r += THREADS)
             t.M[r * t.ld + slot] = (r == cr) ? 1.0 : 0.0;
-        if (threadIdx.x == 0) swap_columns(t, ec, cr);
+        if (threadIdx.x == 0) swap_columns(t, ec, cr, slot);
     }
-    if (threadIdx.x == 0) record_pivot(t, ec, cr);
+    if (threadIdx.x == 0) record_pivot(t, c0, ec, cr);
 }
 
 // ---- the same select, split over many workgroups (large tableaux) -------------------------
@@ -326,33 +335,35 @@ __global__ __launch_bounds__(kGatherThreads) void k_select_gather(TabView t, dou
     t = lp_slice(t);
     double  *rp_v = t.part_v + t.part_cap / 2;      // ratio partials: upper half of the buffers
     int64_t *rp_i = t.part_i + t.part_cap / 2;
+    int64_t *rp_s = t.part_s + t.part_cap / 2;
     Ctl *ctl = t.ctl;
-    if (ctl->status != kRunning) return;
+    const Ctl c0 = *ctl;                            // one load of the whole control block
+    if (c0.status != kRunning) return;
     const int64_t m = t.rows - 1, vc = t.cols - 1;
     const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
     const ValIdx e = n_part > 0
-        ? block_price_partials<kGatherThreads>(t.part_v, t.part_i, n_part, s_v, s_i)
+        ? block_price_partials<kGatherThreads>(t.part_v, t.part_i, t.part_s, n_part, s_v, s_i)
         : block_price<kGatherThreads>(t.M + m * t.ld, vc, sgn, s_v, s_i, t.p2l);
     if (e.i < 0 || !(e.v < 0.0 - price_tol)) {
         if (leader) ctl->status = 0;                // MI_OPTIMAL
         return;
     }
-    if (ctl->max_pivots > 0 && ctl->n_pivots >= ctl->max_pivots) {
+    if (c0.max_pivots > 0 && c0.n_pivots >= c0.max_pivots) {
         if (leader) ctl->status = 3;                // MI_MAX_PIVOTS
         return;
     }
     const int64_t ec   = e.i;                       // LOGICAL column
-    const int64_t slot = t.l2p ? t.l2p[ec] : ec;
+    const int64_t slot = e.s;                       // its physical column
     const int64_t r = (int64_t)blockIdx.x * kGatherThreads + threadIdx.x;
-    ValIdx best; best.v = 0.0; best.i = -1;
+    ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
     if (r < t.rows) {
         const double a = t.M[r * t.ld + slot];
         const double b = r < m ? t.M[r * t.ld + vc] : 0.0;
         t.col[r] = a;
-        if (r < m && ratio_thr < a) { best.v = b / a; best.i = r; }
+        if (r < m && ratio_thr < a) { best.v = b / a; best.i = r; best.s = __double_as_longlong(a); }
     }
     best = block_reduce_min<kGatherThreads>(best, s_v, s_i);
-    if (threadIdx.x == 0) { rp_v[blockIdx.x] = best.v; rp_i[blockIdx.x] = best.i; }
+    if (threadIdx.x == 0) { rp_v[blockIdx.x] = best.v; rp_i[blockIdx.x] = best.i; rp_s[blockIdx.x] = best.s; }
     if (leader) { ctl->ec = ec; ctl->slot = slot; }
 }
 
@@ -363,18 +374,20 @@ __global__ __launch_bounds__(kScaleThreads) void k_select_scale(TabView t, int n
     t = lp_slice(t);
     const double  *rp_v = t.part_v + t.part_cap / 2;
     const int64_t *rp_i = t.part_i + t.part_cap / 2;
+    const int64_t *rp_s = t.part_s + t.part_cap / 2;
     Ctl *ctl = t.ctl;
-    if (ctl->status != kRunning) return;
+    const Ctl c0 = *ctl;                            // one load of the whole control block
+    if (c0.status != kRunning) return;
     const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
-    const ValIdx q = block_price_partials<kScaleThreads>(rp_v, rp_i, n_rp, s_v, s_i);
+    const ValIdx q = block_price_partials<kScaleThreads>(rp_v, rp_i, rp_s, n_rp, s_v, s_i);
     if (q.i < 0) {
         if (leader) ctl->status = 1;                // MI_UNBOUNDED
         return;
     }
     const int64_t cr = q.i;
-    const double row_scale = t.col[cr];             // == M[cr][ec], snapshotted by the gather
-    const int64_t ec   = ctl->ec;                   // LOGICAL column (written by the gather)
-    const int64_t slot = t.p2l ? ctl->slot : -1;    // compact: the slot the leaving column takes
+    const double row_scale = __longlong_as_double(q.s);   // M[cr][slot], carried by the winner
+    const int64_t ec   = c0.ec;                     // LOGICAL column (written by the gather)
+    const int64_t slot = t.p2l ? c0.slot : -1;      // compact: the slot the leaving column takes
     const int64_t npair = t.ld >> 1;
     const int64_t p = (int64_t)blockIdx.x * kScaleThreads + threadIdx.x;
     if (p < npair) {
@@ -388,8 +401,8 @@ __global__ __launch_bounds__(kScaleThreads) void k_select_scale(TabView t, int n
             t.M[r * t.ld + slot] = (r == cr) ? 1.0 : 0.0;
     }
     if (leader) {
-        if (t.p2l) swap_columns(t, ec, cr);
-        record_pivot(t, ec, cr);
+        if (t.p2l) swap_columns(t, ec, cr, slot);
+        record_pivot(t, c0, ec, cr);
     }
 }
 
@@ -403,7 +416,7 @@ __global__ __launch_bounds__(kSelThreads) void k_price_only(TabView t, double sg
     __shared__ double    s_v[kSelWaves];
     __shared__ long long s_i[kSelWaves];
     const int64_t m = t.rows - 1, vc = t.cols - 1;
-    const ValIdx e = n_part > 0 ? block_price_partials(t.part_v, t.part_i, n_part, s_v, s_i)
+    const ValIdx e = n_part > 0 ? block_price_partials(t.part_v, t.part_i, t.part_s, n_part, s_v, s_i)
                                 : block_price(t.M + m * t.ld, vc, sgn, s_v, s_i, t.p2l);
     if (threadIdx.x == 0) {
         if (out2) {                                 // compact shards price GLOBAL columns already
@@ -431,8 +444,9 @@ __global__ __launch_bounds__(kSelThreads) void k_prepare_pivot(TabView t, int64_
         t.col[r] = t.M[r * t.ld + ec];
     block_scale_row(t, cr, t.M[cr * t.ld + ec]);
     if (threadIdx.x == 0) {
+        Ctl c0 = *t.ctl;
         t.ctl->status = kRunning;
-        record_pivot(t, ec, cr);
+        record_pivot(t, c0, ec, cr);
     }
 }
 
@@ -448,9 +462,9 @@ __global__ __launch_bounds__(kSelThreads) void k_shard_contribute(TabView t, con
                                                                  double price_tol,
                                                                  long long *bits_out, int64_t *ec_out)
 {
-    ValIdx best; best.v = 0.0; best.i = -1;
+    ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
     for (int k = 0; k < n_shards; ++k) {
-        ValIdx c; c.v = gathered[2 * k]; c.i = (int64_t)gathered[2 * k + 1];
+        ValIdx c; c.v = gathered[2 * k]; c.i = (int64_t)gathered[2 * k + 1]; c.s = 0;
         best = vi_min(best, c);
     }
     const int64_t ec = (best.i >= 0 && best.v < 0.0 - price_tol) ? best.i : -1;
@@ -479,13 +493,14 @@ __global__ __launch_bounds__(kSelThreads) void k_shard_prepare(TabView t, const 
     __shared__ double    s_v[kSelWaves];
     __shared__ long long s_i[kSelWaves];
     Ctl *ctl = t.ctl;
-    if (ctl->status != kRunning) return;
+    const Ctl c0 = *ctl;                            // one load of the whole control block
+    if (c0.status != kRunning) return;
     const int64_t global_ec = *ec_dev;
     if (global_ec < 0) {
         if (threadIdx.x == 0) ctl->status = 0;      // MI_OPTIMAL
         return;
     }
-    if (ctl->max_pivots > 0 && ctl->n_pivots >= ctl->max_pivots) {
+    if (c0.max_pivots > 0 && c0.n_pivots >= c0.max_pivots) {
         if (threadIdx.x == 0) ctl->status = 3;      // MI_MAX_PIVOTS
         return;
     }
@@ -502,9 +517,9 @@ __global__ __launch_bounds__(kSelThreads) void k_shard_prepare(TabView t, const 
     if (slot >= 0) {
         for (int64_t r = threadIdx.x; r < t.rows; r += kSelThreads)
             t.M[r * t.ld + slot] = (r == cr) ? 1.0 : 0.0;
-        if (threadIdx.x == 0) swap_columns(t, global_ec, cr);
+        if (threadIdx.x == 0) swap_columns(t, global_ec, cr, slot);
     }
-    if (threadIdx.x == 0) record_pivot(t, global_ec, cr);   // basis holds GLOBAL column indices
+    if (threadIdx.x == 0) record_pivot(t, c0, global_ec, cr);   // basis holds GLOBAL column indices
 }
 
 // ------------------------------------------------------------------ the bandwidth kernel
@@ -531,6 +546,7 @@ __global__ __launch_bounds__(BLOCK) void k_update(TabView t, const int tr, const
     const Ctl *__restrict__ ctl = t.ctl;
     double  *__restrict__ part_v = price ? t.part_v : nullptr;
     int64_t *__restrict__ part_i = t.part_i;
+    int64_t *__restrict__ part_s = t.part_s;
     if (ctl->status != kRunning) return;
     const int64_t cr   = ctl->cr;
     const int64_t ldv  = ld >> 1;                              // row length in 16-byte pairs
@@ -589,14 +605,14 @@ __global__ __launch_bounds__(BLOCK) void k_update(TabView t, const int tr, const
         }
     }
     if (prices) {                                              // `last` = new objective-row entries
-        ValIdx best; best.v = 0.0; best.i = -1;
+        ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
         const int64_t c0 = 2 * pair;
         if (active && c0 < vc) {
-            ValIdx c; c.v = last.x * sgn; c.i = t.p2l ? t.p2l[c0] : c0;
+            ValIdx c; c.v = last.x * sgn; c.i = t.p2l ? t.p2l[c0] : c0; c.s = c0;
             best = vi_min(best, c);
         }
         if (active && c0 + 1 < vc) {
-            ValIdx c; c.v = last.y * sgn; c.i = t.p2l ? t.p2l[c0 + 1] : c0 + 1;
+            ValIdx c; c.v = last.y * sgn; c.i = t.p2l ? t.p2l[c0 + 1] : c0 + 1; c.s = c0 + 1;
             best = vi_min(best, c);
         }
         best = wave_reduce_min(best);
@@ -604,6 +620,7 @@ __global__ __launch_bounds__(BLOCK) void k_update(TabView t, const int tr, const
             const int slot = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
             part_v[slot] = best.v;
             part_i[slot] = best.i;
+            part_s[slot] = best.s;
         }
     }
 }
@@ -627,15 +644,17 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_solve(TabView t, double sg
     __shared__ long long s_i[kLpThreads / 64];
     t = lp_slice(t);
     Ctl *ctl = t.ctl;
-    if (ctl->status != kRunning) return;
+    const Ctl c0 = *ctl;                            // one load of the whole control block
+    if (c0.status != kRunning) return;
     const int64_t rows = t.rows, m = rows - 1, vc = t.cols - 1, ld = t.ld, ldv = ld >> 1;
     double  *s_prow = lds;                          // ld doubles (16-byte aligned)
     double  *s_col  = lds + ld;                     // rows doubles
     vec2d   *M2 = reinterpret_cast<vec2d *>(t.M);
     const int64_t total = rows * ldv;               // tableau size in 16-byte pairs
     const int64_t dr = kLpThreads / ldv, dp = kLpThreads % ldv;   // flat-index stride as (row, pair)
-    int64_t n_pivots = ctl->n_pivots;
-    const int64_t max_pivots = ctl->max_pivots;
+    Ctl cl = c0;                                    // running copy (n_pivots / trace_n advance)
+    int64_t n_pivots = c0.n_pivots;
+    const int64_t max_pivots = c0.max_pivots;
 
     ValIdx e = block_price(t.M + m * ld, vc, sgn, s_v, s_i, t.p2l);
     for (;;) {
@@ -648,14 +667,14 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_solve(TabView t, double sg
             break;
         }
         const int64_t ec   = e.i;                   // LOGICAL column
-        const int64_t slot = t.l2p ? t.l2p[ec] : ec;
+        const int64_t slot = e.s;                   // its physical column
         // gather the entering column into LDS + ratio test
-        ValIdx best; best.v = 0.0; best.i = -1;
+        ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
         for (int64_t r = threadIdx.x; r < rows; r += kLpThreads) {
             const double a = t.M[r * ld + slot];
             s_col[r] = a;
             if (r < m && ratio_thr < a) {
-                ValIdx c; c.v = t.M[r * ld + vc] / a; c.i = r;
+                ValIdx c; c.v = t.M[r * ld + vc] / a; c.i = r; c.s = 0;
                 best = vi_min(best, c);
             }
         }
@@ -675,12 +694,12 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_solve(TabView t, double sg
             __syncthreads();                        // row cr has been read
             for (int64_t r = threadIdx.x; r < rows; r += kLpThreads)
                 t.M[r * ld + slot] = (r == cr) ? 1.0 : 0.0;
-            if (threadIdx.x == 0) swap_columns(t, ec, cr);
+            if (threadIdx.x == 0) swap_columns(t, ec, cr, slot);
         }
         __syncthreads();
         // rank-1 update of the whole tableau, 4 independent 16-byte accesses in flight per thread;
         // the threads that write the objective row price it for the next iteration
-        best.v = 0.0; best.i = -1;
+        best.v = 0.0; best.i = -1; best.s = 0;
         int64_t idx = threadIdx.x, r = threadIdx.x / ldv, p = threadIdx.x % ldv;
         while (idx < total) {
             vec2d   v[4];
@@ -710,13 +729,14 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_solve(TabView t, double sg
                     M2[ii[u]] = o;
                     if (ri[u] == m) {
                         const int64_t c0 = 2 * pi[u];
-                        if (c0 < vc)     { ValIdx c; c.v = o.x * sgn; c.i = t.p2l ? t.p2l[c0] : c0;         best = vi_min(best, c); }
-                        if (c0 + 1 < vc) { ValIdx c; c.v = o.y * sgn; c.i = t.p2l ? t.p2l[c0 + 1] : c0 + 1; best = vi_min(best, c); }
+                        if (c0 < vc)     { ValIdx c; c.v = o.x * sgn; c.i = t.p2l ? t.p2l[c0] : c0;         c.s = c0;     best = vi_min(best, c); }
+                        if (c0 + 1 < vc) { ValIdx c; c.v = o.y * sgn; c.i = t.p2l ? t.p2l[c0 + 1] : c0 + 1; c.s = c0 + 1; best = vi_min(best, c); }
                     }
                 }
             }
         }
-        if (threadIdx.x == 0) record_pivot(t, ec, cr);
+        if (threadIdx.x == 0) record_pivot(t, cl, ec, cr);
+        cl.n_pivots += 1; cl.trace_n += 1;
         n_pivots += 1;
         e = block_reduce_min(best, s_v, s_i);       // barrier: the update is complete and visible
     }
