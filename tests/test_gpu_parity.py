@@ -513,6 +513,40 @@ def test_max_pivots_and_resume():
     assert np.array_equal(t.matrix, M) and np.array_equal(t.pivot_trace(), trace)
 
 
+def test_handles_are_independent_across_host_threads():
+    """The ABI promises thread-safety per handle: several host threads solve different LPs on
+    their own handles at the same time (ctypes drops the GIL during the calls) and every result
+    still matches the oracle bit for bit."""
+    import threading
+    jobs = [(120 + 10 * k, 60 + 5 * k, lp.synth.seed_for(7, k)) for k in range(6)]
+    results, errors = {}, []
+
+    def work(k, n, m, seed):
+        try:
+            M0, b0 = lp.synth.tableau(n, m, seed)
+            t = lp.Tableau(None, lp.Problem(type="max"), M0, b0, n + m, m, {})
+            for _ in range(3):                       # solve, download, re-upload, solve again
+                lp.n_solve_tableau(t)
+                results[k] = (t.matrix.copy(), t.basis_columns.copy(), t.pivot_trace())
+                lp.capi.check(lp.capi.lib().mi355x_tab_upload(
+                    t._h, M0.ctypes.data_as(ctypes.c_void_p), b0.ctypes.data_as(ctypes.c_void_p)), "upload")
+                t._touch()
+        except Exception as e:                       # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,) + j) for k, j in enumerate(jobs)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for k, (n, m, seed) in enumerate(jobs):
+        M, b = lp.synth.tableau(n, m, seed)
+        st, npiv, trace = oracle.solve(M, b, trace_cap=1 << 14)
+        Mg, bg, tg = results[k]
+        assert np.array_equal(Mg, M) and np.array_equal(bg, b) and np.array_equal(tg, trace)
+
+
 def test_async_enqueue_matches_blocking_solve():
     """mi355x_tab_solve_async + mi355x_tab_sync (what bench.py times)."""
     n, m = 300, 150
