@@ -635,6 +635,7 @@ __global__ __launch_bounds__(BLOCK) void k_update(TabView t, const int tr, const
 // LPs progress independently and the hardware schedules waiting LPs onto free CUs.  Same
 // arithmetic, same lexicographic reductions => same bits as the lockstep path and the oracle.
 constexpr int kLpThreads = 1024;
+constexpr int kLpUnroll  = 4;   // measured at 128 / 1024 LPs of 257x513: 2 -> 1.76 / 1.49, 4 -> 1.76 / 2.13, 8 -> 1.22 / 1.33 M pivots/s
 
 __global__ __launch_bounds__(kLpThreads) void k_batch_solve(TabView t, double sgn, double price_tol,
                                                            double ratio_thr)
@@ -697,16 +698,17 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_solve(TabView t, double sg
             if (threadIdx.x == 0) swap_columns(t, ec, cr, slot);
         }
         __syncthreads();
-        // rank-1 update of the whole tableau, 4 independent 16-byte accesses in flight per thread;
+        // rank-1 update of the whole tableau, kLpUnroll independent 16-byte accesses in flight per thread
+        // (one workgroup streams at bytes-in-flight / latency: 8 x 16 B x 1024 threads per ~2 us);
         // the threads that write the objective row price it for the next iteration
         best.v = 0.0; best.i = -1; best.s = 0;
         int64_t idx = threadIdx.x, r = threadIdx.x / ldv, p = threadIdx.x % ldv;
         while (idx < total) {
-            vec2d   v[4];
-            int64_t ri[4], pi[4], ii[4];
+            vec2d   v[kLpUnroll];
+            int64_t ri[kLpUnroll], pi[kLpUnroll], ii[kLpUnroll];
             int     n = 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kLpUnroll; ++u) {
                 if (idx < total) {
                     ri[u] = r; pi[u] = p; ii[u] = idx;
                     v[u] = M2[idx];
@@ -716,7 +718,7 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_solve(TabView t, double sg
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kLpUnroll; ++u) {
                 if (u < n) {
                     const double s = s_col[ri[u]];
                     const double2 pp = reinterpret_cast<const double2 *>(s_prow)[pi[u]];
