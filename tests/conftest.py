@@ -12,6 +12,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Make sure the native pieces exist before any test imports them: the HIP extension
+    (hipcc cross-compiles without a GPU) and the C oracle.  Both are no-ops when up to date."""
+    try:
+        import __graft_entry__
+        __graft_entry__.build()
+    except Exception as e:                               # noqa: BLE001
+        print("warning: build() failed before the test session: %r" % (e,))
+
+
 @pytest.fixture(scope="session")
 def golden():
     from tests import goldens
