@@ -32,7 +32,8 @@ def _random_tableau(rng, n, m, kind, density, degenerate):
     return M, np.arange(n, n + m, dtype=np.int64)
 
 
-@settings(max_examples=200, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=200, deadline=None, derandomize=True, database=None,
+          suppress_health_check=list(HealthCheck))
 @given(n=st.integers(1, 700), m=st.integers(1, 400), seed=st.integers(0, 2 ** 31 - 1),
        kind=st.sampled_from(["max", "min"]), density=st.sampled_from([1.0, 0.5, 0.1]),
        degenerate=st.booleans(), select_mode=st.sampled_from([0, 1, 2]),
@@ -62,7 +63,8 @@ def test_random_lps_bitwise(n, m, seed, kind, density, degenerate, select_mode, 
     assert np.array_equal(t.basis_columns, b)
 
 
-@settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=60, deadline=None, derandomize=True, database=None,
+          suppress_health_check=list(HealthCheck))
 @given(n=st.integers(2, 60), mle=st.integers(0, 20), mge=st.integers(0, 15), meq=st.integers(0, 10),
        seed=st.integers(0, 2 ** 31 - 1), kind=st.sampled_from(["max", "min"]))
 def test_random_two_phase_bitwise(n, mle, mge, meq, seed, kind):
