@@ -73,7 +73,7 @@ def cpu_baseline(lp, n, m, seed, pivots):
     run here) timed on the host cores on the first `pivots` pivots of the same LP."""
     import oracle
     M, b = lp.synth.tableau(n, m, seed)
-    threads = os.cpu_count() or 1
+    threads = oracle.omp_threads()
     t0 = time.perf_counter()
     st, npiv, _ = oracle.solve(M, b, max_pivots=pivots, omp=True)
     t_omp = time.perf_counter() - t0

@@ -44,6 +44,7 @@ def lib():
         L = ctypes.CDLL(_LIB_PATH)
         i64, dbl, p = ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
         L.orc_epsilon.restype = dbl
+        L.orc_omp_threads.restype = ctypes.c_int
         L.orc_price.restype = i64
         L.orc_price.argtypes = [p, i64, i64, i64, ctypes.c_int, dbl]
         L.orc_ratio.restype = i64
@@ -62,6 +63,11 @@ def lib():
             f.argtypes = [dbl, dbl, dbl]
         _lib = L
     return _lib
+
+
+def omp_threads():
+    """Threads the OpenMP variant uses."""
+    return int(lib().orc_omp_threads())
 
 
 def _chk(M, basis=None):

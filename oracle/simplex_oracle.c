@@ -50,6 +50,14 @@ static const double CL_DOUBLE_FLOAT_EPSILON = 1.1102230246251568e-16;
 
 double orc_epsilon(void) { return CL_DOUBLE_FLOAT_EPSILON; }
 
+/* threads orc_pivot_omp will use (reported as cpu_baseline.cores by bench.py) */
+#ifdef _OPENMP
+#include <omp.h>
+int orc_omp_threads(void) { return omp_get_max_threads(); }
+#else
+int orc_omp_threads(void) { return 1; }
+#endif
+
 /* find-entering-column, src/simplex.lisp:362-379.
  * max problem: lowest-index strict argmin of the objective row over
  * [0, var_count); returned iff (fp< v 0 factor/8)  <=>  v < 0 - (factor/8)*eps.
