@@ -46,6 +46,10 @@ extern "C" {
 #define MI_MAX_PIVOTS    3   /* pivot cap reached (backend-specific; the reference has no cap) */
 #define MI_ART_NONZERO   4   /* "Artificial variable ~S still non-zero"       simplex.lisp:423-424 */
 #define MI_ART_STUCK     5   /* "Artificial variable still in basis and ..."  simplex.lisp:432-433 */
+#define MI_NONFINITE     6   /* compact column shards only: the entering column holds an inf / NaN;
+                                the reference would spread NaNs over basic columns, which are not
+                                stored there (single tableaux and batches switch to the dense
+                                tableau by themselves and continue) */
 #define MI_RUNNING     100   /* asynchronous use only: the iterations enqueued so far have not
                                 terminated the solve (mi355x_tab_sync) */
 /* errors */

@@ -8,6 +8,7 @@ LIB_PATH = os.path.join(HERE, "libmi355x_simplex.so")
 
 MI_OK = MI_OPTIMAL = 0
 MI_UNBOUNDED, MI_INFEASIBLE, MI_MAX_PIVOTS, MI_ART_NONZERO, MI_ART_STUCK = 1, 2, 3, 4, 5
+MI_NONFINITE = 6
 MI_RUNNING = 100
 MI_BAD_ARG, MI_HIP_ERROR, MI_RCCL_ERROR, MI_NO_DEVICE, MI_NO_MEMORY, MI_UNSUPPORTED = -1, -2, -3, -4, -5, -6
 

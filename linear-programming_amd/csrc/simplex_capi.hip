@@ -295,6 +295,19 @@ int ensure_compact(mi355x_tab *t)
     return MI_OK;
 }
 
+// A select met an inf / NaN in the entering column while on the compact representation
+// (status kNeedDense, the pivot was not applied): the reference would turn basic columns into
+// NaNs, so go back to the dense logical tableau for good and let the pivot be redone there.
+int fall_back_to_dense(mi355x_tab *t)
+{
+    int rc = ensure_dense(t);
+    if (rc != MI_OK) return rc;
+    t->compact_failed = true;
+    launch_ctl_resume(t->v, t->stream);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
 // select of one iteration; prices from the partials of the preceding update when they exist
 void enqueue_select(mi355x_tab *t, int is_max, double f)
 {
@@ -522,6 +535,11 @@ int mi355x_tab_sync(mi355x_tab *t, int64_t *n_pivots)
     rc = read_ctl(t);
     if (rc != MI_OK) return rc;
     if (n_pivots) *n_pivots = t->h_ctl->n_pivots;
+    if (t->h_ctl->status == kNeedDense) {             // see fall_back_to_dense: further
+        rc = fall_back_to_dense(t);                   // iterations continue on the dense tableau
+        if (rc != MI_OK) return rc;
+        return MI_RUNNING;
+    }
     return status_to_rc(t->h_ctl->status);
 }
 
@@ -549,6 +567,12 @@ int mi355x_tab_solve(mi355x_tab *t, int is_max, double f, int64_t max_pivots, in
         HIP_TRY(hipGetLastError());
         rc = read_ctl(t);
         if (rc != MI_OK) return rc;
+        if (t->h_ctl->status == kNeedDense) {         // redo that pivot, and the rest, densely
+            rc = fall_back_to_dense(t);
+            if (rc != MI_OK) return rc;
+            enqueue_select(t, is_max, f);
+            continue;
+        }
         if (t->h_ctl->status != kRunning) break;
         if (chunk < 512) chunk *= 2;
     }
@@ -771,7 +795,13 @@ int mi355x_batch_solve(mi355x_batch *b, int is_max, double f, int64_t max_pivots
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(t->h_ctl, t->v.ctl, n * sizeof(Ctl), hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));
-            break;
+            bool need_dense = false;
+            for (int64_t i = 0; i < n && !need_dense; ++i) need_dense = t->h_ctl[i].status == kNeedDense;
+            if (!need_dense) break;
+            rc = fall_back_to_dense(t);               // some LP met an inf / NaN: finish densely
+            if (rc != MI_OK) return rc;
+            if (!launch_batch_solve(cur(t), is_max, f, t->stream)) return fail(MI_HIP_ERROR, "batch relaunch failed");
+            continue;
         }
         for (int64_t i = 0; i < chunk; ++i) {
             rc = enqueue_update(t, is_max);
@@ -781,8 +811,17 @@ int mi355x_batch_solve(mi355x_batch *b, int is_max, double f, int64_t max_pivots
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(t->h_ctl, t->v.ctl, n * sizeof(Ctl), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
-        bool running = false;
-        for (int64_t i = 0; i < n && !running; ++i) running = t->h_ctl[i].status == kRunning;
+        bool running = false, need_dense = false;
+        for (int64_t i = 0; i < n; ++i) {
+            running |= t->h_ctl[i].status == kRunning;
+            need_dense |= t->h_ctl[i].status == kNeedDense;
+        }
+        if (need_dense) {
+            rc = fall_back_to_dense(t);
+            if (rc != MI_OK) return rc;
+            enqueue_select(t, is_max, f);
+            continue;
+        }
         if (!running) break;
         if (chunk < 256) chunk *= 2;
     }

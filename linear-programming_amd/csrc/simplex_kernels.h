@@ -12,12 +12,17 @@ constexpr double kClEpsilon = 1.1102230246251568e-16;
 
 // device-side status word; values >= 0 other than kRunning are the MI_* outcomes
 constexpr int32_t kRunning = 100;
+// compact representation only: the entering column holds an inf / NaN.  The reference would
+// turn every basic column into NaNs (x - inf*0), which a representation that does not store
+// basic columns cannot reproduce: the pivot is NOT applied and the host re-runs it on the dense
+// tableau (single tableaux, batches) or reports MI_NONFINITE (compact column shards).
+constexpr int32_t kNeedDense = 101;
 
 // Control block living in device memory: the whole price -> ratio -> pivot loop
 // runs without host round trips, kernels communicate through this struct.
 struct Ctl {
     int32_t status;       // kRunning, or MI_OPTIMAL / MI_UNBOUNDED / MI_MAX_PIVOTS
-    int32_t _pad;
+    int32_t poison;       // set by k_select_gather when it meets a non-finite column entry
     int64_t ec;           // entering column chosen by the last select
     int64_t cr;           // pivot row chosen by the last select
     int64_t n_pivots;     // pivots since the last reset
@@ -90,6 +95,8 @@ void launch_compact(const TabView &dense, const TabView &compact, hipStream_t s)
 void launch_expand(const TabView &dense, const TabView &compact, int64_t *brow, hipStream_t s);
 void launch_ctl_reset(const TabView &t, int64_t max_pivots, int reset_trace, hipStream_t s);
 void launch_ctl_finish(const TabView &t, hipStream_t s);
+// kNeedDense -> kRunning (after the host has rebuilt the dense tableau)
+void launch_ctl_resume(const TabView &t, hipStream_t s);
 // synthetic LP straight into HBM
 void launch_synth_fill(const TabView &t, int64_t n_vars, int64_t n_cons, uint64_t seed,
                        const uint64_t *dev_seeds, int64_t col_begin, int64_t col_end, hipStream_t s);

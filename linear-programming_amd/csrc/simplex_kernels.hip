@@ -166,9 +166,11 @@ template <int THREADS = kSelThreads>
 __device__ __forceinline__ ValIdx block_gather_ratio(const TabView &t, int64_t ec,
                                                      const double *__restrict__ col_src,
                                                      double ratio_thr, double *s_v, long long *s_i,
-                                                     const double *__restrict__ rhs_src = nullptr)
+                                                     const double *__restrict__ rhs_src = nullptr,
+                                                     int *nonfinite = nullptr)
 {
     const int64_t m = t.rows - 1, vc = t.cols - 1;
+    int bad = 0;
     ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
     for (int64_t base = 0; base < t.rows; base += (int64_t)kBatch * THREADS) {
         double a[kBatch], b[kBatch];
@@ -181,13 +183,14 @@ __device__ __forceinline__ ValIdx block_gather_ratio(const TabView &t, int64_t e
 #pragma unroll
         for (int g = 0; g < kBatch; ++g) {
             const int64_t r = base + (int64_t)g * THREADS + threadIdx.x;
-            if (r < t.rows) t.col[r] = a[g];
+            if (r < t.rows) { t.col[r] = a[g]; bad |= !(fabs(a[g]) <= 1.7976931348623157e308); }
             if (r < m && ratio_thr < a[g]) {         // (fp< 0 a factor/2) -> (< (+ 0 thr) a)
                 const double q = b[g] / a[g];
                 if (best.i < 0 || q < best.v) { best.v = q; best.i = r; best.s = __double_as_longlong(a[g]); }
             }
         }
     }
+    if (nonfinite) *nonfinite = bad;               // this thread's entries only
     return block_reduce_min<THREADS>(best, s_v, s_i);
 }
 
@@ -300,7 +303,12 @@ __global__ __launch_bounds__(THREADS) void k_select(TabView t, double sgn, doubl
     }
     const int64_t ec   = e.i;                       // LOGICAL column
     const int64_t slot = e.s;                       // where it is stored (travels with the winner)
-    const ValIdx q = block_gather_ratio<THREADS>(t, slot, nullptr, ratio_thr, s_v, s_i);
+    int bad = 0;
+    const ValIdx q = block_gather_ratio<THREADS>(t, slot, nullptr, ratio_thr, s_v, s_i, nullptr, &bad);
+    if (t.p2l && __syncthreads_or(bad)) {           // see kNeedDense
+        if (threadIdx.x == 0) ctl->status = kNeedDense;
+        return;
+    }
     if (q.i < 0) {
         if (threadIdx.x == 0) ctl->status = 1;      // MI_UNBOUNDED
         return;
@@ -360,6 +368,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_select_gather(TabView t, dou
         const double a = t.M[r * t.ld + slot];
         const double b = r < m ? t.M[r * t.ld + vc] : 0.0;
         t.col[r] = a;
+        if (t.p2l && !(fabs(a) <= 1.7976931348623157e308)) atomicOr(&ctl->poison, 1);   // see kNeedDense
         if (r < m && ratio_thr < a) { best.v = b / a; best.i = r; best.s = __double_as_longlong(a); }
     }
     best = block_reduce_min<kGatherThreads>(best, s_v, s_i);
@@ -379,6 +388,10 @@ __global__ __launch_bounds__(kScaleThreads) void k_select_scale(TabView t, int n
     const Ctl c0 = *ctl;                            // one load of the whole control block
     if (c0.status != kRunning) return;
     const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+    if (c0.poison) {                                // the gather met an inf / NaN: see kNeedDense
+        if (leader) ctl->status = kNeedDense;
+        return;
+    }
     const ValIdx q = block_price_partials<kScaleThreads>(rp_v, rp_i, rp_s, n_rp, s_v, s_i);
     if (q.i < 0) {
         if (leader) ctl->status = 1;                // MI_UNBOUNDED
@@ -504,7 +517,12 @@ __global__ __launch_bounds__(kSelThreads) void k_shard_prepare(TabView t, const 
         if (threadIdx.x == 0) ctl->status = 3;      // MI_MAX_PIVOTS
         return;
     }
-    const ValIdx q = block_gather_ratio(t, 0, col_src, ratio_thr, s_v, s_i, t.rhs);
+    int bad = 0;
+    const ValIdx q = block_gather_ratio(t, 0, col_src, ratio_thr, s_v, s_i, t.rhs, &bad);
+    if (t.p2l && __syncthreads_or(bad)) {           // compact shard: cannot follow the reference
+        if (threadIdx.x == 0) ctl->status = 6;      // MI_NONFINITE
+        return;
+    }
     if (q.i < 0) {
         if (threadIdx.x == 0) ctl->status = 1;      // MI_UNBOUNDED
         return;
@@ -671,15 +689,21 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_solve(TabView t, double sg
         const int64_t slot = e.s;                   // its physical column
         // gather the entering column into LDS + ratio test
         ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
+        int bad = 0;
         for (int64_t r = threadIdx.x; r < rows; r += kLpThreads) {
             const double a = t.M[r * ld + slot];
             s_col[r] = a;
+            bad |= !(fabs(a) <= 1.7976931348623157e308);
             if (r < m && ratio_thr < a) {
                 ValIdx c; c.v = t.M[r * ld + vc] / a; c.i = r; c.s = 0;
                 best = vi_min(best, c);
             }
         }
         const ValIdx q = block_reduce_min(best, s_v, s_i);     // barriers: s_col complete
+        if (t.p2l && __syncthreads_or(bad)) {                  // see kNeedDense
+            if (threadIdx.x == 0) ctl->status = kNeedDense;
+            break;
+        }
         if (q.i < 0) {
             if (threadIdx.x == 0) ctl->status = 1;  // MI_UNBOUNDED
             break;
@@ -825,11 +849,18 @@ __global__ void k_ctl_reset(Ctl *ctl, int64_t max_pivots, int reset_trace)
 {
     ctl += blockIdx.x;                                         // one block per LP of a batch
     ctl->status     = kRunning;
+    ctl->poison     = 0;
     ctl->ec         = -1;
     ctl->cr         = -1;
     ctl->n_pivots   = 0;
     ctl->max_pivots = max_pivots;
     if (reset_trace) ctl->trace_n = 0;
+}
+
+__global__ void k_ctl_resume(Ctl *ctl)
+{
+    ctl += blockIdx.x;
+    if (ctl->status == kNeedDense) { ctl->status = kRunning; ctl->poison = 0; }
 }
 
 // After the last enqueued iteration: a tableau that is still "running" has simply used up
@@ -1025,6 +1056,10 @@ void launch_expand(const TabView &d, const TabView &c, int64_t *brow, hipStream_
 void launch_ctl_reset(const TabView &t, int64_t max_pivots, int reset_trace, hipStream_t s)
 {
     hipLaunchKernelGGL(k_ctl_reset, dim3((unsigned)t.n_lps), dim3(1), 0, s, t.ctl, max_pivots, reset_trace);
+}
+void launch_ctl_resume(const TabView &t, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_ctl_resume, dim3((unsigned)t.n_lps), dim3(1), 0, s, t.ctl);
 }
 void launch_ctl_finish(const TabView &t, hipStream_t s)
 {

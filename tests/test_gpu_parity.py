@@ -643,6 +643,60 @@ def test_batch_synthetic_config4_shape_and_statuses(batch_mode):
     assert st[2] == lp.capi.MI_UNBOUNDED
 
 
+def _same_bits_nan_aware(G, M):
+    nan_g, nan_m = np.isnan(G), np.isnan(M)
+    return np.array_equal(nan_g, nan_m) and np.array_equal(G[~nan_g].view(np.int64), M[~nan_m].view(np.int64))
+
+
+def test_batch_with_nonfinite_member_falls_back_to_dense(batch_mode):
+    """One LP of a batch overflows to inf during its pivots: the reference would spread NaNs
+    over basic columns (x - inf*0), which the compact representation does not store, so the whole
+    batch finishes on the dense tableaux -- every member still equals the oracle."""
+    n, m = 12, 8
+    tabs = [lp.synth.tableau(n, m, 300 + k) for k in range(4)]
+    Ms = np.stack([t[0] for t in tabs]); Bs = np.stack([t[1] for t in tabs])
+    Ms[1, :m, :n] *= 1e200                         # products overflow
+    Ms[1, :m, -1] *= 1e150
+    Ms[1, 2, 3] = 1e308
+    batch = lp.TableauBatch.from_arrays(Ms, Bs)
+    st, npv = batch.solve(max_pivots=30)
+    for k in range(4):
+        M, b = Ms[k].copy(), Bs[k].copy()
+        with np.errstate(all="ignore"):
+            so, no, _ = oracle.solve(M, b, max_pivots=30)
+        Mg, bg = batch.download(k)
+        assert (st[k], npv[k]) == (so, no), k
+        assert _same_bits_nan_aware(Mg, M) and np.array_equal(bg, b), k
+
+
+def test_compact_shards_report_nonfinite_columns():
+    """A compact column shard cannot reproduce NaNs in columns nobody stores: MI_NONFINITE."""
+    import importlib
+    import torch
+    cp = importlib.import_module("linear-programming_amd.colpart")
+    n, m = 40, 20
+    M0, b0 = lp.synth.tableau(n, m, 5)
+    M0[3, 7] = np.inf
+    M0[m, 7] = -1e9                                # make column 7 the first entering column
+    shards = []
+    for r, (b, e) in enumerate(cp.partition(n, 2)):
+        local = np.ascontiguousarray(np.concatenate([M0[:, b:e], M0[:, -1:]], axis=1))
+        h = ctypes.c_void_p()
+        lp.capi.check(lp.capi.lib().mi355x_tab_create(ctypes.byref(h), m + 1, local.shape[1],
+                                                      local.ctypes.data_as(ctypes.c_void_p),
+                                                      b0.ctypes.data_as(ctypes.c_void_p), 0), "create")
+        lp.capi.check(lp.capi.lib().mi355x_tab_set_stream(
+            h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), 0), "stream")
+        cols = np.arange(b, e, dtype=np.int64)
+        lp.capi.check(lp.capi.lib().mi355x_shard_set_compact(h, n + m, cols.ctypes.data_as(ctypes.c_void_p)),
+                      "compact")
+        shards.append(cp.Shard(torch, h, b, e, m + 1, 2, torch.device("cuda", 0)))
+    tab = cp.ColumnPartitionedTableau(shards, cp.LocalComm(torch), cp.HipBackend())
+    st, npiv = tab.solve(check_every=4)
+    assert (st, npiv) == (lp.capi.MI_NONFINITE, 0)
+    cp.destroy_shards(shards)
+
+
 # =========================================================================== column partition (config 5)
 @pytest.mark.parametrize("compact", [False, True], ids=["dense-shards", "compact-shards"])
 @pytest.mark.parametrize("n_shards,n,m", [(1, 60, 40), (2, 96, 64), (3, 100, 50), (8, 512, 256)])

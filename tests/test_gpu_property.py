@@ -87,3 +87,34 @@ def test_random_two_phase_bitwise(n, mle, mge, meq, seed, kind):
     if st_o in (oracle.OPTIMAL, oracle.UNBOUNDED):
         assert np.array_equal(main.matrix.view(np.int64), Mm.view(np.int64))
         assert np.array_equal(main.basis_columns, mb)
+
+
+@settings(max_examples=80, deadline=None, derandomize=True, database=None,
+          suppress_health_check=list(HealthCheck))
+@given(n=st.integers(2, 60), m=st.integers(1, 40), seed=st.integers(0, 2 ** 31 - 1),
+       lo=st.sampled_from([-300, -160, -20]), hi=st.sampled_from([20, 160, 300]))
+def test_extreme_magnitudes_bitwise(n, m, seed, lo, hi):
+    """Entries spanning up to 600 orders of magnitude: products overflow to inf, quotients
+    underflow into subnormals, inf - inf gives NaN.  Finite values and infinities must still
+    match the oracle bit for bit (subnormals are never flushed on either side); NaNs must sit
+    in the same places (x86 and gfx950 differ in the sign bit of the default NaN, nothing else)."""
+    rng = np.random.default_rng(seed)
+    mag = lambda shape: rng.uniform(0.5, 2.0, shape) * 10.0 ** rng.integers(lo, hi + 1, shape)   # noqa: E731
+    M0 = np.zeros((m + 1, n + m + 1))
+    M0[:m, :n] = mag((m, n)) * rng.choice([1.0, 1.0, -1.0], (m, n))
+    M0[np.arange(m), n + np.arange(m)] = 1.0
+    M0[:m, -1] = mag(m)
+    M0[m, :n] = -mag(n)
+    b0 = np.arange(n, n + m, dtype=np.int64)
+    M, b = M0.copy(), b0.copy()
+    with np.errstate(all="ignore"):
+        st_o, npiv, trace = oracle.solve(M, b, max_pivots=60, trace_cap=60)
+    t = lp.Tableau(None, lp.Problem(type="max"), M0, b0, n + m, m, {})
+    k = ctypes.c_int64(0)
+    rc = lp.capi.lib().mi355x_tab_solve(t._h, 1, 1024.0, 60, ctypes.byref(k))
+    t._touch()
+    G = t.matrix
+    assert rc == st_o and k.value == npiv and np.array_equal(t.pivot_trace(), trace)
+    nan_o, nan_g = np.isnan(M), np.isnan(G)
+    assert np.array_equal(nan_o, nan_g)
+    assert np.array_equal(G[~nan_g].view(np.int64), M[~nan_o].view(np.int64))
