@@ -32,14 +32,15 @@ from . import capi, synth
 
 
 def partition(var_count, n_shards):
-    """Contiguous column blocks [begin, end) of the var_count non-RHS columns."""
-    per = -(-var_count // n_shards)
-    out = []
+    """Contiguous column blocks [begin, end), sizes differing by at most one."""
+    base, extra = divmod(var_count, n_shards)
+    if base == 0:
+        raise ValueError("more shards (%d) than columns (%d)" % (n_shards, var_count))
+    out, b = [], 0
     for r in range(n_shards):
-        b, e = r * per, min(var_count, (r + 1) * per)
-        if b >= e:
-            raise ValueError("more shards (%d) than column blocks of %d" % (n_shards, per))
+        e = b + base + (1 if r < extra else 0)
         out.append((b, e))
+        b = e
     return out
 
 

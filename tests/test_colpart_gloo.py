@@ -55,6 +55,7 @@ def test_column_partition_protocol_matches_oracle(world, n, m, max_pivots, tmp_p
 def test_partition_helper():
     cp = __import__("importlib").import_module("linear-programming_amd.colpart")
     assert cp.partition(98304, 8) == [(i * 12288, (i + 1) * 12288) for i in range(8)]
-    assert cp.partition(10, 3) == [(0, 4), (4, 8), (8, 10)]
+    assert cp.partition(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    assert cp.partition(7, 5) == [(0, 2), (2, 4), (4, 5), (5, 6), (6, 7)]
     with pytest.raises(ValueError):
         cp.partition(4, 8)

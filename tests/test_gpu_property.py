@@ -118,3 +118,103 @@ def test_extreme_magnitudes_bitwise(n, m, seed, lo, hi):
     nan_o, nan_g = np.isnan(M), np.isnan(G)
     assert np.array_equal(nan_o, nan_g)
     assert np.array_equal(G[~nan_g].view(np.int64), M[~nan_o].view(np.int64))
+
+
+@settings(max_examples=40, deadline=None, derandomize=True, database=None,
+          suppress_health_check=list(HealthCheck))
+@given(n=st.integers(2, 90), m=st.integers(1, 60), seed=st.integers(0, 2 ** 31 - 1),
+       ops=st.lists(st.sampled_from(["solve", "pivot", "price", "copy", "download", "reupload"]),
+                    min_size=3, max_size=12))
+def test_random_entry_point_sequences(n, m, seed, ops):
+    """Arbitrary interleavings of the C-ABI entry points on one handle (which silently moves the
+    tableau between its dense and compact representations) mirrored step by step on the oracle."""
+    L = lp.capi.lib()
+    rng = np.random.default_rng(seed)
+    M0, b0 = lp.synth.tableau(n, m, seed)
+    M, b = M0.copy(), b0.copy()
+    t = lp.Tableau(None, lp.Problem(type="max"), M0, b0, n + m, m, {})
+    for op in ops:
+        if op == "solve":
+            k = int(rng.integers(1, 6))
+            st_o, _, _ = oracle.solve(M, b, max_pivots=k)
+            rc = L.mi355x_tab_solve(t._h, 1, 1024.0, k, None)
+            t._touch()
+            assert rc == st_o
+        elif op == "pivot":
+            ec = oracle.price(M)
+            if ec < 0:
+                continue
+            cr = oracle.ratio(M, ec)
+            if cr < 0:
+                continue
+            assert lp.find_entering_column(t) == ec and lp.find_pivoting_row(t, ec) == cr
+            oracle.pivot(M, b, ec, cr)
+            lp.n_pivot_row(t, ec, cr)
+        elif op == "price":
+            ec = oracle.price(M)
+            assert lp.find_entering_column(t) == (None if ec < 0 else ec)
+        elif op == "copy":
+            t = lp.copy_tableau(t)
+        elif op == "download":
+            assert np.array_equal(t.matrix.view(np.int64), M.view(np.int64))
+            assert np.array_equal(t.basis_columns, b)
+        else:
+            lp.capi.check(L.mi355x_tab_upload(t._h, M0.ctypes.data_as(ctypes.c_void_p),
+                                              b0.ctypes.data_as(ctypes.c_void_p)), "upload")
+            t._touch()
+            M, b = M0.copy(), b0.copy()
+    assert np.array_equal(t.matrix.view(np.int64), M.view(np.int64))
+    assert np.array_equal(t.basis_columns, b)
+
+
+@settings(max_examples=25, deadline=None, derandomize=True, database=None,
+          suppress_health_check=list(HealthCheck))
+@given(n=st.integers(2, 120), m=st.integers(1, 70), nl=st.integers(1, 12),
+       seed=st.integers(0, 2 ** 31 - 1), mode=st.sampled_from([1, 2]), compact=st.sampled_from([0, 1]),
+       cap=st.sampled_from([0, 5, 17]))
+def test_random_batches_bitwise(n, m, nl, seed, mode, compact, cap):
+    L = lp.capi.lib()
+    tabs = [lp.synth.tableau(n, m, seed + 7 * k) for k in range(nl)]
+    Ms = np.stack([x[0] for x in tabs]); Bs = np.stack([x[1] for x in tabs])
+    try:
+        L.mi355x_tune_set_batch_mode(mode)
+        L.mi355x_tune_set_compact(compact)
+        batch = lp.TableauBatch.from_arrays(Ms, Bs)
+        st_g, npv = batch.solve(max_pivots=cap)
+    finally:
+        L.mi355x_tune_set_batch_mode(0)
+        L.mi355x_tune_set_compact(1)
+    for k in range(nl):
+        M, b = Ms[k].copy(), Bs[k].copy()
+        so, no, _ = oracle.solve(M, b, max_pivots=cap)
+        Mg, bg = batch.download(k)
+        assert (st_g[k], npv[k]) == (so, no)
+        assert np.array_equal(Mg.view(np.int64), M.view(np.int64)) and np.array_equal(bg, b)
+
+
+@settings(max_examples=25, deadline=None, derandomize=True, database=None,
+          suppress_health_check=list(HealthCheck))
+@given(n=st.integers(6, 150), m=st.integers(1, 80), shards=st.integers(1, 5),
+       seed=st.integers(0, 2 ** 31 - 1), compact=st.booleans(), cap=st.sampled_from([0, 9]))
+def test_random_column_partitions_bitwise(n, m, shards, seed, compact, cap):
+    import importlib
+    import torch
+    cp = importlib.import_module("linear-programming_amd.colpart")
+    shards = min(shards, n)
+    sh = cp.synthetic_shards(torch, n, m, seed, list(range(shards)), shards, 0, compact=compact)
+    try:
+        tab = cp.ColumnPartitionedTableau(sh, cp.LocalComm(torch), cp.HipBackend())
+        st_g, npiv = tab.solve(max_pivots=cap, check_every=8)
+        M, b = lp.synth.tableau(n, m, seed)
+        so, no, _ = oracle.solve(M, b, max_pivots=cap)
+        assert (st_g, npiv) == (so, no)
+        if compact:
+            got, bs = cp.assemble_compact(sh, n + m)
+            assert np.array_equal(got.view(np.int64), M.view(np.int64)) and np.array_equal(bs, b)
+        else:
+            parts = [cp.download_shard(x) for x in sh]
+            got = np.concatenate([p[0][:, :-1] for p in parts], axis=1)
+            assert np.array_equal(got.view(np.int64), M[:, :-1].view(np.int64))
+            assert all(np.array_equal(p[0][:, -1], M[:, -1]) and np.array_equal(p[1], b) for p in parts)
+    finally:
+        cp.destroy_shards(sh)

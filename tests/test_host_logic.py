@@ -198,3 +198,62 @@ def test_native_problem_validation():
     p.integer_vars = ["x"]
     with pytest.raises(lp.UnsupportedConstraintError):
         lp.NativeProblem(p).solve()
+
+
+# ------------------------------------------------------------------ property: build-tableau
+from hypothesis import HealthCheck, given, settings, strategies as st   # noqa: E402
+
+
+@settings(max_examples=150, deadline=None, derandomize=True, database=None,
+          suppress_health_check=list(HealthCheck))
+@given(n=st.integers(1, 7), seed=st.integers(0, 2 ** 31 - 1), kind=st.sampled_from(["max", "min"]),
+       ncons=st.integers(0, 6))
+def test_random_problems_native_equals_mirror_equals_rational(n, seed, kind, ncons):
+    """Random small problems with every bound flavour (none / lb / ub / both / free), mixed
+    <=, >=, = rows and negative right-hand sides: the C++ build-tableau, the Python mirror and
+    the exact-rational restatement agree (bit for bit between the two float versions)."""
+    rng = np.random.default_rng(seed)
+    names = ["v%d" % i for i in range(n)]
+    q = lambda: Fraction(int(rng.integers(-12, 13)), int(rng.integers(1, 5)))      # noqa: E731
+    bounds = []
+    for v in names:
+        flavour = int(rng.integers(0, 5))
+        lb, ub = q(), None
+        ub = lb + abs(q())
+        if flavour == 1:
+            bounds.append([v, lb, None])
+        elif flavour == 2:
+            bounds.append([v, None, ub])
+        elif flavour == 3:
+            bounds.append([v, lb, ub])
+        elif flavour == 4:
+            bounds.append([v, None, None])
+    cons = []
+    for _ in range(ncons):
+        expr = [[v, q()] for v in names if rng.uniform() < 0.7]
+        expr = [e for e in expr if e[1] != 0] or [[names[0], Fraction(1)]]
+        op = ["<=", ">=", "="][int(rng.integers(0, 3))]
+        rhs = q() if op == "=" else abs(q())       # parsed <= / >= rows carry rhs >= 0
+        cons.append([op, expr, rhs])
+    obj = [[v, q()] for v in names]
+    d = {"type": kind, "vars": names, "objective_var": "obj", "objective": obj, "bounds": bounds,
+         "constraints": cons}
+    p = lp.Problem.from_dict(d)
+    try:
+        exp = rr.build_tableau(d)
+    except rr.Unbounded:
+        with pytest.raises(lp.UnboundedProblemError):
+            lp.build_tableau(p)
+        with pytest.raises(lp.UnboundedProblemError):
+            lp.NativeProblem(p).build_tableau()
+        return
+    exp = list(exp) if isinstance(exp, tuple) else [exp]
+    py = lp.build_tableau(p)
+    py = py if isinstance(py, list) else [py]
+    nat = lp.NativeProblem(p).build_tableau()
+    assert len(exp) == len(py) == len(nat)
+    for e, t, (M, b) in zip(exp, py, nat):
+        Me, be = goldens.to_f64(e)
+        assert np.array_equal(M.view(np.int64), t.matrix.view(np.int64))          # C++ == Python
+        assert b.tolist() == t.basis_columns.tolist() == be.tolist()
+        assert np.allclose(M, Me, rtol=1e-13, atol=1e-13)                          # == exact / float
