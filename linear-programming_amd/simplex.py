@@ -162,6 +162,17 @@ def tableau_reduced_cost(tableau, var):
     return float(tableau.matrix[tableau.constraint_count, mapping[1]])
 
 
+def with_tableau_variables(var_list, tableau):
+    """with-tableau-variables (src/simplex.lisp:125-139) as a function: the values of the given
+    variables (a sequence of names, or a Problem: its objective variable and all its variables)
+    read from the tableau, as a dict."""
+    if isinstance(var_list, Problem):
+        names = [var_list.objective_var] + list(var_list.vars)
+    else:
+        names = list(var_list)
+    return {v: tableau_variable(tableau, v) for v in names}
+
+
 # ------------------------------------------------------------------ build-tableau (host)
 def build_tableau(problem, instance_problem=None, fp_tolerance_factor=1024, device=0):
     """build-tableau (src/simplex.lisp:142-328) in double-float: returns a Tableau, or

@@ -37,3 +37,17 @@ def solution_variable(solution, variable):
 def solution_reduced_cost(solution, variable):
     """solution-reduced-cost (src/solver.lisp:74-80)."""
     return simplex.tableau_reduced_cost(solution, variable)
+
+
+def with_solution_variables(var_list, solution):
+    """with-solution-variables (src/solver.lisp:96-115) as a function: (values, reduced_cost)
+    where `values` maps each requested variable (or, for a Problem, its objective variable and
+    every variable) to its value in the solution and `reduced_cost(var)` is the locally bound
+    `reduced-cost` macro."""
+    from .problem import Problem
+    if isinstance(var_list, Problem):
+        names = [var_list.objective_var] + list(var_list.vars)
+    else:
+        names = list(var_list)
+    values = {v: solution_variable(solution, v) for v in names}
+    return values, (lambda var: solution_reduced_cost(solution, var))

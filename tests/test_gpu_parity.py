@@ -141,6 +141,18 @@ def test_copy_tableau(golden):
     assert not np.array_equal(t1.matrix, t2.matrix)                 # deep copy
 
 
+def test_with_tableau_variables_and_with_solution_variables(golden):
+    """t/simplex.lisp:391-405 and t/solver.lisp:117-127."""
+    problem = _problem(golden["cases"]["basic"])
+    tableau = lp.n_solve_tableau(lp.build_tableau(problem, problem))
+    assert lp.with_tableau_variables(["x", "y", "z", "w"], tableau) == {"x": 0.5, "y": 7.0, "z": 0.0, "w": 28.5}
+    assert lp.with_tableau_variables(problem, tableau) == {"w": 28.5, "x": 0.5, "y": 7.0, "z": 0.0}
+    solution = lp.solve_problem(problem)
+    values, reduced_cost = lp.with_solution_variables(["w", "x", "z"], solution)
+    assert values == {"w": 28.5, "x": 0.5, "z": 0.0}
+    assert reduced_cost("x") == 0.0 and reduced_cost("z") == 0.5
+
+
 ANSWER_CASES = ["basic", "free_x", "free_x_negative", "ub_only_x", "lb_x", "range_y",
                 "free_z_reduced_cost", "widgets", "excessive_constraints", "numerical_issue",
                 "variable_bounds_bug", "variable_bounds_only", "equality", "geq"]
