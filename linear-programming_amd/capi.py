@@ -83,6 +83,7 @@ _EXTRA = {
     "mi355x_tune_set_compact": (_int, [_int]),
     "mi355x_tune_set_alternate_sweep": (_int, [_int]),
     "mi355x_tune_set_batch_mode": (_int, [_int]),
+    "mi355x_tune_set_handover_mode": (_int, [_int]),
 }
 
 _lib = None

@@ -24,6 +24,7 @@ namespace {
 thread_local std::string g_err;
 int g_select_mode = 0;                    // 0 auto, 1 single workgroup, 2 split (tuning/test hook)
 int g_compact_enabled = 1;                // solve loops run on the compact representation
+int g_handover_mode = 0;                  // 0 auto, 1 always the sequential re-elimination
 int g_batch_mode = 0;                     // 0 auto, 1 lockstep launch pairs, 2 one workgroup per LP
 
 int fail(int code, const char *fmt, ...)
@@ -74,6 +75,8 @@ struct mi355x_tab {
                                           // basis / col / prow / ctl / trace / partials with v
     bool        compact = false;          // which representation currently holds the tableau
     bool        compact_failed = false;   // basis is not a set of unit columns: stay dense
+    bool        unit_basis = false;       // basis columns verified to be exact unit vectors and
+                                          // only pivoted by the solve loops since
     int64_t    *brow = nullptr;           // scratch for k_expand (var_count entries)
     int        *flag = nullptr;           // verification flag
     int         n_part = 0;               // pricing partials left by the last update (0 = none)
@@ -204,6 +207,7 @@ int upload(mi355x_tab *t, const double *hm, const int64_t *hb)
     t->n_part = 0;
     t->compact = false;                   // the dense logical tableau is (re)defined by the caller
     t->compact_failed = false;
+    t->unit_basis = false;
     if (hm) {
         const size_t all_rows = (size_t)v.rows * v.n_lps;     // LPs of a batch are stacked
         if (v.ld != v.cols)    // zero the padding columns once per upload
@@ -291,6 +295,7 @@ int ensure_compact(mi355x_tab *t)
     HIP_TRY(hipStreamSynchronize(t->stream));         // p2l / l2p host vectors go out of scope
     t->compact = true;
     t->compact_failed = false;
+    t->unit_basis = true;
     t->n_part = 0;
     return MI_OK;
 }
@@ -303,6 +308,7 @@ int fall_back_to_dense(mi355x_tab *t)
     int rc = ensure_dense(t);
     if (rc != MI_OK) return rc;
     t->compact_failed = true;
+    t->unit_basis = false;
     launch_ctl_resume(t->v, t->stream);
     HIP_TRY(hipGetLastError());
     return MI_OK;
@@ -463,6 +469,7 @@ int mi355x_tab_pivot(mi355x_tab *t, int64_t ec, int64_t cr)
     launch_prepare_pivot(t->v, ec, cr, t->stream);
     launch_update(t->v, 1.0, 0, t->stream);
     t->n_part = 0;
+    t->unit_basis = false;                // a caller-chosen pivot may be anything
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(t->stream));
     return MI_OK;
@@ -634,7 +641,7 @@ int mi355x_solve_two_phase(mi355x_tab *art, mi355x_tab *mt, int main_is_max, dou
     if (n_pivots) n_pivots[0] = n1;
     // copy rows + basis, re-eliminate the objective row                simplex.lisp:437-451
     HIP_TRY(hipStreamSynchronize(mt->stream));
-    launch_handover(art->v, mt->v, art->stream);
+    launch_handover(art->v, mt->v, art->unit_basis && g_handover_mode != 1, art->stream);
     mt->n_part = 0;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(art->stream));
@@ -967,6 +974,7 @@ int         mi355x_tune_variant_count(void) { return update_variant_count(); }
 const char *mi355x_tune_variant_name(int v) { return (v >= 0 && v < update_variant_count()) ? update_variant_name(v) : ""; }
 int         mi355x_tune_set_variant(int v) { set_update_variant(v); return get_update_variant(); }
 int         mi355x_tune_set_select_mode(int mode) { g_select_mode = mode; return g_select_mode; }
+int         mi355x_tune_set_handover_mode(int mode) { g_handover_mode = mode; return mode; }
 int         mi355x_tune_set_batch_mode(int mode) { g_batch_mode = mode; return g_batch_mode; }
 int         mi355x_tune_set_alternate_sweep(int on) { set_alternate_sweep(on); return on; }
 int         mi355x_tune_set_compact(int on) { g_compact_enabled = on ? 1 : 0; return g_compact_enabled; }

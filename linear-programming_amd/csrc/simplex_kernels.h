@@ -86,7 +86,9 @@ void launch_shard_contribute(const TabView &t, const double *gathered, int n_sha
 void launch_shard_prepare(const TabView &t, const double *col, const int64_t *ec_dev,
                           double fp_factor, hipStream_t s);
 // two-phase hand-over (src/simplex.lisp:437-451)
-void launch_handover(const TabView &art, const TabView &main_tab, hipStream_t s);
+// unit_basis: the basic columns of `art` are known to be exact unit vectors (column-parallel
+// re-elimination); otherwise the sequential form
+void launch_handover(const TabView &art, const TabView &main_tab, bool unit_basis, hipStream_t s);
 // whole-batch solve, one workgroup per LP (false: an LP does not fit the LDS budget)
 bool launch_batch_solve(const TabView &t, int is_max, double fp_factor, hipStream_t s);
 // dense logical tableau <-> compact representation

@@ -399,7 +399,8 @@ def test_min_and_max_problems_bitwise(kind):
 @pytest.mark.parametrize("n,mle,mge,meq,seed", [(6, 3, 2, 1, 1), (30, 10, 8, 4, 2),
                                                 (80, 30, 20, 10, 3), (40, 0, 25, 0, 4),
                                                 (300, 100, 60, 30, 5), (12, 4, 4, 4, 6)])
-def test_two_phase_bitwise_vs_oracle(n, mle, mge, meq, seed):
+@pytest.mark.parametrize("handover", [0, 1], ids=["column-parallel", "sequential"])
+def test_two_phase_bitwise_vs_oracle(n, mle, mge, meq, seed, handover):
     """Two-phase branch (src/simplex.lisp:402-452) on random LPs with >= and = rows.  Whatever
     the reference's algorithm does on the input -- including declaring a feasible problem
     infeasible because phase 1 ends a few ulp above its 1024-eps test -- the HIP path does
@@ -409,13 +410,17 @@ def test_two_phase_bitwise_vs_oracle(n, mle, mge, meq, seed):
     assert isinstance(tabs, list)
     st, M_or, b_or, (A_or, ab_or, npv) = _oracle_solve(tabs)
     art, main = tabs
-    if st == oracle.OPTIMAL:
-        lp.n_solve_tableau(tabs)
-        assert main.n_pivots == (int(npv[0]), int(npv[1]))
-    else:
-        assert st == oracle.INFEASIBLE
-        with pytest.raises(lp.InfeasibleProblemError):
+    lp.capi.lib().mi355x_tune_set_handover_mode(handover)
+    try:
+        if st == oracle.OPTIMAL:
             lp.n_solve_tableau(tabs)
+            assert main.n_pivots == (int(npv[0]), int(npv[1]))
+        else:
+            assert st == oracle.INFEASIBLE
+            with pytest.raises(lp.InfeasibleProblemError):
+                lp.n_solve_tableau(tabs)
+    finally:
+        lp.capi.lib().mi355x_tune_set_handover_mode(0)
     assert np.array_equal(art.matrix, A_or) and np.array_equal(art.basis_columns, ab_or)
     assert np.array_equal(main.matrix, M_or) and np.array_equal(main.basis_columns, b_or)
 
