@@ -284,13 +284,13 @@ __global__ __launch_bounds__(THREADS) void k_select(TabView t, double sgn, doubl
     __shared__ long long s_i[THREADS / 64];
     t = lp_slice(t);
     Ctl *ctl = t.ctl;
-    const Ctl c0 = *ctl;                            // one load of the whole control block
-    if (c0.status != kRunning) return;
+    const Ctl c0 = *ctl;                            // in flight together with the pricing inputs
     const int64_t m = t.rows - 1, vc = t.cols - 1;
 
     // n_part > 0: the preceding k_update of this tableau priced the new objective row
     const ValIdx e = n_part > 0 ? block_price_partials<THREADS>(t.part_v, t.part_i, t.part_s, n_part, s_v, s_i)
                                 : block_price<THREADS>(t.M + m * t.ld, vc, sgn, s_v, s_i, t.p2l);
+    if (c0.status != kRunning) return;
     // (fp< v 0 factor/8): v < 0 - tol ; min problems: (fp> v 0 factor/8) <=> -v < 0 - tol
     if (e.i < 0 || !(e.v < 0.0 - price_tol)) {
         if (threadIdx.x == 0) ctl->status = 0;      // MI_OPTIMAL
@@ -345,13 +345,16 @@ __global__ __launch_bounds__(kGatherThreads) void k_select_gather(TabView t, dou
     int64_t *rp_i = t.part_i + t.part_cap / 2;
     int64_t *rp_s = t.part_s + t.part_cap / 2;
     Ctl *ctl = t.ctl;
-    const Ctl c0 = *ctl;                            // one load of the whole control block
-    if (c0.status != kRunning) return;
+    const Ctl c0 = *ctl;                            // one load of the whole control block ...
     const int64_t m = t.rows - 1, vc = t.cols - 1;
     const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+    // ... in flight together with the pricing inputs: the status is only tested afterwards (this
+    // kernel is a chain of dependent memory round trips; a launch after termination merely
+    // reads a few values it does not use)
     const ValIdx e = n_part > 0
         ? block_price_partials<kGatherThreads>(t.part_v, t.part_i, t.part_s, n_part, s_v, s_i)
         : block_price<kGatherThreads>(t.M + m * t.ld, vc, sgn, s_v, s_i, t.p2l);
+    if (c0.status != kRunning) return;
     if (e.i < 0 || !(e.v < 0.0 - price_tol)) {
         if (leader) ctl->status = 0;                // MI_OPTIMAL
         return;
@@ -385,14 +388,14 @@ __global__ __launch_bounds__(kScaleThreads) void k_select_scale(TabView t, int n
     const int64_t *rp_i = t.part_i + t.part_cap / 2;
     const int64_t *rp_s = t.part_s + t.part_cap / 2;
     Ctl *ctl = t.ctl;
-    const Ctl c0 = *ctl;                            // one load of the whole control block
-    if (c0.status != kRunning) return;
+    const Ctl c0 = *ctl;                            // in flight together with the ratio partials
     const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+    const ValIdx q = block_price_partials<kScaleThreads>(rp_v, rp_i, rp_s, n_rp, s_v, s_i);
+    if (c0.status != kRunning) return;
     if (c0.poison) {                                // the gather met an inf / NaN: see kNeedDense
         if (leader) ctl->status = kNeedDense;
         return;
     }
-    const ValIdx q = block_price_partials<kScaleThreads>(rp_v, rp_i, rp_s, n_rp, s_v, s_i);
     if (q.i < 0) {
         if (leader) ctl->status = 1;                // MI_UNBOUNDED
         return;
