@@ -815,7 +815,20 @@ def test_config5_full_size_dense_and_compact_shards_agree():
         out.append((ec.copy(), cr.copy(), last_col, basis, cols.value))
         cp.destroy_shards(sh)
         torch.cuda.empty_cache()
+    # third, independent path: the unpartitioned solver (split select, compact representation)
+    h = ctypes.c_void_p()
+    lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h), n, m, seed, 0, -1, 0), "create")
+    assert L.mi355x_tab_solve(h, 1, 1024.0, K, None) == lp.capi.MI_MAX_PIVOTS
+    ec = np.empty(K, dtype=np.int64); cr = np.empty(K, dtype=np.int64)
+    lp.capi.check(L.mi355x_tab_trace(h, ec.ctypes.data_as(ctypes.c_void_p), cr.ctypes.data_as(ctypes.c_void_p),
+                                     K, ctypes.byref(k)), "trace")
+    last_col = np.empty(m + 1); basis = np.empty(m, dtype=np.int64)
+    lp.capi.check(L.mi355x_tab_download(h, None, basis.ctypes.data_as(ctypes.c_void_p), None,
+                                        last_col.ctypes.data_as(ctypes.c_void_p)), "download")
+    L.mi355x_tab_destroy(h)
     (e0, c0, r0, b0, w0), (e1, c1, r1, b1, w1) = out
+    assert np.array_equal(ec, e0) and np.array_equal(cr, c0)
+    assert np.array_equal(last_col.view(np.int64), r0.view(np.int64)) and np.array_equal(basis, b0)
     assert (w0, w1) == (n + m + 1, n + 1)
     assert np.array_equal(e0, e1) and np.array_equal(c0, c1)
     assert np.array_equal(r0.view(np.int64), r1.view(np.int64)) and np.array_equal(b0, b1)
