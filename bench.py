@@ -37,6 +37,7 @@ WORKLOADS = {
     # name: (n_vars, n_constraints, config id used for the seed)
     "cfg3": (8192, 4096, 3),
     "cfg2": (1024, 512, 2),
+    "cfg5": (65536, 32768, 5),      # the config-5 tableau UNPARTITIONED on one GPU (25.8 GB dense)
 }
 
 
@@ -50,6 +51,8 @@ def parse():
                     help="cfg4: LPs per GPU (BASELINE config 4 = 1024 LPs over 8 GPUs)")
     ap.add_argument("--alternate-sweep", action="store_true",
                     help="tuning: consecutive update launches sweep the tableau in opposite directions")
+    ap.add_argument("--ld-extra", type=int, default=0,
+                    help="tuning: extra padding doubles per tableau row (multiple of 16)")
     ap.add_argument("--force-dense", action="store_true",
                     help="tuning: run the solve loop on the dense tableau (no compact representation)")
     ap.add_argument("--batch-mode", type=int, default=0,
@@ -226,11 +229,13 @@ def main():
         L.mi355x_tune_set_alternate_sweep(1)
     if args.force_dense:
         L.mi355x_tune_set_compact(0)
+    if args.ld_extra:
+        L.mi355x_tune_set_ld_extra(args.ld_extra)
     # One LP supports only so many pivots before it is optimal (config 3: 5 700-6 100, config 2:
     # ~290 with these seeds).  If more timed steps are asked for than one LP safely provides,
     # further LPs of the same shape are generated in HBM BEFORE the timed region and the timed
     # steps simply continue on the next one.
-    capacity = {"cfg3": 4500, "cfg2": 220}[args.workload]
+    capacity = {"cfg3": 4500, "cfg2": 220, "cfg5": 20000}[args.workload]
     per_lp = max(capacity - args.warmup, 1)
     n_lps = -(-args.steps // per_lp)
     handles = []

@@ -84,6 +84,7 @@ _EXTRA = {
     "mi355x_tune_set_alternate_sweep": (_int, [_int]),
     "mi355x_tune_set_batch_mode": (_int, [_int]),
     "mi355x_tune_set_handover_mode": (_int, [_int]),
+    "mi355x_tune_set_ld_extra": (_int, [_int]),
 }
 
 _lib = None

@@ -53,7 +53,8 @@ constexpr int64_t kLdAlign    = 16;       // doubles: rows start on 128-byte bou
 constexpr int     kPartCap    = 16384;    // single tableau: 8192 pricing + 8192 ratio partials
 constexpr int     kBatchPartCap = 512;    // per LP of a batch
 
-int64_t padded_ld(int64_t cols) { return (cols + kLdAlign - 1) / kLdAlign * kLdAlign; }
+int g_ld_extra = 0;                       // tuning hook: extra padding (doubles) per row
+int64_t padded_ld(int64_t cols) { return (cols + kLdAlign - 1) / kLdAlign * kLdAlign + g_ld_extra; }
 
 int device_count_checked()
 {
@@ -974,6 +975,7 @@ int         mi355x_tune_variant_count(void) { return update_variant_count(); }
 const char *mi355x_tune_variant_name(int v) { return (v >= 0 && v < update_variant_count()) ? update_variant_name(v) : ""; }
 int         mi355x_tune_set_variant(int v) { set_update_variant(v); return get_update_variant(); }
 int         mi355x_tune_set_select_mode(int mode) { g_select_mode = mode; return g_select_mode; }
+int         mi355x_tune_set_ld_extra(int doubles) { g_ld_extra = (doubles > 0 ? doubles : 0) / 16 * 16; return g_ld_extra; }
 int         mi355x_tune_set_handover_mode(int mode) { g_handover_mode = mode; return mode; }
 int         mi355x_tune_set_batch_mode(int mode) { g_batch_mode = mode; return g_batch_mode; }
 int         mi355x_tune_set_alternate_sweep(int on) { set_alternate_sweep(on); return on; }
