@@ -54,4 +54,4 @@ if __name__ == "__main__":
     nv = L.mi355x_tune_variant_count()
     sizes = [(8192, 4096)] if len(sys.argv) < 2 else [tuple(map(int, a.split("x"))) for a in sys.argv[1:]]
     for n, m in sizes:
-        run(n, m, 100, range(nv))
+        run(n, m, 100 if n * m < 10**8 else 24, range(nv))
