@@ -75,6 +75,16 @@ double      mi355x_epsilon(void);                  /* CL double-float-epsilon us
 /* Upload a tableau.  host_basis has rows-1 entries (tableau-basis-columns) or is NULL. */
 int  mi355x_tab_create(mi355x_tab **out, int64_t rows, int64_t cols,
                        const double *host_matrix, const int64_t *host_basis, int device);
+/* Upload a tableau in COMPACT form: only the n_stored = var_count - (rows-1) non-basic columns
+ * plus the RHS column (host_stored: rows x (n_stored+1), row-major; stored_cols[j] = logical column
+ * of stored column j); the basic columns are BY DEFINITION the unit vectors host_basis describes
+ * (what build-tableau produces for the slack columns of a single-phase problem).  The handle
+ * behaves exactly like one made by mi355x_tab_create from the equivalent dense tableau -- the
+ * dense logical form is materialised only if an entry point needs it -- but a third less data
+ * crosses PCIe and no dense buffer is allocated for a plain solve + light read-back. */
+int  mi355x_tab_create_compact(mi355x_tab **out, int64_t rows, int64_t var_count, int64_t n_stored,
+                               const double *host_stored, const int64_t *stored_cols,
+                               const int64_t *host_basis, int device);
 /* Replace the contents of an existing handle (same shape). */
 int  mi355x_tab_upload(mi355x_tab *t, const double *host_matrix, const int64_t *host_basis);
 /* copy-tableau (src/simplex.lisp:61-71): device-to-device deep copy of matrix + basis. */

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmi355x_simplex.so")
 SOURCES = ["simplex_kernels.hip", "simplex_capi.hip", "host_problem.cpp", "mps_reader.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-pthread"]
 
 
 def _hipcc():

@@ -22,6 +22,7 @@ SIGNATURES = {
     "mi355x_last_error": (ctypes.c_char_p, []),
     "mi355x_epsilon": (_dbl, []),
     "mi355x_tab_create": (_int, [_pp, _i64, _i64, _p, _p, _int]),
+    "mi355x_tab_create_compact": (_int, [_pp, _i64, _i64, _i64, _p, _p, _p, _int]),
     "mi355x_tab_upload": (_int, [_p, _p, _p]),
     "mi355x_tab_copy": (_int, [_pp, _p]),
     "mi355x_tab_create_synthetic": (_int, [_pp, _i64, _i64, ctypes.c_uint64, _i64, _i64, _int]),

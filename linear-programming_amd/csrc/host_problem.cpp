@@ -20,8 +20,10 @@ extern "C" void mi355x_set_last_error_(const char *msg);   // simplex_capi.hip (
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -81,9 +83,12 @@ Built build(const mi355x_problem &p)
     Built b;
     const int64_t n = p.n_vars;
     b.map.resize((size_t)n);
-    std::vector<Constraint> cons = p.constraints;
+    // constraints in tableau order: the x <= ub rows pushed for doubly-bounded variables
+    // (:198-203) come first, the problem's own rows follow -- by pointer, nothing is copied
+    std::vector<Constraint> pushed;
+    std::vector<const Constraint *> cons;
 
-    if (cons.empty()) {                                                   // :153-186
+    if (p.constraints.empty()) {                                          // :153-186
         HostTableau &t = b.main_tab;
         t.rows = n + 1; t.cols = n + 1;
         t.M.assign((size_t)t.rows * t.cols, 0.0);
@@ -121,7 +126,7 @@ Built build(const mi355x_problem &p)
             Constraint c;
             if (0.0 <= bd.ub) { c.op = 0; c.rhs = bd.ub; } else { c.op = 1; c.rhs = -bd.ub; }
             c.var = {v}; c.coef = {1.0};
-            cons.insert(cons.begin(), c);                                  // (push ... constraints)
+            pushed.insert(pushed.begin(), c);                              // (push ... constraints)
             b.map[(size_t)v] = {kPositive, column, bd.lb};
         } else if (bd.has_lb) {
             b.map[(size_t)v] = {kPositive, column, bd.lb};
@@ -134,9 +139,11 @@ Built build(const mi355x_problem &p)
         ++column;
     }
 
+    for (const auto &c : pushed) cons.push_back(&c);
+    for (const auto &c : p.constraints) cons.push_back(&c);
     const int64_t m = (int64_t)cons.size();                                // :214-221
     int64_t num_slack = 0;
-    for (const auto &c : cons) if (c.op != 2) ++num_slack;
+    for (const Constraint *c : cons) if (c->op != 2) ++num_slack;
     const int64_t num_cols = ncv + num_slack + 1;
     HostTableau &t = b.main_tab;
     t.rows = m + 1; t.cols = num_cols;
@@ -145,7 +152,7 @@ Built build(const mi355x_problem &p)
     std::vector<int64_t> art_rows;                                         // most recent first
     int64_t col_offset = 0;
     for (int64_t row = 0; row < m; ++row) {                                // :223-268
-        const Constraint &c = cons[(size_t)row];
+        const Constraint &c = *cons[(size_t)row];
         int op = c.op;
         t.at(row, num_cols - 1) = c.rhs;
         for (size_t k = 0; k < c.var.size(); ++k) {
@@ -232,6 +239,95 @@ Built build(const mi355x_problem &p)
 int hfail(int code, const char *msg) { mi355x_set_last_error_(msg); return code; }
 
 }  // namespace
+
+// Single-phase problems (every row ends up a `<=` row: all slack columns basic, no artificial
+// tableau) assembled straight into the compact form [structural columns | RHS] that the solve
+// loop runs on -- the slack identity block is never materialised, on the host or on the device.
+// Same arithmetic as build() entry by entry (rows are independent, so they are filled by a few
+// host threads).  Returns false when the problem needs the general path.
+static bool build_compact(const mi355x_problem &p, std::unique_ptr<double[]> &P, int64_t &rows,
+                          int64_t &ncv_out, std::vector<int64_t> &basis, std::vector<Mapping> &map)
+{
+    const int64_t n = p.n_vars;
+    if (p.constraints.empty()) return false;
+    map.assign((size_t)n, Mapping());
+    std::vector<Constraint> pushed;
+    int64_t ncv = n, column = 0;                                           // :189-212
+    for (int64_t v = 0; v < n; ++v) {
+        const Bound &bd = p.bounds[(size_t)v];
+        if (!bd.present) {
+            map[(size_t)v] = {kPositive, column, 0.0};
+        } else if (bd.has_lb && bd.has_ub) {
+            Constraint c;
+            if (0.0 <= bd.ub) { c.op = 0; c.rhs = bd.ub; } else { c.op = 1; c.rhs = -bd.ub; }
+            c.var = {v}; c.coef = {1.0};
+            pushed.insert(pushed.begin(), c);
+            map[(size_t)v] = {kPositive, column, bd.lb};
+        } else if (bd.has_lb) {
+            map[(size_t)v] = {kPositive, column, bd.lb};
+        } else if (bd.has_ub) {
+            map[(size_t)v] = {kNegative, column, bd.ub};
+        } else {
+            map[(size_t)v] = {kSigned, column, 0.0};
+            ++column; ++ncv;
+        }
+        ++column;
+    }
+    std::vector<const Constraint *> cons;
+    for (const auto &c : pushed) cons.push_back(&c);
+    for (const auto &c : p.constraints) cons.push_back(&c);
+    const int64_t m = (int64_t)cons.size();
+    // pass 1: does any row become >= or = (after the sign flip of a negative shifted RHS)?
+    for (const Constraint *c : cons) {
+        double rhs = c->rhs;
+        for (size_t k = 0; k < c->var.size(); ++k) {
+            const Mapping &mp = map[(size_t)c->var[k]];
+            if (mp.kind != kSigned) rhs = rhs - c->coef[k] * mp.offset;
+        }
+        const int op = (rhs < 0.0) ? (c->op == 0 ? 1 : c->op == 1 ? 0 : 2) : c->op;
+        if (op != 0) return false;
+    }
+    const int64_t w = ncv + 1;                                             // stored columns + RHS
+    rows = m + 1; ncv_out = ncv;
+    P.reset(new double[(size_t)rows * w]);                                 // rows are zeroed by the
+    basis.resize((size_t)m);                                               // threads that fill them
+    auto fill = [&](int64_t r0, int64_t r1) {
+        for (int64_t row = r0; row < r1; ++row) {                          // :223-268
+            const Constraint &c = *cons[(size_t)row];
+            double *out = P.get() + (size_t)row * w;
+            std::fill(out, out + w, 0.0);
+            out[ncv] = c.rhs;
+            for (size_t k = 0; k < c.var.size(); ++k) {
+                const Mapping &mp = map[(size_t)c.var[k]];
+                const double coef = c.coef[k];
+                if (mp.kind == kPositive)      { out[mp.col] = coef;  out[ncv] = out[ncv] - coef * mp.offset; }
+                else if (mp.kind == kNegative) { out[mp.col] = -coef; out[ncv] = out[ncv] - coef * mp.offset; }
+                else                           { out[mp.col] = coef;  out[mp.col + 1] = -coef; }
+            }
+            if (out[ncv] < 0.0)
+                for (int64_t cc = 0; cc < w; ++cc) out[cc] = -out[cc];
+            basis[(size_t)row] = ncv + row;                                // its slack column
+        }
+    };
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const int64_t nthreads = (m * w > (1 << 22)) ? (int64_t)hw : 1;
+    std::vector<std::thread> pool;
+    for (int64_t k = 0; k < nthreads; ++k) {
+        const int64_t r0 = m * k / nthreads, r1 = m * (k + 1) / nthreads;
+        if (nthreads == 1) fill(r0, r1); else pool.emplace_back(fill, r0, r1);
+    }
+    for (auto &th : pool) th.join();
+    double *obj = P.get() + (size_t)m * w;                                 // :270-283
+    std::fill(obj, obj + w, 0.0);
+    for (size_t k = 0; k < p.obj_var.size(); ++k) {
+        const Mapping &mp = map[(size_t)p.obj_var[k]];
+        const double coef = p.obj_coef[k];
+        if (mp.kind == kPositive)      { obj[mp.col] = -coef; obj[ncv] = obj[ncv] + coef * mp.offset; }
+        else if (mp.kind == kNegative) { obj[mp.col] = coef;  obj[ncv] = obj[ncv] + coef * mp.offset; }
+        else                           { obj[mp.col] = -coef; obj[mp.col + 1] = coef; }
+    }
+    return true;
+}
 
 struct mi355x_solution {
     int64_t rows = 0, cols = 0;
@@ -382,6 +478,36 @@ int mi355x_simplex_solver(const mi355x_problem *p, double fp_tolerance, int devi
     *out = nullptr;
     for (char f : p->is_integer)
         if (f) return hfail(MI_UNSUPPORTED, "integer constraints cannot be handled by the mi355x-simplex solver");
+    {   // single-phase problems: assemble and upload the compact form directly
+        std::unique_ptr<double[]> P;
+        std::vector<int64_t> basis;
+        std::vector<Mapping> map;
+        int64_t rows = 0, ncv = 0;
+        if (build_compact(*p, P, rows, ncv, basis, map)) {
+            const int64_t m = rows - 1, var_count = ncv + m;
+            mi355x_solution *s = new (std::nothrow) mi355x_solution;
+            if (!s) return hfail(MI_NO_MEMORY, "host allocation failed");
+            s->rows = rows; s->cols = var_count + 1;
+            s->map = map;
+            s->last_row.resize((size_t)var_count + 1);
+            s->last_col.resize((size_t)rows);
+            s->basis.resize((size_t)m);
+            std::vector<int64_t> stored((size_t)ncv);
+            for (int64_t j = 0; j < ncv; ++j) stored[(size_t)j] = j;
+            mi355x_tab *t = nullptr;
+            int rc = mi355x_tab_create_compact(&t, rows, var_count, ncv, P.get(), stored.data(),
+                                               basis.data(), device);
+            P.reset();                                                      // free the host copy early
+            if (rc == MI_OK) rc = mi355x_tab_solve(t, p->is_max ? 1 : 0, fp_tolerance, 0, &s->n_pivots[1]);
+            int drc = MI_OK;
+            if (rc == MI_OPTIMAL)
+                drc = mi355x_tab_download(t, nullptr, s->basis.data(), s->last_row.data(), s->last_col.data());
+            mi355x_tab_destroy(t);
+            if (rc != MI_OPTIMAL || drc != MI_OK) { delete s; return rc != MI_OPTIMAL ? rc : drc; }
+            *out = s;
+            return MI_OPTIMAL;
+        }
+    }
     Built b = build(*p);
     if (b.status != MI_OK) return b.status;
     mi355x_solution *s = new (std::nothrow) mi355x_solution;

@@ -133,7 +133,8 @@ void free_tab(mi355x_tab *t)
 }
 
 // allocate an empty handle of the given shape on `device`
-int alloc_tab(mi355x_tab **out, int64_t rows, int64_t cols, int device, int64_t n_lps = 1)
+int alloc_tab(mi355x_tab **out, int64_t rows, int64_t cols, int device, int64_t n_lps = 1,
+              bool defer_dense = false)
 {
     if (!out) return fail(MI_BAD_ARG, "out is NULL");
     *out = nullptr;
@@ -171,7 +172,7 @@ int alloc_tab(mi355x_tab **out, int64_t rows, int64_t cols, int device, int64_t 
         return fail(e == hipErrorOutOfMemory ? MI_NO_MEMORY : MI_HIP_ERROR,                \
                     "hipMalloc(%zu bytes) failed: %s", (size_t)(bytes), hipGetErrorString(e)); \
     }
-    ALLOC(t->v.M, mbytes);
+    if (!defer_dense) ALLOC(t->v.M, mbytes);         // else: allocated by ensure_dense on demand
     ALLOC(t->v.basis, n_lps * nb * sizeof(int64_t));
     ALLOC(t->v.col, n_lps * rows * sizeof(double));
     ALLOC(t->v.prow, n_lps * t->v.ld * sizeof(double));
@@ -209,6 +210,8 @@ int upload(mi355x_tab *t, const double *hm, const int64_t *hb)
     t->compact = false;                   // the dense logical tableau is (re)defined by the caller
     t->compact_failed = false;
     t->unit_basis = false;
+    if (!t->v.M)
+        HIP_TRY(hipMalloc((void **)&t->v.M, (size_t)v.n_lps * v.rows * v.ld * sizeof(double)));
     if (hm) {
         const size_t all_rows = (size_t)v.rows * v.n_lps;     // LPs of a batch are stacked
         if (v.ld != v.cols)    // zero the padding columns once per upload
@@ -239,6 +242,9 @@ TabView &cur(mi355x_tab *t) { return t->compact ? t->c : t->v; }
 int ensure_dense(mi355x_tab *t)
 {
     if (!t->compact) return MI_OK;
+    if (!t->v.M) {                                    // handle born compact (mi355x_tab_create_compact)
+        HIP_TRY(hipMalloc((void **)&t->v.M, (size_t)t->v.n_lps * t->v.rows * t->v.ld * sizeof(double)));
+    }
     launch_expand(t->v, t->c, t->brow, t->stream);
     HIP_TRY(hipGetLastError());
     t->compact = false;
@@ -381,6 +387,59 @@ int mi355x_tab_create(mi355x_tab **out, int64_t rows, int64_t cols, const double
     if (rc != MI_OK) return rc;
     rc = upload(t, host_matrix, host_basis);
     if (rc != MI_OK) { free_tab(t); return rc; }
+    *out = t;
+    return MI_OK;
+}
+
+int mi355x_tab_create_compact(mi355x_tab **out, int64_t rows, int64_t var_count, int64_t n_stored,
+                              const double *host_stored, const int64_t *stored_cols,
+                              const int64_t *host_basis, int device)
+{
+    if (!out) return fail(MI_BAD_ARG, "out is NULL");
+    *out = nullptr;
+    const int64_t m = rows - 1;
+    if (!host_stored || !stored_cols || !host_basis || m < 1 || n_stored < 1 ||
+        n_stored + m != var_count)
+        return fail(MI_BAD_ARG, "compact upload needs rows >= 2 and n_stored + (rows-1) == var_count");
+    std::vector<int64_t> l2p((size_t)var_count, -2);                 // -2: not yet accounted for
+    for (int64_t i = 0; i < m; ++i) {
+        const int64_t b = host_basis[i];
+        if (b < 0 || b >= var_count || l2p[(size_t)b] != -2) return fail(MI_BAD_ARG, "bad basis entry %lld", (long long)b);
+        l2p[(size_t)b] = -1;
+    }
+    for (int64_t j = 0; j < n_stored; ++j) {
+        const int64_t g = stored_cols[j];
+        if (g < 0 || g >= var_count || l2p[(size_t)g] != -2) return fail(MI_BAD_ARG, "bad stored column %lld", (long long)g);
+        l2p[(size_t)g] = j;
+    }
+    mi355x_tab *t = nullptr;
+    int rc = alloc_tab(&t, rows, var_count + 1, device, 1, /*defer_dense=*/true);
+    if (rc != MI_OK) return rc;
+    TabView &v = t->v;
+    t->c = v;
+    t->c.M = nullptr; t->c.p2l = nullptr; t->c.l2p = nullptr;
+    t->c.cols = n_stored + 1;
+    t->c.ld = padded_ld(n_stored + 1);
+    hipError_t e = hipMalloc((void **)&t->c.M, (size_t)rows * t->c.ld * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->c.p2l, n_stored * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->c.l2p, var_count * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->brow, var_count * sizeof(int64_t));
+    if (e == hipSuccess && t->c.ld != t->c.cols)
+        e = hipMemsetAsync(t->c.M, 0, (size_t)rows * t->c.ld * sizeof(double), t->stream);
+    if (e == hipSuccess)
+        e = hipMemcpy2DAsync(t->c.M, t->c.ld * sizeof(double), host_stored, t->c.cols * sizeof(double),
+                             t->c.cols * sizeof(double), rows, hipMemcpyHostToDevice, t->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(t->c.p2l, stored_cols, n_stored * sizeof(int64_t), hipMemcpyHostToDevice, t->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(t->c.l2p, l2p.data(), var_count * sizeof(int64_t), hipMemcpyHostToDevice, t->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(v.basis, host_basis, m * sizeof(int64_t), hipMemcpyHostToDevice, t->stream);
+    if (e == hipSuccess) { launch_ctl_reset(v, 0, 1, t->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    if (e != hipSuccess) {
+        free_tab(t);
+        return fail(e == hipErrorOutOfMemory ? MI_NO_MEMORY : MI_HIP_ERROR, "compact upload failed: %s", hipGetErrorString(e));
+    }
+    t->compact = true;
+    t->unit_basis = true;
     *out = t;
     return MI_OK;
 }
@@ -656,6 +715,30 @@ int mi355x_tab_download(mi355x_tab *t, double *hm, int64_t *hb, double *last_row
     if (!t) return fail(MI_BAD_ARG, "handle is NULL");
     int rc = use_device(t);
     if (rc != MI_OK) return rc;
+    if (t->compact && !hm) {
+        // what tableau-variable & co. need (objective row, RHS column, basis) straight from the
+        // compact representation: no dense tableau is rebuilt (or even allocated)
+        const TabView &c = t->c;
+        const int64_t n_nb = c.cols - 1;
+        if (hb && c.rows > 1)
+            HIP_TRY(hipMemcpyAsync(hb, c.basis, (c.rows - 1) * sizeof(int64_t), hipMemcpyDeviceToHost, t->stream));
+        if (last_col)
+            HIP_TRY(hipMemcpy2DAsync(last_col, sizeof(double), c.M + n_nb, c.ld * sizeof(double),
+                                     sizeof(double), c.rows, hipMemcpyDeviceToHost, t->stream));
+        if (last_row) {
+            std::vector<double>  obj((size_t)c.cols);
+            std::vector<int64_t> p2l((size_t)std::max<int64_t>(n_nb, 1));
+            HIP_TRY(hipMemcpyAsync(obj.data(), c.M + (c.rows - 1) * c.ld, c.cols * sizeof(double),
+                                   hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipMemcpyAsync(p2l.data(), c.p2l, n_nb * sizeof(int64_t), hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            for (int64_t j = 0; j < t->v.cols; ++j) last_row[j] = 0.0;          // basic columns: +0
+            for (int64_t j = 0; j < n_nb; ++j) last_row[p2l[(size_t)j]] = obj[(size_t)j];
+            last_row[t->v.cols - 1] = obj[(size_t)n_nb];
+        }
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        return MI_OK;
+    }
     rc = ensure_dense(t);
     if (rc != MI_OK) return rc;
     const TabView &v = t->v;

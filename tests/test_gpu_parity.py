@@ -316,6 +316,45 @@ def test_dense_and_compact_representations_bitwise(n, m, seed, compact):
         L.mi355x_tune_set_compact(1)
 
 
+@pytest.mark.parametrize("n,m,seed", [(40, 25, 1), (700, 333, 2), (1500, 300, 3)])
+def test_compact_upload_equals_dense_upload(n, m, seed):
+    """mi355x_tab_create_compact (only [A | b ; -c | 0] crosses the boundary, no dense buffer is
+    ever allocated for solve + light read-back) against the ordinary dense upload of the same
+    tableau and against the oracle; and the dense logical form still materialises on demand."""
+    L = lp.capi.lib()
+    M0, b0 = lp.synth.tableau(n, m, lp.synth.seed_for(11, seed))
+    stored = np.ascontiguousarray(np.concatenate([M0[:, :n], M0[:, -1:]], axis=1))
+    cols = np.arange(n, dtype=np.int64)
+    h = ctypes.c_void_p()
+    lp.capi.check(L.mi355x_tab_create_compact(ctypes.byref(h), m + 1, n + m, n,
+                                              stored.ctypes.data_as(ctypes.c_void_p),
+                                              cols.ctypes.data_as(ctypes.c_void_p),
+                                              b0.ctypes.data_as(ctypes.c_void_p), 0), "create_compact")
+    t = lp.Tableau(None, lp.Problem(type="max"), None, None, n + m, m, {}, _handle=h)
+    assert _layout(t) == (1, n + 1, (n + 1 + 15) // 16 * 16)
+    M, b = M0.copy(), b0.copy()
+    st, npiv, trace = oracle.solve(M, b, trace_cap=1 << 15)
+    k = ctypes.c_int64(0)
+    assert L.mi355x_tab_solve(h, 1, 1024.0, 0, ctypes.byref(k)) == st and k.value == npiv
+    assert np.array_equal(t.pivot_trace(), trace)
+    last_row = np.empty(n + m + 1); last_col = np.empty(m + 1); basis = np.empty(m, dtype=np.int64)
+    lp.capi.check(L.mi355x_tab_download(h, None, basis.ctypes.data_as(ctypes.c_void_p),
+                                        last_row.ctypes.data_as(ctypes.c_void_p),
+                                        last_col.ctypes.data_as(ctypes.c_void_p)), "light download")
+    assert _layout(t)[0] == 1                                  # still compact: nothing was expanded
+    assert np.array_equal(last_row.view(np.int64), M[m].view(np.int64))
+    assert np.array_equal(last_col.view(np.int64), M[:, -1].view(np.int64)) and np.array_equal(basis, b)
+    t._touch()
+    assert np.array_equal(t.matrix.view(np.int64), M.view(np.int64))      # full download expands
+    assert _layout(t)[0] == 0
+    # bad inputs are refused
+    bad = b0.copy(); bad[0] = 0                                 # a stored column cannot be basic too
+    h2 = ctypes.c_void_p()
+    assert L.mi355x_tab_create_compact(ctypes.byref(h2), m + 1, n + m, n, stored.ctypes.data_as(ctypes.c_void_p),
+                                       cols.ctypes.data_as(ctypes.c_void_p),
+                                       bad.ctypes.data_as(ctypes.c_void_p), 0) == lp.capi.MI_BAD_ARG
+
+
 def test_inconsistent_basis_falls_back_to_dense():
     """A caller-supplied basis whose columns are NOT unit vectors (nothing in the reference
     forbids it): the compact representation is refused and the dense path reproduces the
