@@ -43,6 +43,7 @@ class Tableau:
         self._matrix = None
         self._basis = None
         self._stale = True
+        self._light = None
         self._handle = None
         if _handle is not None:
             self._handle = _handle
@@ -79,6 +80,22 @@ class Tableau:
 
     def _touch(self):
         self._stale = True
+        self._light = None
+
+    def _readback(self):
+        """(objective row, RHS column, basis) -- all the read-back functions need
+        (src/simplex.lisp:74-120).  Served from the host copy when it is current, otherwise
+        fetched alone (mi355x_tab_download without the matrix), never the whole tableau."""
+        if not self._stale:
+            return self._matrix[-1], self._matrix[:, -1], self._basis
+        if getattr(self, "_light", None) is None:
+            R, C = self.constraint_count + 1, self.var_count + 1
+            row, col = np.empty(C), np.empty(R)
+            b = np.empty(max(R - 1, 0), dtype=np.int64)
+            capi.check(capi.lib().mi355x_tab_download(self._h, None, _ptr(b) if b.size else None,
+                                                      _ptr(row), _ptr(col)), "mi355x_tab_download")
+            self._light = (row, col, b)
+        return self._light
 
     @property
     def matrix(self):
@@ -129,12 +146,13 @@ def copy_tableau(tableau):
 # ------------------------------------------------------------------ read-back (host, O(n))
 def tableau_objective_value(tableau):
     """tableau-objective-value (src/simplex.lisp:74-78)."""
-    return float(tableau.matrix[tableau.constraint_count, tableau.var_count])
+    return float(tableau._readback()[0][tableau.var_count])
 
 
 def _basic_value(tableau, col):
-    pos = np.nonzero(tableau.basis_columns == col)[0]       # `position`: first match
-    return float(tableau.matrix[pos[0], tableau.var_count]) if pos.size else 0.0
+    _, rhs, basis = tableau._readback()
+    pos = np.nonzero(basis == col)[0]                       # `position`: first match
+    return float(rhs[pos[0]]) if pos.size else 0.0
 
 
 def tableau_variable(tableau, var):
@@ -159,7 +177,7 @@ def tableau_reduced_cost(tableau, var):
         raise KeyError("%s is not a variable in the tableau" % (var,))
     if mapping[0] != "positive":
         raise ValueError("%s has no lower bound" % (var,))
-    return float(tableau.matrix[tableau.constraint_count, mapping[1]])
+    return float(tableau._readback()[0][mapping[1]])
 
 
 def with_tableau_variables(var_list, tableau):
