@@ -134,10 +134,35 @@ the arrays are not), so tableau-variable & co. (src/simplex.lisp:74-120) read GP
       (values (cffi:mem-ref out :pointer) flat basis))))
 
 (defun download-tableau (handle tableau flat basis)
+  "Full write-back: every entry of the solved tableau (400 MB and 5e7 boxed doubles at
+8192 x 4096 -- only worth it when the caller wants to look inside the tableau)."
   (cffi:with-pointer-to-vector-data (pm flat)
     (cffi:with-pointer-to-vector-data (pb basis)
       (check (%tab-download handle pm pb (cffi:null-pointer) (cffi:null-pointer)))))
   (vectors->tableau tableau flat basis))
+
+(defun download-solution (handle tableau basis)
+  "Light write-back (the default): the objective row, the RHS column and the basis are all
+that tableau-objective-value, tableau-variable and tableau-reduced-cost read
+(src/simplex.lisp:74-120), so only those are fetched and stored into the tableau's arrays;
+the interior of the matrix keeps its pre-solve contents."
+  (let* ((matrix (tableau-matrix tableau))
+         (rows (array-dimension matrix 0))
+         (cols (array-dimension matrix 1))
+         (last-row (make-array cols :element-type 'double-float))
+         (last-col (make-array rows :element-type 'double-float))
+         (basis-dst (tableau-basis-columns tableau)))
+    (cffi:with-pointer-to-vector-data (pr last-row)
+      (cffi:with-pointer-to-vector-data (pc last-col)
+        (cffi:with-pointer-to-vector-data (pb basis)
+          (check (%tab-download handle (cffi:null-pointer) pb pr pc)))))
+    (dotimes (r rows)
+      (setf (aref matrix r (1- cols)) (aref last-col r)))
+    (dotimes (c cols)
+      (setf (aref matrix (1- rows) c) (aref last-row c)))
+    (dotimes (i (length basis-dst))
+      (setf (aref basis-dst i) (aref basis i)))
+    tableau))
 
 (defun signal-outcome (status)
   "C outcome -> the reference's conditions (src/conditions.lisp:43-60)."
@@ -156,12 +181,13 @@ the arrays are not), so tableau-variable & co. (src/simplex.lisp:74-120) read GP
 
 ;;; ------------------------------------------------------------------ the *solver* value
 (defun mi355x-simplex-solver (problem &rest args
-                              &key (fp-tolerance 1024) (device 0) (max-pivots 0)
+                              &key (fp-tolerance 1024) (device 0) (max-pivots 0) full-tableau
                               &allow-other-keys)
   "Solver interface function for the MI355X backend (the value of
 linear-programming:*solver*, src/solver.lisp:39-49).  Takes a problem and backend keyword
 arguments -- :fp-tolerance (as the built-in solver, src/simplex.lisp:506-511), :device,
-:max-pivots -- and returns a solved `tableau`."
+:max-pivots, :full-tableau (write every entry of the solved tableau back instead of only what
+the solution-* generics read) -- and returns a solved `tableau`."
   (declare (ignore args))
   (when (problem-integer-vars problem)
     (error 'unsupported-constraint-error
@@ -184,7 +210,9 @@ arguments -- :fp-tolerance (as the built-in solver, src/simplex.lisp:506-511), :
                                                                    (max-problem-p main-tab)
                                                                    factor n-pivots)))))
                             (signal-outcome status)
-                            (download-tableau main-handle main-tab main-flat main-basis))
+                            (if full-tableau
+                                (download-tableau main-handle main-tab main-flat main-basis)
+                                (download-solution main-handle main-tab main-basis)))
                        (%tab-destroy main-handle)))
                 (%tab-destroy art-handle))))
           ;; single phase, src/simplex.lisp:453-461
@@ -194,5 +222,7 @@ arguments -- :fp-tolerance (as the built-in solver, src/simplex.lisp:506-511), :
                                         (%tab-solve handle (max-problem-p tableaus) factor
                                                     max-pivots n-pivots)))))
                    (signal-outcome status)
-                   (download-tableau handle tableaus flat basis))
+                   (if full-tableau
+                       (download-tableau handle tableaus flat basis)
+                       (download-solution handle tableaus basis)))
               (%tab-destroy handle)))))))
