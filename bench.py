@@ -61,6 +61,10 @@ def parse():
                     help="colpart: shards hold all logical columns instead of the non-basic ones only")
     ap.add_argument("--colpart-vars", type=int, default=0,
                     help="colpart: override the number of variables (constraints = vars/2)")
+    ap.add_argument("--block", type=int, default=0,
+                    help="tuning: pivots selected ahead and applied per sweep (0 = library default, 1 = off)")
+    ap.add_argument("--sweep-tr", type=int, default=0, help="tuning: rows per sweep workgroup")
+    ap.add_argument("--sweep-nt", type=int, default=-1, help="tuning: non-temporal sweep accesses (0/1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pivots", type=int, default=400,
                     help="cpu_baseline: pivots timed with all host threads (a quarter of it single-threaded)")
@@ -231,6 +235,10 @@ def main():
         L.mi355x_tune_set_compact(0)
     if args.ld_extra:
         L.mi355x_tune_set_ld_extra(args.ld_extra)
+    if args.block:
+        L.mi355x_tune_set_block(args.block)
+    if args.sweep_tr or args.sweep_nt >= 0:
+        L.mi355x_tune_set_sweep_shape(args.sweep_tr or 4, args.sweep_nt)
     # One LP supports only so many pivots before it is optimal (config 3: 5 700-6 100, config 2:
     # ~290 with these seeds).  If more timed steps are asked for than one LP safely provides,
     # further LPs of the same shape are generated in HBM BEFORE the timed region and the timed
@@ -282,6 +290,9 @@ def main():
     # STORED element read once + written once.  Dense: C = n+m+1 columns (SURVEY 8d's figure);
     # compact: only the n non-basic columns + RHS carry information.
     kernel_bytes = 2 * R * stored_cols.value * 8
+    # blocked pivoting: one launch of the update kernel applies `block` pivots to every element
+    # while it is in registers; the bytes above are then moved once per BLOCK
+    block = L.mi355x_tab_block_size(h)
 
     upd_avg_ms = None
     nl = ctypes.c_int64(0)
@@ -310,7 +321,8 @@ def main():
             roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
                         "traffic_source": traffic_src,
-                        "kernel": L.mi355x_update_kernel_name().decode(),
+                        "kernel": "k_sweep" if block > 1 else L.mi355x_update_kernel_name().decode(),
+                        "pivots_per_launch": block,
                         "kernel_avg_us": upd_avg_ms * 1e3,
                         "algorithmic_bytes_per_launch": kernel_bytes,
                         "representation": "compact [non-basic columns | RHS], %d of %d columns stored"

@@ -86,6 +86,9 @@ _EXTRA = {
     "mi355x_tune_set_batch_mode": (_int, [_int]),
     "mi355x_tune_set_handover_mode": (_int, [_int]),
     "mi355x_tune_set_ld_extra": (_int, [_int]),
+    "mi355x_tune_set_block": (_int, [_int]),
+    "mi355x_tab_block_size": (_int, [_p]),
+    "mi355x_tune_set_sweep_shape": (_int, [_int, _int]),
 }
 
 _lib = None

@@ -26,6 +26,7 @@ int g_select_mode = 0;                    // 0 auto, 1 single workgroup, 2 split
 int g_compact_enabled = 1;                // solve loops run on the compact representation
 int g_handover_mode = 0;                  // 0 auto, 1 always the sequential re-elimination
 int g_batch_mode = 0;                     // 0 auto, 1 lockstep launch pairs, 2 one workgroup per LP
+int g_block_k = 8;                        // pivots selected ahead and applied per sweep (1 = off)
 
 int fail(int code, const char *fmt, ...)
 {
@@ -120,6 +121,11 @@ void free_tab(mi355x_tab *t)
     (void)hipFree(t->v.part_v);
     (void)hipFree(t->v.part_i);
     (void)hipFree(t->v.part_s);
+    (void)hipFree(t->v.bk_col);
+    (void)hipFree(t->v.bk_prow);
+    (void)hipFree(t->v.blk);
+    (void)hipFree(t->v.bk_rmask);
+    (void)hipFree(t->v.bk_smask);
     (void)hipFree(t->c.M);
     (void)hipFree(t->c.p2l);
     (void)hipFree(t->c.l2p);
@@ -186,6 +192,14 @@ int alloc_tab(mi355x_tab **out, int64_t rows, int64_t cols, int device, int64_t 
     ALLOC(t->v.part_i, n_lps * part_cap * sizeof(int64_t));
     ALLOC(t->v.part_s, n_lps * part_cap * sizeof(int64_t));
     t->v.part_cap = part_cap;
+    if (n_lps == 1) {                                 // blocked pivoting
+        t->v.bk_stride = (rows + kLdAlign - 1) / kLdAlign * kLdAlign;
+        ALLOC(t->v.bk_col, (size_t)kMaxBlock * t->v.bk_stride * sizeof(double));
+        ALLOC(t->v.bk_prow, (size_t)kMaxBlock * t->v.ld * sizeof(double));
+        ALLOC(t->v.blk, sizeof(BlockCtl));
+        ALLOC(t->v.bk_rmask, (size_t)t->v.bk_stride * sizeof(uint32_t));
+        ALLOC(t->v.bk_smask, (size_t)t->v.ld * sizeof(uint32_t));
+    }
 #undef ALLOC
     if ((e = hipHostMalloc((void **)&t->h_ctl, n_lps * sizeof(Ctl))) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&t->own_stream, hipStreamNonBlocking)) != hipSuccess) {
@@ -194,7 +208,12 @@ int alloc_tab(mi355x_tab **out, int64_t rows, int64_t cols, int device, int64_t 
     }
     t->stream = t->own_stream;
     memset(t->h_ctl, 0, n_lps * sizeof(Ctl));
-    if ((e = hipMemsetAsync(t->v.ctl, 0, n_lps * sizeof(Ctl), t->stream)) != hipSuccess ||
+    if ((t->v.blk && ((e = hipMemsetAsync(t->v.blk, 0, sizeof(BlockCtl), t->stream)) != hipSuccess ||
+                      (e = hipMemsetAsync(t->v.bk_rmask, 0, t->v.bk_stride * sizeof(uint32_t), t->stream)) != hipSuccess ||
+                      (e = hipMemsetAsync(t->v.bk_smask, 0, t->v.ld * sizeof(uint32_t), t->stream)) != hipSuccess ||
+                      (e = hipMemsetAsync(t->v.bk_col, 0, (size_t)kMaxBlock * t->v.bk_stride * sizeof(double), t->stream)) != hipSuccess ||
+                      (e = hipMemsetAsync(t->v.bk_prow, 0, (size_t)kMaxBlock * t->v.ld * sizeof(double), t->stream)) != hipSuccess)) ||
+        (e = hipMemsetAsync(t->v.ctl, 0, n_lps * sizeof(Ctl), t->stream)) != hipSuccess ||
         (e = hipMemsetAsync(t->v.basis, 0, n_lps * nb * sizeof(int64_t), t->stream)) != hipSuccess) {
         free_tab(t);
         return fail(MI_HIP_ERROR, "memset failed: %s", hipGetErrorString(e));
@@ -363,6 +382,42 @@ int enqueue_iteration(mi355x_tab *t, int is_max, double f)
 {
     enqueue_select(t, is_max, f);
     return enqueue_update(t, is_max);
+}
+
+// ---- blocked pivoting: k look-ahead selects, then one sweep applies them all
+bool block_mode(const mi355x_tab *t)
+{
+    if (g_block_k <= 1 || !t->compact || !block_supported(t->c)) return false;
+    bool split = (t->c.rows > 1024 || t->c.ld > 4096);    // as enqueue_select: small tableaux
+    if (g_select_mode == 1) split = false;                // stay on the single-workgroup select
+    if (g_select_mode == 2) split = true;
+    return split;
+}
+
+int enqueue_block(mi355x_tab *t, int is_max, double f, int k)
+{
+    const TabView &v = t->c;
+    int np = (t->n_part > 0 && t->part_is_max == (is_max ? 1 : 0)) ? t->n_part : 0;
+    for (int j = 0; j < k; ++j) np = launch_lookahead(v, j, is_max, f, np, t->stream);
+    const bool timed = t->timing_stride > 0 && t->n_timed < kTimingCap &&
+                       (t->update_launches++ % t->timing_stride) == 0;
+    if (timed) {
+        if ((int)t->ev0.size() <= t->n_timed) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            t->ev0.push_back(a);
+            t->ev1.push_back(b);
+        }
+        HIP_TRY(hipEventRecord(t->ev0[t->n_timed], t->stream));
+    }
+    t->n_part = launch_sweep(v, k, is_max ? 1.0 : -1.0, t->stream);
+    t->part_is_max = is_max ? 1 : 0;
+    if (timed) {
+        HIP_TRY(hipEventRecord(t->ev1[t->n_timed], t->stream));
+        t->n_timed++;
+    }
+    return MI_OK;
 }
 
 int status_to_rc(int32_t st) { return st == kRunning ? MI_RUNNING : (int)st; }
@@ -575,6 +630,14 @@ int mi355x_tab_solve_async(mi355x_tab *t, int is_max, double f, int64_t n_pivots
     rc = ensure_compact(t);
     if (rc != MI_OK) return rc;
     if (reset) launch_ctl_reset(t->v, 0, 0, t->stream);
+    if (block_mode(t)) {                              // whole blocks, then the remainder
+        for (int64_t left = n_pivots; left > 0; left -= g_block_k) {
+            rc = enqueue_block(t, is_max, f, (int)std::min<int64_t>(left, g_block_k));
+            if (rc != MI_OK) return rc;
+        }
+        HIP_TRY(hipGetLastError());
+        return MI_OK;
+    }
     for (int64_t i = 0; i < n_pivots; ++i) {
         rc = enqueue_iteration(t, is_max, f);
         if (rc != MI_OK) return rc;
@@ -619,6 +682,28 @@ int mi355x_tab_solve(mi355x_tab *t, int is_max, double f, int64_t max_pivots, in
     rc = ensure_compact(t);
     if (rc != MI_OK) return rc;
     launch_ctl_reset(t->v, max_pivots, 0, t->stream);
+    if (block_mode(t)) {
+        // blocks of g_block_k pivots, blind enqueue in growing chunks of blocks; a block whose
+        // look-ahead terminates the solve still sweeps (applies what was selected before)
+        int64_t blocks = 2;
+        for (;;) {
+            for (int64_t i = 0; i < blocks; ++i) {
+                rc = enqueue_block(t, is_max, f, g_block_k);
+                if (rc != MI_OK) return rc;
+            }
+            HIP_TRY(hipGetLastError());
+            rc = read_ctl(t);
+            if (rc != MI_OK) return rc;
+            if (t->h_ctl->status != kRunning) break;
+            if (blocks < 64) blocks *= 2;
+        }
+        if (t->h_ctl->status != kNeedDense) {
+            if (n_pivots) *n_pivots = t->h_ctl->n_pivots;
+            return (int)t->h_ctl->status;
+        }
+        rc = fall_back_to_dense(t);                   // redo that pivot, and the rest, densely
+        if (rc != MI_OK) return rc;
+    }
     // Blind enqueue in growing chunks, one status read-back per chunk.  The stream always
     // ends on a select (it is the select that detects optimality / unboundedness / the cap);
     // an update is a no-op unless the preceding select chose a pivot, so iterations enqueued
@@ -1062,6 +1147,10 @@ int         mi355x_tune_set_ld_extra(int doubles) { g_ld_extra = (doubles > 0 ? 
 int         mi355x_tune_set_handover_mode(int mode) { g_handover_mode = mode; return mode; }
 int         mi355x_tune_set_batch_mode(int mode) { g_batch_mode = mode; return g_batch_mode; }
 int         mi355x_tune_set_alternate_sweep(int on) { set_alternate_sweep(on); return on; }
+// pivots one tableau-update launch of this handle applies in its current representation
+int         mi355x_tab_block_size(mi355x_tab *t) { return (t && block_mode(t)) ? g_block_k : 1; }
+int         mi355x_tune_set_block(int k) { g_block_k = k < 1 ? 1 : (k > kMaxBlock ? kMaxBlock : k); return g_block_k; }
+int         mi355x_tune_set_sweep_shape(int tr, int nt) { set_sweep_shape(tr, nt); return tr; }
 int         mi355x_tune_set_compact(int on) { g_compact_enabled = on ? 1 : 0; return g_compact_enabled; }
 
 }  // extern "C"

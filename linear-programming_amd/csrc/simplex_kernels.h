@@ -31,6 +31,18 @@ struct Ctl {
     int64_t slot;         // physical column of `ec` (== ec unless the representation is compact)
 };
 
+// Blocked pivoting (single compact tableaux): up to kMaxBlock pivots are SELECTED ahead of the
+// tableau update -- each look-ahead step evaluates just the objective row, one column, the RHS
+// column and one row as they would be after the pending pivots -- and then applied to every
+// stored element in ONE sweep (k rank-1 updates per element, in pivot order, operands and
+// roundings unchanged).  This block lives next to the control block.
+constexpr int kMaxBlock = 16;
+struct BlockCtl {
+    int64_t n_pending;            // pivots selected but not yet applied by a sweep
+    int64_t cr[kMaxBlock];        // their pivot rows ...
+    int64_t slot[kMaxBlock];      // ... and the physical slots their entering columns gave up
+};
+
 // One tableau in HBM.  Row-major, leading dimension ld (a multiple of 16 doubles so
 // that every row starts on a 128-byte boundary and 16-byte vector accesses never
 // straddle rows); columns [cols, ld) are padding and hold zeros.
@@ -53,6 +65,14 @@ struct TabView {
     // maps; both null for the dense logical layout
     int64_t *p2l;         // cols-1 entries: logical column stored in physical slot j
     int64_t *l2p;         // logical var_count entries: slot of a logical column, -1 if basic
+    // blocked pivoting: entering-column snapshots (kMaxBlock x bk_stride), normalised pivot rows
+    // (kMaxBlock x ld of the view in use) and the pending list; null when not available
+    double   *bk_col, *bk_prow;
+    BlockCtl *blk;
+    int64_t   bk_stride;
+    // bit i of bk_rmask[r]: row r is the pivot row of pending pivot i; bits i / 16+i of
+    // bk_smask[pair]: the even / odd column of that pair is the slot pending pivot i gave up
+    uint32_t *bk_rmask, *bk_smask;
     // batch of n_lps same-shape LPs: per-LP element strides (all zero for a single tableau)
     int64_t  n_lps;
     int64_t  zs_M, zs_basis, zs_col, zs_prow, zs_part, zs_p2l, zs_l2p;
@@ -76,6 +96,13 @@ void launch_prepare_pivot(const TabView &t, int64_t ec, int64_t cr, hipStream_t 
 // returns the number of pricing partials written (0 if price == 0)
 int  launch_update(const TabView &t, double sgn, int price, hipStream_t s, int64_t launch_index = 0);
 void set_alternate_sweep(int on);
+// blocked pivoting: look-ahead step j of a block (select pivot j as if pivots 0..j-1 of the block
+// had been applied), and the sweep that applies the whole block.  n_part as for launch_select;
+// launch_lookahead returns the number of pricing partials it leaves for step j+1.
+bool block_supported(const TabView &t);
+int  launch_lookahead(const TabView &t, int j, int is_max, double fp_factor, int n_part, hipStream_t s);
+int  launch_sweep(const TabView &t, int kmax, double sgn, hipStream_t s);
+void set_sweep_shape(int tr, int nt);      // tuning hook
 UpdateShape update_shape(const TabView &t);
 // column-partitioned shards (one shard = one handle)
 void launch_shard_price(const TabView &t, int is_max, int64_t col_offset, double *out2, int n_part,

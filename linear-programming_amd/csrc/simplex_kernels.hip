@@ -42,6 +42,7 @@
 // the column-shard steps for one tableau partitioned over several GPUs, the two-phase
 // hand-over, and the synthetic-LP generator.
 #include "simplex_kernels.h"
+#include <type_traits>
 
 namespace mi355x {
 
@@ -646,6 +647,356 @@ __global__ __launch_bounds__(BLOCK) void k_update(TabView t, const int tr, const
     }
 }
 
+// ------------------------------------------------------------------ blocked pivoting
+// k_update moves every stored element through HBM once per pivot.  Nothing in the algorithm needs
+// the whole tableau between two pivots: find-entering-column reads the objective row,
+// find-pivoting-row one column and the RHS column, and the normalisation one row.  Those four
+// pieces can be evaluated AS THEY WOULD BE after the pivots selected so far in the block -- every
+// pending pivot i is the map  x -> x - col_i[r]*prow_i[c]  (x -> prow_i[c] on its own pivot row),
+// applied in pivot order with the operands the sequential loop would have used -- so pivot j+1
+// is selected before pivot j has touched the tableau, and one k_sweep launch then applies all k
+// pending pivots to every element while it is in registers: 2 x 8 bytes of HBM traffic per
+// element per BLOCK instead of per pivot.  Per element the operation sequence (k rounded
+// products, k rounded differences, in pivot order) is exactly that of k k_update launches, so the
+// results stay bit-identical to the reference's n-pivot-row loop (src/simplex.lisp:337-359).
+//
+//   k_la_gather<J> / k_la_scale<J>   look-ahead step J of a block (the split select, plus the
+//                                    pending chain on what it reads; J is a template parameter so
+//                                    that all the chain operands are loaded up front)
+//   k_la_select<J>                   the same in one workgroup (small tableaux)
+//   k_sweep                          applies blk->n_pending pivots; runs even when the solve has
+//                                    just terminated (the pivots selected before the terminating
+//                                    step must still be applied)
+//
+// Compact representation only: pivot i's entering column gives its slot to the leaving basic
+// column, whose pre-pivot content is e_cr -- in the chain that is a RESET of the element to
+// (r == cr_i ? 1 : 0) before pivot i is applied (k_select_scale stores e_cr into the slot for
+// the same reason).
+
+// pending pivot i applied to element x of (row r, column c): colv = col_i[r], prowv = prow_i[c]
+__device__ __forceinline__ double pend(double x, bool is_slot, bool is_cr, double colv, double prowv)
+{
+    if (is_slot) x = is_cr ? 1.0 : 0.0;
+    const double prod = colv * prowv;                          // rounded product
+    const double d = x - prod;                                 // rounded difference
+    return is_cr ? prowv : d;
+}
+
+template <int J>
+__global__ __launch_bounds__(kGatherThreads) void k_la_gather(TabView t, double sgn, double price_tol,
+                                                              double ratio_thr, int n_part)
+{
+    __shared__ double    s_v[kGatherThreads / 64];
+    __shared__ long long s_i[kGatherThreads / 64];
+    constexpr int JJ = J > 0 ? J : 1;
+    double  *rp_v = t.part_v + t.part_cap / 2;
+    int64_t *rp_i = t.part_i + t.part_cap / 2;
+    int64_t *rp_s = t.part_s + t.part_cap / 2;
+    Ctl *ctl = t.ctl;
+    const Ctl c0 = *ctl;
+    BlockCtl *blk = t.blk;
+    const int64_t m = t.rows - 1, vc = t.cols - 1, ld = t.ld;
+    const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+    if (J == 0) {                                   // a new block starts (whatever the status)
+        if (leader) blk->n_pending = 0;
+        const int64_t n = t.bk_stride > (ld >> 1) ? t.bk_stride : (ld >> 1);
+        for (int64_t idx = (int64_t)blockIdx.x * kGatherThreads + threadIdx.x; idx < n;
+             idx += (int64_t)gridDim.x * kGatherThreads) {
+            if (idx < t.bk_stride) t.bk_rmask[idx] = 0u;
+            if (idx < (ld >> 1))   t.bk_smask[idx] = 0u;
+        }
+    }
+    // J > 0: the partials were left by k_la_scale<J-1> (objective row after pivot J-1)
+    const ValIdx e = n_part > 0
+        ? block_price_partials<kGatherThreads>(t.part_v, t.part_i, t.part_s, n_part, s_v, s_i)
+        : block_price<kGatherThreads>(t.M + m * ld, vc, sgn, s_v, s_i, t.p2l);
+    if (c0.status != kRunning) return;
+    if (e.i < 0 || !(e.v < 0.0 - price_tol)) {
+        if (leader) ctl->status = 0;                // MI_OPTIMAL
+        return;
+    }
+    if (c0.max_pivots > 0 && c0.n_pivots >= c0.max_pivots) {
+        if (leader) ctl->status = 3;                // MI_MAX_PIVOTS
+        return;
+    }
+    const int64_t ec = e.i, slot = e.s;
+    int64_t cri[JJ], sli[JJ];
+    double  pa[JJ], pb[JJ];
+#pragma unroll
+    for (int i = 0; i < J; ++i) {                   // wave-uniform operands of the pending chain
+        cri[i] = blk->cr[i];
+        sli[i] = blk->slot[i];
+        pa[i]  = t.bk_prow[(int64_t)i * ld + slot];
+        pb[i]  = t.bk_prow[(int64_t)i * ld + vc];
+    }
+    const int64_t r = (int64_t)blockIdx.x * kGatherThreads + threadIdx.x;
+    ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
+    if (r < t.rows) {
+        double a = t.M[r * ld + slot];
+        double b = r < m ? t.M[r * ld + vc] : 0.0;
+        double ci[JJ];
+#pragma unroll
+        for (int i = 0; i < J; ++i) ci[i] = t.bk_col[(int64_t)i * t.bk_stride + r];
+#pragma unroll
+        for (int i = 0; i < J; ++i) {
+            const bool is_cr = r == cri[i];
+            a = pend(a, slot == sli[i], is_cr, ci[i], pa[i]);
+            b = pend(b, false, is_cr, ci[i], pb[i]);
+        }
+        t.bk_col[(int64_t)J * t.bk_stride + r] = a;
+        if (!(fabs(a) <= 1.7976931348623157e308)) atomicOr(&ctl->poison, 1);   // see kNeedDense
+        if (r < m && ratio_thr < a) { best.v = b / a; best.i = r; best.s = __double_as_longlong(a); }
+    }
+    best = block_reduce_min<kGatherThreads>(best, s_v, s_i);
+    if (threadIdx.x == 0) { rp_v[blockIdx.x] = best.v; rp_i[blockIdx.x] = best.i; rp_s[blockIdx.x] = best.s; }
+    if (leader) { ctl->ec = ec; ctl->slot = slot; }
+}
+
+// Pivot row cr and the objective row, both through the pending chain; the objective row
+// additionally through pivot J itself, priced on the way out (per-wave partials for step J+1 or
+// for nobody if this was the last step: the sweep prices again).  The thread that owns the slot
+// does the bookkeeping: it is the only one that needs the leaving column's index, and the only
+// p2l entry that changes is the one no other thread reads.
+template <int J>
+__global__ __launch_bounds__(kScaleThreads) void k_la_scale(TabView t, int n_rp, double sgn)
+{
+    __shared__ double    s_v[kScaleThreads / 64];
+    __shared__ long long s_i[kScaleThreads / 64];
+    constexpr int JJ = J > 0 ? J : 1;
+    const double  *rp_v = t.part_v + t.part_cap / 2;
+    const int64_t *rp_i = t.part_i + t.part_cap / 2;
+    const int64_t *rp_s = t.part_s + t.part_cap / 2;
+    Ctl *ctl = t.ctl;
+    const Ctl c0 = *ctl;
+    BlockCtl *blk = t.blk;
+    const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+    const ValIdx q = block_price_partials<kScaleThreads>(rp_v, rp_i, rp_s, n_rp, s_v, s_i);
+    if (c0.status != kRunning) return;
+    if (c0.poison) {
+        if (leader) ctl->status = kNeedDense;
+        return;
+    }
+    if (q.i < 0) {
+        if (leader) ctl->status = 1;                // MI_UNBOUNDED
+        return;
+    }
+    const int64_t cr = q.i;
+    const double piv = __longlong_as_double(q.s);
+    const int64_t ec = c0.ec, slot = c0.slot;
+    const int64_t m = t.rows - 1, vc = t.cols - 1, ldv = t.ld >> 1;
+    const int64_t p = (int64_t)blockIdx.x * kScaleThreads + threadIdx.x;
+    ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
+    if (p < ldv) {
+        const double2 *M2 = reinterpret_cast<const double2 *>(t.M);
+        double2 *P2 = reinterpret_cast<double2 *>(t.bk_prow);
+        double2 y = M2[cr * ldv + p];               // row cr
+        double2 z = M2[m * ldv + p];                // objective row (never a pivot row)
+        const bool own = (p == (slot >> 1));
+        const int64_t leaving = own ? t.basis[cr] : -1;
+        int64_t cri[JJ], sli[JJ];
+        double  ccr[JJ], cm[JJ];
+        double2 pi[JJ];
+#pragma unroll
+        for (int i = 0; i < J; ++i) {
+            cri[i] = blk->cr[i];
+            sli[i] = blk->slot[i];
+            ccr[i] = t.bk_col[(int64_t)i * t.bk_stride + cr];
+            cm[i]  = t.bk_col[(int64_t)i * t.bk_stride + m];
+            pi[i]  = P2[(int64_t)i * ldv + p];
+        }
+        const double cmj = t.bk_col[(int64_t)J * t.bk_stride + m];
+#pragma unroll
+        for (int i = 0; i < J; ++i) {
+            const bool is_cr = cr == cri[i];
+            y.x = pend(y.x, 2 * p     == sli[i], is_cr, ccr[i], pi[i].x);
+            y.y = pend(y.y, 2 * p + 1 == sli[i], is_cr, ccr[i], pi[i].y);
+            z.x = pend(z.x, 2 * p     == sli[i], false, cm[i], pi[i].x);
+            z.y = pend(z.y, 2 * p + 1 == sli[i], false, cm[i], pi[i].y);
+        }
+        const double2 pr = scale_pair(t, p, y, piv, slot);
+        P2[(int64_t)J * ldv + p] = pr;
+        z.x = pend(z.x, 2 * p     == slot, false, cmj, pr.x);
+        z.y = pend(z.y, 2 * p + 1 == slot, false, cmj, pr.y);
+        const int64_t c0i = 2 * p;
+        if (c0i < vc) {
+            ValIdx c; c.v = z.x * sgn; c.i = (c0i == slot) ? leaving : t.p2l[c0i]; c.s = c0i;
+            best = vi_min(best, c);
+        }
+        if (c0i + 1 < vc) {
+            ValIdx c; c.v = z.y * sgn; c.i = (c0i + 1 == slot) ? leaving : t.p2l[c0i + 1]; c.s = c0i + 1;
+            best = vi_min(best, c);
+        }
+        if (own) {
+            swap_columns(t, ec, cr, slot);
+            record_pivot(t, c0, ec, cr);
+            blk->cr[J] = cr;
+            blk->slot[J] = slot;
+            blk->n_pending = J + 1;
+            t.bk_rmask[cr] |= 1u << J;              // this thread is the only writer in the launch
+            t.bk_smask[slot >> 1] |= 1u << (J + 16 * (int)(slot & 1));
+        }
+    }
+    best = wave_reduce_min(best);
+    if ((threadIdx.x & 63) == 0) {
+        const int w = blockIdx.x * (kScaleThreads / 64) + (threadIdx.x >> 6);
+        t.part_v[w] = best.v;
+        t.part_i[w] = best.i;
+        t.part_s[w] = best.s;
+    }
+}
+
+// The sweep.  A workgroup owns a strip of <= 256 column pairs x tr rows and walks it four rows
+// at a time; a thread keeps its prow pairs of all pending pivots in registers (loaded once per
+// tile: tall tiles keep that L2 traffic below the tableau's own), the col values of the four
+// rows are wave-uniform and sit in SGPRs (s_load_dwordx8 per pivot, issued by hand so that all
+// of a chunk's loads are in flight together), and v_mul_f64 takes them straight from there.
+// Tiles that hold no pivot row and waves that hold no slot column (nearly all of them) run the
+// bare chain: 2 v_mul_f64 + 2 v_add_f64 per element pair and pivot.
+typedef int    v8i __attribute__((ext_vector_type(8)));
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// CH scalar loads of 4 doubles each (row r.. r+3 of CH consecutive pivots) and the wait for them,
+// as ONE asm statement: the outputs must not be touched (or spilled) before the data has landed,
+// and the compiler cannot know that about a bare s_load.
+template <int CH>
+__device__ __forceinline__ void sload_chunk(v8i (&c)[CH], const double *base, int64_t stride)
+{
+    const double *p0 = base, *p1 = base + stride, *p2 = base + 2 * stride, *p3 = base + 3 * stride;
+    const double *p4 = base + 4 * stride, *p5 = base + 5 * stride, *p6 = base + 6 * stride, *p7 = base + 7 * stride;
+    if constexpr (CH == 2)
+        asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx8 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(c[0]), "=&s"(c[1]) : "s"(p0), "s"(p1));
+    if constexpr (CH == 4)
+        asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %5, 0x0\n\t"
+                     "s_load_dwordx8 %2, %6, 0x0\n\ts_load_dwordx8 %3, %7, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(c[0]), "=&s"(c[1]), "=&s"(c[2]), "=&s"(c[3]) : "s"(p0), "s"(p1), "s"(p2), "s"(p3));
+    if constexpr (CH == 8)
+        asm volatile("s_load_dwordx8 %0, %8, 0x0\n\ts_load_dwordx8 %1, %9, 0x0\n\t"
+                     "s_load_dwordx8 %2, %10, 0x0\n\ts_load_dwordx8 %3, %11, 0x0\n\t"
+                     "s_load_dwordx8 %4, %12, 0x0\n\ts_load_dwordx8 %5, %13, 0x0\n\t"
+                     "s_load_dwordx8 %6, %14, 0x0\n\ts_load_dwordx8 %7, %15, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(c[0]), "=&s"(c[1]), "=&s"(c[2]), "=&s"(c[3]), "=&s"(c[4]), "=&s"(c[5]), "=&s"(c[6]), "=&s"(c[7])
+                     : "s"(p0), "s"(p1), "s"(p2), "s"(p3), "s"(p4), "s"(p5), "s"(p6), "s"(p7));
+}
+
+template <int BLOCK, int KMAX, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_sweep(TabView t, const int tr, const int strip_pairs,
+                                                 const double sgn, const int price)
+{
+    constexpr int U = 4;                                       // rows per step
+    constexpr int CH = KMAX < 8 ? KMAX : 8;                    // pivots per SGPR chunk
+    const BlockCtl *__restrict__ blk = t.blk;
+    const int k = (int)blk->n_pending;
+    if (k == 0) return;
+    double *__restrict__ M = t.M;
+    const int64_t ld = t.ld, rows = t.rows, vc = t.cols - 1;
+    const int64_t ldv  = ld >> 1;
+    const int64_t pair = (int64_t)blockIdx.x * strip_pairs + threadIdx.x;
+    const bool active  = (int)threadIdx.x < strip_pairs && pair < ldv;
+    const int64_t r0 = (int64_t)blockIdx.y * tr;
+    const int64_t r1 = (r0 + tr < rows) ? r0 + tr : rows;
+    double  *__restrict__ part_v = price ? t.part_v : nullptr;
+    const bool prices = (r1 == rows) && part_v != nullptr;
+    if (!active && !prices) return;                            // no workgroup barrier below
+
+    vec2d *Mp = reinterpret_cast<vec2d *>(M) + pair;
+    auto ld2 = [&](int64_t r) -> vec2d {
+        if constexpr (NT) return __builtin_nontemporal_load(Mp + r * ldv);
+        else              return Mp[r * ldv];
+    };
+    auto st2 = [&](int64_t r, vec2d v) {
+        if constexpr (NT) __builtin_nontemporal_store(v, Mp + r * ldv);
+        else              Mp[r * ldv] = v;
+    };
+    vec2d last; last.x = 0.0; last.y = 0.0;
+    if (active) {
+        vec2d x[U], nx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                          // first step's rows, requested first
+            nx[u].x = 0.0; nx[u].y = 0.0;
+            if (r0 + u < r1) nx[u] = ld2(r0 + u);
+        }
+        vec2d p[KMAX];
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i)
+            p[i] = reinterpret_cast<const vec2d *>(t.bk_prow)[(int64_t)i * ldv + pair];
+        const unsigned sm = t.bk_smask[pair];
+        const unsigned sx = sm & 0xffffu, sy = sm >> 16;
+        const bool slot_wave = __any((int)sm) != 0;
+        for (int64_t r = r0; r < r1; r += U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) x[u] = nx[u];
+            if (r + U < r1) {                                  // next step's rows: in flight during the chain
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (r + U + u < r1) nx[u] = ld2(r + U + u);
+            }
+            const uint4 rm = *reinterpret_cast<const uint4 *>(t.bk_rmask + r);   // uniform
+            const unsigned rmu[U] = { rm.x, rm.y, rm.z, rm.w };
+            const bool special = slot_wave || ((rm.x | rm.y | rm.z | rm.w) != 0u);
+            // two copies of the chunk loop, so that the common one is straight-line code
+            auto chain = [&](auto special_tag) {
+                constexpr bool SPECIAL = decltype(special_tag)::value;
+#pragma unroll
+                for (int c0 = 0; c0 < KMAX; c0 += CH) {
+                    if (c0 < k) {
+                        v8i cq[CH];
+                        sload_chunk<CH>(cq, t.bk_col + (int64_t)c0 * t.bk_stride + r, t.bk_stride);
+#pragma unroll
+                        for (int i = 0; i < CH; ++i) {
+                            if (c0 + i < k) {
+                                const v4d cv = __builtin_bit_cast(v4d, cq[i]);
+                                const vec2d pi = p[c0 + i];
+#pragma unroll
+                                for (int u = 0; u < U; ++u) {
+                                    if constexpr (SPECIAL) {
+                                        const bool is_cr = (rmu[u] >> (c0 + i)) & 1u;
+                                        x[u].x = pend(x[u].x, (sx >> (c0 + i)) & 1u, is_cr, cv[u], pi.x);
+                                        x[u].y = pend(x[u].y, (sy >> (c0 + i)) & 1u, is_cr, cv[u], pi.y);
+                                    } else {
+                                        const double m0 = cv[u] * pi.x;
+                                        const double m1 = cv[u] * pi.y;
+                                        x[u].x = x[u].x - m0;
+                                        x[u].y = x[u].y - m1;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            };
+            if (special) chain(std::true_type{});
+            else         chain(std::false_type{});
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (r + u < r1) {
+                    st2(r + u, x[u]);
+                    last = x[u];
+                }
+            }
+        }
+    }
+    if (prices) {                                              // `last` = new objective-row entries
+        ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
+        const int64_t c0 = 2 * pair;
+        if (active && c0 < vc) {
+            ValIdx c; c.v = last.x * sgn; c.i = t.p2l ? t.p2l[c0] : c0; c.s = c0;
+            best = vi_min(best, c);
+        }
+        if (active && c0 + 1 < vc) {
+            ValIdx c; c.v = last.y * sgn; c.i = t.p2l ? t.p2l[c0 + 1] : c0 + 1; c.s = c0 + 1;
+            best = vi_min(best, c);
+        }
+        best = wave_reduce_min(best);
+        if ((threadIdx.x & 63) == 0) {
+            const int w = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+            part_v[w]   = best.v;
+            t.part_i[w] = best.i;
+            t.part_s[w] = best.s;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ batch: one workgroup per LP
 // BASELINE config 4 is many SMALL independent LPs (257 x 769 doubles = 1.6 MB each).  Advancing
 // them in lockstep with the launch pairs above makes every LP wait for the slowest one (78..199
@@ -1230,6 +1581,67 @@ int launch_update(const TabView &t, double sgn, int price, hipStream_t s, int64_
     v.launch(t, dim3((unsigned)g.strips, (unsigned)g.row_chunks, (unsigned)t.n_lps), g.tr,
              g.strip_pairs, sgn, price, (g_alternate_sweep && (launch_index & 1)) ? 1 : 0, s);
     return price ? g.n_partials : 0;
+}
+
+// ---- blocked pivoting launchers
+bool block_supported(const TabView &t)
+{
+    return t.blk && t.bk_col && t.bk_prow && t.p2l && t.n_lps == 1 && select_split_supported(t) &&
+           (int64_t)(((t.ld >> 1) + kScaleThreads - 1) / kScaleThreads) * (kScaleThreads / 64) <= t.part_cap / 2;
+}
+
+template <int J>
+static int launch_lookahead_t(const TabView &t, int is_max, double f, int n_part, hipStream_t s)
+{
+    const int g1 = (int)((t.rows + kGatherThreads - 1) / kGatherThreads);
+    const int g2 = (int)(((t.ld >> 1) + kScaleThreads - 1) / kScaleThreads);
+    hipLaunchKernelGGL(k_la_gather<J>, dim3(g1), dim3(kGatherThreads), 0, s, t, sgn_of(is_max),
+                       (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon, n_part);
+    hipLaunchKernelGGL(k_la_scale<J>, dim3(g2), dim3(kScaleThreads), 0, s, t, g1, sgn_of(is_max));
+    return g2 * (kScaleThreads / 64);
+}
+
+int launch_lookahead(const TabView &t, int j, int is_max, double f, int n_part, hipStream_t s)
+{
+    switch (j) {
+#define MI_LA(J) case J: return launch_lookahead_t<J>(t, is_max, f, n_part, s);
+        MI_LA(0) MI_LA(1) MI_LA(2) MI_LA(3) MI_LA(4) MI_LA(5) MI_LA(6) MI_LA(7)
+        MI_LA(8) MI_LA(9) MI_LA(10) MI_LA(11) MI_LA(12) MI_LA(13) MI_LA(14) MI_LA(15)
+#undef MI_LA
+    }
+    return 0;
+}
+
+static int g_sweep_tr = 16, g_sweep_nt = -1;                    // -1: by size, as for k_update
+void set_sweep_shape(int tr, int nt) { if (tr >= 4) g_sweep_tr = tr / 4 * 4; g_sweep_nt = nt; }
+
+template <int KMAX>
+static void launch_sweep_t(const TabView &t, dim3 grid, int tr, int sp, double sgn, bool nt, hipStream_t s)
+{
+    if (nt) hipLaunchKernelGGL((k_sweep<256, KMAX, true>),  grid, dim3(256), 0, s, t, tr, sp, sgn, 1);
+    else    hipLaunchKernelGGL((k_sweep<256, KMAX, false>), grid, dim3(256), 0, s, t, tr, sp, sgn, 1);
+}
+
+// applies up to kmax pending pivots; returns the number of pricing partials it leaves
+int launch_sweep(const TabView &t, int kmax, double sgn, hipStream_t s)
+{
+    constexpr int block = 256;
+    const int64_t ldv = t.ld >> 1;
+    int strips = (int)((ldv + block - 1) / block);
+    int64_t sp = (ldv + strips - 1) / strips;
+    sp = (sp + 7) / 8 * 8;
+    if (sp > block) sp = block;
+    strips = (int)((ldv + sp - 1) / sp);
+    int64_t tr = g_sweep_tr;
+    while ((t.rows + tr - 1) / tr > 65535) tr *= 2;            // grid.y limit
+    const dim3 grid((unsigned)strips, (unsigned)((t.rows + tr - 1) / tr));
+    const double bytes = (double)t.rows * (double)t.ld * 8.0;
+    const bool nt = g_sweep_nt < 0 ? bytes > kNtThresholdBytes : g_sweep_nt != 0;
+    if (kmax <= 2)      launch_sweep_t<2>(t, grid, (int)tr, (int)sp, sgn, nt, s);
+    else if (kmax <= 4) launch_sweep_t<4>(t, grid, (int)tr, (int)sp, sgn, nt, s);
+    else if (kmax <= 8) launch_sweep_t<8>(t, grid, (int)tr, (int)sp, sgn, nt, s);
+    else                launch_sweep_t<16>(t, grid, (int)tr, (int)sp, sgn, nt, s);
+    return strips * (block / 64);
 }
 
 }  // namespace mi355x

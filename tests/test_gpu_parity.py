@@ -273,6 +273,49 @@ def test_both_select_paths_bitwise_vs_oracle(n, m, seed, mode):
     assert np.array_equal(t.matrix, M) and np.array_equal(t.basis_columns, b)
 
 
+@pytest.fixture
+def block_size(request):
+    L = lp.capi.lib()
+    default = L.mi355x_tune_set_block(8)
+    L.mi355x_tune_set_block(request.param)
+    yield request.param
+    L.mi355x_tune_set_block(default)
+
+
+@pytest.mark.parametrize("block_size", [1, 2, 3, 5, 8, 13, 16], indirect=True)
+@pytest.mark.parametrize("n,m,seed", [(5, 3, 1), (33, 17, 2), (257, 511, 5), (700, 333, 6),
+                                      (2000, 1100, 9)])
+def test_blocked_pivoting_bitwise_vs_oracle(n, m, seed, block_size):
+    """Blocked pivoting (k pivots selected ahead on the objective row / one column / the RHS /
+    one row as they WOULD be, then applied in one sweep) for every block size, including sizes
+    that do not divide the pivot count (the terminating step sits in the middle of a block): same
+    pivot sequence, bit-identical tableau, and a capped solve stops on exactly the same pivot."""
+    L = lp.capi.lib()
+    L.mi355x_tune_set_select_mode(2)                    # small shapes too: the blocked path
+    try:
+        M0, b0 = lp.synth.tableau(n, m, lp.synth.seed_for(9, seed))
+        M, b = M0.copy(), b0.copy()
+        st, npiv, trace = oracle.solve(M, b, trace_cap=1 << 16)
+        t = lp.Tableau(None, lp.Problem(type="max"), M0, b0, n + m, m, {})
+        lp.n_solve_tableau(t)
+        assert st == oracle.OPTIMAL and t.n_pivots == npiv
+        assert np.array_equal(t.pivot_trace(), trace)
+        assert np.array_equal(t.matrix, M) and np.array_equal(t.basis_columns, b)
+        cap = max(1, npiv // 2 + 1)                     # a cap in the middle of a block
+        M, b = M0.copy(), b0.copy()
+        st, _, _ = oracle.solve(M, b, max_pivots=cap)
+        t = lp.Tableau(None, lp.Problem(type="max"), M0, b0, n + m, m, {})
+        rc = L.mi355x_tab_solve(t._h, 1, 1024.0, cap, None)
+        t._touch()
+        assert rc == st == oracle.MAX_PIVOTS
+        assert np.array_equal(t.matrix, M) and np.array_equal(t.basis_columns, b)
+        lp.n_solve_tableau(t)                           # and on to optimality from there
+        st, _, _ = oracle.solve(M, b)
+        assert np.array_equal(t.matrix, M) and np.array_equal(t.basis_columns, b)
+    finally:
+        L.mi355x_tune_set_select_mode(0)
+
+
 def _layout(t):
     c, cols, ld = ctypes.c_int(0), ctypes.c_int64(0), ctypes.c_int64(0)
     lp.capi.check(lp.capi.lib().mi355x_tab_layout(t._h, ctypes.byref(c), ctypes.byref(cols),
