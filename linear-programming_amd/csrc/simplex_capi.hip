@@ -26,7 +26,7 @@ int g_select_mode = 0;                    // 0 auto, 1 single workgroup, 2 split
 int g_compact_enabled = 1;                // solve loops run on the compact representation
 int g_handover_mode = 0;                  // 0 auto, 1 always the sequential re-elimination
 int g_batch_mode = 0;                     // 0 auto, 1 lockstep launch pairs, 2 one workgroup per LP
-int g_block_k = 8;                        // pivots selected ahead and applied per sweep (1 = off)
+int g_block_k = 16;                       // pivots selected ahead and applied per sweep (1 = off)
 
 int fail(int code, const char *fmt, ...)
 {

@@ -682,6 +682,36 @@ __device__ __forceinline__ double pend(double x, bool is_slot, bool is_cr, doubl
     return is_cr ? prowv : d;
 }
 
+// wave-uniform 64-bit value held in VGPRs -> SGPRs (so that addresses built from it are scalar)
+__device__ __forceinline__ int64_t uniform64(int64_t v)
+{
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(v & 0xffffffffll));
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// The wave-uniform operands of the pending chain (one value per pending pivot) are fetched by
+// ONE vector load -- lane i fetches the value of pivot i -- and handed out with v_readlane: a
+// single round trip whatever the number of pending pivots (as scalar loads the compiler issued
+// them one after the other, each waiting for the previous one).
+__device__ __forceinline__ double lane_value(double v, int lane)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)(b & 0xffffffffll), lane);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)((unsigned long long)b >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ int64_t lane_value(int64_t v, int lane)
+{
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)(v & 0xffffffffll), lane);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)((uint64_t)v >> 32), lane);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// Each of the two kernels is: final reduction of the partials the previous launch left ->
+// operands that depend on its result -> chain -> partials for the next launch.  Everything that
+// does NOT depend on the reduction result is requested before it, so that it travels together
+// with the partials (one memory round trip) and only the few dependent operands form the second.
 template <int J>
 __global__ __launch_bounds__(kGatherThreads) void k_la_gather(TabView t, double sgn, double price_tol,
                                                               double ratio_thr, int n_part)
@@ -697,19 +727,31 @@ __global__ __launch_bounds__(kGatherThreads) void k_la_gather(TabView t, double 
     BlockCtl *blk = t.blk;
     const int64_t m = t.rows - 1, vc = t.cols - 1, ld = t.ld;
     const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+    const int64_t r = (int64_t)blockIdx.x * kGatherThreads + threadIdx.x;
+    // independent of the entering column: RHS entry, col snapshots and pivot rows of the pending
+    // pivots, their RHS entries
+    double  b = (r < m) ? t.M[r * ld + vc] : 0.0;
+    double  ci[JJ];
+    const int lane = threadIdx.x & 63;
+    const bool  lj = lane < J;
+    const double  v_pb = lj ? t.bk_prow[(int64_t)lane * ld + vc] : 0.0;
+    const int64_t v_cr = lj ? blk->cr[lane] : -1;
+    const int64_t v_sl = lj ? blk->slot[lane] : -1;
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+        ci[i] = (r < t.rows) ? t.bk_col[(int64_t)i * t.bk_stride + r] : 0.0;
     if (J == 0) {                                   // a new block starts (whatever the status)
         if (leader) blk->n_pending = 0;
         const int64_t n = t.bk_stride > (ld >> 1) ? t.bk_stride : (ld >> 1);
-        for (int64_t idx = (int64_t)blockIdx.x * kGatherThreads + threadIdx.x; idx < n;
-             idx += (int64_t)gridDim.x * kGatherThreads) {
+        for (int64_t idx = r; idx < n; idx += (int64_t)gridDim.x * kGatherThreads) {
             if (idx < t.bk_stride) t.bk_rmask[idx] = 0u;
             if (idx < (ld >> 1))   t.bk_smask[idx] = 0u;
         }
     }
     // J > 0: the partials were left by k_la_scale<J-1> (objective row after pivot J-1)
-    const ValIdx e = n_part > 0
-        ? block_price_partials<kGatherThreads>(t.part_v, t.part_i, t.part_s, n_part, s_v, s_i)
-        : block_price<kGatherThreads>(t.M + m * ld, vc, sgn, s_v, s_i, t.p2l);
+    ValIdx e;
+    if (J == 0 && n_part <= 0) e = block_price<kGatherThreads>(t.M + m * ld, vc, sgn, s_v, s_i, t.p2l);
+    else e = block_price_partials<kGatherThreads>(t.part_v, t.part_i, t.part_s, n_part, s_v, s_i);
     if (c0.status != kRunning) return;
     if (e.i < 0 || !(e.v < 0.0 - price_tol)) {
         if (leader) ctl->status = 0;                // MI_OPTIMAL
@@ -719,30 +761,17 @@ __global__ __launch_bounds__(kGatherThreads) void k_la_gather(TabView t, double 
         if (leader) ctl->status = 3;                // MI_MAX_PIVOTS
         return;
     }
-    const int64_t ec = e.i, slot = e.s;
-    int64_t cri[JJ], sli[JJ];
-    double  pa[JJ], pb[JJ];
+    const int64_t ec = e.i, slot = uniform64(e.s);
+    const double v_pa = lj ? t.bk_prow[(int64_t)lane * ld + slot] : 0.0;
+    double a = (r < t.rows) ? t.M[r * ld + slot] : 0.0;
 #pragma unroll
-    for (int i = 0; i < J; ++i) {                   // wave-uniform operands of the pending chain
-        cri[i] = blk->cr[i];
-        sli[i] = blk->slot[i];
-        pa[i]  = t.bk_prow[(int64_t)i * ld + slot];
-        pb[i]  = t.bk_prow[(int64_t)i * ld + vc];
+    for (int i = 0; i < J; ++i) {                   // (all lanes: v_readlane ignores exec)
+        const bool is_cr = r == lane_value(v_cr, i);
+        a = pend(a, slot == lane_value(v_sl, i), is_cr, ci[i], lane_value(v_pa, i));
+        b = pend(b, false, is_cr, ci[i], lane_value(v_pb, i));
     }
-    const int64_t r = (int64_t)blockIdx.x * kGatherThreads + threadIdx.x;
     ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
     if (r < t.rows) {
-        double a = t.M[r * ld + slot];
-        double b = r < m ? t.M[r * ld + vc] : 0.0;
-        double ci[JJ];
-#pragma unroll
-        for (int i = 0; i < J; ++i) ci[i] = t.bk_col[(int64_t)i * t.bk_stride + r];
-#pragma unroll
-        for (int i = 0; i < J; ++i) {
-            const bool is_cr = r == cri[i];
-            a = pend(a, slot == sli[i], is_cr, ci[i], pa[i]);
-            b = pend(b, false, is_cr, ci[i], pb[i]);
-        }
         t.bk_col[(int64_t)J * t.bk_stride + r] = a;
         if (!(fabs(a) <= 1.7976931348623157e308)) atomicOr(&ctl->poison, 1);   // see kNeedDense
         if (r < m && ratio_thr < a) { best.v = b / a; best.i = r; best.s = __double_as_longlong(a); }
@@ -770,6 +799,27 @@ __global__ __launch_bounds__(kScaleThreads) void k_la_scale(TabView t, int n_rp,
     const Ctl c0 = *ctl;
     BlockCtl *blk = t.blk;
     const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+    const int64_t m = t.rows - 1, vc = t.cols - 1, ldv = t.ld >> 1;
+    const int64_t p = (int64_t)blockIdx.x * kScaleThreads + threadIdx.x;
+    const bool in = p < ldv;
+    const double2 *M2 = reinterpret_cast<const double2 *>(t.M);
+    double2 *P2 = reinterpret_cast<double2 *>(t.bk_prow);
+    // independent of the pivot row: the objective row, the pending pivots' rows / slots / prow
+    // entries / objective-row col entries, this step's objective-row col entry, the column maps
+    double2 z = in ? M2[m * ldv + p] : make_double2(0.0, 0.0);
+    double2 pi[JJ];
+    const int lane = threadIdx.x & 63;
+    const bool  lj = lane < J;
+    const double  v_cm = lj ? t.bk_col[(int64_t)lane * t.bk_stride + m] : 0.0;
+    const int64_t v_cr = lj ? blk->cr[lane] : -1;
+    const int64_t v_sl = lj ? blk->slot[lane] : -1;
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+        pi[i] = in ? P2[(int64_t)i * ldv + p] : make_double2(0.0, 0.0);
+    const double cmj = t.bk_col[(int64_t)J * t.bk_stride + m];
+    const int64_t c0i = 2 * p;
+    const int64_t l0 = (in && c0i < vc) ? t.p2l[c0i] : -1;
+    const int64_t l1 = (in && c0i + 1 < vc) ? t.p2l[c0i + 1] : -1;
     const ValIdx q = block_price_partials<kScaleThreads>(rp_v, rp_i, rp_s, n_rp, s_v, s_i);
     if (c0.status != kRunning) return;
     if (c0.poison) {
@@ -780,50 +830,35 @@ __global__ __launch_bounds__(kScaleThreads) void k_la_scale(TabView t, int n_rp,
         if (leader) ctl->status = 1;                // MI_UNBOUNDED
         return;
     }
-    const int64_t cr = q.i;
+    const int64_t cr = uniform64(q.i);
     const double piv = __longlong_as_double(q.s);
     const int64_t ec = c0.ec, slot = c0.slot;
-    const int64_t m = t.rows - 1, vc = t.cols - 1, ldv = t.ld >> 1;
-    const int64_t p = (int64_t)blockIdx.x * kScaleThreads + threadIdx.x;
     ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
-    if (p < ldv) {
-        const double2 *M2 = reinterpret_cast<const double2 *>(t.M);
-        double2 *P2 = reinterpret_cast<double2 *>(t.bk_prow);
-        double2 y = M2[cr * ldv + p];               // row cr
-        double2 z = M2[m * ldv + p];                // objective row (never a pivot row)
+    const double v_ccr = lj ? t.bk_col[(int64_t)lane * t.bk_stride + cr] : 0.0;
+    double2 y = in ? M2[cr * ldv + p] : make_double2(0.0, 0.0);   // row cr
+#pragma unroll
+    for (int i = 0; i < J; ++i) {                   // (all lanes: v_readlane ignores exec)
+        const bool    is_cr = cr == lane_value(v_cr, i);
+        const int64_t sl = lane_value(v_sl, i);
+        const double  ccr = lane_value(v_ccr, i), cm = lane_value(v_cm, i);
+        y.x = pend(y.x, 2 * p     == sl, is_cr, ccr, pi[i].x);
+        y.y = pend(y.y, 2 * p + 1 == sl, is_cr, ccr, pi[i].y);
+        z.x = pend(z.x, 2 * p     == sl, false, cm, pi[i].x);
+        z.y = pend(z.y, 2 * p + 1 == sl, false, cm, pi[i].y);
+    }
+    if (in) {
         const bool own = (p == (slot >> 1));
         const int64_t leaving = own ? t.basis[cr] : -1;
-        int64_t cri[JJ], sli[JJ];
-        double  ccr[JJ], cm[JJ];
-        double2 pi[JJ];
-#pragma unroll
-        for (int i = 0; i < J; ++i) {
-            cri[i] = blk->cr[i];
-            sli[i] = blk->slot[i];
-            ccr[i] = t.bk_col[(int64_t)i * t.bk_stride + cr];
-            cm[i]  = t.bk_col[(int64_t)i * t.bk_stride + m];
-            pi[i]  = P2[(int64_t)i * ldv + p];
-        }
-        const double cmj = t.bk_col[(int64_t)J * t.bk_stride + m];
-#pragma unroll
-        for (int i = 0; i < J; ++i) {
-            const bool is_cr = cr == cri[i];
-            y.x = pend(y.x, 2 * p     == sli[i], is_cr, ccr[i], pi[i].x);
-            y.y = pend(y.y, 2 * p + 1 == sli[i], is_cr, ccr[i], pi[i].y);
-            z.x = pend(z.x, 2 * p     == sli[i], false, cm[i], pi[i].x);
-            z.y = pend(z.y, 2 * p + 1 == sli[i], false, cm[i], pi[i].y);
-        }
         const double2 pr = scale_pair(t, p, y, piv, slot);
         P2[(int64_t)J * ldv + p] = pr;
         z.x = pend(z.x, 2 * p     == slot, false, cmj, pr.x);
         z.y = pend(z.y, 2 * p + 1 == slot, false, cmj, pr.y);
-        const int64_t c0i = 2 * p;
         if (c0i < vc) {
-            ValIdx c; c.v = z.x * sgn; c.i = (c0i == slot) ? leaving : t.p2l[c0i]; c.s = c0i;
+            ValIdx c; c.v = z.x * sgn; c.i = (c0i == slot) ? leaving : l0; c.s = c0i;
             best = vi_min(best, c);
         }
         if (c0i + 1 < vc) {
-            ValIdx c; c.v = z.y * sgn; c.i = (c0i + 1 == slot) ? leaving : t.p2l[c0i + 1]; c.s = c0i + 1;
+            ValIdx c; c.v = z.y * sgn; c.i = (c0i + 1 == slot) ? leaving : l1; c.s = c0i + 1;
             best = vi_min(best, c);
         }
         if (own) {
@@ -847,36 +882,36 @@ __global__ __launch_bounds__(kScaleThreads) void k_la_scale(TabView t, int n_rp,
 
 // The sweep.  A workgroup owns a strip of <= 256 column pairs x tr rows and walks it four rows
 // at a time; a thread keeps its prow pairs of all pending pivots in registers (loaded once per
-// tile: tall tiles keep that L2 traffic below the tableau's own), the col values of the four
-// rows are wave-uniform and sit in SGPRs (s_load_dwordx8 per pivot, issued by hand so that all
-// of a chunk's loads are in flight together), and v_mul_f64 takes them straight from there.
-// Tiles that hold no pivot row and waves that hold no slot column (nearly all of them) run the
-// bare chain: 2 v_mul_f64 + 2 v_add_f64 per element pair and pivot.
+// tile), the col values of the four rows are wave-uniform and sit in SGPRs (s_load_dwordx8 per
+// pivot, issued by hand so that all of a chunk's loads are in flight together), and v_mul_f64
+// takes them straight from there: per element pair and pivot 2 v_mul_f64 + 2 v_add_f64 and
+// nothing else.  The two exceptions -- the step holds the pivot row of pending pivot i, or the
+// wave holds the slot column pivot i gave up -- are decided per (step, pivot) by a scalar bit
+// test, so only that one link of the chain takes the general form (pend()).
 typedef int    v8i __attribute__((ext_vector_type(8)));
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-// CH scalar loads of 4 doubles each (row r.. r+3 of CH consecutive pivots) and the wait for them,
-// as ONE asm statement: the outputs must not be touched (or spilled) before the data has landed,
-// and the compiler cannot know that about a bare s_load.
+// CH scalar loads of 4 doubles each (rows r .. r+3 of CH consecutive pivots: base + i*off bytes)
+// and the wait for them, as ONE asm statement: the outputs must not be touched (or spilled)
+// before the data has landed, and the compiler cannot know that about a bare s_load.
 template <int CH>
-__device__ __forceinline__ void sload_chunk(v8i (&c)[CH], const double *base, int64_t stride)
+__device__ __forceinline__ void sload_chunk(v8i (&c)[CH], const double *base, const unsigned (&off)[8])
 {
-    const double *p0 = base, *p1 = base + stride, *p2 = base + 2 * stride, *p3 = base + 3 * stride;
-    const double *p4 = base + 4 * stride, *p5 = base + 5 * stride, *p6 = base + 6 * stride, *p7 = base + 7 * stride;
     if constexpr (CH == 2)
-        asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx8 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(c[0]), "=&s"(c[1]) : "s"(p0), "s"(p1));
+        asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, %3\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(c[0]), "=&s"(c[1]) : "s"(base), "s"(off[1]));
     if constexpr (CH == 4)
-        asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %5, 0x0\n\t"
-                     "s_load_dwordx8 %2, %6, 0x0\n\ts_load_dwordx8 %3, %7, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(c[0]), "=&s"(c[1]), "=&s"(c[2]), "=&s"(c[3]) : "s"(p0), "s"(p1), "s"(p2), "s"(p3));
+        asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %4, %5\n\t"
+                     "s_load_dwordx8 %2, %4, %6\n\ts_load_dwordx8 %3, %4, %7\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(c[0]), "=&s"(c[1]), "=&s"(c[2]), "=&s"(c[3])
+                     : "s"(base), "s"(off[1]), "s"(off[2]), "s"(off[3]));
     if constexpr (CH == 8)
-        asm volatile("s_load_dwordx8 %0, %8, 0x0\n\ts_load_dwordx8 %1, %9, 0x0\n\t"
-                     "s_load_dwordx8 %2, %10, 0x0\n\ts_load_dwordx8 %3, %11, 0x0\n\t"
-                     "s_load_dwordx8 %4, %12, 0x0\n\ts_load_dwordx8 %5, %13, 0x0\n\t"
-                     "s_load_dwordx8 %6, %14, 0x0\n\ts_load_dwordx8 %7, %15, 0x0\n\ts_waitcnt lgkmcnt(0)"
+        asm volatile("s_load_dwordx8 %0, %8, 0x0\n\ts_load_dwordx8 %1, %8, %9\n\t"
+                     "s_load_dwordx8 %2, %8, %10\n\ts_load_dwordx8 %3, %8, %11\n\t"
+                     "s_load_dwordx8 %4, %8, %12\n\ts_load_dwordx8 %5, %8, %13\n\t"
+                     "s_load_dwordx8 %6, %8, %14\n\ts_load_dwordx8 %7, %8, %15\n\ts_waitcnt lgkmcnt(0)"
                      : "=&s"(c[0]), "=&s"(c[1]), "=&s"(c[2]), "=&s"(c[3]), "=&s"(c[4]), "=&s"(c[5]), "=&s"(c[6]), "=&s"(c[7])
-                     : "s"(p0), "s"(p1), "s"(p2), "s"(p3), "s"(p4), "s"(p5), "s"(p6), "s"(p7));
+                     : "s"(base), "s"(off[1]), "s"(off[2]), "s"(off[3]), "s"(off[4]), "s"(off[5]), "s"(off[6]), "s"(off[7]));
 }
 
 template <int BLOCK, int KMAX, bool NT>
@@ -884,7 +919,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(TabView t, const int tr, const 
                                                  const double sgn, const int price)
 {
     constexpr int U = 4;                                       // rows per step
-    constexpr int CH = KMAX < 8 ? KMAX : 8;                    // pivots per SGPR chunk
+    constexpr int CH = KMAX < 4 ? KMAX : 4;                    // pivots per SGPR chunk (32 SGPRs: more would spill)
     const BlockCtl *__restrict__ blk = t.blk;
     const int k = (int)blk->n_pending;
     if (k == 0) return;
@@ -910,11 +945,11 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(TabView t, const int tr, const 
     };
     vec2d last; last.x = 0.0; last.y = 0.0;
     if (active) {
-        vec2d x[U], nx[U];
+        vec2d x[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {                          // first step's rows, requested first
-            nx[u].x = 0.0; nx[u].y = 0.0;
-            if (r0 + u < r1) nx[u] = ld2(r0 + u);
+        for (int u = 0; u < U; ++u) {                          // the first step's rows, requested first
+            x[u].x = 0.0; x[u].y = 0.0;
+            if (r0 + u < r1) x[u] = ld2(r0 + u);
         }
         vec2d p[KMAX];
 #pragma unroll
@@ -922,51 +957,72 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(TabView t, const int tr, const 
             p[i] = reinterpret_cast<const vec2d *>(t.bk_prow)[(int64_t)i * ldv + pair];
         const unsigned sm = t.bk_smask[pair];
         const unsigned sx = sm & 0xffffu, sy = sm >> 16;
-        const bool slot_wave = __any((int)sm) != 0;
-        for (int64_t r = r0; r < r1; r += U) {
+        unsigned wm = sx | sy;                                 // pivots whose slot this wave holds
 #pragma unroll
-            for (int u = 0; u < U; ++u) x[u] = nx[u];
-            if (r + U < r1) {                                  // next step's rows: in flight during the chain
+        for (int off = 32; off > 0; off >>= 1) wm |= __shfl_xor(wm, off, 64);
+        wm = __builtin_amdgcn_readfirstlane(wm);
+        const unsigned pending = (k >= 32) ? 0xffffffffu : ((1u << k) - 1u);
+        unsigned off[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) off[i] = (unsigned)(i * t.bk_stride * 8);
+        for (int64_t r = r0; r < r1; r += U) {
+            if (r != r0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
-                    if (r + U + u < r1) nx[u] = ld2(r + U + u);
+                    if (r + u < r1) x[u] = ld2(r + u);
             }
             const uint4 rm = *reinterpret_cast<const uint4 *>(t.bk_rmask + r);   // uniform
             const unsigned rmu[U] = { rm.x, rm.y, rm.z, rm.w };
-            const bool special = slot_wave || ((rm.x | rm.y | rm.z | rm.w) != 0u);
-            // two copies of the chunk loop, so that the common one is straight-line code
-            auto chain = [&](auto special_tag) {
-                constexpr bool SPECIAL = decltype(special_tag)::value;
+            const unsigned general = wm | rm.x | rm.y | rm.z | rm.w;   // bit i: pivot i needs pend()
 #pragma unroll
-                for (int c0 = 0; c0 < KMAX; c0 += CH) {
-                    if (c0 < k) {
-                        v8i cq[CH];
-                        sload_chunk<CH>(cq, t.bk_col + (int64_t)c0 * t.bk_stride + r, t.bk_stride);
+            for (int c0 = 0; c0 < KMAX; c0 += CH) {
+                constexpr unsigned cmask = (1u << CH) - 1u;
+                const unsigned pend_c = (pending >> c0) & cmask;       // pending pivots of this chunk
+                if (pend_c == 0u) continue;
+                v8i cq[CH];
+                sload_chunk<CH>(cq, t.bk_col + (int64_t)c0 * t.bk_stride + r, off);
+                if (pend_c == cmask && ((general >> c0) & cmask) == 0u) {
+                    // the common case: CH links of the bare chain
 #pragma unroll
-                        for (int i = 0; i < CH; ++i) {
-                            if (c0 + i < k) {
-                                const v4d cv = __builtin_bit_cast(v4d, cq[i]);
-                                const vec2d pi = p[c0 + i];
+                    for (int i = 0; i < CH; ++i) {
+                        const v4d cv = __builtin_bit_cast(v4d, cq[i]);
+                        const vec2d pi = p[c0 + i];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const double m0 = cv[u] * pi.x;
+                            const double m1 = cv[u] * pi.y;
+                            x[u].x = x[u].x - m0;
+                            x[u].y = x[u].y - m1;
+                        }
+                    }
+                } else {
+                    // a partial chunk (last block of a solve), a pivot row in this step, or a
+                    // slot column in this wave: the general form of every link
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) {
+                        if ((pend_c >> i) & 1u) {
+                            const v4d cv = __builtin_bit_cast(v4d, cq[i]);
+                            const vec2d pi = p[c0 + i];
+                            if ((general >> (c0 + i)) & 1u) {
 #pragma unroll
                                 for (int u = 0; u < U; ++u) {
-                                    if constexpr (SPECIAL) {
-                                        const bool is_cr = (rmu[u] >> (c0 + i)) & 1u;
-                                        x[u].x = pend(x[u].x, (sx >> (c0 + i)) & 1u, is_cr, cv[u], pi.x);
-                                        x[u].y = pend(x[u].y, (sy >> (c0 + i)) & 1u, is_cr, cv[u], pi.y);
-                                    } else {
-                                        const double m0 = cv[u] * pi.x;
-                                        const double m1 = cv[u] * pi.y;
-                                        x[u].x = x[u].x - m0;
-                                        x[u].y = x[u].y - m1;
-                                    }
+                                    const bool is_cr = (rmu[u] >> (c0 + i)) & 1u;
+                                    x[u].x = pend(x[u].x, (sx >> (c0 + i)) & 1u, is_cr, cv[u], pi.x);
+                                    x[u].y = pend(x[u].y, (sy >> (c0 + i)) & 1u, is_cr, cv[u], pi.y);
+                                }
+                            } else {
+#pragma unroll
+                                for (int u = 0; u < U; ++u) {
+                                    const double m0 = cv[u] * pi.x;
+                                    const double m1 = cv[u] * pi.y;
+                                    x[u].x = x[u].x - m0;
+                                    x[u].y = x[u].y - m1;
                                 }
                             }
                         }
                     }
                 }
-            };
-            if (special) chain(std::true_type{});
-            else         chain(std::false_type{});
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (r + u < r1) {
