@@ -44,8 +44,8 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=3200)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS) + ["cfg4", "colpart"])
     ap.add_argument("--batch-lps", type=int, default=128,
                     help="cfg4: LPs per GPU (BASELINE config 4 = 1024 LPs over 8 GPUs)")
@@ -316,15 +316,28 @@ def main():
         value = N * args.steps / elapsed
         roofline = None
         if upd_avg_ms:
+            # One launch of the dominant kernel moves every STORED element once each way and
+            # applies `block` pivots to it (blocked pivoting; block == 1 is the
+            # plain k_update).  `achieved` is the PHYSICAL rate of that launch -- bytes it has
+            # to move / its duration, directly comparable with the PMC `traffic` and bounded by
+            # the HBM peak.  The contract's literal formula (per-pivot algorithmic bytes x
+            # pivots per launch / duration) is given next to it as `algorithmic_equivalent`: it
+            # exceeds the HBM peak by construction, because the blocked sweep does NOT re-stream
+            # the tableau for every pivot -- that is its point.
             ach = kernel_bytes / (upd_avg_ms * 1e-3) / 1e9
             traffic, traffic_src = pmc_traffic(args.workload)
+            alg = block * kernel_bytes / (upd_avg_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
                         "traffic_source": traffic_src,
                         "kernel": "k_sweep" if block > 1 else L.mi355x_update_kernel_name().decode(),
-                        "pivots_per_launch": block,
                         "kernel_avg_us": upd_avg_ms * 1e3,
-                        "algorithmic_bytes_per_launch": kernel_bytes,
+                        "pivots_per_launch": block,
+                        "bytes_moved_per_launch": kernel_bytes,
+                        "algorithmic_bytes_per_pivot": kernel_bytes,
+                        "algorithmic_equivalent": {
+                            "GBps": alg, "x_peak": alg / HBM_PEAK_GBPS,
+                            "what": "algorithmic bytes per pivot x pivots per launch / launch duration"},
                         "representation": "compact [non-basic columns | RHS], %d of %d columns stored"
                                           % (stored_cols.value, C) if compact.value else "dense",
                         "dense_tableau_bytes_per_pivot": bytes_per_pivot,

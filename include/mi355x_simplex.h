@@ -168,6 +168,11 @@ int  mi355x_tab_timing_enable(mi355x_tab *t, int enable);
 int  mi355x_tab_timing_read(mi355x_tab *t, int64_t *n_launches, double *sum_ms, double *min_ms);
 /* Name of the rank-1 update kernel as it appears in rocprofv3 kernel traces. */
 const char *mi355x_update_kernel_name(void);
+/* Pivots one tableau-update launch of this handle applies in its current representation: > 1
+ * when the solve loops run blocked (up to 16 pivots selected ahead, then applied by one k_sweep
+ * launch; the timing above then brackets the sweeps), 1 for the plain k_update path.
+ * Results do not depend on it. */
+int  mi355x_tab_block_size(mi355x_tab *t);
 
 /* ---- native host side of the hook: problem -> tableau -> solution ------------------- */
 /* The reference's parsed `problem` struct (src/problem.lisp:45-53), variables identified by

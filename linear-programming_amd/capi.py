@@ -43,6 +43,7 @@ SIGNATURES = {
     "mi355x_tab_timing_enable": (_int, [_p, _int]),
     "mi355x_tab_timing_read": (_int, [_p, _p, _p, _p]),
     "mi355x_update_kernel_name": (ctypes.c_char_p, []),
+    "mi355x_tab_block_size": (_int, [_p]),
     "mi355x_problem_create": (_int, [_pp, _int, _i64]),
     "mi355x_problem_set_objective": (_int, [_p, _p, _p, _i64]),
     "mi355x_problem_set_bounds": (_int, [_p, _i64, _int, _dbl, _int, _dbl]),
@@ -87,7 +88,6 @@ _EXTRA = {
     "mi355x_tune_set_handover_mode": (_int, [_int]),
     "mi355x_tune_set_ld_extra": (_int, [_int]),
     "mi355x_tune_set_block": (_int, [_int]),
-    "mi355x_tab_block_size": (_int, [_p]),
     "mi355x_tune_set_sweep_shape": (_int, [_int, _int]),
 }
 

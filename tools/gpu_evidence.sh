@@ -12,5 +12,5 @@ python bench.py > $O/bench.log 2>&1; echo "bench rc=$?"; tail -1 $O/bench.log | 
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats -- python $R/bench.py --no-cpu-baseline > $O/kernel_stats.log 2>&1; echo "rocprof stats rc=$?"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python $R/tools/pmc_probe.py 30 > $O/pmc_$c.log 2>&1; echo "pmc $c rc=$?"
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python $R/tools/pmc_probe.py 64 > $O/pmc_$c.log 2>&1; echo "pmc $c rc=$?"
 done

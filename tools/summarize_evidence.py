@@ -1,5 +1,5 @@
 """Copy the judged summaries from gpurun_out/evidence/ (scratch) into profiles/ and derive the
-corrected per-launch HBM traffic of k_update from the two PMC passes.
+corrected per-launch HBM traffic of the tableau-update kernel (k_sweep / k_update) from the two PMC passes.
 
     python tools/summarize_evidence.py r01
 
@@ -45,15 +45,17 @@ def main(tag):
         if l.startswith("layout"):
             layout = dict(kv.split("=") for kv in l.split()[1:])
     rows, cols, ld = int(layout["rows"]), int(layout["stored_cols"]), int(layout["stored_ld"])
-    f = counter(fpath, "k_update")
-    w = counter(wpath, "k_update")
+    kernel = json.loads(bench)["roofline"]["kernel"]          # k_sweep (blocked) or k_update
+    f = counter(fpath, kernel)
+    w = counter(wpath, kernel)
     cf, cw = max(counter(fpath, "copyBuffer")), max(counter(wpath, "copyBuffer"))
     dense_ld = (8192 + 4096 + 1 + 15) // 16 * 16
     copy_kib = rows * dense_ld * 8 / 1024.0           # mi355x_tab_copy copies the DENSE padded buffer
     favg, wavg = sum(f) / len(f), sum(w) / len(w)
     traffic = (2 * favg + wavg) * 1024
     alg = 2 * rows * cols * 8
-    d = {"workload": "cfg3", "kernel": "k_update", "launches": len(f),
+    d = {"workload": "cfg3", "kernel": kernel, "launches": len(f),
+         "pivots_per_launch": json.loads(bench)["roofline"].get("pivots_per_launch", 1),
          "representation": "compact" if int(layout["compact"]) else "dense",
          "stored_rows_cols_ld": [rows, cols, ld],
          "FETCH_SIZE_KiB_avg": favg, "WRITE_SIZE_KiB_avg": wavg,
