@@ -240,10 +240,10 @@ def main():
     if args.sweep_tr or args.sweep_nt >= 0:
         L.mi355x_tune_set_sweep_shape(args.sweep_tr or 4, args.sweep_nt)
     # One LP supports only so many pivots before it is optimal (config 3: 5 700-6 100, config 2:
-    # ~290 with these seeds).  If more timed steps are asked for than one LP safely provides,
+    # 189-416 with these seeds).  If more timed steps are asked for than one LP safely provides,
     # further LPs of the same shape are generated in HBM BEFORE the timed region and the timed
     # steps simply continue on the next one.
-    capacity = {"cfg3": 4500, "cfg2": 220, "cfg5": 20000}[args.workload]
+    capacity = {"cfg3": 4500, "cfg2": 150, "cfg5": 20000}[args.workload]
     per_lp = max(capacity - args.warmup, 1)
     n_lps = -(-args.steps // per_lp)
     handles = []

@@ -88,6 +88,7 @@ _EXTRA = {
     "mi355x_tune_set_handover_mode": (_int, [_int]),
     "mi355x_tune_set_ld_extra": (_int, [_int]),
     "mi355x_tune_set_block": (_int, [_int]),
+    "mi355x_tune_set_lookahead_mode": (_int, [_int]),
     "mi355x_tune_set_sweep_shape": (_int, [_int, _int]),
 }
 

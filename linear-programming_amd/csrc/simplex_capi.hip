@@ -26,6 +26,7 @@ int g_select_mode = 0;                    // 0 auto, 1 single workgroup, 2 split
 int g_compact_enabled = 1;                // solve loops run on the compact representation
 int g_handover_mode = 0;                  // 0 auto, 1 always the sequential re-elimination
 int g_batch_mode = 0;                     // 0 auto, 1 lockstep launch pairs, 2 one workgroup per LP
+int g_la_mode = 0;                        // look-ahead: 0 auto, 1 two launches per step, 2 one persistent launch per block
 int g_block_k = 16;                       // pivots selected ahead and applied per sweep (1 = off)
 
 int fail(int code, const char *fmt, ...)
@@ -87,6 +88,7 @@ struct mi355x_tab {
     int         timing_stride = 0;        // 0 = off, k = bracket every k-th update launch
     int64_t     update_launches = 0;
     int64_t     sweeps = 0;               // update launches so far: odd ones sweep bottom-up
+    unsigned long long la_epoch = 1;      // next epoch base of the persistent look-ahead kernel
     int         n_timed = 0;
     std::vector<hipEvent_t> ev0, ev1;
 };
@@ -126,6 +128,8 @@ void free_tab(mi355x_tab *t)
     (void)hipFree(t->v.blk);
     (void)hipFree(t->v.bk_rmask);
     (void)hipFree(t->v.bk_smask);
+    (void)hipFree(t->v.la_px);
+    (void)hipFree(t->v.la_rx);
     (void)hipFree(t->c.M);
     (void)hipFree(t->c.p2l);
     (void)hipFree(t->c.l2p);
@@ -199,6 +203,8 @@ int alloc_tab(mi355x_tab **out, int64_t rows, int64_t cols, int device, int64_t 
         ALLOC(t->v.blk, sizeof(BlockCtl));
         ALLOC(t->v.bk_rmask, (size_t)t->v.bk_stride * sizeof(uint32_t));
         ALLOC(t->v.bk_smask, (size_t)t->v.ld * sizeof(uint32_t));
+        ALLOC(t->v.la_px, kMaxLaWorkgroups * sizeof(ExchRec));
+        ALLOC(t->v.la_rx, kMaxLaWorkgroups * sizeof(ExchRec));
     }
 #undef ALLOC
     if ((e = hipHostMalloc((void **)&t->h_ctl, n_lps * sizeof(Ctl))) != hipSuccess ||
@@ -208,9 +214,18 @@ int alloc_tab(mi355x_tab **out, int64_t rows, int64_t cols, int device, int64_t 
     }
     t->stream = t->own_stream;
     memset(t->h_ctl, 0, n_lps * sizeof(Ctl));
+    // pricing / ratio partials are read by launches that may follow a no-op launch: defined contents
+    if ((e = hipMemsetAsync(t->v.part_v, 0, n_lps * part_cap * sizeof(double), t->stream)) != hipSuccess ||
+        (e = hipMemsetAsync(t->v.part_i, 0xff, n_lps * part_cap * sizeof(int64_t), t->stream)) != hipSuccess ||
+        (e = hipMemsetAsync(t->v.part_s, 0, n_lps * part_cap * sizeof(int64_t), t->stream)) != hipSuccess) {
+        free_tab(t);
+        return fail(MI_HIP_ERROR, "memset failed: %s", hipGetErrorString(e));
+    }
     if ((t->v.blk && ((e = hipMemsetAsync(t->v.blk, 0, sizeof(BlockCtl), t->stream)) != hipSuccess ||
                       (e = hipMemsetAsync(t->v.bk_rmask, 0, t->v.bk_stride * sizeof(uint32_t), t->stream)) != hipSuccess ||
                       (e = hipMemsetAsync(t->v.bk_smask, 0, t->v.ld * sizeof(uint32_t), t->stream)) != hipSuccess ||
+                      (e = hipMemsetAsync(t->v.la_px, 0, kMaxLaWorkgroups * sizeof(ExchRec), t->stream)) != hipSuccess ||
+                      (e = hipMemsetAsync(t->v.la_rx, 0, kMaxLaWorkgroups * sizeof(ExchRec), t->stream)) != hipSuccess ||
                       (e = hipMemsetAsync(t->v.bk_col, 0, (size_t)kMaxBlock * t->v.bk_stride * sizeof(double), t->stream)) != hipSuccess ||
                       (e = hipMemsetAsync(t->v.bk_prow, 0, (size_t)kMaxBlock * t->v.ld * sizeof(double), t->stream)) != hipSuccess)) ||
         (e = hipMemsetAsync(t->v.ctl, 0, n_lps * sizeof(Ctl), t->stream)) != hipSuccess ||
@@ -398,7 +413,13 @@ int enqueue_block(mi355x_tab *t, int is_max, double f, int k)
 {
     const TabView &v = t->c;
     int np = (t->n_part > 0 && t->part_is_max == (is_max ? 1 : 0)) ? t->n_part : 0;
-    for (int j = 0; j < k; ++j) np = launch_lookahead(v, j, is_max, f, np, t->stream);
+    const bool persistent = g_la_mode == 2 || (g_la_mode == 0 && la_block_supported(v));
+    if (persistent && la_block_supported(v)) {
+        launch_la_block(v, k, is_max, f, t->la_epoch, t->stream);
+        t->la_epoch += 2 * kMaxBlock + 2;
+    } else {
+        for (int j = 0; j < k; ++j) np = launch_lookahead(v, j, is_max, f, np, t->stream);
+    }
     const bool timed = t->timing_stride > 0 && t->n_timed < kTimingCap &&
                        (t->update_launches++ % t->timing_stride) == 0;
     if (timed) {
@@ -665,6 +686,8 @@ int mi355x_tab_sync(mi355x_tab *t, int64_t *n_pivots)
     rc = read_ctl(t);
     if (rc != MI_OK) return rc;
     if (n_pivots) *n_pivots = t->h_ctl->n_pivots;
+    if (t->h_ctl->status == kSyncLost)
+        return fail(MI_HIP_ERROR, "persistent look-ahead kernel: a workgroup stopped waiting for the others");
     if (t->h_ctl->status == kNeedDense) {             // see fall_back_to_dense: further
         rc = fall_back_to_dense(t);                   // iterations continue on the dense tableau
         if (rc != MI_OK) return rc;
@@ -697,6 +720,8 @@ int mi355x_tab_solve(mi355x_tab *t, int is_max, double f, int64_t max_pivots, in
             if (t->h_ctl->status != kRunning) break;
             if (blocks < 64) blocks *= 2;
         }
+        if (t->h_ctl->status == kSyncLost)
+            return fail(MI_HIP_ERROR, "persistent look-ahead kernel: a workgroup stopped waiting for the others");
         if (t->h_ctl->status != kNeedDense) {
             if (n_pivots) *n_pivots = t->h_ctl->n_pivots;
             return (int)t->h_ctl->status;
@@ -1149,6 +1174,13 @@ int         mi355x_tune_set_batch_mode(int mode) { g_batch_mode = mode; return g
 int         mi355x_tune_set_alternate_sweep(int on) { set_alternate_sweep(on); return on; }
 // pivots one tableau-update launch of this handle applies in its current representation
 int         mi355x_tab_block_size(mi355x_tab *t) { return (t && block_mode(t)) ? g_block_k : 1; }
+int         mi355x_debug_rhs(mi355x_tab *t, double *out, int64_t n, int clear)
+{
+    if (hipMemcpy(out, t->v.rhs, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (clear) (void)hipMemset(t->v.rhs, 0, n * sizeof(double));
+    return 0;
+}
+int         mi355x_tune_set_lookahead_mode(int mode) { g_la_mode = mode; return g_la_mode; }
 int         mi355x_tune_set_block(int k) { g_block_k = k < 1 ? 1 : (k > kMaxBlock ? kMaxBlock : k); return g_block_k; }
 int         mi355x_tune_set_sweep_shape(int tr, int nt) { set_sweep_shape(tr, nt); return tr; }
 int         mi355x_tune_set_compact(int on) { g_compact_enabled = on ? 1 : 0; return g_compact_enabled; }

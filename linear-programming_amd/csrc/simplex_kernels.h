@@ -17,6 +17,9 @@ constexpr int32_t kRunning = 100;
 // basic columns cannot reproduce: the pivot is NOT applied and the host re-runs it on the dense
 // tableau (single tableaux, batches) or reports MI_NONFINITE (compact column shards).
 constexpr int32_t kNeedDense = 101;
+// persistent look-ahead kernel only: a workgroup gave up waiting for the others' records (cannot
+// happen while all its workgroups are resident; bounded so that a bug reports instead of hanging)
+constexpr int32_t kSyncLost = 102;
 
 // Control block living in device memory: the whole price -> ratio -> pivot loop
 // runs without host round trips, kernels communicate through this struct.
@@ -42,6 +45,17 @@ struct BlockCtl {
     int64_t cr[kMaxBlock];        // their pivot rows ...
     int64_t slot[kMaxBlock];      // ... and the physical slots their entering columns gave up
 };
+
+// Record one workgroup of the persistent look-ahead kernel publishes per exchange: a (value,
+// index, payload) reduction candidate, a flag, and the epoch that makes it valid (written last,
+// with release semantics; epochs only ever grow).
+struct ExchRec {
+    double             v;
+    long long          i, s, flag;
+    unsigned long long epoch;
+    long long          pad[3];         // one record per 64-byte line
+};
+constexpr int kMaxLaWorkgroups = 32;
 
 // One tableau in HBM.  Row-major, leading dimension ld (a multiple of 16 doubles so
 // that every row starts on a 128-byte boundary and 16-byte vector accesses never
@@ -73,6 +87,7 @@ struct TabView {
     // bit i of bk_rmask[r]: row r is the pivot row of pending pivot i; bits i / 16+i of
     // bk_smask[pair]: the even / odd column of that pair is the slot pending pivot i gave up
     uint32_t *bk_rmask, *bk_smask;
+    ExchRec  *la_px, *la_rx;      // kMaxLaWorkgroups pricing / ratio records (persistent look-ahead)
     // batch of n_lps same-shape LPs: per-LP element strides (all zero for a single tableau)
     int64_t  n_lps;
     int64_t  zs_M, zs_basis, zs_col, zs_prow, zs_part, zs_p2l, zs_l2p;
@@ -102,6 +117,12 @@ void set_alternate_sweep(int on);
 bool block_supported(const TabView &t);
 int  launch_lookahead(const TabView &t, int j, int is_max, double fp_factor, int n_part, hipStream_t s);
 int  launch_sweep(const TabView &t, int kmax, double sgn, hipStream_t s);
+// the whole look-ahead of a block (steps 0 .. ksteps-1) as ONE launch of a few persistent
+// workgroups that exchange their reduction candidates through la_px / la_rx; epoch_base must
+// grow by at least 2*kMaxBlock+2 from launch to launch on the same tableau
+bool la_block_supported(const TabView &t);
+void launch_la_block(const TabView &t, int ksteps, int is_max, double fp_factor,
+                     unsigned long long epoch_base, hipStream_t s);
 void set_sweep_shape(int tr, int nt);      // tuning hook
 UpdateShape update_shape(const TabView &t);
 // column-partitioned shards (one shard = one handle)

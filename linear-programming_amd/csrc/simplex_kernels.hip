@@ -55,24 +55,61 @@ struct ValIdx {
 };
 
 // lexicographic (value, index) minimum; an empty slot loses against anything
+// (branch-free on purpose: written with early returns the compiler produced a chain of divergent
+// branches per call, and a workgroup reduction -- ten of these in sequence on a lone wave -- took
+// 1.3 us)
 __device__ __forceinline__ ValIdx vi_min(ValIdx a, ValIdx b)
 {
-    if (a.i < 0) return b;
-    if (b.i < 0) return a;
-    if (b.v < a.v || (b.v == a.v && b.i < a.i)) return b;
-    return a;
+    const bool a_empty = a.i < 0, b_empty = b.i < 0;
+    const bool better  = (b.v < a.v) | ((b.v == a.v) & (b.i < a.i));
+    const bool take_b  = a_empty | (!b_empty & better);
+    ValIdx r;
+    r.v = take_b ? b.v : a.v;
+    r.i = take_b ? b.i : a.i;
+    r.s = take_b ? b.s : a.s;
+    return r;
 }
 
+// Wave-wide lexicographic minimum, result valid in lane 0.  A fixed binary tree -- lane l takes
+// lane l+32, then l+16, l+8, ... -- because with NaN candidates vi_min is not associative and the
+// tree order is part of the (tested) behaviour.  The two steps that cross rows of 16 lanes use
+// __shfl_down (ds_bpermute: an LDS round trip per 32-bit word); the four steps inside a row use
+// DPP row shifts, a few cycles each.  (All six as ds_bpermute made one reduction 1.3 us.)
+template <int CTRL>
+__device__ __forceinline__ long long dpp64(long long x)
+{
+    // old = own value: a lane whose partner lies outside its row (or is switched off) combines
+    // with itself, exactly as __shfl_down past the end of the wave does
+    const int xl = (int)(x & 0xffffffffll), xh = (int)((unsigned long long)x >> 32);
+    const int lo = __builtin_amdgcn_update_dpp(xl, xl, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(xh, xh, CTRL, 0xf, 0xf, false);
+    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+template <int CTRL>
+__device__ __forceinline__ ValIdx dpp_validx(ValIdx x)
+{
+    ValIdx y;
+    y.v = __longlong_as_double(dpp64<CTRL>(__double_as_longlong(x.v)));
+    y.i = dpp64<CTRL>((long long)x.i);
+    y.s = dpp64<CTRL>((long long)x.s);
+    return y;
+}
+__device__ __forceinline__ ValIdx shfl_down_validx(ValIdx x, int off)
+{
+    ValIdx y;
+    y.v = __shfl_down(x.v, off, 64);
+    y.i = __shfl_down((long long)x.i, off, 64);
+    y.s = __shfl_down((long long)x.s, off, 64);
+    return y;
+}
 __device__ __forceinline__ ValIdx wave_reduce_min(ValIdx x)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        ValIdx y;
-        y.v = __shfl_down(x.v, off, 64);
-        y.i = __shfl_down((long long)x.i, off, 64);
-        y.s = __shfl_down((long long)x.s, off, 64);
-        x = vi_min(x, y);
-    }
+    x = vi_min(x, shfl_down_validx(x, 32));
+    x = vi_min(x, shfl_down_validx(x, 16));
+    x = vi_min(x, dpp_validx<0x108>(x));          // row_shl:8  (lane l <- lane l+8 of its row)
+    x = vi_min(x, dpp_validx<0x104>(x));          // row_shl:4
+    x = vi_min(x, dpp_validx<0x102>(x));          // row_shl:2
+    x = vi_min(x, dpp_validx<0x101>(x));          // row_shl:1
     return x;
 }
 
@@ -479,12 +516,16 @@ __global__ __launch_bounds__(kSelThreads) void k_shard_contribute(TabView t, con
                                                                  double price_tol,
                                                                  long long *bits_out, int64_t *ec_out)
 {
+    // Iterations enqueued past termination must stay no-ops: the pricing they were given is
+    // that of launches which did nothing (stale or never-written partials), so neither trust it
+    // nor index with it.
+    const bool running = t.ctl->status == kRunning;
     ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
     for (int k = 0; k < n_shards; ++k) {
         ValIdx c; c.v = gathered[2 * k]; c.i = (int64_t)gathered[2 * k + 1]; c.s = 0;
         best = vi_min(best, c);
     }
-    const int64_t ec = (best.i >= 0 && best.v < 0.0 - price_tol) ? best.i : -1;
+    const int64_t ec = (running && best.i >= 0 && best.v < 0.0 - price_tol) ? best.i : -1;
     // dense shard: a fixed block of logical columns; compact shard: whatever non-basic columns
     // currently live in its slots (l2p: global logical column -> local slot, -1 = not here)
     const int64_t lc = ec < 0 ? -1 : (t.l2p ? t.l2p[ec] : ec - col_offset);
@@ -877,6 +918,233 @@ __global__ __launch_bounds__(kScaleThreads) void k_la_scale(TabView t, int n_rp,
         t.part_v[w] = best.v;
         t.part_i[w] = best.i;
         t.part_s[w] = best.s;
+    }
+}
+
+// ---- the look-ahead of a whole block as ONE launch ------------------------------------------
+// Two launches per look-ahead step are two kernel boundaries (2.5 us each) plus cold caches at
+// every start.  For tableaux whose rows and column pairs fit a few workgroups (config 3: 17 x 256
+// threads cover 4097 rows and 4104 pairs) the steps of a block run inside one launch instead:
+// thread g owns row g (entering-column / RHS side) AND column pair g (pivot-row / objective-row
+// side); its col_i[r], prow_i[pair], RHS entry and objective-row pair stay in registers from
+// step to step, and the two reductions of a step go through a message exchange: every workgroup
+// publishes its candidate as a record whose epoch word is stored last with release semantics,
+// and every workgroup's first wave polls all records in parallel (lane l <- workgroup l, acquire)
+// -- no read-modify-write atomics, so nothing serialises (tools/microbench/msg_barrier.hip: 1.9 us
+// per exchange at 17 workgroups, against 2.5 us for a kernel boundary before any data is read).
+// All workgroups reduce the same records with the same comparisons, so they take every decision
+// (entering column, pivot row, termination) identically without further communication.
+__device__ __forceinline__ void publish(ExchRec *rec, ValIdx c, long long flag, unsigned long long epoch)
+{
+    __hip_atomic_store(&rec->v, c.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&rec->i, (long long)c.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&rec->s, (long long)c.s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&rec->flag, flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // release: everything this workgroup stored before (col / prow / bookkeeping; the
+    // __syncthreads before this call ordered the other threads' stores) is visible to whoever
+    // acquires the epoch
+    __hip_atomic_store(&rec->epoch, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// first wave of the workgroup: wait for all nw records of `epoch`, reduce them; result + OR of
+// the flags in LDS (s_res / s_flag); false if the wait was abandoned
+__device__ __forceinline__ bool collect(const ExchRec *recs, int nw, unsigned long long epoch,
+                                        ValIdx *s_res, long long *s_flag)
+{
+    bool fine = true;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const ExchRec *r = recs + lane;
+        bool ok = lane >= nw;
+        unsigned spins = 0;
+        while (!__all(ok)) {
+            if (!ok) ok = __hip_atomic_load(&r->epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
+            if (++spins > (1u << 21)) { fine = false; break; }
+        }
+        ValIdx c; c.v = 0.0; c.i = -1; c.s = 0;
+        long long fl = 0;
+        if (lane < nw) {
+            c.v = __hip_atomic_load(&r->v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c.i = __hip_atomic_load(&r->i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c.s = __hip_atomic_load(&r->s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fl  = __hip_atomic_load(&r->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        c = wave_reduce_min(c);                                  // valid in lane 0
+        fl = __any(fl != 0) ? 1 : 0;
+        if (lane == 0) { *s_res = c; *s_flag = fine ? fl : -1; }
+    }
+    __syncthreads();
+    return *s_flag != -1;
+}
+
+constexpr int kLaThreads = 256;
+
+__device__ __forceinline__ double lane_value_dyn(double v, int lane)    // lane: uniform, run-time
+{
+    return lane_value(v, __builtin_amdgcn_readfirstlane(lane));
+}
+__device__ __forceinline__ int64_t lane_value_dyn(int64_t v, int lane)
+{
+    return lane_value(v, __builtin_amdgcn_readfirstlane(lane));
+}
+
+// The steps are a run-time loop (fully unrolled the kernel was 300 KB of straight-line code and
+// ran at the speed of instruction-cache misses): per-thread col_i[row] / prow_i[pair] of the
+// pending pivots live in LDS ([pivot][thread]: conflict-free), everything else in registers.
+template <int KMAX>
+__global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, double sgn,
+                                                        double price_tol, double ratio_thr,
+                                                        unsigned long long epoch_base)
+{
+    __shared__ double    s_ci[KMAX][kLaThreads];                 // 32 KB
+    __shared__ double2   s_pi[KMAX][kLaThreads];                 // 64 KB
+    __shared__ double    s_v[kLaThreads / 64];
+    __shared__ long long s_i[kLaThreads / 64];
+    __shared__ ValIdx    s_res;
+    __shared__ long long s_flag;
+    Ctl *ctl = t.ctl;
+    const Ctl c0 = *ctl;
+    BlockCtl *blk = t.blk;
+    const int nw = gridDim.x, w = blockIdx.x, tid = threadIdx.x;
+    const bool leader = w == 0 && tid == 0;
+    const int lane = tid & 63;
+    const int64_t m = t.rows - 1, vc = t.cols - 1, ld = t.ld, ldv = ld >> 1;
+    const int64_t g = (int64_t)w * kLaThreads + tid;
+    const bool has_row = g < t.rows, has_pair = g < ldv;
+    const int64_t r = g, p = g;
+    const double2 *M2 = reinterpret_cast<const double2 *>(t.M);
+    double2 *P2 = reinterpret_cast<double2 *>(t.bk_prow);
+
+    // a new block starts (whatever the status): pending list and masks
+    if (leader) blk->n_pending = 0;
+    if (g < t.bk_stride) t.bk_rmask[g] = 0u;
+    if (g < ldv)         t.bk_smask[g] = 0u;
+    if (c0.status != kRunning) return;
+
+    double  b = (has_row && r < m) ? t.M[r * ld + vc] : 0.0;     // RHS entry of my row
+    double2 z = has_pair ? M2[m * ldv + p] : make_double2(0.0, 0.0);   // objective row, my pair
+    int64_t l0 = (has_pair && 2 * p < vc) ? t.p2l[2 * p] : -1;   // logical columns of my pair
+    int64_t l1 = (has_pair && 2 * p + 1 < vc) ? t.p2l[2 * p + 1] : -1;
+    int64_t v_cr = -1, v_sl = -1;                                // lane i: pivot row / slot of pivot i
+
+#pragma unroll 1
+    for (int J = 0; J < ksteps; ++J) {
+        const unsigned long long e_price = epoch_base + 2 * J + 1, e_ratio = epoch_base + 2 * J + 2;
+#ifdef MI355X_LA_TIMING
+        unsigned long long T0 = wall_clock64(), T1, T2, T3, T4, T5, T6;
+#endif
+        // ---- pricing: my pair's candidates -> workgroup winner -> record -> everybody's winner
+        ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
+        if (has_pair && 2 * p < vc)     { ValIdx c; c.v = z.x * sgn; c.i = l0; c.s = 2 * p;     best = vi_min(best, c); }
+        if (has_pair && 2 * p + 1 < vc) { ValIdx c; c.v = z.y * sgn; c.i = l1; c.s = 2 * p + 1; best = vi_min(best, c); }
+        best = block_reduce_min<kLaThreads>(best, s_v, s_i);     // (barriers: earlier stores ordered)
+#ifdef MI355X_LA_TIMING
+        T1 = wall_clock64();
+#endif
+        if (tid == 0) publish(t.la_px + w, best, 0, e_price);
+        if (!collect(t.la_px, nw, e_price, &s_res, &s_flag)) { if (leader) ctl->status = kSyncLost; return; }
+#ifdef MI355X_LA_TIMING
+        T2 = wall_clock64();
+#endif
+        const ValIdx e = s_res;
+        if (e.i < 0 || !(e.v < 0.0 - price_tol)) {
+            if (leader) ctl->status = 0;                         // MI_OPTIMAL
+            return;
+        }
+        if (c0.max_pivots > 0 && c0.n_pivots + J >= c0.max_pivots) {
+            if (leader) ctl->status = 3;                         // MI_MAX_PIVOTS
+            return;
+        }
+        const int64_t ec = e.i, slot = uniform64(e.s);
+        // ---- entering column through the pending chain; RHS entry brought up to date
+        double a = has_row ? t.M[r * ld + slot] : 0.0;
+        const double v_pa = (lane < J) ? t.bk_prow[(int64_t)lane * ld + slot] : 0.0;
+        if (J > 0) {
+            const double pb = t.bk_prow[(int64_t)(J - 1) * ld + vc];
+            b = pend(b, false, r == lane_value_dyn(v_cr, J - 1), s_ci[J - 1][tid], pb);
+        }
+#pragma unroll 2
+        for (int i = 0; i < J; ++i)
+            a = pend(a, slot == lane_value_dyn(v_sl, i), r == lane_value_dyn(v_cr, i), s_ci[i][tid],
+                     lane_value_dyn(v_pa, i));
+        s_ci[J][tid] = a;
+        ValIdx q; q.v = 0.0; q.i = -1; q.s = 0;
+        int bad = 0;
+        if (has_row) {
+            t.bk_col[(int64_t)J * t.bk_stride + r] = a;
+            bad = !(fabs(a) <= 1.7976931348623157e308);
+            if (r < m && ratio_thr < a) { q.v = b / a; q.i = r; q.s = __double_as_longlong(a); }
+        }
+#ifdef MI355X_LA_TIMING
+        T3 = wall_clock64();
+#endif
+        q = block_reduce_min<kLaThreads>(q, s_v, s_i);
+        const int wg_bad = __syncthreads_or(bad);
+#ifdef MI355X_LA_TIMING
+        T4 = wall_clock64();
+#endif
+        if (tid == 0) publish(t.la_rx + w, q, wg_bad ? 1 : 0, e_ratio);
+        if (!collect(t.la_rx, nw, e_ratio, &s_res, &s_flag)) { if (leader) ctl->status = kSyncLost; return; }
+#ifdef MI355X_LA_TIMING
+        T5 = wall_clock64();
+#endif
+        const ValIdx qq = s_res;
+        if (s_flag != 0) {                                       // inf / NaN in the column: see kNeedDense
+            if (leader) ctl->status = kNeedDense;
+            return;
+        }
+        if (qq.i < 0) {
+            if (leader) ctl->status = 1;                         // MI_UNBOUNDED
+            return;
+        }
+        const int64_t cr = uniform64(qq.i);
+        const double piv = __longlong_as_double(qq.s);
+        // ---- pivot row through the chain -> prow_J; objective row through pivot J
+        double2 y = has_pair ? M2[cr * ldv + p] : make_double2(0.0, 0.0);
+        const double v_ccr = (lane < J) ? t.bk_col[(int64_t)lane * t.bk_stride + cr] : 0.0;
+        const double cmj = t.bk_col[(int64_t)J * t.bk_stride + m];
+        const bool own = has_pair && (p == (slot >> 1));
+        const int64_t leaving = own ? t.basis[cr] : -1;
+#pragma unroll 2
+        for (int i = 0; i < J; ++i) {
+            const bool    is_cr = cr == lane_value_dyn(v_cr, i);
+            const int64_t sl = lane_value_dyn(v_sl, i);
+            const double  ccr = lane_value_dyn(v_ccr, i);
+            const double2 pii = s_pi[i][tid];
+            y.x = pend(y.x, 2 * p     == sl, is_cr, ccr, pii.x);
+            y.y = pend(y.y, 2 * p + 1 == sl, is_cr, ccr, pii.y);
+        }
+        double2 pr = make_double2(0.0, 0.0);
+        if (has_pair) {
+            pr = scale_pair(t, p, y, piv, slot);
+            P2[(int64_t)J * ldv + p] = pr;
+            z.x = pend(z.x, 2 * p     == slot, false, cmj, pr.x);
+            z.y = pend(z.y, 2 * p + 1 == slot, false, cmj, pr.y);
+        }
+        s_pi[J][tid] = pr;
+        if (own) {
+            if (2 * p == slot) l0 = leaving; else l1 = leaving;
+            swap_columns(t, ec, cr, slot);
+            Ctl cj = c0;
+            cj.n_pivots = c0.n_pivots + J;
+            cj.trace_n  = c0.trace_n + J;
+            record_pivot(t, cj, ec, cr);
+            ctl->slot = slot;
+            blk->cr[J] = cr;
+            blk->slot[J] = slot;
+            blk->n_pending = J + 1;
+            t.bk_rmask[cr] |= 1u << J;
+            t.bk_smask[slot >> 1] |= 1u << (J + 16 * (int)(slot & 1));
+        }
+        if (lane == J) { v_cr = cr; v_sl = slot; }
+#ifdef MI355X_LA_TIMING
+        T6 = wall_clock64();
+        if (leader) {
+            double *d = t.rhs + J * 8;
+            d[0] += (double)(T1 - T0); d[1] += (double)(T2 - T1); d[2] += (double)(T3 - T2);
+            d[3] += (double)(T4 - T3); d[4] += (double)(T5 - T4); d[5] += (double)(T6 - T5); d[6] += 1.0;
+        }
+#endif
     }
 }
 
@@ -1666,6 +1934,22 @@ int launch_lookahead(const TabView &t, int j, int is_max, double f, int n_part, 
 #undef MI_LA
     }
     return 0;
+}
+
+bool la_block_supported(const TabView &t)
+{
+    if (!block_supported(t) || !t.la_px || !t.la_rx) return false;
+    const int64_t need = t.rows > (t.ld >> 1) ? t.rows : (t.ld >> 1);
+    return (need + kLaThreads - 1) / kLaThreads <= kMaxLaWorkgroups;
+}
+
+void launch_la_block(const TabView &t, int ksteps, int is_max, double f, unsigned long long epoch_base,
+                     hipStream_t s)
+{
+    const int64_t need = t.rows > (t.ld >> 1) ? t.rows : (t.ld >> 1);
+    const int nw = (int)((need + kLaThreads - 1) / kLaThreads);
+    hipLaunchKernelGGL(k_la_block<kMaxBlock>, dim3(nw), dim3(kLaThreads), 0, s, t, ksteps, sgn_of(is_max),
+                       (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon, epoch_base);
 }
 
 static int g_sweep_tr = 16, g_sweep_nt = -1;                    // -1: by size, as for k_update

@@ -282,14 +282,24 @@ def block_size(request):
     L.mi355x_tune_set_block(default)
 
 
+@pytest.fixture(params=[2, 1], ids=["persistent-lookahead", "two-launches-per-step"])
+def lookahead_mode(request):
+    L = lp.capi.lib()
+    L.mi355x_tune_set_lookahead_mode(request.param)
+    yield request.param
+    L.mi355x_tune_set_lookahead_mode(0)
+
+
 @pytest.mark.parametrize("block_size", [1, 2, 3, 5, 8, 13, 16], indirect=True)
 @pytest.mark.parametrize("n,m,seed", [(5, 3, 1), (33, 17, 2), (257, 511, 5), (700, 333, 6),
                                       (2000, 1100, 9)])
-def test_blocked_pivoting_bitwise_vs_oracle(n, m, seed, block_size):
+def test_blocked_pivoting_bitwise_vs_oracle(n, m, seed, block_size, lookahead_mode):
     """Blocked pivoting (k pivots selected ahead on the objective row / one column / the RHS /
     one row as they WOULD be, then applied in one sweep) for every block size, including sizes
     that do not divide the pivot count (the terminating step sits in the middle of a block): same
-    pivot sequence, bit-identical tableau, and a capped solve stops on exactly the same pivot."""
+    pivot sequence, bit-identical tableau, and a capped solve stops on exactly the same pivot.
+    Both forms of the look-ahead: two launches per step, and the whole block as one launch of
+    persistent workgroups that exchange their reduction candidates through memory."""
     L = lp.capi.lib()
     L.mi355x_tune_set_select_mode(2)                    # small shapes too: the blocked path
     try:
