@@ -403,10 +403,12 @@ int enqueue_iteration(mi355x_tab *t, int is_max, double f)
 bool block_mode(const mi355x_tab *t)
 {
     if (g_block_k <= 1 || !t->compact || !block_supported(t->c)) return false;
-    bool split = (t->c.rows > 1024 || t->c.ld > 4096);    // as enqueue_select: small tableaux
-    if (g_select_mode == 1) split = false;                // stay on the single-workgroup select
-    if (g_select_mode == 2) split = true;
-    return split;
+    if (g_select_mode == 1) return false;                 // forced: single-workgroup select, per pivot
+    if (g_select_mode == 2) return true;
+    // the persistent look-ahead pays at every size (a step costs less than the select + update
+    // launches of one pivot); the two-launches-per-step form only where the split select is used
+    if (g_la_mode != 1 && la_block_supported(t->c)) return true;
+    return t->c.rows > 1024 || t->c.ld > 4096;
 }
 
 int enqueue_block(mi355x_tab *t, int is_max, double f, int k)
