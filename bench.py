@@ -63,6 +63,8 @@ def parse():
                     help="colpart: override the number of variables (constraints = vars/2)")
     ap.add_argument("--block", type=int, default=0,
                     help="tuning: pivots selected ahead and applied per sweep (0 = library default, 1 = off)")
+    ap.add_argument("--batch-block", type=int, default=0,
+                    help="tuning, cfg4: pivots per pass of the blocked per-LP kernel (0 = default, 1 = off)")
     ap.add_argument("--sweep-tr", type=int, default=0, help="tuning: rows per sweep workgroup")
     ap.add_argument("--sweep-nt", type=int, default=-1, help="tuning: non-temporal sweep accesses (0/1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -128,12 +130,17 @@ def bench_batch(args, lp, rank, local_rank, N, barrier, torch, dist):
     n, m = 512, 256
     nl = args.batch_lps
     seeds = np.array([lp.synth.seed_for(4, rank * nl + k) for k in range(nl)], dtype=np.uint64)
-    warm = lp.TableauBatch.synthetic(min(nl, 8), n, m, seeds[:min(nl, 8)], device=local_rank)
-    warm.solve(max_pivots=max(args.warmup, 1))           # untimed warm-up on a throw-away batch
-    del warm
-    batch = lp.TableauBatch.synthetic(nl, n, m, seeds, device=local_rank)
     L = lp.capi.lib()
     L.mi355x_tune_set_batch_mode(args.batch_mode)
+    if args.batch_block:
+        L.mi355x_tune_set_batch_block(args.batch_block)
+    # untimed warm-up on a throw-away batch of the same size (same kernels, same grid, clocks up:
+    # the timed region is ONE launch of 20-40 ms)
+    warm = lp.TableauBatch.synthetic(nl, n, m, seeds[::-1].copy(), device=local_rank)
+    warm.solve()
+    del warm
+    batch = lp.TableauBatch.synthetic(nl, n, m, seeds, device=local_rank)
+    lp.capi.check(L.mi355x_batch_prepare(batch._h), "mi355x_batch_prepare")   # no allocation inside the timed solve
     L.mi355x_batch_timing_enable(batch._h, 1)
     barrier()
     torch.cuda.synchronize()

@@ -242,6 +242,9 @@ int  mi355x_batch_solve(mi355x_batch *b, int is_max, double fp_factor, int64_t m
 int  mi355x_batch_download(mi355x_batch *b, int64_t lp_index, double *host_matrix,
                            int64_t *host_basis, double *last_row, double *last_col);
 /* HIP-event timing of the batched update launches (see mi355x_tab_timing_*). */
+/* Optional: do now what the first mi355x_batch_solve would do first -- allocate and fill the
+ * representation the solve loop runs on -- so that a timed solve contains no allocation. */
+int  mi355x_batch_prepare(mi355x_batch *b);
 int  mi355x_batch_timing_enable(mi355x_batch *b, int enable);
 int  mi355x_batch_timing_read(mi355x_batch *b, int64_t *n_launches, double *sum_ms, double *min_ms);
 void mi355x_batch_destroy(mi355x_batch *b);

@@ -67,6 +67,7 @@ SIGNATURES = {
     "mi355x_batch_create_synthetic": (_int, [_pp, _i64, _i64, _i64, _p, _int]),
     "mi355x_batch_solve": (_int, [_p, _int, _dbl, _i64, _p, _p]),
     "mi355x_batch_download": (_int, [_p, _i64, _p, _p, _p, _p]),
+    "mi355x_batch_prepare": (_int, [_p]),
     "mi355x_batch_timing_enable": (_int, [_p, _int]),
     "mi355x_batch_timing_read": (_int, [_p, _p, _p, _p]),
     "mi355x_batch_destroy": (None, [_p]),
@@ -89,6 +90,7 @@ _EXTRA = {
     "mi355x_tune_set_ld_extra": (_int, [_int]),
     "mi355x_tune_set_block": (_int, [_int]),
     "mi355x_tune_set_lookahead_mode": (_int, [_int]),
+    "mi355x_tune_set_batch_block": (_int, [_int]),
     "mi355x_tune_set_sweep_shape": (_int, [_int, _int]),
 }
 

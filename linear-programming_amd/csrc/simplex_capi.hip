@@ -972,6 +972,17 @@ int mi355x_batch_create_synthetic(mi355x_batch **out, int64_t n_lps, int64_t n_v
     return MI_OK;
 }
 
+int mi355x_batch_prepare(mi355x_batch *b)
+{
+    if (!b || !b->t) return fail(MI_BAD_ARG, "batch is NULL");
+    int rc = use_device(b->t);
+    if (rc != MI_OK) return rc;
+    rc = ensure_compact(b->t);
+    if (rc != MI_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(b->t->stream));
+    return MI_OK;
+}
+
 int mi355x_batch_solve(mi355x_batch *b, int is_max, double f, int64_t max_pivots, int32_t *status,
                        int64_t *n_pivots)
 {
@@ -1182,6 +1193,7 @@ int         mi355x_debug_rhs(mi355x_tab *t, double *out, int64_t n, int clear)
     if (clear) (void)hipMemset(t->v.rhs, 0, n * sizeof(double));
     return 0;
 }
+int         mi355x_tune_set_batch_block(int k) { set_batch_block(k); return k; }
 int         mi355x_tune_set_lookahead_mode(int mode) { g_la_mode = mode; return g_la_mode; }
 int         mi355x_tune_set_block(int k) { g_block_k = k < 1 ? 1 : (k > kMaxBlock ? kMaxBlock : k); return g_block_k; }
 int         mi355x_tune_set_sweep_shape(int tr, int nt) { set_sweep_shape(tr, nt); return tr; }

@@ -139,6 +139,7 @@ void launch_shard_prepare(const TabView &t, const double *col, const int64_t *ec
 void launch_handover(const TabView &art, const TabView &main_tab, bool unit_basis, hipStream_t s);
 // whole-batch solve, one workgroup per LP (false: an LP does not fit the LDS budget)
 bool launch_batch_solve(const TabView &t, int is_max, double fp_factor, hipStream_t s);
+void set_batch_block(int k);       // tuning hook: pivots per pass of the blocked per-LP kernel (1 = off)
 // dense logical tableau <-> compact representation
 void launch_verify_basis(const TabView &t, int *flag, hipStream_t s);
 void launch_compact(const TabView &dense, const TabView &compact, hipStream_t s);

@@ -1063,7 +1063,6 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
             const double pb = t.bk_prow[(int64_t)(J - 1) * ld + vc];
             b = pend(b, false, r == lane_value_dyn(v_cr, J - 1), s_ci[J - 1][tid], pb);
         }
-#pragma unroll 2
         for (int i = 0; i < J; ++i)
             a = pend(a, slot == lane_value_dyn(v_sl, i), r == lane_value_dyn(v_cr, i), s_ci[i][tid],
                      lane_value_dyn(v_pa, i));
@@ -1105,7 +1104,6 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
         const double cmj = t.bk_col[(int64_t)J * t.bk_stride + m];
         const bool own = has_pair && (p == (slot >> 1));
         const int64_t leaving = own ? t.basis[cr] : -1;
-#pragma unroll 2
         for (int i = 0; i < J; ++i) {
             const bool    is_cr = cr == lane_value_dyn(v_cr, i);
             const int64_t sl = lane_value_dyn(v_sl, i);
@@ -1446,6 +1444,165 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_solve(TabView t, double sg
     }
 }
 
+// ---- the same with blocked pivoting (compact representation) --------------------------------
+// One workgroup streams its LP at (bytes in flight) / (memory latency) ~ 30 GB/s, so a pivot of a
+// 1 MB tableau costs ~70 us however the loop is written.  Blocked as in k_la_block / k_sweep, but
+// with everything inside the one workgroup: the look-ahead state of up to KB pending pivots
+// (col_i, prow_i), the running objective row, RHS column and column map live in LDS, a look-ahead
+// step is two memory round trips (one strided column, one row) and two workgroup reductions, and
+// the tableau itself is read and written once per KB pivots.
+template <int KB>
+__global__ __launch_bounds__(kLpThreads) void k_batch_block(TabView t, double sgn, double price_tol,
+                                                           double ratio_thr)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double    s_v[kLpThreads / 64];
+    __shared__ long long s_i[kLpThreads / 64];
+    __shared__ long long s_cr[KB], s_sl[KB];
+    t = lp_slice(t);
+    Ctl *ctl = t.ctl;
+    const Ctl c0 = *ctl;
+    if (c0.status != kRunning) return;
+    const int tid = threadIdx.x;
+    const int64_t rows = t.rows, m = rows - 1, vc = t.cols - 1, ld = t.ld, ldv = ld >> 1;
+    const int64_t rp = (rows + 1) & ~(int64_t)1;
+    double    *s_prow = lds;                                   // KB x ld
+    double    *s_col  = s_prow + (int64_t)KB * ld;             // KB x rp
+    double    *s_z    = s_col + (int64_t)KB * rp;              // ld: objective row through all pending pivots
+    double    *s_b    = s_z + ld;                              // rp: RHS column, likewise
+    long long *s_p2l  = reinterpret_cast<long long *>(s_b + rp);   // ld: logical column of a slot
+    unsigned  *s_rm   = reinterpret_cast<unsigned *>(s_p2l + ld);  // rp: row -> pending pivots whose row it is
+    unsigned  *s_sm   = s_rm + rp;                             // ldv: pair -> pending pivots whose slot it holds
+    vec2d *M2 = reinterpret_cast<vec2d *>(t.M);
+    const int64_t total = rows * ldv;
+
+    for (int64_t c = tid; c < ld; c += kLpThreads) {
+        s_z[c] = t.M[m * ld + c];
+        s_p2l[c] = c < vc ? t.p2l[c] : -1;
+    }
+    for (int64_t r = tid; r < rows; r += kLpThreads) s_b[r] = t.M[r * ld + vc];
+    int64_t n_pivots = c0.n_pivots, trace_n = c0.trace_n;
+    int term = -1;                                             // status that ends the solve
+    __syncthreads();
+
+    while (term < 0) {
+        for (int64_t r = tid; r < rp; r += kLpThreads) s_rm[r] = 0u;
+        for (int64_t p = tid; p < ldv; p += kLpThreads) s_sm[p] = 0u;
+        int k = 0;
+        for (int J = 0; J < KB && term < 0; ++J) {
+            // ---- find-entering-column on the running objective row
+            ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
+            for (int64_t c = tid; c < vc; c += kLpThreads) {
+                ValIdx x; x.v = s_z[c] * sgn; x.i = s_p2l[c]; x.s = c;
+                best = vi_min(best, x);
+            }
+            const ValIdx e = block_reduce_min<kLpThreads>(best, s_v, s_i);
+            if (e.i < 0 || !(e.v < 0.0 - price_tol)) { term = 0; break; }          // MI_OPTIMAL
+            if (c0.max_pivots > 0 && n_pivots >= c0.max_pivots) { term = 3; break; }   // MI_MAX_PIVOTS
+            const int64_t ec = e.i, slot = e.s;
+            // ---- entering column through the pending chain, ratio test
+            ValIdx q; q.v = 0.0; q.i = -1; q.s = 0;
+            int bad = 0;
+            for (int64_t r = tid; r < rows; r += kLpThreads) {
+                double a = t.M[r * ld + slot];
+                for (int i = 0; i < J; ++i)
+                    a = pend(a, slot == s_sl[i], r == s_cr[i], s_col[(int64_t)i * rp + r], s_prow[(int64_t)i * ld + slot]);
+                s_col[(int64_t)J * rp + r] = a;
+                bad |= !(fabs(a) <= 1.7976931348623157e308);
+                if (r < m && ratio_thr < a) {
+                    ValIdx x; x.v = s_b[r] / a; x.i = r; x.s = __double_as_longlong(a);
+                    q = vi_min(q, x);
+                }
+            }
+            q = block_reduce_min<kLpThreads>(q, s_v, s_i);     // barriers: s_col[J] complete
+            if (__syncthreads_or(bad)) { term = kNeedDense; break; }
+            if (q.i < 0) { term = 1; break; }                  // MI_UNBOUNDED
+            const int64_t cr = q.i;
+            const double piv = __longlong_as_double(q.s);
+            // ---- pivot row through the chain -> prow_J; objective row through pivot J
+            const double cmj = s_col[(int64_t)J * rp + m];
+            for (int64_t p = tid; p < ldv; p += kLpThreads) {
+                const vec2d y0 = M2[cr * ldv + p];
+                double2 y = make_double2(y0.x, y0.y);
+                for (int i = 0; i < J; ++i) {
+                    const bool   is_cr = cr == s_cr[i];
+                    const double ccr = s_col[(int64_t)i * rp + cr];
+                    const double2 pi = reinterpret_cast<const double2 *>(s_prow + (int64_t)i * ld)[p];
+                    y.x = pend(y.x, 2 * p     == s_sl[i], is_cr, ccr, pi.x);
+                    y.y = pend(y.y, 2 * p + 1 == s_sl[i], is_cr, ccr, pi.y);
+                }
+                const double2 pr = scale_pair(t, p, y, piv, slot);
+                reinterpret_cast<double2 *>(s_prow + (int64_t)J * ld)[p] = pr;
+                double2 z = reinterpret_cast<double2 *>(s_z)[p];
+                z.x = pend(z.x, 2 * p     == slot, false, cmj, pr.x);
+                z.y = pend(z.y, 2 * p + 1 == slot, false, cmj, pr.y);
+                reinterpret_cast<double2 *>(s_z)[p] = z;
+            }
+            __syncthreads();                                   // prow_J complete
+            const double pbj = s_prow[(int64_t)J * ld + vc];
+            for (int64_t r = tid; r < rows; r += kLpThreads)
+                s_b[r] = pend(s_b[r], false, r == cr, s_col[(int64_t)J * rp + r], pbj);
+            if (tid == 0) {                                    // bookkeeping of pivot J
+                const int64_t leaving = t.basis[cr];
+                t.p2l[slot] = leaving;  s_p2l[slot] = leaving;
+                t.l2p[leaving] = slot;  t.l2p[ec] = -1;
+                t.basis[cr] = ec;                              // src/simplex.lisp:358
+                if (t.trace_ec && trace_n < t.trace_cap) { t.trace_ec[trace_n] = ec; t.trace_cr[trace_n] = cr; }
+                s_cr[J] = cr;  s_sl[J] = slot;
+                s_rm[cr] |= 1u << J;
+                s_sm[slot >> 1] |= 1u << (J + 16 * (int)(slot & 1));
+            }
+            n_pivots += 1; trace_n += 1;
+            k = J + 1;
+            __syncthreads();
+        }
+        // ---- the sweep: the k pending pivots applied to every stored element
+        if (k > 0) {
+            for (int64_t base = 0; base < total; base += (int64_t)kLpUnroll * kLpThreads) {
+                vec2d x[kLpUnroll];
+#pragma unroll
+                for (int u = 0; u < kLpUnroll; ++u) {
+                    const int64_t idx = base + (int64_t)u * kLpThreads + tid;
+                    if (idx < total) x[u] = M2[idx];
+                }
+#pragma unroll
+                for (int u = 0; u < kLpUnroll; ++u) {
+                    const int64_t idx = base + (int64_t)u * kLpThreads + tid;
+                    if (idx < total) {
+                        const int64_t r = idx / ldv, p = idx - r * ldv;
+                        const unsigned rm = s_rm[r], sm = s_sm[p];
+                        vec2d v = x[u];
+                        if ((rm | sm) == 0u) {                 // the bare chain
+                            for (int i = 0; i < k; ++i) {
+                                const double  s = s_col[(int64_t)i * rp + r];
+                                const double2 pi = reinterpret_cast<const double2 *>(s_prow + (int64_t)i * ld)[p];
+                                const double m0 = s * pi.x, m1 = s * pi.y;
+                                v.x = v.x - m0;
+                                v.y = v.y - m1;
+                            }
+                        } else {
+                            for (int i = 0; i < k; ++i) {
+                                const double  s = s_col[(int64_t)i * rp + r];
+                                const double2 pi = reinterpret_cast<const double2 *>(s_prow + (int64_t)i * ld)[p];
+                                const bool is_cr = (rm >> i) & 1u;
+                                v.x = pend(v.x, (sm >> i) & 1u, is_cr, s, pi.x);
+                                v.y = pend(v.y, (sm >> (i + 16)) & 1u, is_cr, s, pi.y);
+                            }
+                        }
+                        M2[idx] = v;
+                    }
+                }
+            }
+            __syncthreads();                                   // tableau consistent before the next block reads it
+        }
+    }
+    if (tid == 0) {
+        ctl->status = term;
+        ctl->n_pivots = n_pivots;
+        ctl->trace_n = trace_n;
+    }
+}
+
 // ------------------------------------------------------------------ compact representation
 // Basic columns of a consistent tableau are unit vectors and stay bit-for-bit unchanged under
 // every pivot (x - s*(+0) == x, and a column that becomes basic is produced as x - x = +0 /
@@ -1743,8 +1900,39 @@ void launch_handover(const TabView &art, const TabView &mt, bool unit_basis, hip
     }
 }
 // one launch solves the whole batch; returns false if an LP does not fit the LDS budget
+static int g_batch_block = 0;                                  // 0 = default (16), 1 = per-pivot k_batch_solve
+void set_batch_block(int k) { g_batch_block = k; }
+
+template <int KB>
+static bool launch_batch_block_t(const TabView &t, int is_max, double f, hipStream_t s)
+{
+    const int64_t rp = (t.rows + 1) & ~(int64_t)1, ldv = t.ld >> 1;
+    const size_t bytes = (size_t)((int64_t)KB * (t.ld + rp) + t.ld + rp + t.ld) * 8 + (size_t)(rp + ldv) * 4;
+    if (bytes > 150 * 1024) return false;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_block<KB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipGetLastError();
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_batch_block<KB>, dim3(1, 1, (unsigned)t.n_lps), dim3(kLpThreads), bytes, s, t,
+                       sgn_of(is_max), (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon);
+    return true;
+}
+
 bool launch_batch_solve(const TabView &t, int is_max, double f, hipStream_t s)
 {
+    // blocked (compact representation), largest block that fits the LDS.  Measured at 257 x 513,
+    // steady state (tools/batch_blocks.py): 128 LPs 2.0 M pivots/s per-pivot, 2.55 M at 4, 2.85 M
+    // at 8, 2.93 M at 16; 1024 LPs 2.5 M per-pivot, 4.55 M at 4, 5.94 M at 8, 6.67 M at 16
+    int kb = g_batch_block;
+    if (kb == 0) kb = 16;
+    if (t.p2l && kb > 1 && t.rows >= 2 && (t.ld >> 1) >= 1) {
+        if (kb >= 16 && launch_batch_block_t<16>(t, is_max, f, s)) return true;
+        if (kb >= 8 && launch_batch_block_t<8>(t, is_max, f, s)) return true;
+        if (launch_batch_block_t<4>(t, is_max, f, s)) return true;
+    }
     const size_t lds = (size_t)(t.ld + t.rows) * sizeof(double);
     if (lds > 96 * 1024 || t.ld / 2 < 1) return false;
     hipLaunchKernelGGL(k_batch_solve, dim3(1, 1, (unsigned)t.n_lps), dim3(kLpThreads), lds, s, t,

@@ -696,6 +696,32 @@ def representation(request):
     L.mi355x_tune_set_compact(1)
 
 
+@pytest.mark.parametrize("block", [1, 4, 8, 16])
+@pytest.mark.parametrize("n,m,nl", [(60, 30, 21), (7, 3, 5), (300, 40, 7), (33, 200, 6)])
+def test_batch_blocked_kernel_bitwise_vs_oracle(block, n, m, nl):
+    """The one-workgroup-per-LP kernel with blocked pivoting (look-ahead state in LDS, the tableau
+    read and written once per block) for every block size it is instantiated for, and a pivot cap
+    that falls inside a block: every LP bit-identical to the oracle run on it alone."""
+    L = lp.capi.lib()
+    seeds = [lp.synth.seed_for(4, 100 + k) for k in range(nl)]
+    tabs = [lp.synth.tableau(n, m, s) for s in seeds]
+    Ms = np.stack([t[0] for t in tabs])
+    Bs = np.stack([t[1] for t in tabs])
+    L.mi355x_tune_set_batch_block(block)
+    try:
+        for cap in (0, 5):
+            batch = lp.TableauBatch.from_arrays(Ms, Bs)
+            st, npv = batch.solve(max_pivots=cap)
+            for k in range(nl):
+                M, b = Ms[k].copy(), Bs[k].copy()
+                so, no, _ = oracle.solve(M, b, max_pivots=cap)
+                Mg, bg = batch.download(k)
+                assert (st[k], npv[k]) == (so, no), (k, cap)
+                assert np.array_equal(Mg, M) and np.array_equal(bg, b), (k, cap)
+    finally:
+        L.mi355x_tune_set_batch_block(0)
+
+
 @pytest.mark.parametrize("n,m,nl", [(60, 30, 37), (7, 3, 5), (300, 40, 9), (33, 200, 6)])
 def test_batch_bitwise_vs_oracle(batch_mode, representation, n, m, nl):
     """Every LP of a batch ends bit-identical to the oracle run on it alone (LPs of different
