@@ -276,10 +276,9 @@ def test_both_select_paths_bitwise_vs_oracle(n, m, seed, mode):
 @pytest.fixture
 def block_size(request):
     L = lp.capi.lib()
-    default = L.mi355x_tune_set_block(8)
     L.mi355x_tune_set_block(request.param)
     yield request.param
-    L.mi355x_tune_set_block(default)
+    L.mi355x_tune_set_block(16)                         # the library default
 
 
 @pytest.fixture(params=[2, 1], ids=["persistent-lookahead", "two-launches-per-step"])

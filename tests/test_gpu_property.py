@@ -37,8 +37,10 @@ def _random_tableau(rng, n, m, kind, density, degenerate):
 @given(n=st.integers(1, 700), m=st.integers(1, 400), seed=st.integers(0, 2 ** 31 - 1),
        kind=st.sampled_from(["max", "min"]), density=st.sampled_from([1.0, 0.5, 0.1]),
        degenerate=st.booleans(), select_mode=st.sampled_from([0, 1, 2]),
-       compact=st.sampled_from([0, 1]), variant=st.integers(0, 17))
-def test_random_lps_bitwise(n, m, seed, kind, density, degenerate, select_mode, compact, variant):
+       compact=st.sampled_from([0, 1]), variant=st.integers(0, 17),
+       block=st.sampled_from([1, 2, 5, 8, 16]), lookahead=st.sampled_from([0, 1, 2]))
+def test_random_lps_bitwise(n, m, seed, kind, density, degenerate, select_mode, compact, variant,
+                            block, lookahead):
     L = lp.capi.lib()
     rng = np.random.default_rng(seed)
     M0, b0 = _random_tableau(rng, n, m, kind, density, degenerate)
@@ -49,6 +51,8 @@ def test_random_lps_bitwise(n, m, seed, kind, density, degenerate, select_mode, 
         L.mi355x_tune_set_select_mode(select_mode)
         L.mi355x_tune_set_compact(compact)
         L.mi355x_tune_set_variant(variant % L.mi355x_tune_variant_count())
+        L.mi355x_tune_set_block(block)               # pivots per sweep (1 = per-pivot kernels)
+        L.mi355x_tune_set_lookahead_mode(lookahead)  # auto / two launches per step / one persistent launch
         t = lp.Tableau(None, lp.Problem(type=kind), M0, b0, n + m, m, {})
         k = ctypes.c_int64(0)
         rc = L.mi355x_tab_solve(t._h, int(kind == "max"), 1024.0, cap, ctypes.byref(k))
@@ -57,6 +61,8 @@ def test_random_lps_bitwise(n, m, seed, kind, density, degenerate, select_mode, 
         L.mi355x_tune_set_select_mode(0)
         L.mi355x_tune_set_compact(1)
         L.mi355x_tune_set_variant(0)
+        L.mi355x_tune_set_block(16)
+        L.mi355x_tune_set_lookahead_mode(0)
     assert rc == st_o and k.value == npiv
     assert np.array_equal(t.pivot_trace(), trace)
     assert np.array_equal(t.matrix.view(np.int64), M.view(np.int64))      # bits, incl. signed zeros
