@@ -59,6 +59,8 @@ def parse():
                     help="cfg4: 0 auto, 1 lockstep launch pairs, 2 one workgroup per LP")
     ap.add_argument("--colpart-dense", action="store_true",
                     help="colpart: shards hold all logical columns instead of the non-basic ones only")
+    ap.add_argument("--colpart-block", type=int, default=0,
+                    help="colpart: pivots per sweep of the shards (0 = 16, 1 = per-pivot updates)")
     ap.add_argument("--colpart-vars", type=int, default=0,
                     help="colpart: override the number of variables (constraints = vars/2)")
     ap.add_argument("--block", type=int, default=0,

@@ -281,6 +281,17 @@ int  mi355x_shard_contribute(mi355x_tab *t, const double *dev_gathered, int n_sh
                              int64_t *dev_ec);
 int  mi355x_shard_pivot(mi355x_tab *t, const int64_t *dev_col_bits, const int64_t *dev_ec,
                         double fp_factor);
+/* Blocked form of the three steps: `step` = 0 .. 15 within a block.  The
+ * exchanges are the same two per pivot; the shard's slice of the tableau is NOT updated by
+ * mi355x_shard_la_pivot -- the pending pivots are chained through on whatever a step reads --
+ * and mi355x_shard_sweep applies all pending pivots in one pass (call it after the last step of
+ * a block, at the latest after 16 steps, and before anything else touches the shard). */
+int  mi355x_shard_la_contribute(mi355x_tab *t, int step, const double *dev_gathered, int n_shards,
+                                int64_t col_offset, double fp_factor, int64_t *dev_col_bits,
+                                int64_t *dev_ec);
+int  mi355x_shard_la_pivot(mi355x_tab *t, int step, const int64_t *dev_col_bits, const int64_t *dev_ec,
+                           double fp_factor);
+int  mi355x_shard_sweep(mi355x_tab *t);
 
 #ifdef __cplusplus
 }

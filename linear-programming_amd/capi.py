@@ -76,6 +76,9 @@ SIGNATURES = {
     "mi355x_shard_price": (_int, [_p, _int, _i64, _p]),
     "mi355x_shard_contribute": (_int, [_p, _p, _int, _i64, _dbl, _p, _p]),
     "mi355x_shard_pivot": (_int, [_p, _p, _p, _dbl]),
+    "mi355x_shard_la_contribute": (_int, [_p, _int, _p, _int, _i64, _dbl, _p, _p]),
+    "mi355x_shard_la_pivot": (_int, [_p, _int, _p, _p, _dbl]),
+    "mi355x_shard_sweep": (_int, [_p]),
 }
 # tuning hooks exported by the library but not part of include/mi355x_simplex.h
 _EXTRA = {

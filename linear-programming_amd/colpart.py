@@ -80,6 +80,22 @@ class HipBackend:
                                              ctypes.c_void_p(sh.ec.data_ptr()), self.f),
                    "mi355x_shard_pivot")
 
+    # blocked form: step j of a block does not touch the shard's slice of the
+    # tableau; sweep() applies the pending pivots in one pass
+    def la_contribute(self, sh, j):
+        capi.check(self.L.mi355x_shard_la_contribute(
+            sh.handle, int(j), ctypes.c_void_p(sh.gathered.data_ptr()), sh.n_shards, sh.col_begin, self.f,
+            ctypes.c_void_p(sh.bits.data_ptr()), ctypes.c_void_p(sh.ec.data_ptr())),
+            "mi355x_shard_la_contribute")
+
+    def la_pivot(self, sh, j):
+        capi.check(self.L.mi355x_shard_la_pivot(sh.handle, int(j), ctypes.c_void_p(sh.bits.data_ptr()),
+                                                ctypes.c_void_p(sh.ec.data_ptr()), self.f),
+                   "mi355x_shard_la_pivot")
+
+    def sweep(self, sh):
+        capi.check(self.L.mi355x_shard_sweep(sh.handle), "mi355x_shard_sweep")
+
     def reset(self, sh, max_pivots=0):
         capi.check(self.L.mi355x_tab_reset(sh.handle, int(max_pivots)), "mi355x_tab_reset")
 
@@ -137,13 +153,23 @@ class LocalComm:
 
 
 class ColumnPartitionedTableau:
-    """The driver: `shards` are this process's shards (one under torch.distributed)."""
+    """The driver: `shards` are this process's shards (one under torch.distributed).
 
-    def __init__(self, shards, comm, backend):
+    block > 1: blocked pivoting -- the same two exchanges per pivot, but the shards' slices of the
+    tableau are swept once per `block` pivots (<= 16) instead of updated after every pivot; the
+    pending pivots are chained through on what a step reads.  Same pivots, same bits."""
+
+    MAX_BLOCK = 16
+
+    def __init__(self, shards, comm, backend, block=1):
         self.shards, self.comm, self.backend = list(shards), comm, backend
+        self.block = max(1, min(int(block), self.MAX_BLOCK))
+        self._j = 0                                  # steps of the current block already enqueued
 
     def step(self):
         """Enqueue one pivot; no host synchronisation."""
+        if self.block > 1:
+            return self._step_blocked()
         for sh in self.shards:
             self.backend.price(sh)
         self.comm.gather(self.shards)
@@ -153,7 +179,29 @@ class ColumnPartitionedTableau:
         for sh in self.shards:
             self.backend.pivot(sh)
 
+    def _step_blocked(self):
+        j = self._j
+        for sh in self.shards:
+            self.backend.price(sh)
+        self.comm.gather(self.shards)
+        for sh in self.shards:
+            self.backend.la_contribute(sh, j)
+        self.comm.reduce(self.shards)
+        for sh in self.shards:
+            self.backend.la_pivot(sh, j)
+        self._j = j + 1
+        if self._j == self.block:
+            self.flush()
+
+    def flush(self):
+        """Apply the pending pivots of an unfinished block (no-op when there are none)."""
+        if self.block > 1 and self._j > 0:
+            for sh in self.shards:
+                self.backend.sweep(sh)
+            self._j = 0
+
     def reset(self, max_pivots=0):
+        self.flush()
         for sh in self.shards:
             self.backend.reset(sh, max_pivots)
 
@@ -164,6 +212,7 @@ class ColumnPartitionedTableau:
             self.step()
 
     def status(self):
+        self.flush()                                 # the tableau is whole whenever the host looks
         sts = [self.backend.status(sh) for sh in self.shards]
         assert all(s == sts[0] for s in sts), "shards disagree: %r" % (sts,)
         return sts[0]
@@ -266,7 +315,8 @@ def bench(args, rank, local_rank, world):
                               compact=not getattr(args, "colpart_dense", False))
     staged = world > 1 and dist.get_backend() != "nccl"          # test hook: ranks share one GPU
     comm = DistComm(dist, stage_through_host=staged) if world > 1 else LocalComm(torch)
-    tab = ColumnPartitionedTableau(shards, comm, HipBackend())
+    block = getattr(args, "colpart_block", 0) or ColumnPartitionedTableau.MAX_BLOCK
+    tab = ColumnPartitionedTableau(shards, comm, HipBackend(), block=block)
     tab.reset()
     tab.run(args.warmup)
     st, done = tab.status()
@@ -289,7 +339,7 @@ def bench(args, rank, local_rank, world):
     R, C = m + 1, n + m + 1
     value = args.steps / elapsed
     dense = getattr(args, "colpart_dense", False)
-    stored_bytes = 2.0 * R * ((n + m if dense else n) + world) * 8      # per pivot, all shards
+    stored_bytes = 2.0 * R * ((n + m if dense else n) + world) * 8 / block   # per pivot, all shards
     rec = {
         "metric": "simplex pivots/sec, one column-partitioned dense tableau",
         "value": value, "unit": "pivots/s", "n_gpus": world, "steps": args.steps,
@@ -301,7 +351,8 @@ def bench(args, rank, local_rank, world):
                                % (n, m, R, C, R * C * 8 / 1e9, world,
                                   "dense" if getattr(args, "colpart_dense", False) else "compact"),
                    "parallelism": "column partition, per-pivot all-gather(16 B/rank) + int64 "
-                                  "all-reduce(%d B) over RCCL" % (R * 8)},
+                                  "all-reduce(%d B) over RCCL; shards swept once per %d pivots"
+                                  % (R * 8, block)},
         "aggregate_GBps": stored_bytes * value / 1e9,
         "dense_equivalent_GBps": 2.0 * R * C * 8 * value / 1e9,
         "roofline": {"bound": "hbm", "achieved": stored_bytes * value / 1e9 / world,

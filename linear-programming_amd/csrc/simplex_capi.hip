@@ -1137,6 +1137,69 @@ int mi355x_shard_pivot(mi355x_tab *t, const int64_t *dev_col_bits, const int64_t
     return MI_OK;
 }
 
+// ---- blocked column shards: step j of a block, then the sweep --------------
+int mi355x_shard_la_contribute(mi355x_tab *t, int j, const double *dev_gathered, int n_shards,
+                               int64_t col_offset, double f, int64_t *dev_col_bits, int64_t *dev_ec)
+{
+    if (!t || !dev_gathered || !dev_col_bits || !dev_ec) return fail(MI_BAD_ARG, "NULL argument");
+    if (n_shards < 1 || j < 0 || j >= kMaxBlock) return fail(MI_BAD_ARG, "n_shards < 1 or step outside [0,%d)", kMaxBlock);
+    if (!t->v.blk) return fail(MI_UNSUPPORTED, "no block state on this handle");
+    int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    rc = ensure_dense(t);
+    if (rc != MI_OK) return rc;
+    launch_shard_la_contribute(t->v, j, dev_gathered, n_shards, col_offset, f, dev_col_bits, dev_ec, t->stream);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int mi355x_shard_la_pivot(mi355x_tab *t, int j, const int64_t *dev_col_bits, const int64_t *dev_ec, double f)
+{
+    if (!t || !dev_col_bits || !dev_ec) return fail(MI_BAD_ARG, "NULL argument");
+    if (j < 0 || j >= kMaxBlock) return fail(MI_BAD_ARG, "step outside [0,%d)", kMaxBlock);
+    if (!t->v.blk) return fail(MI_UNSUPPORTED, "no block state on this handle");
+    int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    rc = ensure_dense(t);
+    if (rc != MI_OK) return rc;
+    // the step prices the local objective-row slice as it will be, for the next mi355x_shard_price
+    t->n_part = launch_shard_la_prepare(t->v, j, reinterpret_cast<const double *>(dev_col_bits), dev_ec, f,
+                                        t->shard_is_max, t->stream);
+    t->part_is_max = t->shard_is_max;
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int mi355x_shard_sweep(mi355x_tab *t)
+{
+    if (!t) return fail(MI_BAD_ARG, "handle is NULL");
+    if (!t->v.blk) return fail(MI_UNSUPPORTED, "no block state on this handle");
+    int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    rc = ensure_dense(t);
+    if (rc != MI_OK) return rc;
+    const bool timed = t->timing_stride > 0 && t->n_timed < kTimingCap &&
+                       (t->update_launches++ % t->timing_stride) == 0;
+    if (timed) {
+        if ((int)t->ev0.size() <= t->n_timed) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            t->ev0.push_back(a);
+            t->ev1.push_back(b);
+        }
+        HIP_TRY(hipEventRecord(t->ev0[t->n_timed], t->stream));
+    }
+    t->n_part = launch_sweep(t->v, kMaxBlock, t->shard_is_max ? 1.0 : -1.0, t->stream);
+    t->part_is_max = t->shard_is_max;
+    if (timed) {
+        HIP_TRY(hipEventRecord(t->ev1[t->n_timed], t->stream));
+        t->n_timed++;
+    }
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
 int mi355x_shard_set_compact(mi355x_tab *t, int64_t global_var_count, const int64_t *global_cols)
 {
     if (!t || !global_cols) return fail(MI_BAD_ARG, "NULL argument");

@@ -133,6 +133,12 @@ void launch_shard_contribute(const TabView &t, const double *gathered, int n_sha
                              int64_t *ec_out, hipStream_t s);
 void launch_shard_prepare(const TabView &t, const double *col, const int64_t *ec_dev,
                           double fp_factor, hipStream_t s);
+// ... and their blocked forms: step j of a block (no update), the sweep is launch_sweep
+void launch_shard_la_contribute(const TabView &t, int j, const double *gathered, int n_shards,
+                                int64_t col_offset, double fp_factor, int64_t *bits_out,
+                                int64_t *ec_out, hipStream_t s);
+int  launch_shard_la_prepare(const TabView &t, int j, const double *col, const int64_t *ec_dev,
+                             double fp_factor, int is_max, hipStream_t s);
 // two-phase hand-over (src/simplex.lisp:437-451)
 // unit_basis: the basic columns of `art` are known to be exact unit vectors (column-parallel
 // re-elimination); otherwise the sequential form

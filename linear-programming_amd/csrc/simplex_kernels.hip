@@ -921,6 +921,142 @@ __global__ __launch_bounds__(kScaleThreads) void k_la_scale(TabView t, int n_rp,
     }
 }
 
+// ---- column shards, blocked: the per-pivot exchanges stay what they are -- one
+// 16-byte all-gather and one column all-reduce per pivot -- but the shard's slice of the tableau is
+// swept once per block.  Step j of a block on every shard: price (k_price_only, from the partials
+// the previous step left) -> exchange -> k_shard_la_contribute -> exchange -> k_shard_la_prepare;
+// after the last step k_sweep.  The chain of the pending pivots needs col_i (every shard has the
+// whole exchanged column), prow_i on the shard's own columns and on its RHS copy (local), and the
+// pivot rows (identical everywhere), so it needs no exchange of its own.
+__global__ __launch_bounds__(kSelThreads) void k_shard_la_contribute(TabView t, int j, const double *gathered,
+                                                                    int n_shards, int64_t col_offset,
+                                                                    double price_tol, long long *bits_out,
+                                                                    int64_t *ec_out)
+{
+    const bool running = t.ctl->status == kRunning;
+    BlockCtl *blk = t.blk;
+    const int64_t ldv = t.ld >> 1, vcl = t.cols - 1;
+    const int64_t gid = blockIdx.x * (int64_t)kSelThreads + threadIdx.x, gsz = (int64_t)gridDim.x * kSelThreads;
+    if (j == 0) {                                   // a new block starts (whatever the status)
+        if (gid == 0) blk->n_pending = 0;
+        const int64_t n = t.bk_stride > ldv ? t.bk_stride : ldv;
+        for (int64_t idx = gid; idx < n; idx += gsz) {
+            if (idx < t.bk_stride) t.bk_rmask[idx] = 0u;
+            if (idx < ldv)         t.bk_smask[idx] = 0u;
+        }
+    }
+    ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
+    for (int k = 0; k < n_shards; ++k) {
+        ValIdx c; c.v = gathered[2 * k]; c.i = (int64_t)gathered[2 * k + 1]; c.s = 0;
+        best = vi_min(best, c);
+    }
+    const int64_t ec = (running && best.i >= 0 && best.v < 0.0 - price_tol) ? best.i : -1;
+    const int64_t lc = ec < 0 ? -1 : (t.l2p ? t.l2p[ec] : ec - col_offset);
+    const bool mine = ec >= 0 && lc >= 0 && lc < vcl;
+    for (int64_t r = gid; r < t.rows; r += gsz) {
+        double a = mine ? t.M[r * t.ld + lc] : 0.0;
+        double b = ec >= 0 ? t.M[r * t.ld + vcl] : 0.0;
+        if (ec >= 0) {
+            for (int i = 0; i < j; ++i) {
+                const bool   is_cr = r == blk->cr[i];
+                const double ci = t.bk_col[(int64_t)i * t.bk_stride + r];
+                if (mine) a = pend(a, lc == blk->slot[i], is_cr, ci, t.bk_prow[(int64_t)i * t.ld + lc]);
+                b = pend(b, false, is_cr, ci, t.bk_prow[(int64_t)i * t.ld + vcl]);
+            }
+            t.rhs[r] = b;
+        }
+        bits_out[r] = mine ? __double_as_longlong(a) : 0ll;
+    }
+    if (gid == 0) *ec_out = ec;
+}
+
+__global__ __launch_bounds__(kSelThreads) void k_shard_la_prepare(TabView t, int j, const double *col_src,
+                                                                 const int64_t *ec_dev, double ratio_thr,
+                                                                 double sgn)
+{
+    __shared__ double    s_v[kSelWaves];
+    __shared__ long long s_i[kSelWaves];
+    Ctl *ctl = t.ctl;
+    const Ctl c0 = *ctl;
+    BlockCtl *blk = t.blk;
+    if (c0.status != kRunning) return;
+    const int64_t global_ec = *ec_dev;
+    if (global_ec < 0) {
+        if (threadIdx.x == 0) ctl->status = 0;      // MI_OPTIMAL
+        return;
+    }
+    if (c0.max_pivots > 0 && c0.n_pivots >= c0.max_pivots) {
+        if (threadIdx.x == 0) ctl->status = 3;      // MI_MAX_PIVOTS
+        return;
+    }
+    int bad = 0;
+    const ValIdx q = block_gather_ratio(t, 0, col_src, ratio_thr, s_v, s_i, t.rhs, &bad);
+    if (t.p2l && __syncthreads_or(bad)) {           // compact shard: cannot follow the reference
+        if (threadIdx.x == 0) ctl->status = 6;      // MI_NONFINITE
+        return;
+    }
+    if (q.i < 0) {
+        if (threadIdx.x == 0) ctl->status = 1;      // MI_UNBOUNDED
+        return;
+    }
+    const int64_t cr = q.i, m = t.rows - 1, vcl = t.cols - 1, ldv = t.ld >> 1;
+    const double piv = col_src[cr];
+    const int64_t slot = t.p2l ? t.l2p[global_ec] : -1;   // compact owner: the slot the leaving column takes
+    for (int64_t r = threadIdx.x; r < t.rows; r += kSelThreads)
+        t.bk_col[(int64_t)j * t.bk_stride + r] = col_src[r];
+    const double cmj = col_src[m];
+    const double2 *M2 = reinterpret_cast<const double2 *>(t.M);
+    double2 *P2 = reinterpret_cast<double2 *>(t.bk_prow);
+    ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
+    int64_t leaving = -1;
+    if (slot >= 0) leaving = t.basis[cr];           // (read by everyone before thread 0 overwrites it below)
+    __syncthreads();
+    for (int64_t p = threadIdx.x; p < ldv; p += kSelThreads) {
+        double2 y = M2[cr * ldv + p], z = M2[m * ldv + p];
+        for (int i = 0; i < j; ++i) {
+            const int64_t cri = blk->cr[i], sli = blk->slot[i];
+            const double  ccr = t.bk_col[(int64_t)i * t.bk_stride + cr], cm = t.bk_col[(int64_t)i * t.bk_stride + m];
+            const double2 pi = P2[(int64_t)i * ldv + p];
+            y.x = pend(y.x, 2 * p     == sli, cr == cri, ccr, pi.x);
+            y.y = pend(y.y, 2 * p + 1 == sli, cr == cri, ccr, pi.y);
+            z.x = pend(z.x, 2 * p     == sli, false, cm, pi.x);
+            z.y = pend(z.y, 2 * p + 1 == sli, false, cm, pi.y);
+        }
+        const double2 pr = scale_pair(t, p, y, piv, slot);
+        P2[(int64_t)j * ldv + p] = pr;
+        z.x = pend(z.x, 2 * p     == slot, false, cmj, pr.x);
+        z.y = pend(z.y, 2 * p + 1 == slot, false, cmj, pr.y);
+        const int64_t c0i = 2 * p;
+        if (c0i < vcl) {
+            ValIdx c; c.v = z.x * sgn; c.i = (c0i == slot) ? leaving : (t.p2l ? t.p2l[c0i] : c0i); c.s = c0i;
+            best = vi_min(best, c);
+        }
+        if (c0i + 1 < vcl) {
+            ValIdx c; c.v = z.y * sgn; c.i = (c0i + 1 == slot) ? leaving : (t.p2l ? t.p2l[c0i + 1] : c0i + 1); c.s = c0i + 1;
+            best = vi_min(best, c);
+        }
+    }
+    best = wave_reduce_min(best);                    // per-wave pricing partials for the next step
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        t.part_v[w] = best.v;
+        t.part_i[w] = best.i;
+        t.part_s[w] = best.s;
+    }
+    __syncthreads();                                 // every p2l read above precedes the swap
+    if (threadIdx.x == 0) {
+        if (slot >= 0) {
+            swap_columns(t, global_ec, cr, slot);
+            t.bk_smask[slot >> 1] |= 1u << (j + 16 * (int)(slot & 1));
+        }
+        record_pivot(t, c0, global_ec, cr);          // basis holds GLOBAL column indices
+        blk->cr[j] = cr;
+        blk->slot[j] = slot;
+        blk->n_pending = j + 1;
+        t.bk_rmask[cr] |= 1u << j;
+    }
+}
+
 // ---- the look-ahead of a whole block as ONE launch ------------------------------------------
 // Two launches per look-ahead step are two kernel boundaries (2.5 us each) plus cold caches at
 // every start.  For tableaux whose rows and column pairs fit a few workgroups (config 3: 17 x 256
@@ -1882,6 +2018,22 @@ void launch_shard_prepare(const TabView &t, const double *col, const int64_t *ec
 {
     hipLaunchKernelGGL(k_shard_prepare, dim3(1), dim3(kSelThreads), 0, s, t, col, ec_dev,
                        0.0 + (f / 2.0) * kClEpsilon);
+}
+void launch_shard_la_contribute(const TabView &t, int j, const double *gathered, int n_shards,
+                                int64_t col_offset, double f, int64_t *bits_out, int64_t *ec_out,
+                                hipStream_t s)
+{
+    int blocks = (int)((t.rows + kSelThreads - 1) / kSelThreads);
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(k_shard_la_contribute, dim3(blocks), dim3(kSelThreads), 0, s, t, j, gathered,
+                       n_shards, col_offset, (f / 8.0) * kClEpsilon, (long long *)bits_out, ec_out);
+}
+int launch_shard_la_prepare(const TabView &t, int j, const double *col, const int64_t *ec_dev, double f,
+                            int is_max, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_shard_la_prepare, dim3(1), dim3(kSelThreads), 0, s, t, j, col, ec_dev,
+                       0.0 + (f / 2.0) * kClEpsilon, sgn_of(is_max));
+    return kSelWaves;                                // pricing partials left for the next step
 }
 void launch_handover(const TabView &art, const TabView &mt, bool unit_basis, hipStream_t s)
 {

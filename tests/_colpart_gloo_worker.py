@@ -15,6 +15,7 @@ from tests.helpers import lp_amd  # noqa: E402
 def main():
     out_dir, n, m, seed = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     max_pivots = int(sys.argv[5])
+    block = int(sys.argv[6]) if len(sys.argv) > 6 else 1
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     lp = lp_amd()
@@ -24,7 +25,7 @@ def main():
     b, e = cp.partition(n + m, world)[rank]
     local = np.concatenate([M[:, b:e], M[:, -1:]], axis=1)
     sh = cp.Shard(torch, FakeHandle(local, basis), b, e, m + 1, world, torch.device("cpu"))
-    tab = cp.ColumnPartitionedTableau([sh], cp.DistComm(dist), OracleShardBackend())
+    tab = cp.ColumnPartitionedTableau([sh], cp.DistComm(dist), OracleShardBackend(), block=block)
     st, npiv = tab.solve(max_pivots=max_pivots, check_every=16)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), M=sh.handle.M, basis=sh.handle.basis,
              trace=np.array(sh.handle.trace, dtype=np.int64).reshape(-1, 2), status=st, npiv=npiv,

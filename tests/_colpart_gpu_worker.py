@@ -20,7 +20,9 @@ def main():
     cp = __import__("importlib").import_module("linear-programming_amd.colpart")
     compact = len(sys.argv) > 6 and sys.argv[6] == "compact"
     shards = cp.synthetic_shards(torch, n, m, seed, [rank], world, 0, compact=compact)
-    tab = cp.ColumnPartitionedTableau(shards, cp.DistComm(dist, stage_through_host=True), cp.HipBackend())
+    # multi-process runs use the blocked form (the default of bench.py --workload colpart)
+    tab = cp.ColumnPartitionedTableau(shards, cp.DistComm(dist, stage_through_host=True), cp.HipBackend(),
+                                      block=16)
     st, npiv = tab.solve(max_pivots=max_pivots, check_every=8)
     M, b = cp.download_shard(shards[0])
     cols = cp.shard_columns(shards[0]) if compact else np.arange(shards[0].col_begin, shards[0].col_end)

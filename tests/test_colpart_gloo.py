@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _run(world, n, m, seed, max_pivots, tmp_path):
+def _run(world, n, m, seed, max_pivots, tmp_path, block=1):
     port = _free_port()
     procs = []
     for r in range(world):
@@ -31,16 +31,19 @@ def _run(world, n, m, seed, max_pivots, tmp_path):
                    MASTER_PORT=str(port), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen(
             [sys.executable, os.path.join(ROOT, "tests", "_colpart_gloo_worker.py"), str(tmp_path),
-             str(n), str(m), str(seed), str(max_pivots)], env=env, cwd=ROOT))
+             str(n), str(m), str(seed), str(max_pivots), str(block)], env=env, cwd=ROOT))
     for p in procs:
         assert p.wait(timeout=240) == 0
     return [np.load(os.path.join(tmp_path, "rank%d.npz" % r)) for r in range(world)]
 
 
+@pytest.mark.parametrize("block", [1, 5, 16], ids=["per-pivot", "blocks-of-5", "blocks-of-16"])
 @pytest.mark.parametrize("world,n,m,max_pivots", [(2, 40, 24, 0), (3, 50, 31, 0), (2, 64, 32, 9)])
-def test_column_partition_protocol_matches_oracle(world, n, m, max_pivots, tmp_path):
+def test_column_partition_protocol_matches_oracle(world, n, m, max_pivots, block, tmp_path):
+    """Per-pivot updates and the blocked form (same exchanges, the shards swept once per block,
+    pending pivots chained through on what a step reads; a cap that ends inside a block)."""
     seed = lp.synth.seed_for(5, world)
-    res = _run(world, n, m, seed, max_pivots, tmp_path)
+    res = _run(world, n, m, seed, max_pivots, tmp_path, block)
     M, b = lp.synth.tableau(n, m, seed)
     st, npiv, trace = oracle.solve(M, b, max_pivots=max_pivots, trace_cap=4096)
     got = np.concatenate([r["M"][:, :-1] for r in res], axis=1)

@@ -825,7 +825,7 @@ def test_compact_shards_report_nonfinite_columns():
         lp.capi.check(lp.capi.lib().mi355x_shard_set_compact(h, n + m, cols.ctypes.data_as(ctypes.c_void_p)),
                       "compact")
         shards.append(cp.Shard(torch, h, b, e, m + 1, 2, torch.device("cuda", 0)))
-    tab = cp.ColumnPartitionedTableau(shards, cp.LocalComm(torch), cp.HipBackend())
+    tab = cp.ColumnPartitionedTableau(shards, cp.LocalComm(torch), cp.HipBackend(), block=8)
     st, npiv = tab.solve(check_every=4)
     assert (st, npiv) == (lp.capi.MI_NONFINITE, 0)
     cp.destroy_shards(shards)
@@ -834,17 +834,19 @@ def test_compact_shards_report_nonfinite_columns():
 # =========================================================================== column partition (config 5)
 @pytest.mark.parametrize("compact", [False, True], ids=["dense-shards", "compact-shards"])
 @pytest.mark.parametrize("n_shards,n,m", [(1, 60, 40), (2, 96, 64), (3, 100, 50), (8, 512, 256)])
-def test_column_partition_logical_shards_bitwise(n_shards, n, m, compact):
+@pytest.mark.parametrize("block", [1, 7, 16], ids=["per-pivot", "blocks-of-7", "blocks-of-16"])
+def test_column_partition_logical_shards_bitwise(n_shards, n, m, compact, block):
     """One tableau as N column shards on ONE device (exchanges = local tensor ops with the
     collectives' semantics): same pivot sequence and same bits as the unpartitioned solve, with
     shards that hold fixed blocks of all columns and with compact shards (non-basic columns
-    only, slots handed over at every pivot)."""
+    only, slots handed over at every pivot); updated after every pivot, or blocked (the same
+    exchanges, every shard swept once per block, the solve ending inside a block)."""
     import importlib
     import torch
     cp = importlib.import_module("linear-programming_amd.colpart")
     seed = lp.synth.seed_for(5, n_shards)
     shards = cp.synthetic_shards(torch, n, m, seed, list(range(n_shards)), n_shards, 0, compact=compact)
-    tab = cp.ColumnPartitionedTableau(shards, cp.LocalComm(torch), cp.HipBackend())
+    tab = cp.ColumnPartitionedTableau(shards, cp.LocalComm(torch), cp.HipBackend(), block=block)
     st, npiv = tab.solve(check_every=32)
     M, b = lp.synth.tableau(n, m, seed)
     so, no, trace = oracle.solve(M, b, trace_cap=1 << 16)
@@ -952,13 +954,14 @@ def test_config5_full_size_dense_and_compact_shards_agree():
     assert len(set(e0.tolist())) == K and (e0 < n).all()      # structural columns entered
 
 
-def test_column_partition_pivot_cap_and_unbounded():
+@pytest.mark.parametrize("block", [1, 4, 16])
+def test_column_partition_pivot_cap_and_unbounded(block):
     import importlib
     import torch
     cp = importlib.import_module("linear-programming_amd.colpart")
     n, m, seed = 80, 40, lp.synth.seed_for(5, 99)
     shards = cp.synthetic_shards(torch, n, m, seed, [0, 1, 2], 3, 0)
-    tab = cp.ColumnPartitionedTableau(shards, cp.LocalComm(torch), cp.HipBackend())
+    tab = cp.ColumnPartitionedTableau(shards, cp.LocalComm(torch), cp.HipBackend(), block=block)
     st, npiv = tab.solve(max_pivots=11, check_every=4)
     assert (st, npiv) == (lp.capi.MI_MAX_PIVOTS, 11)
     M, b = lp.synth.tableau(n, m, seed)
