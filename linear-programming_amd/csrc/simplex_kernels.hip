@@ -37,10 +37,25 @@
 // reduction is an exact comparison on (value, index) pairs, so results are bit-identical to the
 // reference algorithm for any parallel schedule.
 //
+// That is the PER-PIVOT form (dense fall-back, step-wise entry points, lockstep batches).  The
+// solve loops themselves run BLOCKED (section "blocked pivoting" below): up to 16 pivots are
+// selected ahead of the tableau -- the objective row, one column, the RHS column and one row are
+// evaluated as they WOULD be after the pending pivots -- and then applied to every stored element
+// in one pass, with the same operands and roundings as 16 k_update launches:
+//     k_la_block                         the look-ahead of a whole block as ONE launch of <= 32
+//                                        persistent workgroups that exchange their reduction
+//                                        candidates through memory (release/acquire records)
+//     k_la_gather<j> + k_la_scale<j>     the same as two launches per step (tableaux too large
+//                                        for the persistent form)
+//     k_sweep                            applies the pending pivots (col values in SGPRs, prow in
+//                                        registers: 2 v_mul_f64 + 2 v_add_f64 per pair and pivot)
+//     k_batch_block                      all of it inside one workgroup per LP of a batch (LDS)
+//     k_shard_la_contribute/_la_prepare  the look-ahead step of a column shard (the two
+//                                        exchanges per pivot are the per-pivot path's)
+//
 // Further down: the compact representation [non-basic columns | RHS] the solve loops run on
-// (basic columns never change under a pivot), k_batch_solve (one workgroup per LP of a batch),
-// the column-shard steps for one tableau partitioned over several GPUs, the two-phase
-// hand-over, and the synthetic-LP generator.
+// (basic columns never change under a pivot), the per-pivot batch kernel k_batch_solve, the
+// per-pivot column-shard steps, the two-phase hand-over, and the synthetic-LP generator.
 #include "simplex_kernels.h"
 #include <type_traits>
 
