@@ -1391,17 +1391,17 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(TabView t, const int tr, const 
             const uint4 rm = *reinterpret_cast<const uint4 *>(t.bk_rmask + r);   // uniform
             const unsigned rmu[U] = { rm.x, rm.y, rm.z, rm.w };
             const unsigned general = wm | rm.x | rm.y | rm.z | rm.w;   // bit i: pivot i needs pend()
-            constexpr unsigned full = KMAX >= 32 ? 0xffffffffu : ((1u << KMAX) - 1u);
-            if (pending == full && general == 0u) {
-                // the common case, straight-line: every link the bare chain, the col values of
-                // CHF pivots loaded per scalar round trip
-                constexpr int CHF = KMAX < 8 ? KMAX : 8;
 #pragma unroll
-                for (int c0 = 0; c0 < KMAX; c0 += CHF) {
-                    v8i cq[CHF];
-                    sload_chunk<CHF>(cq, t.bk_col + (int64_t)c0 * t.bk_stride + r, off);
+            for (int c0 = 0; c0 < KMAX; c0 += CH) {
+                constexpr unsigned cmask = (1u << CH) - 1u;
+                const unsigned pend_c = (pending >> c0) & cmask;       // pending pivots of this chunk
+                if (pend_c == 0u) continue;
+                v8i cq[CH];
+                sload_chunk<CH>(cq, t.bk_col + (int64_t)c0 * t.bk_stride + r, off);
+                if (pend_c == cmask && ((general >> c0) & cmask) == 0u) {
+                    // the common case: CH links of the bare chain
 #pragma unroll
-                    for (int i = 0; i < CHF; ++i) {
+                    for (int i = 0; i < CH; ++i) {
                         const v4d cv = __builtin_bit_cast(v4d, cq[i]);
                         const vec2d pi = p[c0 + i];
 #pragma unroll
@@ -1412,17 +1412,9 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(TabView t, const int tr, const 
                             x[u].y = x[u].y - m1;
                         }
                     }
-                }
-            } else {
-                // a partial last block, a pivot row in this step, or a slot column in this wave:
-                // per link, the bare chain or its general form
-#pragma unroll
-                for (int c0 = 0; c0 < KMAX; c0 += CH) {
-                    constexpr unsigned cmask = (1u << CH) - 1u;
-                    const unsigned pend_c = (pending >> c0) & cmask;
-                    if (pend_c == 0u) continue;
-                    v8i cq[CH];
-                    sload_chunk<CH>(cq, t.bk_col + (int64_t)c0 * t.bk_stride + r, off);
+                } else {
+                    // a partial chunk (last block of a solve), a pivot row in this step, or a
+                    // slot column in this wave: the general form of every link
 #pragma unroll
                     for (int i = 0; i < CH; ++i) {
                         if ((pend_c >> i) & 1u) {
