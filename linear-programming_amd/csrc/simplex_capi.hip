@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
 #include <new>
 #include <string>
@@ -54,6 +55,12 @@ constexpr int     kTimingCap  = 4096;
 constexpr int64_t kLdAlign    = 16;       // doubles: rows start on 128-byte boundaries
 constexpr int     kPartCap    = 16384;    // single tableau: 8192 pricing + 8192 ratio partials
 constexpr int     kBatchPartCap = 512;    // per LP of a batch
+
+// debugging aid (MI355X_POISON_ALLOC=1): buffers that are supposed to be written before they are
+// read are filled with 0xFF bytes (NaN doubles, -1 indices) instead of being left as allocated,
+// so that a read of never-written memory shows up deterministically
+bool poison_allocations() { static const bool on = getenv("MI355X_POISON_ALLOC") != nullptr; return on; }
+void poison(void *p, size_t bytes, hipStream_t s) { if (p && poison_allocations()) (void)hipMemsetAsync(p, 0xff, bytes, s); }
 
 int g_ld_extra = 0;                       // tuning hook: extra padding (doubles) per row
 int64_t padded_ld(int64_t cols) { return (cols + kLdAlign - 1) / kLdAlign * kLdAlign + g_ld_extra; }
@@ -214,6 +221,12 @@ int alloc_tab(mi355x_tab **out, int64_t rows, int64_t cols, int device, int64_t 
     }
     t->stream = t->own_stream;
     memset(t->h_ctl, 0, n_lps * sizeof(Ctl));
+    poison(t->v.M, t->v.M ? mbytes : 0, t->stream);
+    poison(t->v.col, n_lps * rows * sizeof(double), t->stream);
+    poison(t->v.prow, n_lps * t->v.ld * sizeof(double), t->stream);
+    poison(t->v.rhs, rows * sizeof(double), t->stream);
+    poison(t->v.trace_ec, kTraceCap * sizeof(int64_t), t->stream);
+    poison(t->v.trace_cr, kTraceCap * sizeof(int64_t), t->stream);
     // pricing / ratio partials are read by launches that may follow a no-op launch: defined contents
     if ((e = hipMemsetAsync(t->v.part_v, 0, n_lps * part_cap * sizeof(double), t->stream)) != hipSuccess ||
         (e = hipMemsetAsync(t->v.part_i, 0xff, n_lps * part_cap * sizeof(int64_t), t->stream)) != hipSuccess ||
@@ -325,7 +338,10 @@ int ensure_compact(mi355x_tab *t)
         if (nl > 1) { t->c.zs_M = v.rows * t->c.ld; t->c.zs_p2l = n_nb; t->c.zs_l2p = vc; }
     }
     // allocate whatever is still missing (a failed attempt must not leave a half-built view)
-    if (!t->c.M)   HIP_TRY(hipMalloc((void **)&t->c.M, (size_t)nl * v.rows * t->c.ld * sizeof(double)));
+    if (!t->c.M) {
+        HIP_TRY(hipMalloc((void **)&t->c.M, (size_t)nl * v.rows * t->c.ld * sizeof(double)));
+        poison(t->c.M, (size_t)nl * v.rows * t->c.ld * sizeof(double), t->stream);
+    }
     if (!t->c.p2l) HIP_TRY(hipMalloc((void **)&t->c.p2l, nl * n_nb * sizeof(int64_t)));
     if (!t->c.l2p) HIP_TRY(hipMalloc((void **)&t->c.l2p, nl * vc * sizeof(int64_t)));
     if (!t->brow)  HIP_TRY(hipMalloc((void **)&t->brow, nl * vc * sizeof(int64_t)));

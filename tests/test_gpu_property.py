@@ -64,7 +64,12 @@ def test_random_lps_bitwise(n, m, seed, kind, density, degenerate, select_mode, 
         L.mi355x_tune_set_block(16)
         L.mi355x_tune_set_lookahead_mode(0)
     assert rc == st_o and k.value == npiv
-    assert np.array_equal(t.pivot_trace(), trace)
+    got = t.pivot_trace()
+    if not np.array_equal(got, trace):              # say where, for the report
+        d = np.where((got != trace[:len(got)]).any(axis=1))[0] if len(got) <= len(trace) else []
+        raise AssertionError("pivot trace differs from the oracle's at pivot(s) %s: got %s, expected %s"
+                             % (list(d[:4]), got[d[:4]].tolist() if len(d) else got.shape,
+                                trace[d[:4]].tolist() if len(d) else trace.shape))
     assert np.array_equal(t.matrix.view(np.int64), M.view(np.int64))      # bits, incl. signed zeros
     assert np.array_equal(t.basis_columns, b)
 
@@ -120,7 +125,13 @@ def test_extreme_magnitudes_bitwise(n, m, seed, lo, hi):
     rc = lp.capi.lib().mi355x_tab_solve(t._h, 1, 1024.0, 60, ctypes.byref(k))
     t._touch()
     G = t.matrix
-    assert rc == st_o and k.value == npiv and np.array_equal(t.pivot_trace(), trace)
+    got = t.pivot_trace()
+    if not np.array_equal(got, trace):              # say where, for the report
+        d = np.where((got != trace[:len(got)]).any(axis=1))[0] if len(got) <= len(trace) else []
+        raise AssertionError("pivot trace differs from the oracle's at pivot(s) %s: got %s, expected %s"
+                             % (list(d[:4]), got[d[:4]].tolist() if len(d) else got.shape,
+                                trace[d[:4]].tolist() if len(d) else trace.shape))
+    assert rc == st_o and k.value == npiv
     nan_o, nan_g = np.isnan(M), np.isnan(G)
     assert np.array_equal(nan_o, nan_g)
     assert np.array_equal(G[~nan_g].view(np.int64), M[~nan_o].view(np.int64))
