@@ -325,6 +325,23 @@ def test_blocked_pivoting_bitwise_vs_oracle(n, m, seed, block_size, lookahead_mo
         L.mi355x_tune_set_select_mode(0)
 
 
+@pytest.mark.parametrize("n,m,cap", [(2600, 2300, 200), (4000, 4000, 100)])
+def test_blocked_pivoting_many_lookahead_workgroups_bitwise(n, m, cap):
+    """The persistent look-ahead with 9 and 16 workgroups exchanging their candidates (the small
+    parity shapes need 1-5): the first pivots (ending inside a block), bit for bit against the
+    OpenMP oracle."""
+    M0, b0 = lp.synth.tableau(n, m, lp.synth.seed_for(9, 77))
+    M, b = M0.copy(), b0.copy()
+    st, npiv, trace = oracle.solve(M, b, max_pivots=cap, trace_cap=1 << 16, omp=True)
+    t = lp.Tableau(None, lp.Problem(type="max"), M0, b0, n + m, m, {})
+    k = ctypes.c_int64(0)
+    rc = lp.capi.lib().mi355x_tab_solve(t._h, 1, 1024.0, cap, ctypes.byref(k))
+    t._touch()
+    assert (rc, k.value) == (st, npiv)
+    assert np.array_equal(t.pivot_trace(), trace)
+    assert np.array_equal(t.matrix, M) and np.array_equal(t.basis_columns, b)
+
+
 def _layout(t):
     c, cols, ld = ctypes.c_int(0), ctypes.c_int64(0), ctypes.c_int64(0)
     lp.capi.check(lp.capi.lib().mi355x_tab_layout(t._h, ctypes.byref(c), ctypes.byref(cols),
