@@ -20,6 +20,16 @@ def pytest_sessionstart(session):
         __graft_entry__.build()
     except Exception as e:                               # noqa: BLE001
         print("warning: build() failed before the test session: %r" % (e,))
+    # GPU session: bring torch (used by the column-partition tests for device buffers and
+    # torch.distributed) in NOW.  Imported for the first time two hundred GPU tests into the
+    # process it crashed inside its own import once in eight runs of the suite (segmentation fault
+    # in `import torch`, nothing of this package on the stack); at start-up it never has.
+    mexpr = session.config.getoption("markexpr", "") or ""
+    if "gpu" in mexpr and "not gpu" not in mexpr:
+        try:
+            import torch  # noqa: F401
+        except Exception as e:                           # noqa: BLE001
+            print("warning: torch is not importable: %r" % (e,))
 
 
 @pytest.fixture(scope="session")
