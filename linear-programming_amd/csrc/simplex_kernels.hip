@@ -1625,7 +1625,6 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_block(TabView t, double sg
     unsigned  *s_rm   = reinterpret_cast<unsigned *>(s_p2l + ld);  // rp: row -> pending pivots whose row it is
     unsigned  *s_sm   = s_rm + rp;                             // ldv: pair -> pending pivots whose slot it holds
     vec2d *M2 = reinterpret_cast<vec2d *>(t.M);
-    const int64_t total = rows * ldv;
 
     for (int64_t c = tid; c < ld; c += kLpThreads) {
         s_z[c] = t.M[m * ld + c];
@@ -1707,42 +1706,71 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_block(TabView t, double sg
             k = J + 1;
             __syncthreads();
         }
-        // ---- the sweep: the k pending pivots applied to every stored element
+        // ---- the sweep: the k pending pivots applied to every stored element.  Full strips of
+        // 256 column pairs: a thread owns one pair (its prow entries of the pending pivots in
+        // registers) and every fourth row; the row's col values come out of LDS as broadcasts.
+        // The pairs left over beyond the last full strip: flat, operands from LDS.
         if (k > 0) {
-            for (int64_t base = 0; base < total; base += (int64_t)kLpUnroll * kLpThreads) {
-                vec2d x[kLpUnroll];
+            constexpr int kSU = KB >= 16 ? 2 : 4;                  // rows in flight per thread (128 VGPRs at most)
+            const int pp = tid & 255, rq = tid >> 8;               // pair within the strip, row phase
+            const int64_t full = ldv & ~(int64_t)255;
+            for (int64_t s0 = 0; s0 < full; s0 += 256) {
+                const int64_t p = s0 + pp;
+                double2 pr[KB];
 #pragma unroll
-                for (int u = 0; u < kLpUnroll; ++u) {
-                    const int64_t idx = base + (int64_t)u * kLpThreads + tid;
-                    if (idx < total) x[u] = M2[idx];
-                }
+                for (int i = 0; i < KB; ++i)
+                    pr[i] = reinterpret_cast<const double2 *>(s_prow + (int64_t)i * ld)[p];
+                const unsigned sm = s_sm[p];
+                for (int64_t r = rq; r < rows; r += 4 * kSU) {
+                    vec2d x[kSU];
 #pragma unroll
-                for (int u = 0; u < kLpUnroll; ++u) {
-                    const int64_t idx = base + (int64_t)u * kLpThreads + tid;
-                    if (idx < total) {
-                        const int64_t r = idx / ldv, p = idx - r * ldv;
-                        const unsigned rm = s_rm[r], sm = s_sm[p];
-                        vec2d v = x[u];
-                        if ((rm | sm) == 0u) {                 // the bare chain
-                            for (int i = 0; i < k; ++i) {
-                                const double  s = s_col[(int64_t)i * rp + r];
-                                const double2 pi = reinterpret_cast<const double2 *>(s_prow + (int64_t)i * ld)[p];
-                                const double m0 = s * pi.x, m1 = s * pi.y;
-                                v.x = v.x - m0;
-                                v.y = v.y - m1;
+                    for (int u = 0; u < kSU; ++u)
+                        if (r + 4 * u < rows) x[u] = M2[(r + 4 * u) * ldv + p];
+#pragma unroll
+                    for (int u = 0; u < kSU; ++u) {
+                        const int64_t rr = r + 4 * u;
+                        if (rr < rows) {
+                            const unsigned rm = s_rm[rr];
+                            vec2d v = x[u];
+                            if ((rm | sm) == 0u) {             // the bare chain
+#pragma unroll
+                                for (int i = 0; i < KB; ++i) {
+                                    if (i < k) {
+                                        const double s = s_col[(int64_t)i * rp + rr];
+                                        const double m0 = s * pr[i].x, m1 = s * pr[i].y;
+                                        v.x = v.x - m0;
+                                        v.y = v.y - m1;
+                                    }
+                                }
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < KB; ++i) {
+                                    if (i < k) {
+                                        const double s = s_col[(int64_t)i * rp + rr];
+                                        const bool is_cr = (rm >> i) & 1u;
+                                        v.x = pend(v.x, (sm >> i) & 1u, is_cr, s, pr[i].x);
+                                        v.y = pend(v.y, (sm >> (i + 16)) & 1u, is_cr, s, pr[i].y);
+                                    }
+                                }
                             }
-                        } else {
-                            for (int i = 0; i < k; ++i) {
-                                const double  s = s_col[(int64_t)i * rp + r];
-                                const double2 pi = reinterpret_cast<const double2 *>(s_prow + (int64_t)i * ld)[p];
-                                const bool is_cr = (rm >> i) & 1u;
-                                v.x = pend(v.x, (sm >> i) & 1u, is_cr, s, pi.x);
-                                v.y = pend(v.y, (sm >> (i + 16)) & 1u, is_cr, s, pi.y);
-                            }
+                            M2[rr * ldv + p] = v;
                         }
-                        M2[idx] = v;
                     }
                 }
+            }
+            const int64_t rem = ldv - full, total_rem = rows * rem;   // < 256 pairs per row
+            for (int64_t idx = tid; idx < total_rem; idx += kLpThreads) {
+                const int64_t r = idx / rem, p = full + (idx - r * rem);
+                const unsigned rm = s_rm[r], sm = s_sm[p];
+                vec2d v = M2[r * ldv + p];
+                for (int i = 0; i < k; ++i) {
+                    const double  s = s_col[(int64_t)i * rp + r];
+                    const double2 pi = reinterpret_cast<const double2 *>(s_prow + (int64_t)i * ld)[p];
+                    const bool is_cr = (rm >> i) & 1u;
+                    v.x = pend(v.x, (sm >> i) & 1u, is_cr, s, pi.x);
+                    v.y = pend(v.y, (sm >> (i + 16)) & 1u, is_cr, s, pi.y);
+                }
+                M2[r * ldv + p] = v;
             }
             __syncthreads();                                   // tableau consistent before the next block reads it
         }
@@ -2091,8 +2119,8 @@ static bool launch_batch_block_t(const TabView &t, int is_max, double f, hipStre
 bool launch_batch_solve(const TabView &t, int is_max, double f, hipStream_t s)
 {
     // blocked (compact representation), largest block that fits the LDS.  Measured at 257 x 513,
-    // steady state (tools/batch_blocks.py): 128 LPs 2.0 M pivots/s per-pivot, 2.55 M at 4, 2.85 M
-    // at 8, 2.93 M at 16; 1024 LPs 2.5 M per-pivot, 4.55 M at 4, 5.94 M at 8, 6.67 M at 16
+    // steady state (tools/batch_blocks.py): 128 LPs 2.0 M pivots/s per-pivot, 3.36 M at 8, 3.44 M
+    // at 16; 1024 LPs 2.5 M per-pivot, 7.3 M at 8, 7.9 M at 16
     int kb = g_batch_block;
     if (kb == 0) kb = 16;
     if (t.p2l && kb > 1 && t.rows >= 2 && (t.ld >> 1) >= 1) {
