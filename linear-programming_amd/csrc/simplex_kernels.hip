@@ -1602,13 +1602,17 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_solve(TabView t, double sg
 // (col_i, prow_i), the running objective row, RHS column and column map live in LDS, a look-ahead
 // step is two memory round trips (one strided column, one row) and two workgroup reductions, and
 // the tableau itself is read and written once per KB pivots.
+// 512 threads: the look-ahead never has more than a few hundred elements to spread, and the sweep
+// wants 256 VGPRs per thread (16 prow pairs + four rows in flight; at 1024 threads it spilled).
+constexpr int kBbThreads = 512, kRowPhases = kBbThreads / 256;
+
 template <int KB>
-__global__ __launch_bounds__(kLpThreads) void k_batch_block(TabView t, double sgn, double price_tol,
+__global__ __launch_bounds__(kBbThreads) void k_batch_block(TabView t, double sgn, double price_tol,
                                                            double ratio_thr)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    __shared__ double    s_v[kLpThreads / 64];
-    __shared__ long long s_i[kLpThreads / 64];
+    __shared__ double    s_v[kBbThreads / 64];
+    __shared__ long long s_i[kBbThreads / 64];
     __shared__ long long s_cr[KB], s_sl[KB];
     t = lp_slice(t);
     Ctl *ctl = t.ctl;
@@ -1626,34 +1630,34 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_block(TabView t, double sg
     unsigned  *s_sm   = s_rm + rp;                             // ldv: pair -> pending pivots whose slot it holds
     vec2d *M2 = reinterpret_cast<vec2d *>(t.M);
 
-    for (int64_t c = tid; c < ld; c += kLpThreads) {
+    for (int64_t c = tid; c < ld; c += kBbThreads) {
         s_z[c] = t.M[m * ld + c];
         s_p2l[c] = c < vc ? t.p2l[c] : -1;
     }
-    for (int64_t r = tid; r < rows; r += kLpThreads) s_b[r] = t.M[r * ld + vc];
+    for (int64_t r = tid; r < rows; r += kBbThreads) s_b[r] = t.M[r * ld + vc];
     int64_t n_pivots = c0.n_pivots, trace_n = c0.trace_n;
     int term = -1;                                             // status that ends the solve
     __syncthreads();
 
     while (term < 0) {
-        for (int64_t r = tid; r < rp; r += kLpThreads) s_rm[r] = 0u;
-        for (int64_t p = tid; p < ldv; p += kLpThreads) s_sm[p] = 0u;
+        for (int64_t r = tid; r < rp; r += kBbThreads) s_rm[r] = 0u;
+        for (int64_t p = tid; p < ldv; p += kBbThreads) s_sm[p] = 0u;
         int k = 0;
         for (int J = 0; J < KB && term < 0; ++J) {
             // ---- find-entering-column on the running objective row
             ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
-            for (int64_t c = tid; c < vc; c += kLpThreads) {
+            for (int64_t c = tid; c < vc; c += kBbThreads) {
                 ValIdx x; x.v = s_z[c] * sgn; x.i = s_p2l[c]; x.s = c;
                 best = vi_min(best, x);
             }
-            const ValIdx e = block_reduce_min<kLpThreads>(best, s_v, s_i);
+            const ValIdx e = block_reduce_min<kBbThreads>(best, s_v, s_i);
             if (e.i < 0 || !(e.v < 0.0 - price_tol)) { term = 0; break; }          // MI_OPTIMAL
             if (c0.max_pivots > 0 && n_pivots >= c0.max_pivots) { term = 3; break; }   // MI_MAX_PIVOTS
             const int64_t ec = e.i, slot = e.s;
             // ---- entering column through the pending chain, ratio test
             ValIdx q; q.v = 0.0; q.i = -1; q.s = 0;
             int bad = 0;
-            for (int64_t r = tid; r < rows; r += kLpThreads) {
+            for (int64_t r = tid; r < rows; r += kBbThreads) {
                 double a = t.M[r * ld + slot];
                 for (int i = 0; i < J; ++i)
                     a = pend(a, slot == s_sl[i], r == s_cr[i], s_col[(int64_t)i * rp + r], s_prow[(int64_t)i * ld + slot]);
@@ -1664,14 +1668,14 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_block(TabView t, double sg
                     q = vi_min(q, x);
                 }
             }
-            q = block_reduce_min<kLpThreads>(q, s_v, s_i);     // barriers: s_col[J] complete
+            q = block_reduce_min<kBbThreads>(q, s_v, s_i);     // barriers: s_col[J] complete
             if (__syncthreads_or(bad)) { term = kNeedDense; break; }
             if (q.i < 0) { term = 1; break; }                  // MI_UNBOUNDED
             const int64_t cr = q.i;
             const double piv = __longlong_as_double(q.s);
             // ---- pivot row through the chain -> prow_J; objective row through pivot J
             const double cmj = s_col[(int64_t)J * rp + m];
-            for (int64_t p = tid; p < ldv; p += kLpThreads) {
+            for (int64_t p = tid; p < ldv; p += kBbThreads) {
                 const vec2d y0 = M2[cr * ldv + p];
                 double2 y = make_double2(y0.x, y0.y);
                 for (int i = 0; i < J; ++i) {
@@ -1690,7 +1694,7 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_block(TabView t, double sg
             }
             __syncthreads();                                   // prow_J complete
             const double pbj = s_prow[(int64_t)J * ld + vc];
-            for (int64_t r = tid; r < rows; r += kLpThreads)
+            for (int64_t r = tid; r < rows; r += kBbThreads)
                 s_b[r] = pend(s_b[r], false, r == cr, s_col[(int64_t)J * rp + r], pbj);
             if (tid == 0) {                                    // bookkeeping of pivot J
                 const int64_t leaving = t.basis[cr];
@@ -1711,7 +1715,7 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_block(TabView t, double sg
         // registers) and every fourth row; the row's col values come out of LDS as broadcasts.
         // The pairs left over beyond the last full strip: flat, operands from LDS.
         if (k > 0) {
-            constexpr int kSU = KB >= 16 ? 2 : 4;                  // rows in flight per thread (128 VGPRs at most)
+            constexpr int kSU = 4;                                 // rows in flight per thread
             const int pp = tid & 255, rq = tid >> 8;               // pair within the strip, row phase
             const int64_t full = ldv & ~(int64_t)255;
             for (int64_t s0 = 0; s0 < full; s0 += 256) {
@@ -1721,14 +1725,19 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_block(TabView t, double sg
                 for (int i = 0; i < KB; ++i)
                     pr[i] = reinterpret_cast<const double2 *>(s_prow + (int64_t)i * ld)[p];
                 const unsigned sm = s_sm[p];
-                for (int64_t r = rq; r < rows; r += 4 * kSU) {
-                    vec2d x[kSU];
+                vec2d x[kSU], nx[kSU];
 #pragma unroll
-                    for (int u = 0; u < kSU; ++u)
-                        if (r + 4 * u < rows) x[u] = M2[(r + 4 * u) * ldv + p];
+                for (int u = 0; u < kSU; ++u)
+                    if (rq + kRowPhases * u < rows) nx[u] = M2[(rq + kRowPhases * u) * ldv + p];
+                for (int64_t r = rq; r < rows; r += kRowPhases * kSU) {
+#pragma unroll
+                    for (int u = 0; u < kSU; ++u) x[u] = nx[u];
+#pragma unroll
+                    for (int u = 0; u < kSU; ++u)                  // the next rows travel during the chain
+                        if (r + kRowPhases * (kSU + u) < rows) nx[u] = M2[(r + kRowPhases * (kSU + u)) * ldv + p];
 #pragma unroll
                     for (int u = 0; u < kSU; ++u) {
-                        const int64_t rr = r + 4 * u;
+                        const int64_t rr = r + kRowPhases * u;
                         if (rr < rows) {
                             const unsigned rm = s_rm[rr];
                             vec2d v = x[u];
@@ -1759,7 +1768,7 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_block(TabView t, double sg
                 }
             }
             const int64_t rem = ldv - full, total_rem = rows * rem;   // < 256 pairs per row
-            for (int64_t idx = tid; idx < total_rem; idx += kLpThreads) {
+            for (int64_t idx = tid; idx < total_rem; idx += kBbThreads) {
                 const int64_t r = idx / rem, p = full + (idx - r * rem);
                 const unsigned rm = s_rm[r], sm = s_sm[p];
                 vec2d v = M2[r * ldv + p];
@@ -2111,7 +2120,7 @@ static bool launch_batch_block_t(const TabView &t, int is_max, double f, hipStre
         (void)hipGetLastError();
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_batch_block<KB>, dim3(1, 1, (unsigned)t.n_lps), dim3(kLpThreads), bytes, s, t,
+    hipLaunchKernelGGL(k_batch_block<KB>, dim3(1, 1, (unsigned)t.n_lps), dim3(kBbThreads), bytes, s, t,
                        sgn_of(is_max), (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon);
     return true;
 }
