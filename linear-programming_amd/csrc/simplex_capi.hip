@@ -1273,12 +1273,6 @@ int         mi355x_debug_rhs(mi355x_tab *t, double *out, int64_t n, int clear)
     return 0;
 }
 int         mi355x_tune_set_batch_block(int k) { set_batch_block(k); return k; }
-int         mi355x_debug_batch_part(mi355x_batch *b, double *out, int64_t n, int clear)
-{
-    if (hipMemcpy(out, b->t->v.part_v, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    if (clear) (void)hipMemset(b->t->v.part_v, 0, n * sizeof(double));
-    return 0;
-}
 int         mi355x_tune_set_lookahead_mode(int mode) { g_la_mode = mode; return g_la_mode; }
 int         mi355x_tune_set_block(int k) { g_block_k = k < 1 ? 1 : (k > kMaxBlock ? kMaxBlock : k); return g_block_k; }
 int         mi355x_tune_set_sweep_shape(int tr, int nt) { set_sweep_shape(tr, nt); return tr; }
