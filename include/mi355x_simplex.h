@@ -136,6 +136,11 @@ int  mi355x_solve_two_phase(mi355x_tab *art, mi355x_tab *main_tab, int main_is_m
  * last_row: cols (objective row), last_col: rows (RHS column). */
 int  mi355x_tab_download(mi355x_tab *t, double *host_matrix, int64_t *host_basis,
                          double *last_row, double *last_col);
+/* A sub-block of the logical tableau -- (aref matrix r c) for r in [row0, row0+n_rows),
+ * c in [col0, col0+n_cols) -- into a tightly packed row-major host array of n_rows*n_cols
+ * doubles: single columns / rows / entries of tableaux too large to download whole. */
+int  mi355x_tab_download_block(mi355x_tab *t, int64_t row0, int64_t n_rows, int64_t col0,
+                               int64_t n_cols, double *host_block);
 /* (entering column, pivot row) of the pivots made by solve calls since the last
  * upload / trace reset, oldest first; at most cap pairs are written, *n = number
  * of pivots recorded on the device (tracing holds up to 2^20 pairs). */

@@ -1,0 +1,65 @@
+/* mi355x_simplex_tune.h -- tuning, measurement and test hooks of libmi355x_simplex.so.
+ *
+ * NOT part of the drop-in boundary (that is mi355x_simplex.h, every entry of which restates a
+ * function of the reference): nothing here corresponds to anything in
+ * neil-lindquist/linear-programming.  bench.py, tools/ and tests/ use these to pick between
+ * implementations of the same bit-identical path and to read back measurement data.
+ *
+ * State model: every mi355x_tune_set_* hook sets PROCESS-GLOBAL state that is read when a solve
+ * entry point enqueues work.  The per-handle thread-safety promise of mi355x_simplex.h holds for
+ * a fixed setting of these knobs only: change them while no other thread is inside the library
+ * (bench.py and the tests do so before they create the handles they measure).  Every hook
+ * returns the value now in effect.
+ */
+#ifndef MI355X_SIMPLEX_TUNE_H
+#define MI355X_SIMPLEX_TUNE_H
+
+#include "mi355x_simplex.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- the per-pivot update kernel (k_update): compiled tilings ------------------------- */
+int         mi355x_tune_variant_count(void);
+const char *mi355x_tune_variant_name(int variant);
+int         mi355x_tune_set_variant(int variant);            /* 0 = default (by size)           */
+int         mi355x_tune_set_alternate_sweep(int on);         /* odd launches sweep bottom-up     */
+int         mi355x_tune_set_ld_extra(int doubles);           /* extra row padding, multiple of 16 */
+
+/* ---- which implementation of the solve loop runs -------------------------------------- */
+int         mi355x_tune_set_select_mode(int mode);           /* 0 auto, 1 one workgroup, 2 split */
+int         mi355x_tune_set_compact(int on);                 /* 1: [non-basic | RHS] (default)   */
+int         mi355x_tune_set_block(int k);                    /* pivots per sweep, 1..16 (1 = off) */
+int         mi355x_tune_set_lookahead_mode(int mode);        /* 0 auto, 1 two launches per step,
+                                                                2 one persistent launch per block */
+int         mi355x_tune_set_sweep_shape(int rows_per_workgroup, int nontemporal /* -1 by size */);
+int         mi355x_tune_set_handover_mode(int mode);         /* 0 auto, 1 sequential re-elimination */
+int         mi355x_tune_set_batch_mode(int mode);            /* 0 auto, 1 lockstep, 2 workgroup per LP */
+int         mi355x_tune_set_batch_block(int k);              /* blocked per-LP kernel, 1 = off   */
+
+/* ---- persistent look-ahead (k_la_block) ------------------------------------------------ */
+int         mi355x_tune_set_la_one_xcd(int on);              /* 1 (default): all its workgroups on
+                                                                one XCD, verified inside the launch */
+int         mi355x_tune_set_la_max_spins(unsigned polls);    /* polls before a workgroup gives up
+                                                                on a record; 0 = default (2^21)  */
+int         mi355x_tune_set_la_fault(int step_plus_1);       /* TEST: the last workgroup stops
+                                                                publishing from that step on     */
+/* 1 once an exchange of the persistent look-ahead was lost on this handle: the solve carried on
+ * (and stays) on the two-launch look-ahead */
+int         mi355x_tab_la_lost(const mi355x_tab *t);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+/* HIP-event brackets on the handle's stream (what `mi355x_tab_timing_*` of the main header
+ * brackets is the tableau update / sweep; `which` selects another kernel class):
+ * 0 update / sweep, 1 look-ahead (select) */
+int         mi355x_tab_timing_read_kind(mi355x_tab *t, int which, int64_t *n_launches,
+                                        double *sum_ms, double *min_ms);
+/* debugging aid: copies n doubles of the handle's scratch `rhs` buffer (the per-phase clocks of
+ * a -DMI355X_LA_TIMING build); clear != 0 zeroes it afterwards */
+int         mi355x_debug_rhs(mi355x_tab *t, double *out, int64_t n, int clear);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -39,14 +39,15 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def build(force=False, verbose=False, extra_flags=(), out=None):
+    """extra_flags / out: instrumented builds next to the product library (tools/la_timing.py)."""
+    if out is None and not force and not needs_build():
         return LIB
-    cmd = [_hipcc()] + FLAGS + ["-shared", "-o", LIB] + sources()
+    cmd = [_hipcc()] + FLAGS + list(extra_flags) + ["-shared", "-o", out or LIB] + sources()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":

@@ -4,7 +4,9 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmi355x_simplex.so")
+# MI355X_SIMPLEX_LIB: an alternative build of the same library (tools/la_timing.py loads one
+# compiled with -DMI355X_LA_TIMING); there is still no fallback of any kind
+LIB_PATH = os.environ.get("MI355X_SIMPLEX_LIB") or os.path.join(HERE, "libmi355x_simplex.so")
 
 MI_OK = MI_OPTIMAL = 0
 MI_UNBOUNDED, MI_INFEASIBLE, MI_MAX_PIVOTS, MI_ART_NONZERO, MI_ART_STUCK = 1, 2, 3, 4, 5
@@ -35,6 +37,7 @@ SIGNATURES = {
     "mi355x_tab_solve": (_int, [_p, _int, _dbl, _i64, _p]),
     "mi355x_solve_two_phase": (_int, [_p, _p, _int, _dbl, _p]),
     "mi355x_tab_download": (_int, [_p, _p, _p, _p, _p]),
+    "mi355x_tab_download_block": (_int, [_p, _i64, _i64, _i64, _i64, _p]),
     "mi355x_tab_trace": (_int, [_p, _p, _p, _i64, _p]),
     "mi355x_tab_set_stream": (_int, [_p, _p, _int]),
     "mi355x_tab_solve_async": (_int, [_p, _int, _dbl, _i64, _int]),
@@ -80,8 +83,14 @@ SIGNATURES = {
     "mi355x_shard_la_pivot": (_int, [_p, _int, _p, _p, _dbl]),
     "mi355x_shard_sweep": (_int, [_p]),
 }
-# tuning hooks exported by the library but not part of include/mi355x_simplex.h
+# tuning / measurement / test hooks: include/mi355x_simplex_tune.h (not the drop-in boundary)
 _EXTRA = {
+    "mi355x_tune_set_la_one_xcd": (_int, [_int]),
+    "mi355x_tune_set_la_max_spins": (_int, [ctypes.c_uint]),
+    "mi355x_tune_set_la_fault": (_int, [_int]),
+    "mi355x_tab_la_lost": (_int, [_p]),
+    "mi355x_tab_timing_read_kind": (_int, [_p, _int, _p, _p, _p]),
+    "mi355x_debug_rhs": (_int, [_p, _p, _i64, _int]),
     "mi355x_tune_variant_count": (_int, []),
     "mi355x_tune_variant_name": (ctypes.c_char_p, [_int]),
     "mi355x_tune_set_variant": (_int, [_int]),

@@ -6,6 +6,7 @@
 // two-phase driver of src/simplex.lisp:402-452, and HIP-event timing of the update kernel.
 // No CPU compute path exists here: without a device every entry point fails.
 #include "../../include/mi355x_simplex.h"
+#include "../../include/mi355x_simplex_tune.h"
 #include "simplex_kernels.h"
 
 #include <algorithm>
@@ -95,9 +96,14 @@ struct mi355x_tab {
     int         timing_stride = 0;        // 0 = off, k = bracket every k-th update launch
     int64_t     update_launches = 0;
     int64_t     sweeps = 0;               // update launches so far: odd ones sweep bottom-up
-    unsigned long long la_epoch = 1;      // next epoch base of the persistent look-ahead kernel
+    unsigned    la_epoch = 1;             // next epoch base of the persistent look-ahead kernel
+    bool        la_lost = false;          // an exchange of the persistent look-ahead was lost once
+                                          // (its workgroups were not co-resident): this handle
+                                          // stays on the two-launch look-ahead
     int         n_timed = 0;
-    std::vector<hipEvent_t> ev0, ev1;
+    std::vector<hipEvent_t> ev0, ev1;     // around the update / sweep launches
+    int         n_timed_la = 0;
+    std::vector<hipEvent_t> la0, la1;     // around the look-ahead of the same blocks
 };
 
 struct mi355x_batch {
@@ -119,6 +125,8 @@ void free_tab(mi355x_tab *t)
     if (t->own_stream) (void)hipStreamSynchronize(t->own_stream);
     for (auto e : t->ev0) (void)hipEventDestroy(e);
     for (auto e : t->ev1) (void)hipEventDestroy(e);
+    for (auto e : t->la0) (void)hipEventDestroy(e);
+    for (auto e : t->la1) (void)hipEventDestroy(e);
     (void)hipFree(t->v.M);
     (void)hipFree(t->v.basis);
     (void)hipFree(t->v.col);
@@ -366,7 +374,7 @@ int fall_back_to_dense(mi355x_tab *t)
     if (rc != MI_OK) return rc;
     t->compact_failed = true;
     t->unit_basis = false;
-    launch_ctl_resume(t->v, t->stream);
+    launch_ctl_resume(t->v, t->stream, kNeedDense);
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }
@@ -431,31 +439,63 @@ int enqueue_block(mi355x_tab *t, int is_max, double f, int k)
 {
     const TabView &v = t->c;
     int np = (t->n_part > 0 && t->part_is_max == (is_max ? 1 : 0)) ? t->n_part : 0;
-    const bool persistent = g_la_mode == 2 || (g_la_mode == 0 && la_block_supported(v));
-    if (persistent && la_block_supported(v)) {
+    const bool persistent = (g_la_mode == 2 || (g_la_mode == 0 && !t->la_lost)) && la_block_supported(v);
+    const bool timed = t->timing_stride > 0 && t->n_timed < kTimingCap &&
+                       (t->update_launches++ % t->timing_stride) == 0;
+    auto ensure_events = [](std::vector<hipEvent_t> &a, std::vector<hipEvent_t> &b, int n) -> hipError_t {
+        while ((int)a.size() <= n) {
+            hipEvent_t x, y;
+            hipError_t e = hipEventCreate(&x);
+            if (e != hipSuccess) return e;
+            if ((e = hipEventCreate(&y)) != hipSuccess) { (void)hipEventDestroy(x); return e; }
+            a.push_back(x);
+            b.push_back(y);
+        }
+        return hipSuccess;
+    };
+    if (timed) {
+        HIP_TRY(ensure_events(t->la0, t->la1, t->n_timed_la));
+        HIP_TRY(ensure_events(t->ev0, t->ev1, t->n_timed));
+        HIP_TRY(hipEventRecord(t->la0[t->n_timed_la], t->stream));
+    }
+    unsigned stamp = 0;
+    if (persistent) {
+        if (t->la_epoch > 0x7fff0000u) {              // 32-bit tags: start over on clean records
+            HIP_TRY(hipMemsetAsync(v.la_px, 0, kMaxLaWorkgroups * sizeof(ExchRec), t->stream));
+            HIP_TRY(hipMemsetAsync(v.la_rx, 0, kMaxLaWorkgroups * sizeof(ExchRec), t->stream));
+            t->la_epoch = 1;
+        }
+        stamp = t->la_epoch;
         launch_la_block(v, k, is_max, f, t->la_epoch, t->stream);
         t->la_epoch += 2 * kMaxBlock + 2;
     } else {
         for (int j = 0; j < k; ++j) np = launch_lookahead(v, j, is_max, f, np, t->stream);
     }
-    const bool timed = t->timing_stride > 0 && t->n_timed < kTimingCap &&
-                       (t->update_launches++ % t->timing_stride) == 0;
     if (timed) {
-        if ((int)t->ev0.size() <= t->n_timed) {
-            hipEvent_t a, b;
-            HIP_TRY(hipEventCreate(&a));
-            HIP_TRY(hipEventCreate(&b));
-            t->ev0.push_back(a);
-            t->ev1.push_back(b);
-        }
+        HIP_TRY(hipEventRecord(t->la1[t->n_timed_la], t->stream));
+        t->n_timed_la++;
         HIP_TRY(hipEventRecord(t->ev0[t->n_timed], t->stream));
     }
-    t->n_part = launch_sweep(v, k, is_max ? 1.0 : -1.0, t->stream);
+    t->n_part = launch_sweep(v, k, is_max ? 1.0 : -1.0, t->stream, stamp);
     t->part_is_max = is_max ? 1 : 0;
     if (timed) {
         HIP_TRY(hipEventRecord(t->ev1[t->n_timed], t->stream));
         t->n_timed++;
     }
+    return MI_OK;
+}
+
+// The persistent look-ahead gave up waiting for a workgroup's record (status kSyncLost): its
+// workgroups were not all resident at the same time -- a GPU shared with other work.  Nothing is
+// lost: the pivots selected before that exchange have been applied by the sweep that followed,
+// everything enqueued behind it was a no-op.  Continue on the two-launch look-ahead, which needs
+// no co-residency, for the rest of this handle's life.
+int recover_lost_exchange(mi355x_tab *t)
+{
+    t->la_lost = true;
+    t->n_part = 0;
+    launch_ctl_resume(t->v, t->stream, kSyncLost);
+    HIP_TRY(hipGetLastError());
     return MI_OK;
 }
 
@@ -468,7 +508,8 @@ extern "C" {
 int mi355x_abi_version(void) { return MI355X_SIMPLEX_ABI_VERSION; }
 int mi355x_device_count(void) { return device_count_checked(); }
 const char *mi355x_last_error(void) { return g_err.c_str(); }
-void mi355x_set_last_error_(const char *msg) { g_err = msg ? msg : ""; }   // for host_problem.cpp
+// for host_problem.cpp / mps_reader.cpp (same library, not exported)
+__attribute__((visibility("hidden"))) void mi355x_set_last_error_(const char *msg) { g_err = msg ? msg : ""; }
 double mi355x_epsilon(void) { return kClEpsilon; }
 const char *mi355x_update_kernel_name(void) { return update_kernel_symbol(); }
 
@@ -549,8 +590,12 @@ int mi355x_tab_upload(mi355x_tab *t, const double *host_matrix, const int64_t *h
 int mi355x_tab_copy(mi355x_tab **out, const mi355x_tab *src)
 {
     if (!src) return fail(MI_BAD_ARG, "src is NULL");
+    if (src->v.p2l)                         // a compact column shard has no dense logical form
+        return fail(MI_UNSUPPORTED, "copy-tableau of a compact column shard is not supported");
     mi355x_tab *t = nullptr;
-    int rc = ensure_dense(const_cast<mi355x_tab *>(src));
+    int rc = use_device(src);
+    if (rc != MI_OK) return rc;
+    rc = ensure_dense(const_cast<mi355x_tab *>(src));
     if (rc != MI_OK) return rc;
     rc = alloc_tab(&t, src->v.rows, src->v.cols, src->device);
     if (rc != MI_OK) return rc;
@@ -704,8 +749,11 @@ int mi355x_tab_sync(mi355x_tab *t, int64_t *n_pivots)
     rc = read_ctl(t);
     if (rc != MI_OK) return rc;
     if (n_pivots) *n_pivots = t->h_ctl->n_pivots;
-    if (t->h_ctl->status == kSyncLost)
-        return fail(MI_HIP_ERROR, "persistent look-ahead kernel: a workgroup stopped waiting for the others");
+    if (t->h_ctl->status == kSyncLost) {              // see recover_lost_exchange
+        rc = recover_lost_exchange(t);
+        if (rc != MI_OK) return rc;
+        return MI_RUNNING;
+    }
     if (t->h_ctl->status == kNeedDense) {             // see fall_back_to_dense: further
         rc = fall_back_to_dense(t);                   // iterations continue on the dense tableau
         if (rc != MI_OK) return rc;
@@ -735,11 +783,14 @@ int mi355x_tab_solve(mi355x_tab *t, int is_max, double f, int64_t max_pivots, in
             HIP_TRY(hipGetLastError());
             rc = read_ctl(t);
             if (rc != MI_OK) return rc;
+            if (t->h_ctl->status == kSyncLost) {      // see recover_lost_exchange
+                rc = recover_lost_exchange(t);
+                if (rc != MI_OK) return rc;
+                continue;
+            }
             if (t->h_ctl->status != kRunning) break;
             if (blocks < 64) blocks *= 2;
         }
-        if (t->h_ctl->status == kSyncLost)
-            return fail(MI_HIP_ERROR, "persistent look-ahead kernel: a workgroup stopped waiting for the others");
         if (t->h_ctl->status != kNeedDense) {
             if (n_pivots) *n_pivots = t->h_ctl->n_pivots;
             return (int)t->h_ctl->status;
@@ -886,6 +937,27 @@ int mi355x_tab_download(mi355x_tab *t, double *hm, int64_t *hb, double *last_row
     return MI_OK;
 }
 
+int mi355x_tab_download_block(mi355x_tab *t, int64_t row0, int64_t n_rows, int64_t col0, int64_t n_cols,
+                              double *host_block)
+{
+    if (!t || !host_block) return fail(MI_BAD_ARG, "NULL argument");
+    if (row0 < 0 || n_rows < 1 || col0 < 0 || n_cols < 1 || row0 + n_rows > t->v.rows ||
+        col0 + n_cols > t->v.cols)
+        return fail(MI_BAD_ARG, "block [%lld,+%lld) x [%lld,+%lld) outside %lldx%lld", (long long)row0,
+                    (long long)n_rows, (long long)col0, (long long)n_cols, (long long)t->v.rows,
+                    (long long)t->v.cols);
+    int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    rc = ensure_dense(t);
+    if (rc != MI_OK) return rc;
+    const TabView &v = t->v;
+    HIP_TRY(hipMemcpy2DAsync(host_block, n_cols * sizeof(double), v.M + row0 * v.ld + col0,
+                             v.ld * sizeof(double), n_cols * sizeof(double), n_rows,
+                             hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    return MI_OK;
+}
+
 int mi355x_tab_trace(mi355x_tab *t, int64_t *ecs, int64_t *crs, int64_t cap, int64_t *n)
 {
     if (!t) return fail(MI_BAD_ARG, "handle is NULL");
@@ -916,27 +988,36 @@ int mi355x_tab_timing_enable(mi355x_tab *t, int enable)
     if (!t) return fail(MI_BAD_ARG, "handle is NULL");
     t->timing_stride = enable > 0 ? enable : 0;
     t->update_launches = 0;
+    t->n_timed_la = 0;
+    return MI_OK;
+}
+
+int mi355x_tab_timing_read_kind(mi355x_tab *t, int which, int64_t *n_launches, double *sum_ms, double *min_ms)
+{
+    if (!t) return fail(MI_BAD_ARG, "handle is NULL");
+    if (which != 0 && which != 1) return fail(MI_BAD_ARG, "which must be 0 (update / sweep) or 1 (look-ahead)");
+    int rc = use_device(t);
+    if (rc != MI_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    std::vector<hipEvent_t> &a = which ? t->la0 : t->ev0, &b = which ? t->la1 : t->ev1;
+    int &n = which ? t->n_timed_la : t->n_timed;
+    double sum = 0.0, mn = 0.0;
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, a[i], b[i]));
+        sum += ms;
+        if (i == 0 || ms < mn) mn = ms;
+    }
+    if (n_launches) *n_launches = n;
+    if (sum_ms) *sum_ms = sum;
+    if (min_ms) *min_ms = mn;
+    n = 0;
     return MI_OK;
 }
 
 int mi355x_tab_timing_read(mi355x_tab *t, int64_t *n_launches, double *sum_ms, double *min_ms)
 {
-    if (!t) return fail(MI_BAD_ARG, "handle is NULL");
-    int rc = use_device(t);
-    if (rc != MI_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(t->stream));
-    double sum = 0.0, mn = 0.0;
-    for (int i = 0; i < t->n_timed; ++i) {
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, t->ev0[i], t->ev1[i]));
-        sum += ms;
-        if (i == 0 || ms < mn) mn = ms;
-    }
-    if (n_launches) *n_launches = t->n_timed;
-    if (sum_ms) *sum_ms = sum;
-    if (min_ms) *min_ms = mn;
-    t->n_timed = 0;
-    return MI_OK;
+    return mi355x_tab_timing_read_kind(t, 0, n_launches, sum_ms, min_ms);
 }
 
 // ---- batches of independent LPs ---------------------------------------------------------
@@ -1277,5 +1358,14 @@ int         mi355x_tune_set_lookahead_mode(int mode) { g_la_mode = mode; return 
 int         mi355x_tune_set_block(int k) { g_block_k = k < 1 ? 1 : (k > kMaxBlock ? kMaxBlock : k); return g_block_k; }
 int         mi355x_tune_set_sweep_shape(int tr, int nt) { set_sweep_shape(tr, nt); return tr; }
 int         mi355x_tune_set_compact(int on) { g_compact_enabled = on ? 1 : 0; return g_compact_enabled; }
+// persistent look-ahead: all workgroups on one XCD (1, default) or spread (0); polls before a
+// workgroup gives up on a record (0 = default 2^21); test hook: the last workgroup stops
+// publishing from step `step_plus_1 - 1` of every block on (0 = off)
+int         mi355x_tune_set_la_one_xcd(int on) { set_la_one_xcd(on); return on; }
+int         mi355x_tune_set_la_max_spins(unsigned n) { set_la_max_spins(n); return (int)n; }
+int         mi355x_tune_set_la_fault(int step_plus_1) { set_la_fault(step_plus_1); return step_plus_1; }
+// 1 once an exchange of the persistent look-ahead was lost on this handle (it then stays on the
+// two-launch look-ahead)
+int         mi355x_tab_la_lost(const mi355x_tab *t) { return (t && t->la_lost) ? 1 : 0; }
 
 }  // extern "C"

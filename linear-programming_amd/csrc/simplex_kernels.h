@@ -42,18 +42,17 @@ struct Ctl {
 constexpr int kMaxBlock = 16;
 struct BlockCtl {
     int64_t n_pending;            // pivots selected but not yet applied by a sweep
+    int64_t stamp;                // persistent look-ahead: epoch base of the launch that wrote the list
     int64_t cr[kMaxBlock];        // their pivot rows ...
     int64_t slot[kMaxBlock];      // ... and the physical slots their entering columns gave up
 };
 
-// Record one workgroup of the persistent look-ahead kernel publishes per exchange: a (value,
-// index, payload) reduction candidate, a flag, and the epoch that makes it valid (written last,
-// with release semantics; epochs only ever grow).
+// Record one workgroup of the persistent look-ahead kernel publishes per exchange: eight
+// self-validating granules {tag = 32-bit epoch, 32 bits of payload}, each written by one 8-byte
+// store (a reduction candidate (value, index, payload), a flag and two doubles; layout in
+// simplex_kernels.hip, la_exchange).  One record per 64-byte line.
 struct ExchRec {
-    double             v;
-    long long          i, s, flag;
-    unsigned long long epoch;
-    long long          pad[3];         // one record per 64-byte line
+    unsigned long long g[8];
 };
 constexpr int kMaxLaWorkgroups = 32;
 
@@ -116,13 +115,20 @@ void set_alternate_sweep(int on);
 // launch_lookahead returns the number of pricing partials it leaves for step j+1.
 bool block_supported(const TabView &t);
 int  launch_lookahead(const TabView &t, int j, int is_max, double fp_factor, int n_part, hipStream_t s);
-int  launch_sweep(const TabView &t, int kmax, double sgn, hipStream_t s);
+// stamp != 0: apply the pending list only if the look-ahead launch with that epoch base wrote it
+int  launch_sweep(const TabView &t, int kmax, double sgn, hipStream_t s, unsigned stamp = 0);
 // the whole look-ahead of a block (steps 0 .. ksteps-1) as ONE launch of a few persistent
-// workgroups that exchange their reduction candidates through la_px / la_rx; epoch_base must
-// grow by at least 2*kMaxBlock+2 from launch to launch on the same tableau
+// workgroups that exchange their reduction candidates through la_px / la_rx; epoch_base (> 0)
+// must grow by at least 2*kMaxBlock+2 from launch to launch on the same tableau (the records
+// are zeroed whenever the host wraps it around)
 bool la_block_supported(const TabView &t);
 void launch_la_block(const TabView &t, int ksteps, int is_max, double fp_factor,
-                     unsigned long long epoch_base, hipStream_t s);
+                     unsigned epoch_base, hipStream_t s);
+// tuning / test hooks of the persistent look-ahead: all its workgroups on one XCD (default on),
+// polls before a workgroup gives up waiting (kSyncLost), a workgroup that stops publishing
+void set_la_one_xcd(int on);
+void set_la_max_spins(unsigned n);
+void set_la_fault(int step_plus_1);
 void set_sweep_shape(int tr, int nt);      // tuning hook
 UpdateShape update_shape(const TabView &t);
 // column-partitioned shards (one shard = one handle)
@@ -152,8 +158,9 @@ void launch_compact(const TabView &dense, const TabView &compact, hipStream_t s)
 void launch_expand(const TabView &dense, const TabView &compact, int64_t *brow, hipStream_t s);
 void launch_ctl_reset(const TabView &t, int64_t max_pivots, int reset_trace, hipStream_t s);
 void launch_ctl_finish(const TabView &t, hipStream_t s);
-// kNeedDense -> kRunning (after the host has rebuilt the dense tableau)
-void launch_ctl_resume(const TabView &t, hipStream_t s);
+// `from` -> kRunning (kNeedDense: after the host has rebuilt the dense tableau; kSyncLost: after
+// it has switched the handle to the two-launch look-ahead)
+void launch_ctl_resume(const TabView &t, hipStream_t s, int32_t from);
 // synthetic LP straight into HBM
 void launch_synth_fill(const TabView &t, int64_t n_vars, int64_t n_cons, uint64_t seed,
                        const uint64_t *dev_seeds, int64_t col_begin, int64_t col_end, hipStream_t s);

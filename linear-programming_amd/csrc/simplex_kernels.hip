@@ -1077,58 +1077,39 @@ __global__ __launch_bounds__(kSelThreads) void k_shard_la_prepare(TabView t, int
 // every start.  For tableaux whose rows and column pairs fit a few workgroups (config 3: 17 x 256
 // threads cover 4097 rows and 4104 pairs) the steps of a block run inside one launch instead:
 // thread g owns row g (entering-column / RHS side) AND column pair g (pivot-row / objective-row
-// side); its col_i[r], prow_i[pair], RHS entry and objective-row pair stay in registers from
-// step to step, and the two reductions of a step go through a message exchange: every workgroup
-// publishes its candidate as a record whose epoch word is stored last with release semantics,
-// and every workgroup's first wave polls all records in parallel (lane l <- workgroup l, acquire)
-// -- no read-modify-write atomics, so nothing serialises (tools/microbench/msg_barrier.hip: 1.9 us
-// per exchange at 17 workgroups, against 2.5 us for a kernel boundary before any data is read).
-// All workgroups reduce the same records with the same comparisons, so they take every decision
-// (entering column, pivot row, termination) identically without further communication.
-__device__ __forceinline__ void publish(ExchRec *rec, ValIdx c, long long flag, unsigned long long epoch)
-{
-    __hip_atomic_store(&rec->v, c.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&rec->i, (long long)c.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&rec->s, (long long)c.s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&rec->flag, flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // release: everything this workgroup stored before (col / prow / bookkeeping; the
-    // __syncthreads before this call ordered the other threads' stores) is visible to whoever
-    // acquires the epoch
-    __hip_atomic_store(&rec->epoch, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// first wave of the workgroup: wait for all nw records of `epoch`, reduce them; result + OR of
-// the flags in LDS (s_res / s_flag); false if the wait was abandoned
-__device__ __forceinline__ bool collect(const ExchRec *recs, int nw, unsigned long long epoch,
-                                        ValIdx *s_res, long long *s_flag)
-{
-    bool fine = true;
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        const ExchRec *r = recs + lane;
-        bool ok = lane >= nw;
-        unsigned spins = 0;
-        while (!__all(ok)) {
-            if (!ok) ok = __hip_atomic_load(&r->epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
-            if (++spins > (1u << 21)) { fine = false; break; }
-        }
-        ValIdx c; c.v = 0.0; c.i = -1; c.s = 0;
-        long long fl = 0;
-        if (lane < nw) {
-            c.v = __hip_atomic_load(&r->v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            c.i = __hip_atomic_load(&r->i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            c.s = __hip_atomic_load(&r->s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            fl  = __hip_atomic_load(&r->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        c = wave_reduce_min(c);                                  // valid in lane 0
-        fl = __any(fl != 0) ? 1 : 0;
-        if (lane == 0) { *s_res = c; *s_flag = fine ? fl : -1; }
-    }
-    __syncthreads();
-    return *s_flag != -1;
-}
-
-constexpr int kLaThreads = 256;
+// side); its col_i[r], prow_i[pair], RHS entry and objective-row pair stay in registers / LDS from
+// step to step, and the two reductions of a step go through a message exchange between the
+// workgroups.  All workgroups reduce the same records with the same comparisons, so they take
+// every decision (entering column, pivot row, termination) identically without further
+// communication.
+//
+// The hand-off protocol.  gfx950: a CU's vector L1 is never refreshed by another CU's stores, the
+// eight XCDs' L2s are not coherent with each other, and a workgroup barrier does NOT wait for the
+// other waves' outstanding stores.  Hence:
+//   * a record is eight self-validating 8-byte granules {tag = epoch, 32 bits of payload}, each
+//     written by ONE store and polled with L1-bypassing (sc1) loads until all tags match: no
+//     fence, no release/acquire pair, no read-modify-write;
+//   * what a step has just produced and the next half-step needs at once travels IN the records
+//     (the pivot-row entry of the winning candidate, the RHS entry of the new pivot row, the
+//     objective-row entry of the new column);
+//   * everything else another workgroup reads inside the launch (col_i, prow_i of the older
+//     pending pivots, basis) is stored WRITE-THROUGH (sc1: relaxed agent-scope atomic stores) and
+//     read with sc1 loads, and every wave drains its stores (s_waitcnt vmcnt(0)) half a step
+//     after issuing them -- before the barrier of the NEXT exchange, which is the first one whose
+//     records anybody takes as evidence that those stores have landed.  (Round 1 published behind
+//     a plain __syncthreads(), i.e. possibly before the other waves' col / prow stores had left
+//     the CU: a reader on another XCD could chain a stale value -- the one-in-thousands
+//     pivot-trace mismatch recorded in round 1's DESIGN.md.)
+//   * words that only LATER launches read but that several workgroups write in turn (column
+//     maps, basis) go write-through as well (two L2s holding different dirty versions of one word
+//     are written back in an unspecified order); the control block, the pending list and the
+//     trace have ONE writer, the leader thread; a mask word is written by its owner only.
+//   * one-XCD mode (a pure speed option): the launch is 8x as wide and only every eighth block
+//     takes part, which is where the dispatcher puts one XCD's blocks.  Nothing RELIES on that:
+//     the first exchange of a launch (write-through, valid anywhere) carries every workgroup's
+//     HW_REG_XCC_ID, and only if they all agree do the later stores become plain stores that stay
+//     in the one shared L2 (where the sc1 loads find them a fabric round trip sooner).
+struct LaMsg { ValIdx c; unsigned flag, same; double u, w; };
 
 __device__ __forceinline__ double lane_value_dyn(double v, int lane)    // lane: uniform, run-time
 {
@@ -1139,24 +1120,140 @@ __device__ __forceinline__ int64_t lane_value_dyn(int64_t v, int lane)
     return lane_value(v, __builtin_amdgcn_readfirstlane(lane));
 }
 
+template <class T> __device__ __forceinline__ void st_wt(T *p, T v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one untorn store; local == true: all readers share this XCD's L2, the line may stay there
+template <class T> __device__ __forceinline__ void st_x(T *p, T v, bool local)
+{
+    if (local) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else       __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class T> __device__ __forceinline__ T ld_l2(const T *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// this wave's outstanding loads and stores have completed -- inline asm: the compiler neither
+// moves nor drops it
+__device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ unsigned xcc_id()
+{
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xfu;
+}
+
+constexpr int kLaThreads = 256;
+constexpr unsigned kEmptyIdx = 0x7fffffffu;
+
+__device__ __forceinline__ unsigned long long dbits(double x) { return (unsigned long long)__double_as_longlong(x); }
+__device__ __forceinline__ double join_bits(unsigned long long lo, unsigned long long hi)
+{
+    return __longlong_as_double((long long)(((hi & 0xffffffffull) << 32) | (lo & 0xffffffffull)));
+}
+
+// Exchange of one reduction between the workgroups.  `mine` is this thread's candidate; the
+// workgroup's winner (same order as block_reduce_min: wave tree, then waves 0..3 in turn) is
+// published together with two doubles the first wave computes from it (extra(c, u, w)), every
+// record is collected, and their winner (wave tree over the workgroups) is handed to every
+// thread with the two doubles of the records picked by pick_u(winner) / w_from.
+// PRICE: granules v v i s u u w w   (s = slot: 32 bits)      RATIO: v v i|flag s s u u w
+// false: a record did not arrive within max_spins polls.
+template <bool PRICE, class Extra, class PickU>
+__device__ __forceinline__ bool la_exchange(ValIdx mine, unsigned myflag, ExchRec *recs, int nw, int w,
+                                            unsigned tag, unsigned max_spins, bool mute, bool local,
+                                            int w_from, LaMsg *s_wave, LaMsg *s_res, LaMsg &out,
+                                            Extra extra, PickU pick_u)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    mine = wave_reduce_min(mine);
+    const unsigned wf = __any(myflag != 0u) ? 1u : 0u;
+    if (lane == 0) { s_wave[wave].c = mine; s_wave[wave].flag = wf; }
+    __syncthreads();
+    if (tid < 64) {
+        ValIdx c = s_wave[0].c;
+        unsigned f = s_wave[0].flag;
+#pragma unroll
+        for (int k = 1; k < kLaThreads / 64; ++k) { c = vi_min(c, s_wave[k].c); f |= s_wave[k].flag; }
+        double u = 0.0, x2 = 0.0;
+        extra(c, u, x2);
+        if (!mute) {
+            const unsigned long long vb = dbits(c.v), sb = (unsigned long long)c.s, ub = dbits(u), wb = dbits(x2);
+            const unsigned iw = (c.i < 0 ? kEmptyIdx : (unsigned)c.i) | (f ? 0x80000000u : 0u);
+            unsigned val;
+            if (PRICE) val = lane == 0 ? (unsigned)vb : lane == 1 ? (unsigned)(vb >> 32) : lane == 2 ? iw
+                           : lane == 3 ? (unsigned)sb : lane == 4 ? (unsigned)ub : lane == 5 ? (unsigned)(ub >> 32)
+                           : lane == 6 ? (unsigned)wb : (unsigned)(wb >> 32);
+            else       val = lane == 0 ? (unsigned)vb : lane == 1 ? (unsigned)(vb >> 32) : lane == 2 ? iw
+                           : lane == 3 ? (unsigned)sb : lane == 4 ? (unsigned)(sb >> 32) : lane == 5 ? (unsigned)ub
+                           : lane == 6 ? (unsigned)(ub >> 32) : (unsigned)wb;   // (ratio: w = low word only, unused)
+            if (lane < 8) st_x(&recs[w].g[lane], ((unsigned long long)tag << 32) | val, local);
+        }
+        const ExchRec *r = recs + (lane < nw ? lane : 0);
+        unsigned long long g[8];
+        unsigned spins = 0;
+        bool fine = true;
+        for (;;) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] = ld_l2(&r->g[k]);
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ok &= (unsigned)(g[k] >> 32) == tag;
+            if (__all(ok | (lane >= nw))) break;
+            if (++spins > max_spins) { fine = false; break; }
+        }
+        ValIdx x; x.v = 0.0; x.i = -1; x.s = 0;
+        unsigned fl = 0u;
+        double ru, rw;
+        const unsigned iw = (unsigned)g[2];
+        if (lane < nw) {
+            x.v = join_bits(g[0], g[1]);
+            x.i = (iw & kEmptyIdx) == kEmptyIdx ? -1 : (int64_t)(iw & kEmptyIdx);
+            x.s = PRICE ? (int64_t)(g[3] & 0xffffffffull) : (int64_t)(((g[4] & 0xffffffffull) << 32) | (g[3] & 0xffffffffull));
+            fl = iw >> 31;
+        }
+        ru = PRICE ? join_bits(g[4], g[5]) : join_bits(g[5], g[6]);
+        rw = PRICE ? join_bits(g[6], g[7]) : 0.0;
+        x = wave_reduce_min(x);                     // valid in lane 0
+        fl = __any(fl != 0u) ? 1u : 0u;
+        x.v = lane_value(x.v, 0); x.i = lane_value(x.i, 0); x.s = lane_value(x.s, 0);
+        const int wu = pick_u(x);                   // uniform: the record whose u belongs to the winner
+        const double bu = lane_value_dyn(ru, wu < 0 ? 0 : wu);
+        const double bw = PRICE ? lane_value_dyn(rw, w_from) : lane_value_dyn(ru, w_from);
+        // do all records carry the same first double?  (the XCC ids of the first exchange)
+        const unsigned same = __all((lane >= nw) | (dbits(ru) == dbits(lane_value(ru, 0)))) ? 1u : 0u;
+        if (lane == 0) { s_res->c = x; s_res->flag = fine ? fl : 2u; s_res->same = same; s_res->u = bu; s_res->w = bw; }
+    }
+    __syncthreads();
+    out = *s_res;
+    return out.flag != 2u;
+}
 // The steps are a run-time loop (fully unrolled the kernel was 300 KB of straight-line code and
 // ran at the speed of instruction-cache misses): per-thread col_i[row] / prow_i[pair] of the
 // pending pivots live in LDS ([pivot][thread]: conflict-free), everything else in registers.
+// one_xcd: see above.  fault > 0 (test hook): the last workgroup stops publishing from step
+// `fault - 1` on, as a workgroup that is not resident would.
 template <int KMAX>
 __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, double sgn,
                                                         double price_tol, double ratio_thr,
-                                                        unsigned long long epoch_base)
+                                                        unsigned epoch_base, unsigned max_spins,
+                                                        int one_xcd, int fault)
 {
     __shared__ double    s_ci[KMAX][kLaThreads];                 // 32 KB
     __shared__ double2   s_pi[KMAX][kLaThreads];                 // 64 KB
-    __shared__ double    s_v[kLaThreads / 64];
-    __shared__ long long s_i[kLaThreads / 64];
-    __shared__ ValIdx    s_res;
-    __shared__ long long s_flag;
+    __shared__ LaMsg     s_wave[kLaThreads / 64];
+    __shared__ LaMsg     s_res;
+    int nw = gridDim.x, w = blockIdx.x;
+    if (one_xcd) {                                               // only every eighth block takes part
+        if (w & 7) return;
+        w >>= 3; nw >>= 3;
+    }
     Ctl *ctl = t.ctl;
     const Ctl c0 = *ctl;
     BlockCtl *blk = t.blk;
-    const int nw = gridDim.x, w = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const bool leader = w == 0 && tid == 0;
     const int lane = tid & 63;
     const int64_t m = t.rows - 1, vc = t.cols - 1, ld = t.ld, ldv = ld >> 1;
@@ -1164,10 +1261,14 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
     const bool has_row = g < t.rows, has_pair = g < ldv;
     const int64_t r = g, p = g;
     const double2 *M2 = reinterpret_cast<const double2 *>(t.M);
-    double2 *P2 = reinterpret_cast<double2 *>(t.bk_prow);
+    const int w_vc = (int)((vc >> 1) / kLaThreads), w_m = (int)(m / kLaThreads);   // owners of the RHS pair / objective row
+    const int lt_vc = (int)((vc >> 1) - (int64_t)w_vc * kLaThreads), lt_m = (int)(m - (int64_t)w_m * kLaThreads);
 
-    // a new block starts (whatever the status): pending list and masks
-    if (leader) blk->n_pending = 0;
+    // a new block starts (whatever the status): pending list, stamp (the sweep applies the list
+    // only under this launch's stamp -- had the leader's workgroup never run, the list would be
+    // the previous block's) and this thread's OWN mask words, which only it ever writes
+    if (leader) { blk->n_pending = 0; blk->stamp = epoch_base; }
+    unsigned my_rm = 0u, my_sm = 0u;
     if (g < t.bk_stride) t.bk_rmask[g] = 0u;
     if (g < ldv)         t.bk_smask[g] = 0u;
     if (c0.status != kRunning) return;
@@ -1177,28 +1278,41 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
     int64_t l0 = (has_pair && 2 * p < vc) ? t.p2l[2 * p] : -1;   // logical columns of my pair
     int64_t l1 = (has_pair && 2 * p + 1 < vc) ? t.p2l[2 * p + 1] : -1;
     int64_t v_cr = -1, v_sl = -1;                                // lane i: pivot row / slot of pivot i
+    bool local = false;                                          // all workgroups on one XCD (verified)
+    const double my_xcc = (double)xcc_id();
 
 #pragma unroll 1
     for (int J = 0; J < ksteps; ++J) {
-        const unsigned long long e_price = epoch_base + 2 * J + 1, e_ratio = epoch_base + 2 * J + 2;
+        const unsigned e_price = epoch_base + 2 * J + 1, e_ratio = epoch_base + 2 * J + 2;
+        const bool mute = fault > 0 && J >= fault - 1 && w == nw - 1;
 #ifdef MI355X_LA_TIMING
-        unsigned long long T0 = wall_clock64(), T1, T2, T3, T4, T5, T6;
+        unsigned long long T0 = wall_clock64(), T2, T3, T5, T6;
 #endif
-        // ---- pricing: my pair's candidates -> workgroup winner -> record -> everybody's winner
+        // ---- pricing: my pair's candidates -> workgroup winner -> record -> everybody's winner.
+        // The record also carries the winner's entry of prow_{J-1} and (from its owner) the RHS
+        // entry of prow_{J-1}: what the chain below needs of the row that was stored last.
         ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
         if (has_pair && 2 * p < vc)     { ValIdx c; c.v = z.x * sgn; c.i = l0; c.s = 2 * p;     best = vi_min(best, c); }
         if (has_pair && 2 * p + 1 < vc) { ValIdx c; c.v = z.y * sgn; c.i = l1; c.s = 2 * p + 1; best = vi_min(best, c); }
-        best = block_reduce_min<kLaThreads>(best, s_v, s_i);     // (barriers: earlier stores ordered)
-#ifdef MI355X_LA_TIMING
-        T1 = wall_clock64();
-#endif
-        if (tid == 0) publish(t.la_px + w, best, 0, e_price);
-        if (!collect(t.la_px, nw, e_price, &s_res, &s_flag)) { if (leader) ctl->status = kSyncLost; return; }
+        LaMsg e;
+        if (!la_exchange<true>(best, 0u, t.la_px, nw, w, e_price, max_spins, mute, local, w_vc, s_wave, &s_res, e,
+                [&](const ValIdx &c, double &u, double &x2) {
+                    if (J == 0) { u = my_xcc; return; }
+                    if (c.i >= 0) {
+                        const double2 q = s_pi[J - 1][(int)((c.s >> 1) - (int64_t)w * kLaThreads)];
+                        u = (c.s & 1) ? q.y : q.x;
+                    }
+                    if (w == w_vc) { const double2 q = s_pi[J - 1][lt_vc]; x2 = (vc & 1) ? q.y : q.x; }
+                },
+                [&](const ValIdx &c) { return c.i < 0 ? -1 : (int)((c.s >> 1) / kLaThreads); })) {
+            if (tid == 0) st_wt(&ctl->status, kSyncLost);        // same word, same value from everyone
+            return;
+        }
+        if (J == 0) local = one_xcd != 0 && e.same != 0u;        // same records, same decision everywhere
 #ifdef MI355X_LA_TIMING
         T2 = wall_clock64();
 #endif
-        const ValIdx e = s_res;
-        if (e.i < 0 || !(e.v < 0.0 - price_tol)) {
+        if (e.c.i < 0 || !(e.c.v < 0.0 - price_tol)) {
             if (leader) ctl->status = 0;                         // MI_OPTIMAL
             return;
         }
@@ -1206,55 +1320,55 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
             if (leader) ctl->status = 3;                         // MI_MAX_PIVOTS
             return;
         }
-        const int64_t ec = e.i, slot = uniform64(e.s);
+        const int64_t ec = e.c.i, slot = uniform64(e.c.s);
         // ---- entering column through the pending chain; RHS entry brought up to date
         double a = has_row ? t.M[r * ld + slot] : 0.0;
-        const double v_pa = (lane < J) ? t.bk_prow[(int64_t)lane * ld + slot] : 0.0;
-        if (J > 0) {
-            const double pb = t.bk_prow[(int64_t)(J - 1) * ld + vc];
-            b = pend(b, false, r == lane_value_dyn(v_cr, J - 1), s_ci[J - 1][tid], pb);
-        }
+        double v_pa = (lane < J - 1) ? ld_l2(&t.bk_prow[(int64_t)lane * ld + slot]) : 0.0;
+        drain_vmem();                  // the loads -- and what this wave stored in the previous half-step
+        if (lane == J - 1) v_pa = e.u;
+        if (J > 0) b = pend(b, false, r == lane_value_dyn(v_cr, J - 1), s_ci[J - 1][tid], e.w);
         for (int i = 0; i < J; ++i)
             a = pend(a, slot == lane_value_dyn(v_sl, i), r == lane_value_dyn(v_cr, i), s_ci[i][tid],
                      lane_value_dyn(v_pa, i));
         s_ci[J][tid] = a;
         ValIdx q; q.v = 0.0; q.i = -1; q.s = 0;
-        int bad = 0;
+        unsigned bad = 0u;
         if (has_row) {
-            t.bk_col[(int64_t)J * t.bk_stride + r] = a;
+            st_x(&t.bk_col[(int64_t)J * t.bk_stride + r], a, local);
             bad = !(fabs(a) <= 1.7976931348623157e308);
             if (r < m && ratio_thr < a) { q.v = b / a; q.i = r; q.s = __double_as_longlong(a); }
         }
 #ifdef MI355X_LA_TIMING
         T3 = wall_clock64();
 #endif
-        q = block_reduce_min<kLaThreads>(q, s_v, s_i);
-        const int wg_bad = __syncthreads_or(bad);
-#ifdef MI355X_LA_TIMING
-        T4 = wall_clock64();
-#endif
-        if (tid == 0) publish(t.la_rx + w, q, wg_bad ? 1 : 0, e_ratio);
-        if (!collect(t.la_rx, nw, e_ratio, &s_res, &s_flag)) { if (leader) ctl->status = kSyncLost; return; }
+        // ---- ratio test; the record of the objective row's owner carries col_J[m]
+        LaMsg qq;
+        if (!la_exchange<false>(q, bad, t.la_rx, nw, w, e_ratio, max_spins, mute, local, w_m, s_wave, &s_res, qq,
+                [&](const ValIdx &, double &u, double &) { if (w == w_m) u = s_ci[J][lt_m]; },
+                [&](const ValIdx &) { return -1; })) {
+            if (tid == 0) st_wt(&ctl->status, kSyncLost);
+            return;
+        }
 #ifdef MI355X_LA_TIMING
         T5 = wall_clock64();
 #endif
-        const ValIdx qq = s_res;
-        if (s_flag != 0) {                                       // inf / NaN in the column: see kNeedDense
+        if (qq.flag != 0u) {                                     // inf / NaN in the column: see kNeedDense
             if (leader) ctl->status = kNeedDense;
             return;
         }
-        if (qq.i < 0) {
+        if (qq.c.i < 0) {
             if (leader) ctl->status = 1;                         // MI_UNBOUNDED
             return;
         }
-        const int64_t cr = uniform64(qq.i);
-        const double piv = __longlong_as_double(qq.s);
+        const int64_t cr = uniform64(qq.c.i);
+        const double piv = __longlong_as_double(qq.c.s);
+        const double cmj = qq.w;                                 // col_J[m]
         // ---- pivot row through the chain -> prow_J; objective row through pivot J
         double2 y = has_pair ? M2[cr * ldv + p] : make_double2(0.0, 0.0);
-        const double v_ccr = (lane < J) ? t.bk_col[(int64_t)lane * t.bk_stride + cr] : 0.0;
-        const double cmj = t.bk_col[(int64_t)J * t.bk_stride + m];
+        const double v_ccr = (lane < J) ? ld_l2(&t.bk_col[(int64_t)lane * t.bk_stride + cr]) : 0.0;
         const bool own = has_pair && (p == (slot >> 1));
-        const int64_t leaving = own ? t.basis[cr] : -1;
+        const int64_t leaving = own ? ld_l2(&t.basis[cr]) : -1;
+        drain_vmem();                  // the loads -- and the col_J entry stored above
         for (int i = 0; i < J; ++i) {
             const bool    is_cr = cr == lane_value_dyn(v_cr, i);
             const int64_t sl = lane_value_dyn(v_sl, i);
@@ -1266,36 +1380,49 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
         double2 pr = make_double2(0.0, 0.0);
         if (has_pair) {
             pr = scale_pair(t, p, y, piv, slot);
-            P2[(int64_t)J * ldv + p] = pr;
+            st_x(&t.bk_prow[(int64_t)J * ld + 2 * p], pr.x, local);
+            st_x(&t.bk_prow[(int64_t)J * ld + 2 * p + 1], pr.y, local);
             z.x = pend(z.x, 2 * p     == slot, false, cmj, pr.x);
             z.y = pend(z.y, 2 * p + 1 == slot, false, cmj, pr.y);
         }
         s_pi[J][tid] = pr;
-        if (own) {
+        if (own) {                                               // the slot changes hands
             if (2 * p == slot) l0 = leaving; else l1 = leaving;
-            swap_columns(t, ec, cr, slot);
-            Ctl cj = c0;
-            cj.n_pivots = c0.n_pivots + J;
-            cj.trace_n  = c0.trace_n + J;
-            record_pivot(t, cj, ec, cr);
+            st_x(&t.p2l[slot], leaving, local);
+            st_x(&t.l2p[leaving], slot, local);
+            st_x(&t.l2p[ec], (int64_t)-1, local);
+            st_x(&t.basis[cr], ec, local);                       // src/simplex.lisp:358
+            my_sm |= 1u << (J + 16 * (int)(slot & 1));
+            t.bk_smask[p] = my_sm;
+        }
+        if (has_row && r == cr) {
+            my_rm |= 1u << J;
+            t.bk_rmask[r] = my_rm;
+        }
+        if (leader) {                                            // the one writer of these words
+            const int64_t tn = c0.trace_n + J;
+            ctl->ec = ec;
+            ctl->cr = cr;
             ctl->slot = slot;
+            if (t.trace_ec && tn < t.trace_cap) { t.trace_ec[tn] = ec; t.trace_cr[tn] = cr; }
+            ctl->trace_n  = tn + 1;
+            ctl->n_pivots = c0.n_pivots + J + 1;
             blk->cr[J] = cr;
             blk->slot[J] = slot;
             blk->n_pending = J + 1;
-            t.bk_rmask[cr] |= 1u << J;
-            t.bk_smask[slot >> 1] |= 1u << (J + 16 * (int)(slot & 1));
         }
         if (lane == J) { v_cr = cr; v_sl = slot; }
 #ifdef MI355X_LA_TIMING
         T6 = wall_clock64();
         if (leader) {
             double *d = t.rhs + J * 8;
-            d[0] += (double)(T1 - T0); d[1] += (double)(T2 - T1); d[2] += (double)(T3 - T2);
-            d[3] += (double)(T4 - T3); d[4] += (double)(T5 - T4); d[5] += (double)(T6 - T5); d[6] += 1.0;
+            d[0] += 0.0; d[1] += (double)(T2 - T0); d[2] += (double)(T3 - T2);
+            d[3] += 0.0; d[4] += (double)(T5 - T3); d[5] += (double)(T6 - T5); d[6] += 1.0;
         }
 #endif
     }
 }
+
 
 // The sweep.  A workgroup owns a strip of <= 256 column pairs x tr rows and walks it four rows
 // at a time; a thread keeps its prow pairs of all pending pivots in registers (loaded once per
@@ -1333,13 +1460,14 @@ __device__ __forceinline__ void sload_chunk(v8i (&c)[CH], const double *base, co
 
 template <int BLOCK, int KMAX, bool NT>
 __global__ __launch_bounds__(BLOCK) void k_sweep(TabView t, const int tr, const int strip_pairs,
-                                                 const double sgn, const int price)
+                                                 const double sgn, const int price, const unsigned stamp)
 {
     constexpr int U = 4;                                       // rows per step
     constexpr int CH = KMAX < 4 ? KMAX : 4;                    // pivots per SGPR chunk (32 SGPRs: more would spill)
     const BlockCtl *__restrict__ blk = t.blk;
     const int k = (int)blk->n_pending;
     if (k == 0) return;
+    if (stamp != 0u && (unsigned)blk->stamp != stamp) return;  // the list is not this block's
     double *__restrict__ M = t.M;
     const int64_t ld = t.ld, rows = t.rows, vc = t.cols - 1;
     const int64_t ldv  = ld >> 1;
@@ -1880,10 +2008,10 @@ __global__ void k_ctl_reset(Ctl *ctl, int64_t max_pivots, int reset_trace)
     if (reset_trace) ctl->trace_n = 0;
 }
 
-__global__ void k_ctl_resume(Ctl *ctl)
+__global__ void k_ctl_resume(Ctl *ctl, int32_t from)
 {
     ctl += blockIdx.x;
-    if (ctl->status == kNeedDense) { ctl->status = kRunning; ctl->poison = 0; }
+    if (ctl->status == from) { ctl->status = kRunning; ctl->poison = 0; }
 }
 
 // After the last enqueued iteration: a tableau that is still "running" has simply used up
@@ -2170,9 +2298,9 @@ void launch_ctl_reset(const TabView &t, int64_t max_pivots, int reset_trace, hip
 {
     hipLaunchKernelGGL(k_ctl_reset, dim3((unsigned)t.n_lps), dim3(1), 0, s, t.ctl, max_pivots, reset_trace);
 }
-void launch_ctl_resume(const TabView &t, hipStream_t s)
+void launch_ctl_resume(const TabView &t, hipStream_t s, int32_t from)
 {
-    hipLaunchKernelGGL(k_ctl_resume, dim3((unsigned)t.n_lps), dim3(1), 0, s, t.ctl);
+    hipLaunchKernelGGL(k_ctl_resume, dim3((unsigned)t.n_lps), dim3(1), 0, s, t.ctl, from);
 }
 void launch_ctl_finish(const TabView &t, hipStream_t s)
 {
@@ -2335,27 +2463,36 @@ bool la_block_supported(const TabView &t)
     return (need + kLaThreads - 1) / kLaThreads <= kMaxLaWorkgroups;
 }
 
-void launch_la_block(const TabView &t, int ksteps, int is_max, double f, unsigned long long epoch_base,
-                     hipStream_t s)
+static int      g_la_one_xcd = 1, g_la_fault = 0;
+static unsigned g_la_max_spins = 1u << 21;
+void set_la_one_xcd(int on) { g_la_one_xcd = on ? 1 : 0; }
+void set_la_max_spins(unsigned n) { g_la_max_spins = n ? n : (1u << 21); }
+void set_la_fault(int step_plus_1) { g_la_fault = step_plus_1 > 0 ? step_plus_1 : 0; }
+
+void launch_la_block(const TabView &t, int ksteps, int is_max, double f, unsigned epoch_base, hipStream_t s)
 {
     const int64_t need = t.rows > (t.ld >> 1) ? t.rows : (t.ld >> 1);
     const int nw = (int)((need + kLaThreads - 1) / kLaThreads);
-    hipLaunchKernelGGL(k_la_block<kMaxBlock>, dim3(nw), dim3(kLaThreads), 0, s, t, ksteps, sgn_of(is_max),
-                       (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon, epoch_base);
+    // one-XCD mode: 8 x nw blocks, every eighth takes part (the kernel verifies where they run)
+    const int one_xcd = g_la_one_xcd && nw > 1;
+    hipLaunchKernelGGL(k_la_block<kMaxBlock>, dim3(one_xcd ? 8 * nw : nw), dim3(kLaThreads), 0, s, t, ksteps,
+                       sgn_of(is_max), (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon, epoch_base,
+                       g_la_max_spins, one_xcd, g_la_fault);
 }
 
 static int g_sweep_tr = 16, g_sweep_nt = -1;                    // -1: by size, as for k_update
 void set_sweep_shape(int tr, int nt) { if (tr >= 4) g_sweep_tr = tr / 4 * 4; g_sweep_nt = nt; }
 
 template <int KMAX>
-static void launch_sweep_t(const TabView &t, dim3 grid, int tr, int sp, double sgn, bool nt, hipStream_t s)
+static void launch_sweep_t(const TabView &t, dim3 grid, int tr, int sp, double sgn, bool nt, unsigned stamp,
+                           hipStream_t s)
 {
-    if (nt) hipLaunchKernelGGL((k_sweep<256, KMAX, true>),  grid, dim3(256), 0, s, t, tr, sp, sgn, 1);
-    else    hipLaunchKernelGGL((k_sweep<256, KMAX, false>), grid, dim3(256), 0, s, t, tr, sp, sgn, 1);
+    if (nt) hipLaunchKernelGGL((k_sweep<256, KMAX, true>),  grid, dim3(256), 0, s, t, tr, sp, sgn, 1, stamp);
+    else    hipLaunchKernelGGL((k_sweep<256, KMAX, false>), grid, dim3(256), 0, s, t, tr, sp, sgn, 1, stamp);
 }
 
 // applies up to kmax pending pivots; returns the number of pricing partials it leaves
-int launch_sweep(const TabView &t, int kmax, double sgn, hipStream_t s)
+int launch_sweep(const TabView &t, int kmax, double sgn, hipStream_t s, unsigned stamp)
 {
     constexpr int block = 256;
     const int64_t ldv = t.ld >> 1;
@@ -2369,10 +2506,10 @@ int launch_sweep(const TabView &t, int kmax, double sgn, hipStream_t s)
     const dim3 grid((unsigned)strips, (unsigned)((t.rows + tr - 1) / tr));
     const double bytes = (double)t.rows * (double)t.ld * 8.0;
     const bool nt = g_sweep_nt < 0 ? bytes > kNtThresholdBytes : g_sweep_nt != 0;
-    if (kmax <= 2)      launch_sweep_t<2>(t, grid, (int)tr, (int)sp, sgn, nt, s);
-    else if (kmax <= 4) launch_sweep_t<4>(t, grid, (int)tr, (int)sp, sgn, nt, s);
-    else if (kmax <= 8) launch_sweep_t<8>(t, grid, (int)tr, (int)sp, sgn, nt, s);
-    else                launch_sweep_t<16>(t, grid, (int)tr, (int)sp, sgn, nt, s);
+    if (kmax <= 2)      launch_sweep_t<2>(t, grid, (int)tr, (int)sp, sgn, nt, stamp, s);
+    else if (kmax <= 4) launch_sweep_t<4>(t, grid, (int)tr, (int)sp, sgn, nt, stamp, s);
+    else if (kmax <= 8) launch_sweep_t<8>(t, grid, (int)tr, (int)sp, sgn, nt, stamp, s);
+    else                launch_sweep_t<16>(t, grid, (int)tr, (int)sp, sgn, nt, stamp, s);
     return strips * (block / 64);
 }
 

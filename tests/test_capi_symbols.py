@@ -13,10 +13,11 @@ from tests.helpers import ROOT, lp_amd
 
 lp = lp_amd()
 HEADER = os.path.join(ROOT, "include", "mi355x_simplex.h")
+TUNE_HEADER = os.path.join(ROOT, "include", "mi355x_simplex_tune.h")
 
 
-def declared_functions():
-    src = open(HEADER).read()
+def declared_functions(header=HEADER):
+    src = open(header).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(mi355x_[a-z0-9_]+)\s*\(", src)))
 
@@ -38,6 +39,21 @@ def test_every_declared_symbol_is_exported_and_bound():
     for name in names:
         assert hasattr(L, name), "%s declared in the header but not exported" % name
     assert sorted(lp.capi.SIGNATURES) == names, "capi.py and the header disagree"
+
+
+def test_tuning_hooks_are_declared_exported_and_bound():
+    """include/mi355x_simplex_tune.h is the one place the non-boundary hooks are declared; the
+    library exports exactly the union of the two headers (nothing undeclared)."""
+    names = declared_functions(TUNE_HEADER)
+    assert len(names) >= 15 and not set(names) & set(declared_functions())
+    L = ctypes.CDLL(lp.capi.LIB_PATH)
+    for name in names:
+        assert hasattr(L, name), "%s declared in the tuning header but not exported" % name
+    assert sorted(lp.capi._EXTRA) == names, "capi.py and the tuning header disagree"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lp.capi.LIB_PATH], text=True)
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l and "mi355x_" in l}
+    assert exported == set(names) | set(declared_functions()), \
+        "undeclared exports: %s" % sorted(exported - set(names) - set(declared_functions()))
 
 
 def test_exports_are_plain_c_symbols():

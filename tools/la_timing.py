@@ -1,17 +1,26 @@
-"""Where the persistent look-ahead kernel (k_la_block) spends a step: needs the library built
-with -DMI355X_LA_TIMING (the leader thread then accumulates wall_clock64 deltas of the six phases
-of every step in the handle's otherwise unused `rhs` buffer).
+"""Where the persistent look-ahead kernel (k_la_block) spends a step.  Builds an instrumented
+copy of the library (-DMI355X_LA_TIMING: the leader thread accumulates wall_clock64 deltas of the
+phases of every step in the handle's otherwise unused `rhs` buffer) next to the product library,
+loads THAT copy and runs config 3.
 
-    hipcc ... -DMI355X_LA_TIMING ...   (see linear-programming_amd/build.py for the flags)
-    python tools/la_timing.py
+    python tools/la_timing.py [one_xcd (1|0)] [n_vars n_cons]
 """
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "linear-programming_amd"))
+import build as _build
+out = os.path.join(ROOT, "gpurun_out", "libmi355x_simplex_la_timing.so")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(s) for s in _build.sources()):
+    _build.build(extra_flags=["-DMI355X_LA_TIMING"], out=out)
+os.environ["MI355X_SIMPLEX_LIB"] = out
 import numpy as np
 from tests.helpers import lp_amd
 lp = lp_amd(); L = lp.capi.lib()
-L.mi355x_debug_rhs.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]
-n, m = 8192, 4096
+one_xcd = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+n, m = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (8192, 4096)
+L.mi355x_tune_set_la_one_xcd(one_xcd)
 h = ctypes.c_void_p()
 lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h), n, m, lp.synth.seed_for(3), 0, -1, 0), "create")
 npv = ctypes.c_int64(0)
@@ -19,13 +28,22 @@ lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, 64, 1), "warm")
 L.mi355x_tab_sync(h, ctypes.byref(npv))
 out = np.zeros(128)
 L.mi355x_debug_rhs(h, out.ctypes.data_as(ctypes.c_void_p), 128, 1)
+L.mi355x_tab_timing_enable(h, 1)
 lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, 1600, 0), "run")
 L.mi355x_tab_sync(h, ctypes.byref(npv))
 L.mi355x_debug_rhs(h, out.ctypes.data_as(ctypes.c_void_p), 128, 0)
 d = out.reshape(16, 8)
 if d[:, 6].sum() == 0:
     sys.exit("no samples: the library was built without -DMI355X_LA_TIMING")
-print("us per step: price-reduce | price-exchange | column+chain | ratio-reduce | ratio-exchange | row+chain+bookkeeping")
+print("one_xcd=%d  %d x %d   us per step: price reduce+exchange | column+chain | ratio reduce+exchange | row+chain+bookkeeping" % (one_xcd, n, m))
+tot = 0.0
 for J in range(16):
     c = d[J, 6]
-    print(J, int(c), " ".join("%7.2f" % (d[J, k] / c * 0.01) for k in range(6)), "  total %.2f" % (d[J, :6].sum() / c * 0.01))
+    row = [d[J, k] / c * 0.01 for k in (1, 2, 4, 5)]
+    tot += sum(row)
+    print("%2d %5d " % (J, int(c)) + " ".join("%7.2f" % x for x in row) + "   total %.2f" % sum(row))
+print("sum over the 16 steps: %.1f us per block" % tot)
+for kind, name in ((1, "look-ahead"), (0, "sweep")):
+    nl, sm, mn = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+    L.mi355x_tab_timing_read_kind(h, kind, ctypes.byref(nl), ctypes.byref(sm), ctypes.byref(mn))
+    print("%s: %d launches, avg %.1f us, min %.1f us (HIP events)" % (name, nl.value, sm.value / max(nl.value, 1) * 1e3, mn.value * 1e3))
