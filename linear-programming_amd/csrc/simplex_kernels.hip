@@ -1154,24 +1154,81 @@ __device__ __forceinline__ double join_bits(unsigned long long lo, unsigned long
     return __longlong_as_double((long long)(((hi & 0xffffffffull) << 32) | (lo & 0xffffffffull)));
 }
 
+// The reductions of the look-ahead move (value, 32-bit index) pairs only -- half the DPP /
+// ds_bpermute traffic of a ValIdx -- and fetch the winner's payload from the lane that holds it
+// afterwards (indices are unique, so that lane is).  Same decision rule, same tree as
+// vi_min / wave_reduce_min.
+struct Cand { double v; int i; };                                // i < 0: empty
+__device__ __forceinline__ Cand cand_min(Cand a, Cand b)
+{
+    const bool a_empty = a.i < 0, b_empty = b.i < 0;
+    const bool better  = (b.v < a.v) | ((b.v == a.v) & (b.i < a.i));
+    const bool take_b  = a_empty | (!b_empty & better);
+    Cand r;
+    r.v = take_b ? b.v : a.v;
+    r.i = take_b ? b.i : a.i;
+    return r;
+}
+template <int CTRL> __device__ __forceinline__ Cand dpp_cand(Cand x)
+{
+    Cand y;
+    y.v = __longlong_as_double(dpp64<CTRL>(__double_as_longlong(x.v)));
+    y.i = __builtin_amdgcn_update_dpp(x.i, x.i, CTRL, 0xf, 0xf, false);
+    return y;
+}
+__device__ __forceinline__ Cand shfl_down_cand(Cand x, int off)
+{
+    Cand y;
+    y.v = __shfl_down(x.v, off, 64);
+    y.i = __shfl_down(x.i, off, 64);
+    return y;
+}
+// winner of the wave in EVERY lane, plus the lane that holds it (-1: all empty)
+__device__ __forceinline__ Cand wave_reduce_cand(Cand x, int &src)
+{
+    const int mine = x.i;
+    x = cand_min(x, shfl_down_cand(x, 32));
+    x = cand_min(x, shfl_down_cand(x, 16));
+    x = cand_min(x, dpp_cand<0x108>(x));
+    x = cand_min(x, dpp_cand<0x104>(x));
+    x = cand_min(x, dpp_cand<0x102>(x));
+    x = cand_min(x, dpp_cand<0x101>(x));
+    x.v = lane_value(x.v, 0);
+    x.i = __builtin_amdgcn_readfirstlane(x.i);
+    const unsigned long long m = __ballot((mine == x.i) & (x.i >= 0));
+    src = m ? (int)__ffsll((long long)m) - 1 : -1;
+    return x;
+}
+__device__ __forceinline__ int64_t lane_pick(int64_t v, int src) { return lane_value_dyn(v, src < 0 ? 0 : src); }
+__device__ __forceinline__ double  lane_pick(double v, int src)  { return lane_value_dyn(v, src < 0 ? 0 : src); }
+
 // Exchange of one reduction between the workgroups.  `mine` is this thread's candidate; the
 // workgroup's winner (same order as block_reduce_min: wave tree, then waves 0..3 in turn) is
 // published together with two doubles the first wave computes from it (extra(c, u, w)), every
 // record is collected, and their winner (wave tree over the workgroups) is handed to every
-// thread with the two doubles of the records picked by pick_u(winner) / w_from.
-// PRICE: granules v v i s u u w w   (s = slot: 32 bits)      RATIO: v v i|flag s s u u w
+// thread with the first double of the winner's record and the second double (PRICE) / first
+// double (RATIO) of record w_from.
+// PRICE: granules v v i s u u w w   (s = slot: 32 bits)      RATIO: v v i|flag s s u u -
 // false: a record did not arrive within max_spins polls.
-template <bool PRICE, class Extra, class PickU>
+template <bool PRICE, class Extra>
 __device__ __forceinline__ bool la_exchange(ValIdx mine, unsigned myflag, ExchRec *recs, int nw, int w,
                                             unsigned tag, unsigned max_spins, bool mute, bool local,
                                             int w_from, LaMsg *s_wave, LaMsg *s_res, LaMsg &out,
-                                            Extra extra, PickU pick_u)
+                                            Extra extra, unsigned long long *ts)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    mine = wave_reduce_min(mine);
+    {
+        Cand c; c.v = mine.v; c.i = (int)mine.i;
+        int src;
+        c = wave_reduce_cand(c, src);
+        mine.v = c.v; mine.i = c.i; mine.s = lane_pick(mine.s, src);
+    }
     const unsigned wf = __any(myflag != 0u) ? 1u : 0u;
     if (lane == 0) { s_wave[wave].c = mine; s_wave[wave].flag = wf; }
     __syncthreads();
+#ifdef MI355X_LA_TIMING
+    if (ts) ts[0] = wall_clock64();
+#endif
     if (tid < 64) {
         ValIdx c = s_wave[0].c;
         unsigned f = s_wave[0].flag;
@@ -1188,9 +1245,12 @@ __device__ __forceinline__ bool la_exchange(ValIdx mine, unsigned myflag, ExchRe
                            : lane == 6 ? (unsigned)wb : (unsigned)(wb >> 32);
             else       val = lane == 0 ? (unsigned)vb : lane == 1 ? (unsigned)(vb >> 32) : lane == 2 ? iw
                            : lane == 3 ? (unsigned)sb : lane == 4 ? (unsigned)(sb >> 32) : lane == 5 ? (unsigned)ub
-                           : lane == 6 ? (unsigned)(ub >> 32) : (unsigned)wb;   // (ratio: w = low word only, unused)
+                           : lane == 6 ? (unsigned)(ub >> 32) : 0u;
             if (lane < 8) st_x(&recs[w].g[lane], ((unsigned long long)tag << 32) | val, local);
         }
+#ifdef MI355X_LA_TIMING
+        if (ts) ts[1] = wall_clock64();
+#endif
         const ExchRec *r = recs + (lane < nw ? lane : 0);
         unsigned long long g[8];
         unsigned spins = 0;
@@ -1204,35 +1264,61 @@ __device__ __forceinline__ bool la_exchange(ValIdx mine, unsigned myflag, ExchRe
             if (__all(ok | (lane >= nw))) break;
             if (++spins > max_spins) { fine = false; break; }
         }
-        ValIdx x; x.v = 0.0; x.i = -1; x.s = 0;
+#ifdef MI355X_LA_TIMING
+        if (ts) { ts[2] = wall_clock64(); ts[5] = spins; }
+#endif
+        Cand x; x.v = 0.0; x.i = -1;
+        int64_t xs = 0;
         unsigned fl = 0u;
-        double ru, rw;
         const unsigned iw = (unsigned)g[2];
         if (lane < nw) {
             x.v = join_bits(g[0], g[1]);
-            x.i = (iw & kEmptyIdx) == kEmptyIdx ? -1 : (int64_t)(iw & kEmptyIdx);
-            x.s = PRICE ? (int64_t)(g[3] & 0xffffffffull) : (int64_t)(((g[4] & 0xffffffffull) << 32) | (g[3] & 0xffffffffull));
+            x.i = (iw & kEmptyIdx) == kEmptyIdx ? -1 : (int)(iw & kEmptyIdx);
+            xs = PRICE ? (int64_t)(g[3] & 0xffffffffull) : (int64_t)(((g[4] & 0xffffffffull) << 32) | (g[3] & 0xffffffffull));
             fl = iw >> 31;
         }
-        ru = PRICE ? join_bits(g[4], g[5]) : join_bits(g[5], g[6]);
-        rw = PRICE ? join_bits(g[6], g[7]) : 0.0;
-        x = wave_reduce_min(x);                     // valid in lane 0
+        const double ru = PRICE ? join_bits(g[4], g[5]) : join_bits(g[5], g[6]);
+        const double rw = PRICE ? join_bits(g[6], g[7]) : 0.0;
+        int src;
+        x = wave_reduce_cand(x, src);               // uniform
         fl = __any(fl != 0u) ? 1u : 0u;
-        x.v = lane_value(x.v, 0); x.i = lane_value(x.i, 0); x.s = lane_value(x.s, 0);
-        const int wu = pick_u(x);                   // uniform: the record whose u belongs to the winner
-        const double bu = lane_value_dyn(ru, wu < 0 ? 0 : wu);
+        const int64_t bs = lane_pick(xs, src);
+        const double bu = lane_pick(ru, src);       // the winner's own record
         const double bw = PRICE ? lane_value_dyn(rw, w_from) : lane_value_dyn(ru, w_from);
         // do all records carry the same first double?  (the XCC ids of the first exchange)
         const unsigned same = __all((lane >= nw) | (dbits(ru) == dbits(lane_value(ru, 0)))) ? 1u : 0u;
-        if (lane == 0) { s_res->c = x; s_res->flag = fine ? fl : 2u; s_res->same = same; s_res->u = bu; s_res->w = bw; }
+        if (lane == 0) {
+            s_res->c.v = x.v; s_res->c.i = x.i; s_res->c.s = bs;
+            s_res->flag = fine ? fl : 2u; s_res->same = same; s_res->u = bu; s_res->w = bw;
+        }
+#ifdef MI355X_LA_TIMING
+        if (ts) ts[3] = wall_clock64();
+#endif
     }
     __syncthreads();
+#ifdef MI355X_LA_TIMING
+    if (ts) ts[4] = wall_clock64();
+#endif
     out = *s_res;
     return out.flag != 2u;
 }
+
+// One link of the pending chain with the product taken out of the dependent path: the chain of a
+// value through pivots 0..J-1 is then J independent multiplications followed by J dependent
+// (select, subtract, select) triples instead of J dependent (multiply, subtract) pairs with their
+// operand fetches in between -- with one wave per SIMD every dependent instruction costs its full
+// latency.  Links i >= J are exact identities: operands 0.0 give x - (+0.0) == x bit for bit.
+__device__ __forceinline__ double pend_prod(double x, bool is_slot, bool is_cr, double prod, double prowv)
+{
+    if (is_slot) x = is_cr ? 1.0 : 0.0;
+    const double d = x - prod;                                   // rounded difference
+    return is_cr ? prowv : d;
+}
+
 // The steps are a run-time loop (fully unrolled the kernel was 300 KB of straight-line code and
 // ran at the speed of instruction-cache misses): per-thread col_i[row] / prow_i[pair] of the
 // pending pivots live in LDS ([pivot][thread]: conflict-free), everything else in registers.
+// The chains over the pending pivots are unrolled in groups of four links.
 // one_xcd: see above.  fault > 0 (test hook): the last workgroup stops publishing from step
 // `fault - 1` on, as a workgroup that is not resident would.
 template <int KMAX>
@@ -1241,6 +1327,7 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
                                                         unsigned epoch_base, unsigned max_spins,
                                                         int one_xcd, int fault)
 {
+    static_assert(KMAX % 4 == 0 && KMAX <= 64, "chains are unrolled in groups of four; one lane per pending pivot");
     __shared__ double    s_ci[KMAX][kLaThreads];                 // 32 KB
     __shared__ double2   s_pi[KMAX][kLaThreads];                 // 64 KB
     __shared__ LaMsg     s_wave[kLaThreads / 64];
@@ -1280,6 +1367,11 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
     int64_t v_cr = -1, v_sl = -1;                                // lane i: pivot row / slot of pivot i
     bool local = false;                                          // all workgroups on one XCD (verified)
     const double my_xcc = (double)xcc_id();
+    unsigned long long *ts_p = nullptr, *ts_r = nullptr;
+#ifdef MI355X_LA_TIMING
+    unsigned long long tsp[6] = {0, 0, 0, 0, 0, 0}, tsr[6] = {0, 0, 0, 0, 0, 0};
+    if (leader) { ts_p = tsp; ts_r = tsr; }
+#endif
 
 #pragma unroll 1
     for (int J = 0; J < ksteps; ++J) {
@@ -1303,8 +1395,7 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
                         u = (c.s & 1) ? q.y : q.x;
                     }
                     if (w == w_vc) { const double2 q = s_pi[J - 1][lt_vc]; x2 = (vc & 1) ? q.y : q.x; }
-                },
-                [&](const ValIdx &c) { return c.i < 0 ? -1 : (int)((c.s >> 1) / kLaThreads); })) {
+                }, ts_p)) {
             if (tid == 0) st_wt(&ctl->status, kSyncLost);        // same word, same value from everyone
             return;
         }
@@ -1327,9 +1418,21 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
         drain_vmem();                  // the loads -- and what this wave stored in the previous half-step
         if (lane == J - 1) v_pa = e.u;
         if (J > 0) b = pend(b, false, r == lane_value_dyn(v_cr, J - 1), s_ci[J - 1][tid], e.w);
-        for (int i = 0; i < J; ++i)
-            a = pend(a, slot == lane_value_dyn(v_sl, i), r == lane_value_dyn(v_cr, i), s_ci[i][tid],
-                     lane_value_dyn(v_pa, i));
+#pragma unroll
+        for (int i0 = 0; i0 < KMAX; i0 += 4) {
+            if (i0 < J) {
+                double prod[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double ci = (i0 + k < J) ? s_ci[i0 + k][tid] : 0.0;
+                    prod[k] = ci * lane_value(v_pa, i0 + k);           // rounded product
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    a = pend_prod(a, slot == lane_value(v_sl, i0 + k), r == lane_value(v_cr, i0 + k), prod[k],
+                                  lane_value(v_pa, i0 + k));
+            }
+        }
         s_ci[J][tid] = a;
         ValIdx q; q.v = 0.0; q.i = -1; q.s = 0;
         unsigned bad = 0u;
@@ -1344,8 +1447,7 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
         // ---- ratio test; the record of the objective row's owner carries col_J[m]
         LaMsg qq;
         if (!la_exchange<false>(q, bad, t.la_rx, nw, w, e_ratio, max_spins, mute, local, w_m, s_wave, &s_res, qq,
-                [&](const ValIdx &, double &u, double &) { if (w == w_m) u = s_ci[J][lt_m]; },
-                [&](const ValIdx &) { return -1; })) {
+                [&](const ValIdx &, double &u, double &) { if (w == w_m) u = s_ci[J][lt_m]; }, ts_r)) {
             if (tid == 0) st_wt(&ctl->status, kSyncLost);
             return;
         }
@@ -1369,13 +1471,25 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
         const bool own = has_pair && (p == (slot >> 1));
         const int64_t leaving = own ? ld_l2(&t.basis[cr]) : -1;
         drain_vmem();                  // the loads -- and the col_J entry stored above
-        for (int i = 0; i < J; ++i) {
-            const bool    is_cr = cr == lane_value_dyn(v_cr, i);
-            const int64_t sl = lane_value_dyn(v_sl, i);
-            const double  ccr = lane_value_dyn(v_ccr, i);
-            const double2 pii = s_pi[i][tid];
-            y.x = pend(y.x, 2 * p     == sl, is_cr, ccr, pii.x);
-            y.y = pend(y.y, 2 * p + 1 == sl, is_cr, ccr, pii.y);
+#pragma unroll
+        for (int i0 = 0; i0 < KMAX; i0 += 4) {
+            if (i0 < J) {
+                double2 pii[4], prod[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    pii[k] = (i0 + k < J) ? s_pi[i0 + k][tid] : make_double2(0.0, 0.0);
+                    const double ccr = lane_value(v_ccr, i0 + k);
+                    prod[k].x = ccr * pii[k].x;                        // rounded products
+                    prod[k].y = ccr * pii[k].y;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool    is_cr = cr == lane_value(v_cr, i0 + k);
+                    const int64_t sl = lane_value(v_sl, i0 + k);
+                    y.x = pend_prod(y.x, 2 * p     == sl, is_cr, prod[k].x, pii[k].x);
+                    y.y = pend_prod(y.y, 2 * p + 1 == sl, is_cr, prod[k].y, pii[k].y);
+                }
+            }
         }
         double2 pr = make_double2(0.0, 0.0);
         if (has_pair) {
@@ -1415,14 +1529,18 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
 #ifdef MI355X_LA_TIMING
         T6 = wall_clock64();
         if (leader) {
-            double *d = t.rhs + J * 8;
-            d[0] += 0.0; d[1] += (double)(T2 - T0); d[2] += (double)(T3 - T2);
-            d[3] += 0.0; d[4] += (double)(T5 - T3); d[5] += (double)(T6 - T5); d[6] += 1.0;
+            double *d = t.rhs + J * 24;
+            d[0] += 1.0; d[1] += (double)(T2 - T0); d[2] += (double)(T3 - T2);
+            d[3] += (double)(T5 - T3); d[4] += (double)(T6 - T5);
+            // inside the exchanges: entry -> barrier 1 -> published -> all records in -> reduced -> barrier 2
+            d[5] += (double)(tsp[0] - T0); d[6] += (double)(tsp[1] - tsp[0]); d[7] += (double)(tsp[2] - tsp[1]);
+            d[8] += (double)(tsp[3] - tsp[2]); d[9] += (double)(tsp[4] - tsp[3]); d[10] += (double)tsp[5];
+            d[11] += (double)(tsr[0] - T3); d[12] += (double)(tsr[1] - tsr[0]); d[13] += (double)(tsr[2] - tsr[1]);
+            d[14] += (double)(tsr[3] - tsr[2]); d[15] += (double)(tsr[4] - tsr[3]); d[16] += (double)tsr[5];
         }
 #endif
     }
 }
-
 
 // The sweep.  A workgroup owns a strip of <= 256 column pairs x tr rows and walks it four rows
 // at a time; a thread keeps its prow pairs of all pending pivots in registers (loaded once per
