@@ -218,8 +218,8 @@ int alloc_tab(mi355x_tab **out, int64_t rows, int64_t cols, int device, int64_t 
         ALLOC(t->v.blk, sizeof(BlockCtl));
         ALLOC(t->v.bk_rmask, (size_t)t->v.bk_stride * sizeof(uint32_t));
         ALLOC(t->v.bk_smask, (size_t)t->v.ld * sizeof(uint32_t));
-        ALLOC(t->v.la_px, kMaxLaWorkgroups * sizeof(ExchRec));
-        ALLOC(t->v.la_rx, kMaxLaWorkgroups * sizeof(ExchRec));
+        ALLOC(t->v.la_px, kMaxLaRecords * sizeof(ExchRec));
+        ALLOC(t->v.la_rx, kMaxLaRecords * sizeof(ExchRec));
     }
 #undef ALLOC
     if ((e = hipHostMalloc((void **)&t->h_ctl, n_lps * sizeof(Ctl))) != hipSuccess ||
@@ -245,8 +245,8 @@ int alloc_tab(mi355x_tab **out, int64_t rows, int64_t cols, int device, int64_t 
     if ((t->v.blk && ((e = hipMemsetAsync(t->v.blk, 0, sizeof(BlockCtl), t->stream)) != hipSuccess ||
                       (e = hipMemsetAsync(t->v.bk_rmask, 0, t->v.bk_stride * sizeof(uint32_t), t->stream)) != hipSuccess ||
                       (e = hipMemsetAsync(t->v.bk_smask, 0, t->v.ld * sizeof(uint32_t), t->stream)) != hipSuccess ||
-                      (e = hipMemsetAsync(t->v.la_px, 0, kMaxLaWorkgroups * sizeof(ExchRec), t->stream)) != hipSuccess ||
-                      (e = hipMemsetAsync(t->v.la_rx, 0, kMaxLaWorkgroups * sizeof(ExchRec), t->stream)) != hipSuccess ||
+                      (e = hipMemsetAsync(t->v.la_px, 0, kMaxLaRecords * sizeof(ExchRec), t->stream)) != hipSuccess ||
+                      (e = hipMemsetAsync(t->v.la_rx, 0, kMaxLaRecords * sizeof(ExchRec), t->stream)) != hipSuccess ||
                       (e = hipMemsetAsync(t->v.bk_col, 0, (size_t)kMaxBlock * t->v.bk_stride * sizeof(double), t->stream)) != hipSuccess ||
                       (e = hipMemsetAsync(t->v.bk_prow, 0, (size_t)kMaxBlock * t->v.ld * sizeof(double), t->stream)) != hipSuccess)) ||
         (e = hipMemsetAsync(t->v.ctl, 0, n_lps * sizeof(Ctl), t->stream)) != hipSuccess ||
@@ -461,8 +461,8 @@ int enqueue_block(mi355x_tab *t, int is_max, double f, int k)
     unsigned stamp = 0;
     if (persistent) {
         if (t->la_epoch > 0x7fff0000u) {              // 32-bit tags: start over on clean records
-            HIP_TRY(hipMemsetAsync(v.la_px, 0, kMaxLaWorkgroups * sizeof(ExchRec), t->stream));
-            HIP_TRY(hipMemsetAsync(v.la_rx, 0, kMaxLaWorkgroups * sizeof(ExchRec), t->stream));
+            HIP_TRY(hipMemsetAsync(v.la_px, 0, kMaxLaRecords * sizeof(ExchRec), t->stream));
+            HIP_TRY(hipMemsetAsync(v.la_rx, 0, kMaxLaRecords * sizeof(ExchRec), t->stream));
             t->la_epoch = 1;
         }
         stamp = t->la_epoch;

@@ -55,6 +55,7 @@ struct ExchRec {
     unsigned long long g[8];
 };
 constexpr int kMaxLaWorkgroups = 32;
+constexpr int kMaxLaRecords = 4 * kMaxLaWorkgroups;     // one record per wave of a 256-thread workgroup
 
 // One tableau in HBM.  Row-major, leading dimension ld (a multiple of 16 doubles so
 // that every row starts on a 128-byte boundary and 16-byte vector accesses never
@@ -86,7 +87,7 @@ struct TabView {
     // bit i of bk_rmask[r]: row r is the pivot row of pending pivot i; bits i / 16+i of
     // bk_smask[pair]: the even / odd column of that pair is the slot pending pivot i gave up
     uint32_t *bk_rmask, *bk_smask;
-    ExchRec  *la_px, *la_rx;      // kMaxLaWorkgroups pricing / ratio records (persistent look-ahead)
+    ExchRec  *la_px, *la_rx;      // kMaxLaRecords pricing / ratio records (persistent look-ahead)
     // batch of n_lps same-shape LPs: per-LP element strides (all zero for a single tableau)
     int64_t  n_lps;
     int64_t  zs_M, zs_basis, zs_col, zs_prow, zs_part, zs_p2l, zs_l2p;

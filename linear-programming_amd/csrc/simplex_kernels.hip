@@ -1201,124 +1201,196 @@ __device__ __forceinline__ Cand wave_reduce_cand(Cand x, int &src)
 }
 __device__ __forceinline__ int64_t lane_pick(int64_t v, int src) { return lane_value_dyn(v, src < 0 ? 0 : src); }
 __device__ __forceinline__ double  lane_pick(double v, int src)  { return lane_value_dyn(v, src < 0 ? 0 : src); }
+__device__ __forceinline__ int     lane_pick(int v, int src)
+{
+    return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src < 0 ? 0 : src));
+}
 
-// Exchange of one reduction between the workgroups.  `mine` is this thread's candidate; the
-// workgroup's winner (same order as block_reduce_min: wave tree, then waves 0..3 in turn) is
-// published together with two doubles the first wave computes from it (extra(c, u, w)), every
-// record is collected, and their winner (wave tree over the workgroups) is handed to every
-// thread with the first double of the winner's record and the second double (PRICE) / first
-// double (RATIO) of record w_from.
+// The same arg-min in ~30 instead of ~140 instructions for the common case -- no NaN among the
+// wave's candidates and a unique minimum: the minimum VALUE by a butterfly of v_min_f64 (gfx950's
+// v_permlane32_swap / v_permlane16_swap across the rows of 16 lanes, DPP row rotations inside
+// them; every lane ends up with it), then the lane that holds it by a ballot.  Without NaNs the
+// lexicographic (value, index) minimum is unique and independent of the reduction order, so this
+// IS the tree's winner; with a NaN candidate (vi_min is then order dependent) or an exact tie
+// (lowest index decides) the tree itself runs.
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double min_f64(double a, double b)     // operands are never NaN here
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double wave_allmin_f64(double x)
+{
+    {   // lanes l and l ^ 32: whichever half a swap puts where, {r.x, r.y} is the pair in every lane
+        const long long b = __double_as_longlong(x);
+        const unsigned lo = (unsigned)b, hi = (unsigned)((unsigned long long)b >> 32);
+        const v2u l2 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const v2u h2 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        x = min_f64(__longlong_as_double((long long)(((unsigned long long)h2.x << 32) | l2.x)),
+                    __longlong_as_double((long long)(((unsigned long long)h2.y << 32) | l2.y)));
+    }
+    {   // rows 0 <-> 1, 2 <-> 3
+        const long long b = __double_as_longlong(x);
+        const unsigned lo = (unsigned)b, hi = (unsigned)((unsigned long long)b >> 32);
+        const v2u l2 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const v2u h2 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        x = min_f64(__longlong_as_double((long long)(((unsigned long long)h2.x << 32) | l2.x)),
+                    __longlong_as_double((long long)(((unsigned long long)h2.y << 32) | l2.y)));
+    }
+    x = min_f64(x, __longlong_as_double(dpp64<0x128>(__double_as_longlong(x))));   // row_ror:8
+    x = min_f64(x, __longlong_as_double(dpp64<0x124>(__double_as_longlong(x))));   // row_ror:4
+    x = min_f64(x, __longlong_as_double(dpp64<0x122>(__double_as_longlong(x))));   // row_ror:2
+    x = min_f64(x, __longlong_as_double(dpp64<0x121>(__double_as_longlong(x))));   // row_ror:1
+    return x;
+}
+__device__ __forceinline__ Cand wave_argmin(Cand x, int &src)
+{
+    const bool valid = x.i >= 0;
+    if (__any(valid & (x.v != x.v))) return wave_reduce_cand(x, src);
+    const double key = valid ? x.v : __builtin_huge_val();
+    const double vmin = wave_allmin_f64(key);
+    const unsigned long long mask = __ballot(valid & (key == vmin));
+    if (__popcll(mask) > 1) return wave_reduce_cand(x, src);
+    src = mask ? (int)__ffsll((long long)mask) - 1 : -1;
+    Cand r;
+    r.v = lane_pick(x.v, src);
+    r.i = mask ? lane_pick(x.i, src) : -1;
+    if (!mask) r.v = 0.0;
+    return r;
+}
+
+// Exchange of one reduction between the workgroups.  `mine` is this thread's candidate.  Every
+// WAVE reduces its 64 candidates (tree of wave_reduce_min) and publishes its winner at once as
+// record 4 w + wave -- together with two doubles it picks out of its lanes' registers
+// (extra(winner, lane that holds it, u, x2)) -- so nothing waits for a workgroup barrier on the
+// way out; the first wave of every workgroup collects all records (lane l: records l and l + 64),
+// reduces them (tree again) and hands the winner to the other waves through LDS, with the first
+// double of the winner's own record and the second double (PRICE) / first double (RATIO) of
+// record rec_from.
 // PRICE: granules v v i s u u w w   (s = slot: 32 bits)      RATIO: v v i|flag s s u u -
 // false: a record did not arrive within max_spins polls.
+constexpr int kLaWaves = kLaThreads / 64;
+
+template <bool PRICE>
+__device__ __forceinline__ void decode_rec(const unsigned long long (&g)[8], bool valid, Cand &x, int64_t &xs,
+                                           unsigned &fl, double &ru, double &rw)
+{
+    const unsigned iw = (unsigned)g[2];
+    x.v = 0.0; x.i = -1; xs = 0; fl = 0u;
+    if (valid) {
+        x.v = join_bits(g[0], g[1]);
+        x.i = (iw & kEmptyIdx) == kEmptyIdx ? -1 : (int)(iw & kEmptyIdx);
+        xs = PRICE ? (int64_t)(g[3] & 0xffffffffull) : (int64_t)(((g[4] & 0xffffffffull) << 32) | (g[3] & 0xffffffffull));
+        fl = iw >> 31;
+    }
+    ru = PRICE ? join_bits(g[4], g[5]) : join_bits(g[5], g[6]);
+    rw = PRICE ? join_bits(g[6], g[7]) : 0.0;
+}
+
 template <bool PRICE, class Extra>
 __device__ __forceinline__ bool la_exchange(ValIdx mine, unsigned myflag, ExchRec *recs, int nw, int w,
                                             unsigned tag, unsigned max_spins, bool mute, bool local,
-                                            int w_from, LaMsg *s_wave, LaMsg *s_res, LaMsg &out,
-                                            Extra extra, unsigned long long *ts)
+                                            int rec_from, LaMsg *s_res, LaMsg &out, Extra extra,
+                                            unsigned long long *ts)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    {
+    const int nrec = nw * kLaWaves;
+    {   // ---- this wave's winner -> its record
         Cand c; c.v = mine.v; c.i = (int)mine.i;
         int src;
-        c = wave_reduce_cand(c, src);
-        mine.v = c.v; mine.i = c.i; mine.s = lane_pick(mine.s, src);
+        c = wave_argmin(c, src);
+        const int64_t cs = lane_pick(mine.s, src);
+        const unsigned wf = __any(myflag != 0u) ? 1u : 0u;
+        double u = 0.0, x2 = 0.0;
+        ValIdx win; win.v = c.v; win.i = c.i; win.s = cs;
+        extra(win, src, u, x2);
+        if (!mute) {
+            const unsigned long long vb = dbits(c.v), sb = (unsigned long long)cs, ub = dbits(u), wb = dbits(x2);
+            const unsigned iw = (c.i < 0 ? kEmptyIdx : (unsigned)c.i) | (wf ? 0x80000000u : 0u);
+            const unsigned word[8] = { (unsigned)vb, (unsigned)(vb >> 32), iw, (unsigned)sb,
+                                       PRICE ? (unsigned)ub : (unsigned)(sb >> 32),
+                                       PRICE ? (unsigned)(ub >> 32) : (unsigned)ub,
+                                       PRICE ? (unsigned)wb : (unsigned)(ub >> 32),
+                                       PRICE ? (unsigned)(wb >> 32) : 0u };
+            unsigned val = word[0];                              // lane k stores granule k
+#pragma unroll
+            for (int k = 1; k < 8; ++k) val = lane == k ? word[k] : val;
+            if (lane < 8) st_x(&recs[w * kLaWaves + wave].g[lane], ((unsigned long long)tag << 32) | val, local);
+        }
     }
-    const unsigned wf = __any(myflag != 0u) ? 1u : 0u;
-    if (lane == 0) { s_wave[wave].c = mine; s_wave[wave].flag = wf; }
-    __syncthreads();
 #ifdef MI355X_LA_TIMING
     if (ts) ts[0] = wall_clock64();
 #endif
     if (tid < 64) {
-        ValIdx c = s_wave[0].c;
-        unsigned f = s_wave[0].flag;
+        // ---- collect: lane l <- records l and l + 64
+        const bool v0 = lane < nrec, v1 = lane + 64 < nrec;
+        const ExchRec *r0 = recs + (v0 ? lane : 0), *r1 = recs + (v1 ? lane + 64 : 0);
+        unsigned long long g0[8], g1[8];
 #pragma unroll
-        for (int k = 1; k < kLaThreads / 64; ++k) { c = vi_min(c, s_wave[k].c); f |= s_wave[k].flag; }
-        double u = 0.0, x2 = 0.0;
-        extra(c, u, x2);
-        if (!mute) {
-            const unsigned long long vb = dbits(c.v), sb = (unsigned long long)c.s, ub = dbits(u), wb = dbits(x2);
-            const unsigned iw = (c.i < 0 ? kEmptyIdx : (unsigned)c.i) | (f ? 0x80000000u : 0u);
-            unsigned val;
-            if (PRICE) val = lane == 0 ? (unsigned)vb : lane == 1 ? (unsigned)(vb >> 32) : lane == 2 ? iw
-                           : lane == 3 ? (unsigned)sb : lane == 4 ? (unsigned)ub : lane == 5 ? (unsigned)(ub >> 32)
-                           : lane == 6 ? (unsigned)wb : (unsigned)(wb >> 32);
-            else       val = lane == 0 ? (unsigned)vb : lane == 1 ? (unsigned)(vb >> 32) : lane == 2 ? iw
-                           : lane == 3 ? (unsigned)sb : lane == 4 ? (unsigned)(sb >> 32) : lane == 5 ? (unsigned)ub
-                           : lane == 6 ? (unsigned)(ub >> 32) : 0u;
-            if (lane < 8) st_x(&recs[w].g[lane], ((unsigned long long)tag << 32) | val, local);
-        }
-#ifdef MI355X_LA_TIMING
-        if (ts) ts[1] = wall_clock64();
-#endif
-        const ExchRec *r = recs + (lane < nw ? lane : 0);
-        unsigned long long g[8];
+        for (int k = 0; k < 8; ++k) g1[k] = 0ull;
         unsigned spins = 0;
         bool fine = true;
         for (;;) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) g[k] = ld_l2(&r->g[k]);
-            bool ok = true;
+            for (int k = 0; k < 8; ++k) g0[k] = ld_l2(&r0->g[k]);
+            if (nrec > 64) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) ok &= (unsigned)(g[k] >> 32) == tag;
-            if (__all(ok | (lane >= nw))) break;
+                for (int k = 0; k < 8; ++k) g1[k] = ld_l2(&r1->g[k]);
+            }
+            bool ok0 = true, ok1 = true;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { ok0 &= (unsigned)(g0[k] >> 32) == tag; ok1 &= (unsigned)(g1[k] >> 32) == tag; }
+            if (__all((ok0 | !v0) & (ok1 | !v1))) break;
             if (++spins > max_spins) { fine = false; break; }
         }
 #ifdef MI355X_LA_TIMING
-        if (ts) { ts[2] = wall_clock64(); ts[5] = spins; }
+        if (ts) { ts[1] = wall_clock64(); ts[3] = spins; }
 #endif
-        Cand x; x.v = 0.0; x.i = -1;
-        int64_t xs = 0;
-        unsigned fl = 0u;
-        const unsigned iw = (unsigned)g[2];
-        if (lane < nw) {
-            x.v = join_bits(g[0], g[1]);
-            x.i = (iw & kEmptyIdx) == kEmptyIdx ? -1 : (int)(iw & kEmptyIdx);
-            xs = PRICE ? (int64_t)(g[3] & 0xffffffffull) : (int64_t)(((g[4] & 0xffffffffull) << 32) | (g[3] & 0xffffffffull));
-            fl = iw >> 31;
-        }
-        const double ru = PRICE ? join_bits(g[4], g[5]) : join_bits(g[5], g[6]);
-        const double rw = PRICE ? join_bits(g[6], g[7]) : 0.0;
+        Cand x0, x1;
+        int64_t s0, s1;
+        unsigned f0, f1;
+        double u0, u1, w0, w1;
+        decode_rec<PRICE>(g0, v0, x0, s0, f0, u0, w0);
+        decode_rec<PRICE>(g1, v1, x1, s1, f1, u1, w1);
+        // lane-local fold of the two records (= the 64-apart level of a 128-wide tree)
+        const Cand x01 = cand_min(x0, x1);
+        const bool hi = x01.i != x0.i;                            // record l + 64 won (indices are unique)
         int src;
-        x = wave_reduce_cand(x, src);               // uniform
-        fl = __any(fl != 0u) ? 1u : 0u;
-        const int64_t bs = lane_pick(xs, src);
-        const double bu = lane_pick(ru, src);       // the winner's own record
-        const double bw = PRICE ? lane_value_dyn(rw, w_from) : lane_value_dyn(ru, w_from);
+        const Cand x = wave_argmin(x01, src);                     // uniform
+        const unsigned fl = __any((f0 | f1) != 0u) ? 1u : 0u;
+        const int64_t bs = lane_pick(hi ? s1 : s0, src);
+        const double bu = lane_pick(hi ? u1 : u0, src);           // the winner's own record
+        const double fsel = PRICE ? (rec_from < 64 ? w0 : w1) : (rec_from < 64 ? u0 : u1);
+        const double bw = lane_value_dyn(fsel, rec_from & 63);
         // do all records carry the same first double?  (the XCC ids of the first exchange)
-        const unsigned same = __all((lane >= nw) | (dbits(ru) == dbits(lane_value(ru, 0)))) ? 1u : 0u;
+        const unsigned long long ref = dbits(lane_value(u0, 0));
+        const unsigned same = __all(((dbits(u0) == ref) | !v0) & ((dbits(u1) == ref) | !v1)) ? 1u : 0u;
         if (lane == 0) {
             s_res->c.v = x.v; s_res->c.i = x.i; s_res->c.s = bs;
             s_res->flag = fine ? fl : 2u; s_res->same = same; s_res->u = bu; s_res->w = bw;
         }
-#ifdef MI355X_LA_TIMING
-        if (ts) ts[3] = wall_clock64();
-#endif
     }
     __syncthreads();
 #ifdef MI355X_LA_TIMING
-    if (ts) ts[4] = wall_clock64();
+    if (ts) ts[2] = wall_clock64();
 #endif
     out = *s_res;
     return out.flag != 2u;
 }
 
-// One link of the pending chain with the product taken out of the dependent path: the chain of a
-// value through pivots 0..J-1 is then J independent multiplications followed by J dependent
-// (select, subtract, select) triples instead of J dependent (multiply, subtract) pairs with their
-// operand fetches in between -- with one wave per SIMD every dependent instruction costs its full
-// latency.  Links i >= J are exact identities: operands 0.0 give x - (+0.0) == x bit for bit.
-__device__ __forceinline__ double pend_prod(double x, bool is_slot, bool is_cr, double prod, double prowv)
-{
-    if (is_slot) x = is_cr ? 1.0 : 0.0;
-    const double d = x - prod;                                   // rounded difference
-    return is_cr ? prowv : d;
-}
-
 // The steps are a run-time loop (fully unrolled the kernel was 300 KB of straight-line code and
 // ran at the speed of instruction-cache misses): per-thread col_i[row] / prow_i[pair] of the
 // pending pivots live in LDS ([pivot][thread]: conflict-free), everything else in registers.
-// The chains over the pending pivots are unrolled in groups of four links.
+//
+// With ONE wave per SIMD every instruction of the critical wave costs its full issue + latency,
+// so the chains through the pending pivots are written for instruction count: the product of a
+// link does not depend on the chained value (J independent multiplications, then J dependent
+// subtractions), the two rare exceptions of a link -- the element lies on pending pivot i's row /
+// in the slot it gave up -- are bit tests on masks the thread keeps anyway (my_rm, my_sm) plus a
+// wave-uniform mask over the pending pivots, and a wave none of whose lanes is an exception runs
+// the bare chain.  Links i >= J of a group of four are exact identities (operands 0.0:
+// x - (+0.0) == x bit for bit).
 // one_xcd: see above.  fault > 0 (test hook): the last workgroup stops publishing from step
 // `fault - 1` on, as a workgroup that is not resident would.
 template <int KMAX>
@@ -1327,10 +1399,9 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
                                                         unsigned epoch_base, unsigned max_spins,
                                                         int one_xcd, int fault)
 {
-    static_assert(KMAX % 4 == 0 && KMAX <= 64, "chains are unrolled in groups of four; one lane per pending pivot");
+    static_assert(KMAX % 4 == 0 && KMAX <= 16, "groups of four links; 16 + 16 bits of my_sm");
     __shared__ double    s_ci[KMAX][kLaThreads];                 // 32 KB
     __shared__ double2   s_pi[KMAX][kLaThreads];                 // 64 KB
-    __shared__ LaMsg     s_wave[kLaThreads / 64];
     __shared__ LaMsg     s_res;
     int nw = gridDim.x, w = blockIdx.x;
     if (one_xcd) {                                               // only every eighth block takes part
@@ -1342,20 +1413,22 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
     BlockCtl *blk = t.blk;
     const int tid = threadIdx.x;
     const bool leader = w == 0 && tid == 0;
-    const int lane = tid & 63;
+    const int lane = tid & 63, wave = tid >> 6;
     const int64_t m = t.rows - 1, vc = t.cols - 1, ld = t.ld, ldv = ld >> 1;
     const int64_t g = (int64_t)w * kLaThreads + tid;
     const bool has_row = g < t.rows, has_pair = g < ldv;
     const int64_t r = g, p = g;
     const double2 *M2 = reinterpret_cast<const double2 *>(t.M);
-    const int w_vc = (int)((vc >> 1) / kLaThreads), w_m = (int)(m / kLaThreads);   // owners of the RHS pair / objective row
-    const int lt_vc = (int)((vc >> 1) - (int64_t)w_vc * kLaThreads), lt_m = (int)(m - (int64_t)w_m * kLaThreads);
+    // thread that owns the RHS pair / the objective row: workgroup, wave, lane, record
+    const int g_vc = (int)(vc >> 1), g_m = (int)m;
+    const int rec_vc = g_vc / 64, rec_m = g_m / 64;              // (= 4 * workgroup + wave)
+    const bool wave_has_vc = (int)(g / 64) == rec_vc, wave_has_m = (int)(g / 64) == rec_m;
 
     // a new block starts (whatever the status): pending list, stamp (the sweep applies the list
     // only under this launch's stamp -- had the leader's workgroup never run, the list would be
     // the previous block's) and this thread's OWN mask words, which only it ever writes
     if (leader) { blk->n_pending = 0; blk->stamp = epoch_base; }
-    unsigned my_rm = 0u, my_sm = 0u;
+    unsigned my_rm = 0u, my_sm = 0u;     // bit i: my row is pivot row i / bits i, 16+i: my pair's columns are slot i
     if (g < t.bk_stride) t.bk_rmask[g] = 0u;
     if (g < ldv)         t.bk_smask[g] = 0u;
     if (c0.status != kRunning) return;
@@ -1365,11 +1438,12 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
     int64_t l0 = (has_pair && 2 * p < vc) ? t.p2l[2 * p] : -1;   // logical columns of my pair
     int64_t l1 = (has_pair && 2 * p + 1 < vc) ? t.p2l[2 * p + 1] : -1;
     int64_t v_cr = -1, v_sl = -1;                                // lane i: pivot row / slot of pivot i
+    double2 pr = make_double2(0.0, 0.0);                         // my pair of the last normalised pivot row
     bool local = false;                                          // all workgroups on one XCD (verified)
     const double my_xcc = (double)xcc_id();
     unsigned long long *ts_p = nullptr, *ts_r = nullptr;
 #ifdef MI355X_LA_TIMING
-    unsigned long long tsp[6] = {0, 0, 0, 0, 0, 0}, tsr[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tsp[4] = {0, 0, 0, 0}, tsr[4] = {0, 0, 0, 0};
     if (leader) { ts_p = tsp; ts_r = tsr; }
 #endif
 
@@ -1380,21 +1454,18 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
 #ifdef MI355X_LA_TIMING
         unsigned long long T0 = wall_clock64(), T2, T3, T5, T6;
 #endif
-        // ---- pricing: my pair's candidates -> workgroup winner -> record -> everybody's winner.
+        // ---- pricing: my pair's candidates -> wave winner -> record -> everybody's winner.
         // The record also carries the winner's entry of prow_{J-1} and (from its owner) the RHS
         // entry of prow_{J-1}: what the chain below needs of the row that was stored last.
         ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
         if (has_pair && 2 * p < vc)     { ValIdx c; c.v = z.x * sgn; c.i = l0; c.s = 2 * p;     best = vi_min(best, c); }
         if (has_pair && 2 * p + 1 < vc) { ValIdx c; c.v = z.y * sgn; c.i = l1; c.s = 2 * p + 1; best = vi_min(best, c); }
         LaMsg e;
-        if (!la_exchange<true>(best, 0u, t.la_px, nw, w, e_price, max_spins, mute, local, w_vc, s_wave, &s_res, e,
-                [&](const ValIdx &c, double &u, double &x2) {
+        if (!la_exchange<true>(best, 0u, t.la_px, nw, w, e_price, max_spins, mute, local, rec_vc, &s_res, e,
+                [&](const ValIdx &c, int src, double &u, double &x2) {
                     if (J == 0) { u = my_xcc; return; }
-                    if (c.i >= 0) {
-                        const double2 q = s_pi[J - 1][(int)((c.s >> 1) - (int64_t)w * kLaThreads)];
-                        u = (c.s & 1) ? q.y : q.x;
-                    }
-                    if (w == w_vc) { const double2 q = s_pi[J - 1][lt_vc]; x2 = (vc & 1) ? q.y : q.x; }
+                    u = lane_pick((c.s & 1) ? pr.y : pr.x, src);            // prow_{J-1}[winner's slot]
+                    if (wave_has_vc) x2 = lane_value_dyn((vc & 1) ? pr.y : pr.x, g_vc & 63);
                 }, ts_p)) {
             if (tid == 0) st_wt(&ctl->status, kSyncLost);        // same word, same value from everyone
             return;
@@ -1417,20 +1488,34 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
         double v_pa = (lane < J - 1) ? ld_l2(&t.bk_prow[(int64_t)lane * ld + slot]) : 0.0;
         drain_vmem();                  // the loads -- and what this wave stored in the previous half-step
         if (lane == J - 1) v_pa = e.u;
-        if (J > 0) b = pend(b, false, r == lane_value_dyn(v_cr, J - 1), s_ci[J - 1][tid], e.w);
+        if (J > 0) b = pend(b, false, (my_rm >> (J - 1)) & 1u, s_ci[J - 1][tid], e.w);
+        {
+            // pending pivots whose given-up slot is the entering column's slot (uniform); lanes on a pending pivot row
+            const unsigned slmask = (unsigned)__ballot((lane < J) & (v_sl == slot));
+            const bool bare = slmask == 0u && !__any(my_rm != 0u);
 #pragma unroll
-        for (int i0 = 0; i0 < KMAX; i0 += 4) {
-            if (i0 < J) {
-                double prod[4];
+            for (int i0 = 0; i0 < KMAX; i0 += 4) {
+                if (i0 < J) {
+                    double prod[4], pa[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const double ci = (i0 + k < J) ? s_ci[i0 + k][tid] : 0.0;
-                    prod[k] = ci * lane_value(v_pa, i0 + k);           // rounded product
+                    for (int k = 0; k < 4; ++k) {
+                        const double ci = (i0 + k < J) ? s_ci[i0 + k][tid] : 0.0;
+                        pa[k] = lane_value(v_pa, i0 + k);
+                        prod[k] = ci * pa[k];                          // rounded product
+                    }
+                    if (bare) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) a = a - prod[k];   // rounded difference
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const bool is_cr = (my_rm >> (i0 + k)) & 1u;
+                            if ((slmask >> (i0 + k)) & 1u) a = is_cr ? 1.0 : 0.0;
+                            const double d = a - prod[k];
+                            a = is_cr ? pa[k] : d;
+                        }
+                    }
                 }
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    a = pend_prod(a, slot == lane_value(v_sl, i0 + k), r == lane_value(v_cr, i0 + k), prod[k],
-                                  lane_value(v_pa, i0 + k));
             }
         }
         s_ci[J][tid] = a;
@@ -1444,10 +1529,11 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
 #ifdef MI355X_LA_TIMING
         T3 = wall_clock64();
 #endif
-        // ---- ratio test; the record of the objective row's owner carries col_J[m]
+        // ---- ratio test; the record of the objective row's wave carries col_J[m]
         LaMsg qq;
-        if (!la_exchange<false>(q, bad, t.la_rx, nw, w, e_ratio, max_spins, mute, local, w_m, s_wave, &s_res, qq,
-                [&](const ValIdx &, double &u, double &) { if (w == w_m) u = s_ci[J][lt_m]; }, ts_r)) {
+        if (!la_exchange<false>(q, bad, t.la_rx, nw, w, e_ratio, max_spins, mute, local, rec_m, &s_res, qq,
+                [&](const ValIdx &, int, double &u, double &) { if (wave_has_m) u = lane_value_dyn(a, g_m & 63); },
+                ts_r)) {
             if (tid == 0) st_wt(&ctl->status, kSyncLost);
             return;
         }
@@ -1471,27 +1557,39 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
         const bool own = has_pair && (p == (slot >> 1));
         const int64_t leaving = own ? ld_l2(&t.basis[cr]) : -1;
         drain_vmem();                  // the loads -- and the col_J entry stored above
+        {
+            // pending pivots whose pivot row is the new pivot row (uniform); lanes holding a given-up slot
+            const unsigned crmask = (unsigned)__ballot((lane < J) & (v_cr == cr));
+            const bool bare = crmask == 0u && !__any(my_sm != 0u);
 #pragma unroll
-        for (int i0 = 0; i0 < KMAX; i0 += 4) {
-            if (i0 < J) {
-                double2 pii[4], prod[4];
+            for (int i0 = 0; i0 < KMAX; i0 += 4) {
+                if (i0 < J) {
+                    double2 pii[4], prod[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    pii[k] = (i0 + k < J) ? s_pi[i0 + k][tid] : make_double2(0.0, 0.0);
-                    const double ccr = lane_value(v_ccr, i0 + k);
-                    prod[k].x = ccr * pii[k].x;                        // rounded products
-                    prod[k].y = ccr * pii[k].y;
-                }
+                    for (int k = 0; k < 4; ++k) {
+                        pii[k] = (i0 + k < J) ? s_pi[i0 + k][tid] : make_double2(0.0, 0.0);
+                        const double ccr = lane_value(v_ccr, i0 + k);
+                        prod[k].x = ccr * pii[k].x;                    // rounded products
+                        prod[k].y = ccr * pii[k].y;
+                    }
+                    if (bare) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const bool    is_cr = cr == lane_value(v_cr, i0 + k);
-                    const int64_t sl = lane_value(v_sl, i0 + k);
-                    y.x = pend_prod(y.x, 2 * p     == sl, is_cr, prod[k].x, pii[k].x);
-                    y.y = pend_prod(y.y, 2 * p + 1 == sl, is_cr, prod[k].y, pii[k].y);
+                        for (int k = 0; k < 4; ++k) { y.x = y.x - prod[k].x; y.y = y.y - prod[k].y; }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const bool is_cr = (crmask >> (i0 + k)) & 1u;          // uniform
+                            if ((my_sm >> (i0 + k)) & 1u)      y.x = is_cr ? 1.0 : 0.0;
+                            if ((my_sm >> (16 + i0 + k)) & 1u) y.y = is_cr ? 1.0 : 0.0;
+                            const double dx = y.x - prod[k].x, dy = y.y - prod[k].y;
+                            y.x = is_cr ? pii[k].x : dx;
+                            y.y = is_cr ? pii[k].y : dy;
+                        }
+                    }
                 }
             }
         }
-        double2 pr = make_double2(0.0, 0.0);
+        pr = make_double2(0.0, 0.0);
         if (has_pair) {
             pr = scale_pair(t, p, y, piv, slot);
             st_x(&t.bk_prow[(int64_t)J * ld + 2 * p], pr.x, local);
@@ -1532,11 +1630,9 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
             double *d = t.rhs + J * 24;
             d[0] += 1.0; d[1] += (double)(T2 - T0); d[2] += (double)(T3 - T2);
             d[3] += (double)(T5 - T3); d[4] += (double)(T6 - T5);
-            // inside the exchanges: entry -> barrier 1 -> published -> all records in -> reduced -> barrier 2
-            d[5] += (double)(tsp[0] - T0); d[6] += (double)(tsp[1] - tsp[0]); d[7] += (double)(tsp[2] - tsp[1]);
-            d[8] += (double)(tsp[3] - tsp[2]); d[9] += (double)(tsp[4] - tsp[3]); d[10] += (double)tsp[5];
-            d[11] += (double)(tsr[0] - T3); d[12] += (double)(tsr[1] - tsr[0]); d[13] += (double)(tsr[2] - tsr[1]);
-            d[14] += (double)(tsr[3] - tsr[2]); d[15] += (double)(tsr[4] - tsr[3]); d[16] += (double)tsr[5];
+            // inside the exchanges: entry -> own record published -> all records in -> result in every thread
+            d[5] += (double)(tsp[0] - T0); d[6] += (double)(tsp[1] - tsp[0]); d[7] += (double)(tsp[2] - tsp[1]); d[8] += (double)tsp[3];
+            d[9] += (double)(tsr[0] - T3); d[10] += (double)(tsr[1] - tsr[0]); d[11] += (double)(tsr[2] - tsr[1]); d[12] += (double)tsr[3];
         }
 #endif
     }
