@@ -74,20 +74,31 @@ def parse():
                     help="cpu_baseline: pivots timed with all host threads (a quarter of it single-threaded)")
     ap.add_argument("--no-events", action="store_true",
                     help="do not bracket the update launches with HIP events (roofline = null)")
-    ap.add_argument("--event-stride", type=int, default=8,
-                    help="bracket every k-th update launch of the timed region with a HIP event pair")
+    ap.add_argument("--event-stride", type=int, default=0,
+                    help="bracket every k-th block of the timed region with HIP event pairs (0 = every "
+                         "block of a short run, <= ~400 samples of a long one)")
+    ap.add_argument("--no-per-pivot", action="store_true",
+                    help="skip the extra per-pivot (k_update) measurement after the timed region")
     return ap.parse_args()
+
+
+F64_VALU_PEAK_TFLOPS = 39.3     # non-FMA f64 vector rate: 256 CUs x 64 lanes x 2.4 GHz x 1 flop
+                                # (the product and the difference are rounded separately: no FMA)
 
 
 def cpu_baseline(lp, n, m, seed, pivots):
     """The oracle (C restatement of the reference algorithm; the Lisp reference itself cannot
-    run here) timed on the host cores on the first `pivots` pivots of the same LP."""
+    run here) timed on the host cores on the first `pivots` pivots of the same LP.  Also returns
+    what the in-run parity check compares the GPU with: the pivot trace, the RHS column and the
+    objective row after those pivots."""
     import oracle
     M, b = lp.synth.tableau(n, m, seed)
     threads = oracle.omp_threads()
     t0 = time.perf_counter()
-    st, npiv, _ = oracle.solve(M, b, max_pivots=pivots, omp=True)
+    st, npiv, trace = oracle.solve(M, b, max_pivots=pivots, trace_cap=pivots, omp=True)
     t_omp = time.perf_counter() - t0
+    state = {"status": st, "pivots": npiv, "trace": trace, "rhs": M[:, -1].copy(), "obj": M[m].copy(),
+             "basis": b.copy()}
     single = max(2, pivots // 4)
     t0 = time.perf_counter()
     st1, npiv1, _ = oracle.solve(M, b, max_pivots=single, omp=False)
@@ -99,7 +110,68 @@ def cpu_baseline(lp, n, m, seed, pivots):
                   "%.3f pivots/s over the next %d pivots" % (npiv, n, m, npiv1 / t_one, npiv1),
         "single_thread_value": npiv1 / t_one,
         "GBps": 2.0 * (m + 1) * (n + m + 1) * 8 * npiv / t_omp / 1e9,
-    }
+    }, state
+
+
+def parity_in_run(lp, L, n, m, seed, device, state):
+    """the GPU's first K pivots of the benchmark LP against the oracle's --
+    pivot sequence, RHS column, objective row and basis, bit for bit (a fresh handle, the default
+    solve path, outside the timed region)."""
+    import numpy as np
+    K = int(state["pivots"])
+    h = ctypes.c_void_p()
+    lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h), n, m, seed, 0, -1, device), "parity handle")
+    k = ctypes.c_int64(0)
+    rc = L.mi355x_tab_solve(h, 1, 1024.0, K, ctypes.byref(k))
+    ec = np.empty(max(K, 1), dtype=np.int64); cr = np.empty(max(K, 1), dtype=np.int64); cnt = ctypes.c_int64(0)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)                                   # noqa: E731
+    lp.capi.check(L.mi355x_tab_trace(h, vp(ec), vp(cr), K, ctypes.byref(cnt)), "trace")
+    last_row = np.empty(n + m + 1); last_col = np.empty(m + 1); basis = np.empty(m, dtype=np.int64)
+    lp.capi.check(L.mi355x_tab_download(h, None, vp(basis), vp(last_row), vp(last_col)), "download")
+    L.mi355x_tab_destroy(h)
+    got = np.stack([ec[:K], cr[:K]], axis=1)
+    out = {"pivots": K, "status_equal": int(rc) == int(state["status"]) and int(k.value) == K,
+           "trace_identical": bool(np.array_equal(got, state["trace"])),
+           "rhs_column_bitwise": bool(np.array_equal(last_col.view(np.int64), state["rhs"].view(np.int64))),
+           "objective_row_bitwise": bool(np.array_equal(last_row.view(np.int64), state["obj"].view(np.int64))),
+           "basis_identical": bool(np.array_equal(basis, state["basis"])),
+           "objective_value": float(last_col[-1]),
+           "checked_against": "oracle (C restatement of src/simplex.lisp:337-461), same LP, first %d pivots" % K}
+    out["identical"] = all(out[x] for x in ("status_equal", "trace_identical", "rhs_column_bitwise",
+                                            "objective_row_bitwise", "basis_identical"))
+    return out
+
+
+def per_pivot_record(lp, L, n, m, seed, device, kernel_bytes, restore_block, pivots=192):
+    """The north star's own target -- >= 60 % of the HBM roofline on the 8192 x 4096 f64 PIVOT
+    kernel -- measured on the per-pivot path (`--block 1`: k_update, the literal n-pivot-row, one
+    launch per pivot) in the same run, outside the timed region."""
+    L.mi355x_tune_set_block(1)
+    try:
+        h = ctypes.c_void_p()
+        lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h), n, m, seed, 0, -1, device), "per-pivot handle")
+        npv = ctypes.c_int64(0)
+        lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, 32, 1), "warm")
+        L.mi355x_tab_sync(h, ctypes.byref(npv))
+        L.mi355x_tab_timing_enable(h, 1)
+        t0 = time.perf_counter()
+        lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, pivots, 0), "per-pivot run")
+        L.mi355x_tab_sync(h, ctypes.byref(npv))
+        dt = time.perf_counter() - t0
+        nl, sm, mn = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+        L.mi355x_tab_timing_read(h, ctypes.byref(nl), ctypes.byref(sm), ctypes.byref(mn))
+        L.mi355x_tab_destroy(h)
+    finally:
+        L.mi355x_tune_set_block(restore_block)
+    avg_ms = sm.value / max(nl.value, 1)
+    ach = kernel_bytes / (avg_ms * 1e-3) / 1e9
+    traffic, src = pmc_traffic("cfg3", "k_update")
+    return {"kernel": L.mi355x_update_kernel_name().decode(), "what": "per-pivot path (block = 1): one k_update launch per pivot",
+            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+            "traffic": traffic, "traffic_source": src,
+            "kernel_avg_us": avg_ms * 1e3, "kernel_min_us": mn.value * 1e3, "launches_timed": int(nl.value),
+            "bytes_moved_per_launch": kernel_bytes, "pivots_per_launch": 1,
+            "pivots_per_s_whole_iteration": pivots / dt}
 
 
 def baseline_metric():
@@ -111,18 +183,24 @@ def baseline_metric():
         return "simplex pivots/sec + achieved HBM GB/s, dense 8192\u00d74096 f64 tableau"
 
 
-def pmc_traffic(workload):
-    """HBM bytes per k_update launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and
     WRITE_SIZE in separate runs, FETCH doubled per the gfx950 correction, calibrated on a copy of
-    the same buffer -- profiles/r01_cfg3_pmc_traffic.json).  PMC counters cannot be collected
-    from inside this process, so the number is the last profiled one for this workload, or None."""
-    path = os.path.join(ROOT, "profiles", "r01_%s_pmc_traffic.json" % workload)
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        return d["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
-    except Exception:
-        return None, None
+    the same buffer -- profiles/rNN_cfg3_pmc_traffic.json).  PMC counters cannot be collected
+    from inside this process, so the number is the last profiled one for this kernel, or None."""
+    for tag in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", "%s_%s_pmc_traffic.json" % (tag, workload))
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except Exception:
+            continue
+        for name, rec in d.get("kernels", {}).items():
+            if name.startswith(kernel) or kernel.startswith(name):
+                return rec["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+        if "kernels" not in d and (d.get("kernel", "").startswith(kernel) or kernel.startswith(d.get("kernel", "?"))):
+            return d["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
 
 
 def bench_batch(args, lp, rank, local_rank, N, barrier, torch, dist):
@@ -247,7 +325,7 @@ def main():
     if args.block:
         L.mi355x_tune_set_block(args.block)
     if args.sweep_tr or args.sweep_nt >= 0:
-        L.mi355x_tune_set_sweep_shape(args.sweep_tr or 4, args.sweep_nt)
+        L.mi355x_tune_set_sweep_shape(args.sweep_tr, args.sweep_nt)
     # One LP supports only so many pivots before it is optimal (config 3: 5 700-6 100, config 2:
     # 189-416 with these seeds).  If more timed steps are asked for than one LP safely provides,
     # further LPs of the same shape are generated in HBM BEFORE the timed region and the timed
@@ -269,7 +347,11 @@ def main():
         lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, args.warmup, 1), "warmup")
         L.mi355x_tab_sync(h, ctypes.byref(npv))
         if not args.no_events:
-            L.mi355x_tab_timing_enable(h, max(1, args.event_stride))
+            # every launch of a short run (the driver's 20-step run is two blocks), every k-th of a
+            # long one (<= ~400 event pairs per kernel class)
+            launches = max(1, args.steps // max(L.mi355x_tab_block_size(h), 1))
+            stride = args.event_stride if args.event_stride > 0 else max(1, launches // 400)
+            L.mi355x_tab_timing_enable(h, stride)
         handles.append(h)
     seed = lp.synth.seed_for(cfg, rank)
     h = handles[0]
@@ -303,18 +385,40 @@ def main():
     # while it is in registers; the bytes above are then moved once per BLOCK
     block = L.mi355x_tab_block_size(h)
 
-    upd_avg_ms = None
-    nl = ctypes.c_int64(0)
-    if not args.no_events:
-        tot_n, tot_ms = 0, 0.0
+    def read_events(kind):
+        tot_n, tot_ms, mn_ms = 0, 0.0, None
         for hk in handles:
-            sm, mn = ctypes.c_double(0), ctypes.c_double(0)
-            L.mi355x_tab_timing_read(hk, ctypes.byref(nl), ctypes.byref(sm), ctypes.byref(mn))
-            tot_n += nl.value
+            nlk, sm, mn = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+            L.mi355x_tab_timing_read_kind(hk, kind, ctypes.byref(nlk), ctypes.byref(sm), ctypes.byref(mn))
+            tot_n += nlk.value
             tot_ms += sm.value
-        nl = ctypes.c_int64(tot_n)
-        if tot_n > 0:
-            upd_avg_ms = tot_ms / tot_n
+            if nlk.value:
+                mn_ms = mn.value if mn_ms is None else min(mn_ms, mn.value)
+        return tot_n, (tot_ms / tot_n if tot_n else None), mn_ms
+
+    upd_n, upd_avg_ms, upd_min_ms = (0, None, None)
+    la_n, la_avg_ms, la_min_ms = (0, None, None)
+    extra_samples = 0
+    if not args.no_events:
+        upd_n, upd_avg_ms, upd_min_ms = read_events(0)
+        la_n, la_avg_ms, la_min_ms = read_events(1)
+        if upd_n < 8 and block > 1 and N == 1:
+            # a short run (the driver's 20 steps are ONE full block): more event samples from full
+            # blocks run right AFTER the timed region on the same tableau -- kernel statistics
+            # only, not part of `value`
+            lp.capi.check(L.mi355x_tab_solve_async(handles[-1], 1, 1024.0, 12 * block, 0), "extra event samples")
+            L.mi355x_tab_sync(handles[-1], ctypes.byref(npv))
+            n2, a2, m2 = read_events(0)
+            l2, la2, lm2 = read_events(1)
+            if n2:
+                extra_samples = n2
+                upd_avg_ms = ((upd_avg_ms or 0.0) * upd_n + a2 * n2) / (upd_n + n2)
+                upd_min_ms = m2 if upd_min_ms is None else min(upd_min_ms, m2)
+                upd_n += n2
+            if l2:
+                la_avg_ms = ((la_avg_ms or 0.0) * la_n + la2 * l2) / (la_n + l2)
+                la_min_ms = lm2 if la_min_ms is None else min(la_min_ms, lm2)
+                la_n += l2
 
     if N > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -324,33 +428,84 @@ def main():
     if rank == 0:
         value = N * args.steps / elapsed
         roofline = None
+        Cs = stored_cols.value
         if upd_avg_ms:
-            # One launch of the dominant kernel moves every STORED element once each way and
-            # applies `block` pivots to it (blocked pivoting; block == 1 is the
-            # plain k_update).  `achieved` is the PHYSICAL rate of that launch -- bytes it has
-            # to move / its duration, directly comparable with the PMC `traffic` and bounded by
-            # the HBM peak.  The contract's literal formula (per-pivot algorithmic bytes x
-            # pivots per launch / duration) is given next to it as `algorithmic_equivalent`: it
-            # exceeds the HBM peak by construction, because the blocked sweep does NOT re-stream
-            # the tableau for every pivot -- that is its point.
+            # ---- the model the path is held to ----------------------------
+            # Blocked pivoting: per block of `block` pivots ONE sweep moves every stored element
+            # through HBM once each way (bound: HBM, 2*R*Cs*8 bytes) and applies `block` rank-1
+            # updates to it while it is in registers (2*block*R*Cs f64 operations, product and
+            # difference rounded separately: the non-FMA vector rate is the second bound), and ONE
+            # look-ahead launch selects the block's pivots: per pivot two dependent HBM round trips
+            # (the entering column: R scattered doubles, the pivot row: Cs doubles) and two
+            # all-to-all exchanges between its workgroups -- latency-bound by construction (a few MB
+            # per launch), so its roofline entry is a time share and a per-step latency, not a rate
+            # to maximise.  `achieved` is the PHYSICAL rate of the kernel (bytes it has to move /
+            # its duration), comparable with the PMC `traffic` and bounded by the peak; the
+            # contract's literal formula (per-pivot algorithmic bytes x pivots per launch / duration)
+            # is `algorithmic_equivalent` and exceeds the peak by construction (the sweep does not
+            # re-stream the tableau per pivot).
+            upd_name = "k_sweep16" if block == 16 else ("k_sweep" if block > 1 else L.mi355x_update_kernel_name().decode())
             ach = kernel_bytes / (upd_avg_ms * 1e-3) / 1e9
-            traffic, traffic_src = pmc_traffic(args.workload)
             alg = block * kernel_bytes / (upd_avg_ms * 1e-3) / 1e9
+            flops = 2.0 * block * R * Cs
+            valu_min_us = flops / (F64_VALU_PEAK_TFLOPS * 1e12) * 1e6
+            hbm_min_us = kernel_bytes / (HBM_PEAK_GBPS * 1e9) * 1e6
+            traffic, traffic_src = pmc_traffic(args.workload, upd_name)
+            per_block_ms = upd_avg_ms + (la_avg_ms or 0.0)
+            kernels = [{
+                "kernel": upd_name, "role": "tableau update: applies %d pivot(s) to every stored element" % block,
+                "avg_us": upd_avg_ms * 1e3, "min_us": upd_min_ms * 1e3, "launches_timed": int(upd_n),
+                "time_share": upd_avg_ms / per_block_ms,
+                "bound": "hbm", "bytes_moved_per_launch": kernel_bytes, "achieved": ach, "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                "second_bound": {"what": "f64 vector ALU, non-FMA (2 * pivots * R * stored_cols operations)",
+                                 "flops_per_launch": flops, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "achieved": flops / (upd_avg_ms * 1e-3) / 1e12,
+                                 "frac": flops / (upd_avg_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TFLOPS,
+                                 "min_us": valu_min_us},
+                "min_us_by_bound": {"hbm": hbm_min_us, "f64_valu": valu_min_us},
+                "binding_bound": "hbm" if hbm_min_us >= valu_min_us else "f64_valu",
+            }]
+            if la_avg_ms:
+                la_bytes = block * (R * 8 * 2 + Cs * 8 * 2 + Cs * 8)      # column + RHS entries, pivot row + objective row, prow
+                la_traffic, la_src = pmc_traffic(args.workload, "k_la_block")
+                kernels.append({
+                    "kernel": "k_la_block", "role": "look-ahead: selects the block's %d pivots (find-entering-column, "
+                                                    "find-pivoting-row, row normalisation) ahead of the tableau" % block,
+                    "avg_us": la_avg_ms * 1e3, "min_us": la_min_ms * 1e3, "launches_timed": int(la_n),
+                    "time_share": la_avg_ms / per_block_ms,
+                    "bound": "latency", "us_per_pivot": la_avg_ms * 1e3 / block,
+                    "dependent_steps_per_pivot": "2 HBM round trips (entering column, pivot row) + 2 exchanges between the workgroups",
+                    "bytes_moved_per_launch": la_bytes, "achieved": la_bytes / (la_avg_ms * 1e-3) / 1e9,
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": la_bytes / (la_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "traffic": la_traffic, "traffic_source": la_src})
+            kernels.sort(key=lambda kk: -kk["time_share"])
+            whole = kernel_bytes / block * value / N / 1e9
             roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
-                        "traffic_source": traffic_src,
-                        "kernel": "k_sweep" if block > 1 else L.mi355x_update_kernel_name().decode(),
-                        "kernel_avg_us": upd_avg_ms * 1e3,
-                        "pivots_per_launch": block,
-                        "bytes_moved_per_launch": kernel_bytes,
+                        "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                        "kernel": upd_name,
+                        "what": "the kernel that moves the tableau (>99 % of the HBM bytes of an iteration); "
+                                "every kernel above 10 % of the time is in `kernels`, largest first",
+                        "kernel_avg_us": upd_avg_ms * 1e3, "kernel_time_share": upd_avg_ms / per_block_ms,
+                        "dominant_by_time": {"kernel": kernels[0]["kernel"], "time_share": kernels[0]["time_share"]},
+                        "pivots_per_launch": block, "bytes_moved_per_launch": kernel_bytes,
                         "algorithmic_bytes_per_pivot": kernel_bytes,
+                        "binding_bound": kernels[0]["binding_bound"] if kernels[0]["kernel"] == upd_name
+                                         else [kk for kk in kernels if kk["kernel"] == upd_name][0]["binding_bound"],
                         "algorithmic_equivalent": {
                             "GBps": alg, "x_peak": alg / HBM_PEAK_GBPS,
                             "what": "algorithmic bytes per pivot x pivots per launch / launch duration"},
                         "representation": "compact [non-basic columns | RHS], %d of %d columns stored"
-                                          % (stored_cols.value, C) if compact.value else "dense",
+                                          % (Cs, C) if compact.value else "dense",
                         "dense_tableau_bytes_per_pivot": bytes_per_pivot,
-                        "launches_timed": int(nl.value)}
+                        "launches_timed": int(upd_n),
+                        "launches_timed_after_the_timed_region": int(extra_samples),
+                        "kernels": kernels,
+                        "whole_iteration": {"what": "physical bytes per pivot (stored tableau once each way per block "
+                                                    "/ pivots per block) x pivots/s, all kernels and gaps included",
+                                            "physical_bytes_per_pivot": kernel_bytes / block, "GBps": whole,
+                                            "frac": whole / HBM_PEAK_GBPS,
+                                            "us_per_pivot": 1e6 / (value / N)}}
         rec = {
             "metric": baseline_metric() if args.workload == "cfg3"
                       else "simplex pivots/sec (%s)" % args.workload,
@@ -366,8 +521,11 @@ def main():
             "dense_equivalent_GBps": bytes_per_pivot * value / N / 1e9,
             "roofline": roofline,
         }
+        if N == 1 and args.workload == "cfg3" and not args.no_per_pivot:
+            rec["per_pivot_kernel"] = per_pivot_record(lp, L, n, m, seed, local_rank, kernel_bytes, args.block or 16)
         if N == 1 and not args.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(lp, n, m, seed, args.cpu_pivots)
+            rec["cpu_baseline"], state = cpu_baseline(lp, n, m, seed, args.cpu_pivots)
+            rec["parity_in_run"] = parity_in_run(lp, L, n, m, seed, local_rank, state)
         print(json.dumps(rec), flush=True)
     for hk in handles:
         L.mi355x_tab_destroy(hk)

@@ -34,6 +34,8 @@ int         mi355x_tune_set_block(int k);                    /* pivots per sweep
 int         mi355x_tune_set_lookahead_mode(int mode);        /* 0 auto, 1 two launches per step,
                                                                 2 one persistent launch per block */
 int         mi355x_tune_set_sweep_shape(int rows_per_workgroup, int nontemporal /* -1 by size */);
+int         mi355x_tune_set_sweep_impl(int impl);            /* 0 k_sweep16 for full blocks, 1 k_sweep
+                                                                always; 4 / 8: rows per step of k_sweep16 */
 int         mi355x_tune_set_handover_mode(int mode);         /* 0 auto, 1 sequential re-elimination */
 int         mi355x_tune_set_batch_mode(int mode);            /* 0 auto, 1 lockstep, 2 workgroup per LP */
 int         mi355x_tune_set_batch_block(int k);              /* blocked per-LP kernel, 1 = off   */

@@ -440,7 +440,9 @@ int enqueue_block(mi355x_tab *t, int is_max, double f, int k)
     const TabView &v = t->c;
     int np = (t->n_part > 0 && t->part_is_max == (is_max ? 1 : 0)) ? t->n_part : 0;
     const bool persistent = (g_la_mode == 2 || (g_la_mode == 0 && !t->la_lost)) && la_block_supported(v);
-    const bool timed = t->timing_stride > 0 && t->n_timed < kTimingCap &&
+    // event pairs around FULL blocks only: the statistics are per (look-ahead of g_block_k
+    // pivots, sweep of g_block_k pivots), the partial last block of a run is left out
+    const bool timed = t->timing_stride > 0 && t->n_timed < kTimingCap && k == g_block_k &&
                        (t->update_launches++ % t->timing_stride) == 0;
     auto ensure_events = [](std::vector<hipEvent_t> &a, std::vector<hipEvent_t> &b, int n) -> hipError_t {
         while ((int)a.size() <= n) {
@@ -1358,6 +1360,7 @@ int         mi355x_tune_set_lookahead_mode(int mode) { g_la_mode = mode; return 
 int         mi355x_tune_set_block(int k) { g_block_k = k < 1 ? 1 : (k > kMaxBlock ? kMaxBlock : k); return g_block_k; }
 int         mi355x_tune_set_sweep_shape(int tr, int nt) { set_sweep_shape(tr, nt); return tr; }
 int         mi355x_tune_set_compact(int on) { g_compact_enabled = on ? 1 : 0; return g_compact_enabled; }
+int         mi355x_tune_set_sweep_impl(int impl) { set_sweep_impl(impl); return impl; }
 // persistent look-ahead: all workgroups on one XCD (1, default) or spread (0); polls before a
 // workgroup gives up on a record (0 = default 2^21); test hook: the last workgroup stops
 // publishing from step `step_plus_1 - 1` of every block on (0 = off)

@@ -131,6 +131,7 @@ void set_la_one_xcd(int on);
 void set_la_max_spins(unsigned n);
 void set_la_fault(int step_plus_1);
 void set_sweep_shape(int tr, int nt);      // tuning hook
+void set_sweep_impl(int impl);             // tuning / test hook: 0 k_sweep16 for full blocks (default), 1 k_sweep always
 UpdateShape update_shape(const TabView &t);
 // column-partitioned shards (one shard = one handle)
 void launch_shard_price(const TabView &t, int is_max, int64_t col_offset, double *out2, int n_part,

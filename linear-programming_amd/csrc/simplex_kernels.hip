@@ -1812,6 +1812,238 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(TabView t, const int tr, const 
     }
 }
 
+// ---- the sweep of a FULL block of 16 pending pivots (what a solve runs all the time; k_sweep
+// above keeps the partial last block, other block sizes and the step that holds a pivot row) ----
+// Same tile, same operands, same roundings; written so that the compiler has nothing to spill or
+// copy in the row loop:
+//   * two register sets of four rows (the loads of the next step are in flight while this one
+//     is computed; the step function is instantiated for (A, B) and (B, A), so there is no copy);
+//   * the col values of a chunk of 4 pivots x 4 rows (32 SGPRs) are requested while the previous
+//     chunk is being applied (two SGPR sets; a scalar load has the latency of an L2 hit);
+//   * a lane that holds a slot column is no special case in the row loop: pivot i's entering
+//     column gave its slot to the leaving basic column, whose content before pivot i is e_cr, so
+//     the chain of that column STARTS at pivot i from (r == cr_i ? 1 : 0).  The lane therefore
+//     replaces what it loads by that unit entry and has its prow entries of the pivots before i
+//     zeroed: unit - col*0 == unit bit for bit, links 0..i-1 are identities (col is finite: the
+//     look-ahead refuses non-finite entering columns on this representation);
+//   * a step that contains the pivot row of a pending pivot (16 of ~1000 steps) takes pend().
+constexpr int kSweepK = 16;
+typedef int    v16i __attribute__((ext_vector_type(16)));
+typedef double v8d  __attribute__((ext_vector_type(8)));
+
+// One chunk of col values = 32 SGPRs = CP pending pivots x U rows (U = 4: 4 pivots, U = 8: 2):
+// requested by one asm statement, waited for by another -- the registers are tied through the
+// wait, so nothing reads them before the data has landed.
+template <int U> struct ColChunk;
+template <> struct ColChunk<4> {
+    static constexpr int CP = 4;
+    v8i c[4];
+    __device__ __forceinline__ void issue(const double *base, unsigned o1)
+    {
+        const unsigned o2 = 2u * o1, o3 = 3u * o1;
+        asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %4, %5\n\t"
+                     "s_load_dwordx8 %2, %4, %6\n\ts_load_dwordx8 %3, %4, %7"
+                     : "=&s"(c[0]), "=&s"(c[1]), "=&s"(c[2]), "=&s"(c[3])
+                     : "s"(base), "s"(o1), "s"(o2), "s"(o3));
+    }
+    __device__ __forceinline__ void wait()
+    {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(c[0]), "+s"(c[1]), "+s"(c[2]), "+s"(c[3]));
+    }
+    __device__ __forceinline__ double col(int i, int u) const { return __builtin_bit_cast(v4d, c[i])[u]; }
+};
+template <> struct ColChunk<8> {
+    static constexpr int CP = 2;
+    v16i c[2];
+    __device__ __forceinline__ void issue(const double *base, unsigned o1)
+    {
+        asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, %3"
+                     : "=&s"(c[0]), "=&s"(c[1]) : "s"(base), "s"(o1));
+    }
+    __device__ __forceinline__ void wait() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(c[0]), "+s"(c[1])); }
+    __device__ __forceinline__ double col(int i, int u) const { return __builtin_bit_cast(v8d, c[i])[u]; }
+};
+
+template <bool NT, int U>
+__global__ __launch_bounds__(256) void k_sweep16(TabView t, const int tr, const int strip_pairs,
+                                                 const double sgn, const int price, const unsigned stamp)
+{
+    constexpr int K = kSweepK, CP = ColChunk<U>::CP, NCH = K / CP;
+    const BlockCtl *__restrict__ blk = t.blk;
+    const int k = (int)blk->n_pending;
+    if (k == 0) return;
+    if (stamp != 0u && (unsigned)blk->stamp != stamp) return;  // the list is not this block's
+    double *__restrict__ M = t.M;
+    const int64_t ld = t.ld, rows = t.rows, vc = t.cols - 1;
+    const int64_t ldv  = ld >> 1;
+    const int64_t pair = (int64_t)blockIdx.x * strip_pairs + threadIdx.x;
+    const bool active  = (int)threadIdx.x < strip_pairs && pair < ldv;
+    const int64_t r0 = (int64_t)blockIdx.y * tr;
+    const int64_t r1 = (r0 + tr < rows) ? r0 + tr : rows;
+    double  *__restrict__ part_v = price ? t.part_v : nullptr;
+    const bool prices = (r1 == rows) && part_v != nullptr;
+    if (!active && !prices) return;                            // no workgroup barrier below
+
+    vec2d *Mp = reinterpret_cast<vec2d *>(M) + pair;
+    auto ld2 = [&](int64_t r) -> vec2d {
+        if constexpr (NT) return __builtin_nontemporal_load(Mp + r * ldv);
+        else              return Mp[r * ldv];
+    };
+    auto st2 = [&](int64_t r, vec2d v) {
+        if constexpr (NT) __builtin_nontemporal_store(v, Mp + r * ldv);
+        else              Mp[r * ldv] = v;
+    };
+    vec2d last; last.x = 0.0; last.y = 0.0;
+    if (active) {
+        const unsigned sm = t.bk_smask[pair];
+        if (k != K) {
+            // a partial block (the look-ahead terminated inside it): one row at a time, operands
+            // from memory -- runs once per solve
+            const unsigned sx = sm & 0xffffu, sy = sm >> 16;
+            for (int64_t r = r0; r < r1; ++r) {
+                vec2d x = ld2(r);
+                const unsigned rm = t.bk_rmask[r];
+                for (int i = 0; i < k; ++i) {
+                    const double cv = t.bk_col[(int64_t)i * t.bk_stride + r];
+                    const vec2d pi = reinterpret_cast<const vec2d *>(t.bk_prow)[(int64_t)i * ldv + pair];
+                    const bool is_cr = (rm >> i) & 1u;
+                    x.x = pend(x.x, (sx >> i) & 1u, is_cr, cv, pi.x);
+                    x.y = pend(x.y, (sy >> i) & 1u, is_cr, cv, pi.y);
+                }
+                st2(r, x);
+                last = x;
+            }
+        } else {
+            vec2d xa[U], xb[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {                      // the first step's rows, requested first
+                xa[u].x = 0.0; xa[u].y = 0.0; xb[u] = xa[u];
+                if (r0 + u < r1) xa[u] = ld2(r0 + u);
+            }
+            vec2d p[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i)
+                p[i] = reinterpret_cast<const vec2d *>(t.bk_prow)[(int64_t)i * ldv + pair];
+            const unsigned sx = sm & 0xffffu, sy = sm >> 16;
+            // slot columns: chain starts at the last pivot that handed the slot over
+            const bool wave_slots = __any(sm != 0u);
+            int64_t crx = -1, cry = -1;
+            if (wave_slots) {
+                const int lx = sx ? 31 - __clz((int)sx) : -1, ly = sy ? 31 - __clz((int)sy) : -1;
+                if (lx >= 0) crx = blk->cr[lx];
+                if (ly >= 0) cry = blk->cr[ly];
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    if (i < lx) p[i].x = 0.0;
+                    if (i < ly) p[i].y = 0.0;
+                }
+            }
+            const unsigned o1 = (unsigned)(t.bk_stride * 8);
+            const double *colbase = t.bk_col;
+            const int64_t chunk_stride = (int64_t)CP * t.bk_stride;
+
+            auto step = [&](vec2d (&cur)[U], vec2d (&nxt)[U], const int64_t r) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)                   // next step's rows travel during this one
+                    if (r + U + u < r1) nxt[u] = ld2(r + U + u);
+                unsigned rmu[U];                               // uniform
+#pragma unroll
+                for (int u4 = 0; u4 < U; u4 += 4) {
+                    const uint4 rm = *reinterpret_cast<const uint4 *>(t.bk_rmask + r + u4);
+                    rmu[u4] = rm.x; rmu[u4 + 1] = rm.y; rmu[u4 + 2] = rm.z; rmu[u4 + 3] = rm.w;
+                }
+                unsigned rm_any = 0u;
+#pragma unroll
+                for (int u = 0; u < U; ++u) rm_any |= rmu[u];
+                if (wave_slots) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (crx >= 0) cur[u].x = (r + u == crx) ? 1.0 : 0.0;
+                        if (cry >= 0) cur[u].y = (r + u == cry) ? 1.0 : 0.0;
+                    }
+                }
+                const double *cb = colbase + r;
+                if (rm_any == 0u) {
+                    ColChunk<U> A, B;
+                    auto apply = [&](const ColChunk<U> &c, const int i0) {
+#pragma unroll
+                        for (int i = 0; i < CP; ++i) {
+                            const vec2d pi = p[i0 + i];
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                const double cv = c.col(i, u);
+                                const double m0 = cv * pi.x;          // rounded products
+                                const double m1 = cv * pi.y;
+                                cur[u].x = cur[u].x - m0;             // rounded differences
+                                cur[u].y = cur[u].y - m1;
+                            }
+                        }
+                    };
+                    A.issue(cb, o1);
+                    A.wait();
+#pragma unroll
+                    for (int c = 0; c < NCH; c += 2) {        // two SGPR sets, alternating
+                        B.issue(cb + (int64_t)(c + 1) * chunk_stride, o1);
+                        apply(A, c * CP);
+                        B.wait();
+                        if (c + 2 < NCH) A.issue(cb + (int64_t)(c + 2) * chunk_stride, o1);
+                        apply(B, (c + 1) * CP);
+                        if (c + 2 < NCH) A.wait();
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        ColChunk<U> C;
+                        C.issue(cb + (int64_t)c * chunk_stride, o1);
+                        C.wait();
+#pragma unroll
+                        for (int i = 0; i < CP; ++i) {
+                            const int pi_idx = c * CP + i;
+                            const vec2d pi = p[pi_idx];
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                const bool is_cr = (rmu[u] >> pi_idx) & 1u;
+                                cur[u].x = pend(cur[u].x, (sx >> pi_idx) & 1u, is_cr, C.col(i, u), pi.x);
+                                cur[u].y = pend(cur[u].y, (sy >> pi_idx) & 1u, is_cr, C.col(i, u), pi.y);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (r + u < r1) {
+                        st2(r + u, cur[u]);
+                        last = cur[u];
+                    }
+                }
+            };
+            for (int64_t r = r0; r < r1; r += 2 * U) {
+                step(xa, xb, r);
+                if (r + U < r1) step(xb, xa, r + U);
+            }
+        }
+    }
+    if (prices) {                                              // `last` = new objective-row entries
+        ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
+        const int64_t c0 = 2 * pair;
+        if (active && c0 < vc) {
+            ValIdx c; c.v = last.x * sgn; c.i = t.p2l ? t.p2l[c0] : c0; c.s = c0;
+            best = vi_min(best, c);
+        }
+        if (active && c0 + 1 < vc) {
+            ValIdx c; c.v = last.y * sgn; c.i = t.p2l ? t.p2l[c0 + 1] : c0 + 1; c.s = c0 + 1;
+            best = vi_min(best, c);
+        }
+        best = wave_reduce_min(best);
+        if ((threadIdx.x & 63) == 0) {
+            const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+            part_v[w]   = best.v;
+            t.part_i[w] = best.i;
+            t.part_s[w] = best.s;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ batch: one workgroup per LP
 // BASELINE config 4 is many SMALL independent LPs (257 x 769 doubles = 1.6 MB each).  Advancing
 // them in lockstep with the launch pairs above makes every LP wait for the slowest one (78..199
@@ -2694,8 +2926,12 @@ void launch_la_block(const TabView &t, int ksteps, int is_max, double f, unsigne
                        g_la_max_spins, one_xcd, g_la_fault);
 }
 
-static int g_sweep_tr = 16, g_sweep_nt = -1;                    // -1: by size, as for k_update
-void set_sweep_shape(int tr, int nt) { if (tr >= 4) g_sweep_tr = tr / 4 * 4; g_sweep_nt = nt; }
+static int g_sweep_tr = 0, g_sweep_nt = -1;                     // 0 / -1: by size
+static int g_sweep_impl = 0;                                    // 0: k_sweep16 for full blocks, 1: k_sweep always
+static int g_sweep_u = 4;                                       // rows per step of k_sweep16: 4, or 8 (measured
+                                                                // slower: 199 VGPRs, 2 waves per SIMD, 125 vs 103 us)
+void set_sweep_shape(int tr, int nt) { g_sweep_tr = tr >= 4 ? tr / 4 * 4 : 0; g_sweep_nt = nt; }
+void set_sweep_impl(int impl) { g_sweep_impl = impl == 1 ? 1 : 0; if (impl == 4 || impl == 8) g_sweep_u = impl; }
 
 template <int KMAX>
 static void launch_sweep_t(const TabView &t, dim3 grid, int tr, int sp, double sgn, bool nt, unsigned stamp,
@@ -2715,11 +2951,30 @@ int launch_sweep(const TabView &t, int kmax, double sgn, hipStream_t s, unsigned
     sp = (sp + 7) / 8 * 8;
     if (sp > block) sp = block;
     strips = (int)((ldv + sp - 1) / sp);
+    // rows per workgroup: 32 (config 3, measured: 8 rows 116 us, 16 rows 105, 32 rows 103, 64 rows
+    // 114), fewer when the tableau would otherwise not fill the chip with workgroups
     int64_t tr = g_sweep_tr;
+    if (tr == 0) {
+        tr = 32;
+        while (tr > 4 && ((t.rows + tr - 1) / tr) * strips < 2048) tr /= 2;
+    }
     while ((t.rows + tr - 1) / tr > 65535) tr *= 2;            // grid.y limit
     const dim3 grid((unsigned)strips, (unsigned)((t.rows + tr - 1) / tr));
     const double bytes = (double)t.rows * (double)t.ld * 8.0;
     const bool nt = g_sweep_nt < 0 ? bytes > kNtThresholdBytes : g_sweep_nt != 0;
+    if (kmax == kSweepK && g_sweep_impl == 0) {
+        // rows in flight per thread and step: 8 when the tile is a multiple of 8 rows (bk_rmask is
+        // padded to a multiple of 16 rows, so the uint4 mask loads of the last tile stay inside)
+        const bool u8 = g_sweep_u == 8 && tr % 8 == 0;
+        if (u8) {
+            if (nt) hipLaunchKernelGGL((k_sweep16<true, 8>),  grid, dim3(256), 0, s, t, (int)tr, (int)sp, sgn, 1, stamp);
+            else    hipLaunchKernelGGL((k_sweep16<false, 8>), grid, dim3(256), 0, s, t, (int)tr, (int)sp, sgn, 1, stamp);
+        } else {
+            if (nt) hipLaunchKernelGGL((k_sweep16<true, 4>),  grid, dim3(256), 0, s, t, (int)tr, (int)sp, sgn, 1, stamp);
+            else    hipLaunchKernelGGL((k_sweep16<false, 4>), grid, dim3(256), 0, s, t, (int)tr, (int)sp, sgn, 1, stamp);
+        }
+        return strips * (block / 64);
+    }
     if (kmax <= 2)      launch_sweep_t<2>(t, grid, (int)tr, (int)sp, sgn, nt, stamp, s);
     else if (kmax <= 4) launch_sweep_t<4>(t, grid, (int)tr, (int)sp, sgn, nt, stamp, s);
     else if (kmax <= 8) launch_sweep_t<8>(t, grid, (int)tr, (int)sp, sgn, nt, stamp, s);

@@ -37,7 +37,7 @@ d = out.reshape(16, 24)
 if d[:, 0].sum() == 0:
     sys.exit("no samples: the library was built without -DMI355X_LA_TIMING")
 print("one_xcd=%d  %d x %d   us per step (leader thread):" % (one_xcd, n, m))
-print(" J     n | price-xchg column+chain ratio-xchg row+chain+bk |  total || price: reduce->bar1 publish poll reduce bar2 polls || ratio: ...")
+print(" J     n | price-xchg column+chain ratio-xchg row+chain+bk |  total || price: ->published  ->records in  ->result  extra polls || ratio: ...")
 tot = 0.0
 for J in range(16):
     c = d[J, 0]
@@ -45,8 +45,8 @@ for J in range(16):
         continue
     row = [d[J, k] / c * 0.01 for k in (1, 2, 3, 4)]
     tot += sum(row)
-    px = [d[J, k] / c * 0.01 for k in (5, 6, 7, 8, 9)] + [d[J, 10] / c]
-    rx = [d[J, k] / c * 0.01 for k in (11, 12, 13, 14, 15)] + [d[J, 16] / c]
+    px = [d[J, k] / c * 0.01 for k in (5, 6, 7)] + [d[J, 8] / c]
+    rx = [d[J, k] / c * 0.01 for k in (9, 10, 11)] + [d[J, 12] / c]
     print("%2d %5d | " % (J, int(c)) + " ".join("%7.2f" % x for x in row) + " | %6.2f || " % sum(row)
           + " ".join("%5.2f" % x for x in px) + " || " + " ".join("%5.2f" % x for x in rx))
 print("sum over the 16 steps: %.1f us per block" % tot)
