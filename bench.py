@@ -76,7 +76,7 @@ def parse():
                     help="do not bracket the update launches with HIP events (roofline = null)")
     ap.add_argument("--event-stride", type=int, default=0,
                     help="bracket every k-th block of the timed region with HIP event pairs (0 = every "
-                         "block of a short run, <= ~400 samples of a long one)")
+                         "block of a short run, ~50 samples of a long one)")
     ap.add_argument("--no-per-pivot", action="store_true",
                     help="skip the extra per-pivot (k_update) measurement after the timed region")
     return ap.parse_args()
@@ -348,9 +348,9 @@ def main():
         L.mi355x_tab_sync(h, ctypes.byref(npv))
         if not args.no_events:
             # every launch of a short run (the driver's 20-step run is two blocks), every k-th of a
-            # long one (<= ~400 event pairs per kernel class)
+            # long one (~50 event pairs per kernel class: the event records are host work inside the timed region)
             launches = max(1, args.steps // max(L.mi355x_tab_block_size(h), 1))
-            stride = args.event_stride if args.event_stride > 0 else max(1, launches // 400)
+            stride = args.event_stride if args.event_stride > 0 else max(1, launches // 50)
             L.mi355x_tab_timing_enable(h, stride)
         handles.append(h)
     seed = lp.synth.seed_for(cfg, rank)

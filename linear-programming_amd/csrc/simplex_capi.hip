@@ -716,9 +716,13 @@ int mi355x_tab_solve_async(mi355x_tab *t, int is_max, double f, int64_t n_pivots
     rc = ensure_compact(t);
     if (rc != MI_OK) return rc;
     if (reset) launch_ctl_reset(t->v, 0, 0, t->stream);
-    if (block_mode(t)) {                              // whole blocks, then the remainder
-        for (int64_t left = n_pivots; left > 0; left -= g_block_k) {
-            rc = enqueue_block(t, is_max, f, (int)std::min<int64_t>(left, g_block_k));
+    if (block_mode(t)) {
+        // whole blocks; a remainder is spread evenly over the blocks (every sweep costs one pass
+        // over the tableau however few pivots it applies: 20 pivots are two blocks of 10, not 16 + 4)
+        const int64_t nblk = (n_pivots + g_block_k - 1) / g_block_k;
+        for (int64_t b = 0; b < nblk; ++b) {
+            const int64_t k = n_pivots / nblk + (b < n_pivots % nblk ? 1 : 0);
+            rc = enqueue_block(t, is_max, f, (int)k);
             if (rc != MI_OK) return rc;
         }
         HIP_TRY(hipGetLastError());
