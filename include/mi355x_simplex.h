@@ -298,6 +298,56 @@ int  mi355x_shard_la_pivot(mi355x_tab *t, int step, const int64_t *dev_col_bits,
                            double fp_factor);
 int  mi355x_shard_sweep(mi355x_tab *t);
 
+/* ---- column-partitioned tableau: the whole solve behind one handle (BASELINE config 5) ---- */
+/* n-solve-tableau (src/simplex.lisp:453-461, single phase) on ONE tableau whose non-RHS columns
+ * are distributed over n_devices GPUs: the driver of the per-shard steps above lives in the
+ * library, with the two exchanges per pivot issued from C++ on the shards' streams --
+ *   * one process, several GPUs (what the Lisp host uses: `:devices n`): one shard and one host
+ *     thread per device, RCCL communicators from ncclCommInitAll, exchange A = ncclAllGather of
+ *     16 bytes per shard, exchange B = ncclAllReduce(int64 SUM) of the entering column's bit
+ *     patterns (owner's bits + zeros == a broadcast whose root no host needs to know);
+ *   * fewer visible devices than shards: the shards become LOGICAL shards on device 0 and the
+ *     exchanges device-local kernels with the collectives' semantics (same pivots, same bits:
+ *     how the partitioned path is tested on one GPU);
+ *   * one process per GPU (torch.distributed.run / mpirun): every rank creates the handle with
+ *     world/rank and the 128-byte id rank 0 obtained from mi355x_rccl_unique_id, the
+ *     communicator comes from ncclCommInitRank, the per-pivot loop is still entirely in here.
+ * Shards are compact (only non-basic columns are distributed) whenever the basis columns of the
+ * uploaded tableau are exact unit vectors, dense otherwise; pivoting is blocked (16 pivots per
+ * sweep of a shard's slice).  A failing RCCL call returns MI_RCCL_ERROR.
+ * n_devices >= 1.  Results are bit-identical to mi355x_tab_solve on one device. */
+typedef struct mi355x_colpart mi355x_colpart;
+int  mi355x_colpart_create(mi355x_colpart **out, int64_t rows, int64_t cols,
+                           const double *host_matrix, const int64_t *host_basis, int n_devices);
+/* the synthetic LP of mi355x_tab_create_synthetic generated shard by shard in HBM (benchmarks) */
+int  mi355x_colpart_create_synthetic(mi355x_colpart **out, int64_t n_vars, int64_t n_cons,
+                                     uint64_t seed, int n_devices);
+/* one process per GPU: this rank's shard of a world of `world` shards, on `device` */
+int  mi355x_rccl_unique_id(void *id128);
+int  mi355x_colpart_create_synthetic_rank(mi355x_colpart **out, int64_t n_vars, int64_t n_cons,
+                                          uint64_t seed, int world, int rank, int device,
+                                          const void *id128);
+/* number of shards, of distinct physical devices they live on, and whether the exchanges are
+ * RCCL collectives (1) or device-local kernels (0) */
+int  mi355x_colpart_info(const mi355x_colpart *p, int *n_shards, int *n_devices_used, int *uses_rccl);
+/* n-solve-tableau; max_pivots = 0: no cap.  MI_OPTIMAL / MI_UNBOUNDED / MI_MAX_PIVOTS /
+ * MI_NONFINITE (compact shards, see above) or an error */
+int  mi355x_colpart_solve(mi355x_colpart *p, int is_max, double fp_factor, int64_t max_pivots,
+                          int64_t *n_pivots);
+/* benchmarks: enqueue exactly n_pivots iterations (reset != 0: restart the pivot count), then
+ * mi355x_colpart_sync waits, applies pending pivots and reports like mi355x_tab_sync */
+int  mi355x_colpart_solve_async(mi355x_colpart *p, int is_max, double fp_factor, int64_t n_pivots,
+                                int reset);
+int  mi355x_colpart_sync(mi355x_colpart *p, int64_t *n_pivots);
+/* read-back as mi355x_tab_download (any pointer may be NULL).  host_matrix (the whole logical
+ * tableau) needs every shard in this process; basis, last row and last column are complete in
+ * the one-process modes, and basis / last column also on every rank of the multi-process mode. */
+int  mi355x_colpart_download(mi355x_colpart *p, double *host_matrix, int64_t *host_basis,
+                             double *last_row, double *last_col);
+int  mi355x_colpart_trace(mi355x_colpart *p, int64_t *entering_cols, int64_t *pivot_rows,
+                          int64_t cap, int64_t *n);
+void mi355x_colpart_destroy(mi355x_colpart *p);
+
 #ifdef __cplusplus
 }
 #endif

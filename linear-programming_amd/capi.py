@@ -82,6 +82,17 @@ SIGNATURES = {
     "mi355x_shard_la_contribute": (_int, [_p, _int, _p, _int, _i64, _dbl, _p, _p]),
     "mi355x_shard_la_pivot": (_int, [_p, _int, _p, _p, _dbl]),
     "mi355x_shard_sweep": (_int, [_p]),
+    "mi355x_colpart_create": (_int, [_pp, _i64, _i64, _p, _p, _int]),
+    "mi355x_colpart_create_synthetic": (_int, [_pp, _i64, _i64, ctypes.c_uint64, _int]),
+    "mi355x_rccl_unique_id": (_int, [_p]),
+    "mi355x_colpart_create_synthetic_rank": (_int, [_pp, _i64, _i64, ctypes.c_uint64, _int, _int, _int, _p]),
+    "mi355x_colpart_info": (_int, [_p, _p, _p, _p]),
+    "mi355x_colpart_solve": (_int, [_p, _int, _dbl, _i64, _p]),
+    "mi355x_colpart_solve_async": (_int, [_p, _int, _dbl, _i64, _int]),
+    "mi355x_colpart_sync": (_int, [_p, _p]),
+    "mi355x_colpart_download": (_int, [_p, _p, _p, _p, _p]),
+    "mi355x_colpart_trace": (_int, [_p, _p, _p, _i64, _p]),
+    "mi355x_colpart_destroy": (None, [_p]),
 }
 # tuning / measurement / test hooks: include/mi355x_simplex_tune.h (not the drop-in boundary)
 _EXTRA = {
@@ -127,9 +138,10 @@ def _share_hip_runtime_with_torch():
         spec = importlib.util.find_spec("torch")
         if spec is None or not spec.origin:
             return
-        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
-        if os.path.exists(cand):
-            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        for name in ("libamdhip64.so", "librccl.so"):        # same story for the RCCL the library links
+            cand = os.path.join(os.path.dirname(spec.origin), "lib", name)
+            if os.path.exists(cand):
+                ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
     except Exception:
         pass
 

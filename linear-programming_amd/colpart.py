@@ -300,32 +300,152 @@ def destroy_shards(shards):
             sh.handle = None
 
 
+# ------------------------------------------------------------------ the C-ABI driver
+class NativeColumnPartition:
+    """mi355x_colpart_*: the same protocol driven from C++ inside the library (the per-pivot loop,
+    the RCCL communicators and both exchanges live there; what the Lisp host reaches with
+    `:devices n`).  One process: n_devices shards, one GPU each when that many are visible
+    (RCCL, one host thread per shard), logical shards on device 0 otherwise."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def from_arrays(cls, matrix, basis, n_devices):
+        M = np.ascontiguousarray(matrix, dtype=np.float64)
+        b = np.ascontiguousarray(basis, dtype=np.int64)
+        h = ctypes.c_void_p()
+        capi.check(capi.lib().mi355x_colpart_create(ctypes.byref(h), M.shape[0], M.shape[1],
+                                                    M.ctypes.data_as(ctypes.c_void_p),
+                                                    b.ctypes.data_as(ctypes.c_void_p), int(n_devices)),
+                   "mi355x_colpart_create")
+        obj = cls(h)
+        obj.rows, obj.cols = M.shape
+        return obj
+
+    @classmethod
+    def synthetic(cls, n_vars, n_cons, seed, n_devices):
+        h = ctypes.c_void_p()
+        capi.check(capi.lib().mi355x_colpart_create_synthetic(ctypes.byref(h), n_vars, n_cons, seed,
+                                                              int(n_devices)), "mi355x_colpart_create_synthetic")
+        obj = cls(h)
+        obj.rows, obj.cols = n_cons + 1, n_vars + n_cons + 1
+        return obj
+
+    @classmethod
+    def synthetic_rank(cls, n_vars, n_cons, seed, world, rank, device, unique_id):
+        """One process per GPU: `unique_id` = the 128 bytes rank 0 got from rccl_unique_id()."""
+        h = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        capi.check(capi.lib().mi355x_colpart_create_synthetic_rank(ctypes.byref(h), n_vars, n_cons, seed,
+                                                                   int(world), int(rank), int(device), buf),
+                   "mi355x_colpart_create_synthetic_rank")
+        obj = cls(h)
+        obj.rows, obj.cols = n_cons + 1, n_vars + n_cons + 1
+        return obj
+
+    @staticmethod
+    def rccl_unique_id():
+        buf = ctypes.create_string_buffer(128)
+        capi.check(capi.lib().mi355x_rccl_unique_id(buf), "mi355x_rccl_unique_id")
+        return buf.raw
+
+    def info(self):
+        a, b, c = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        capi.check(capi.lib().mi355x_colpart_info(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "info")
+        return {"n_shards": a.value, "n_devices_used": b.value, "uses_rccl": bool(c.value)}
+
+    def solve(self, is_max=True, fp_tolerance=1024, max_pivots=0):
+        n = ctypes.c_int64(0)
+        rc = capi.check(capi.lib().mi355x_colpart_solve(self._h, int(bool(is_max)), float(fp_tolerance),
+                                                        int(max_pivots), ctypes.byref(n)), "mi355x_colpart_solve")
+        return rc, int(n.value)
+
+    def solve_async(self, n_pivots, is_max=True, fp_tolerance=1024, reset=False):
+        capi.check(capi.lib().mi355x_colpart_solve_async(self._h, int(bool(is_max)), float(fp_tolerance),
+                                                         int(n_pivots), int(bool(reset))), "mi355x_colpart_solve_async")
+
+    def sync(self):
+        n = ctypes.c_int64(0)
+        rc = capi.check(capi.lib().mi355x_colpart_sync(self._h, ctypes.byref(n)), "mi355x_colpart_sync")
+        return rc, int(n.value)
+
+    def download(self, matrix=True):
+        M = np.empty((self.rows, self.cols)) if matrix else None
+        b = np.empty(self.rows - 1, dtype=np.int64)
+        last_row, last_col = np.empty(self.cols), np.empty(self.rows)
+        capi.check(capi.lib().mi355x_colpart_download(
+            self._h, M.ctypes.data_as(ctypes.c_void_p) if matrix else None, b.ctypes.data_as(ctypes.c_void_p),
+            last_row.ctypes.data_as(ctypes.c_void_p), last_col.ctypes.data_as(ctypes.c_void_p)), "mi355x_colpart_download")
+        return M, b, last_row, last_col
+
+    def trace(self, cap):
+        ec = np.empty(max(cap, 1), dtype=np.int64); cr = np.empty(max(cap, 1), dtype=np.int64)
+        n = ctypes.c_int64(0)
+        capi.check(capi.lib().mi355x_colpart_trace(self._h, ec.ctypes.data_as(ctypes.c_void_p),
+                                                   cr.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(n)), "trace")
+        k = min(int(n.value), cap)
+        return np.stack([ec[:k], cr[:k]], axis=1)
+
+    def close(self):
+        h, self._h = self._h, None
+        if h:
+            capi.lib().mi355x_colpart_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ------------------------------------------------------------------ bench.py --workload colpart
 def bench(args, rank, local_rank, world):
     """ONE dense LP (BASELINE config 5: 65536 vars x 32768 constraints, 32769 x 98305 f64 =
-    25.8 GB) column-partitioned over `world` ranks, strong scaling: K pivots timed with the
-    per-pivot RCCL exchange in the timed region."""
+    25.8 GB) column-partitioned over `world` ranks, strong scaling: K pivots timed with both
+    per-pivot exchanges in the timed region.  The per-pivot loop runs in the library
+    (mi355x_colpart_*: RCCL collectives issued from C++ on the shard's stream); this function only
+    distributes the RCCL id, starts the K pivots and waits.  Test set-up (ranks sharing one GPU,
+    where RCCL refuses to run: BENCH_DIST_BACKEND=gloo): the Python protocol driver above with the
+    exchanges staged through the host."""
     import torch
     import torch.distributed as dist
     n, m = 65536, 32768
     if getattr(args, "colpart_vars", None):
         n, m = args.colpart_vars, args.colpart_vars // 2
     seed = synth.seed_for(5)
-    shards = synthetic_shards(torch, n, m, seed, [rank], world, local_rank,
-                              compact=not getattr(args, "colpart_dense", False))
     staged = world > 1 and dist.get_backend() != "nccl"          # test hook: ranks share one GPU
-    comm = DistComm(dist, stage_through_host=staged) if world > 1 else LocalComm(torch)
+    dense = getattr(args, "colpart_dense", False)
     block = getattr(args, "colpart_block", 0) or ColumnPartitionedTableau.MAX_BLOCK
-    tab = ColumnPartitionedTableau(shards, comm, HipBackend(), block=block)
-    tab.reset()
-    tab.run(args.warmup)
-    st, done = tab.status()
+    native = not staged and not dense and block == ColumnPartitionedTableau.MAX_BLOCK
+    if native:
+        if world > 1:
+            box = [NativeColumnPartition.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            tab = NativeColumnPartition.synthetic_rank(n, m, seed, world, rank, local_rank, box[0])
+        else:
+            tab = NativeColumnPartition.synthetic(n, m, seed, 1)
+        info = tab.info()
+        tab.solve_async(args.warmup, reset=True)
+        st, done = tab.sync()
+    else:
+        shards = synthetic_shards(torch, n, m, seed, [rank], world, local_rank, compact=not dense)
+        comm = DistComm(dist, stage_through_host=staged) if world > 1 else LocalComm(torch)
+        tab = ColumnPartitionedTableau(shards, comm, HipBackend(), block=block)
+        info = {"n_shards": world, "n_devices_used": 1 if staged else world, "uses_rccl": world > 1 and not staged}
+        tab.reset()
+        tab.run(args.warmup)
+        st, done = tab.status()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    tab.run(args.steps)
-    st, done = tab.status()
+    if native:
+        tab.solve_async(args.steps)
+        st, done = tab.sync()
+    else:
+        tab.run(args.steps)
+        st, done = tab.status()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -338,7 +458,6 @@ def bench(args, rank, local_rank, world):
         elapsed = float(tt.item())
     R, C = m + 1, n + m + 1
     value = args.steps / elapsed
-    dense = getattr(args, "colpart_dense", False)
     stored_bytes = 2.0 * R * ((n + m if dense else n) + world) * 8 / block   # per pivot, all shards
     rec = {
         "metric": "simplex pivots/sec, one column-partitioned dense tableau",
@@ -348,11 +467,16 @@ def bench(args, rank, local_rank, world):
         "data": "synthetic",
         "config": {"workload": "BASELINE config 5: ONE dense LP %d vars x %d constraints, %dx%d f64 "
                                "tableau (%.1f GB) column-partitioned over %d GPU(s), %s shards"
-                               % (n, m, R, C, R * C * 8 / 1e9, world,
-                                  "dense" if getattr(args, "colpart_dense", False) else "compact"),
+                               % (n, m, R, C, R * C * 8 / 1e9, world, "dense" if dense else "compact"),
                    "parallelism": "column partition, per-pivot all-gather(16 B/rank) + int64 "
                                   "all-reduce(%d B) over RCCL; shards swept once per %d pivots"
-                                  % (R * 8, block)},
+                                  % (R * 8, block),
+                   "driver": "mi355x_colpart_* (C++ loop, RCCL from the library)" if native
+                             else "Python protocol driver (torch.distributed)"},
+        "rccl_ranks": world if info["uses_rccl"] else 0,
+        "exchange_bytes_per_pivot_per_rank": 16 * world + 8 * R,
+        "us_per_pivot": elapsed / args.steps * 1e6,
+        "per_gpu_physical_GBps": stored_bytes * value / 1e9 / world,
         "aggregate_GBps": stored_bytes * value / 1e9,
         "dense_equivalent_GBps": 2.0 * R * C * 8 * value / 1e9,
         "roofline": {"bound": "hbm", "achieved": stored_bytes * value / 1e9 / world,
@@ -360,7 +484,10 @@ def bench(args, rank, local_rank, world):
                      "frac": stored_bytes * value / 1e9 / world / 8000.0, "traffic": None,
                      "note": "whole-iteration rate per GPU (exchanges included), not kernel-only"},
     }
-    destroy_shards(shards)
+    if native:
+        tab.close()
+    else:
+        destroy_shards(shards)
     return rec
 
 

@@ -9,7 +9,10 @@
 #include "../../include/mi355x_simplex_tune.h"
 #include "simplex_kernels.h"
 
+#include <rccl/rccl.h>
+
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -17,6 +20,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace mi355x;
@@ -1341,6 +1345,506 @@ int mi355x_shard_columns(mi355x_tab *t, int64_t *global_cols)
     HIP_TRY(hipStreamSynchronize(t->stream));
     return MI_OK;
 }
+
+// ---- column-partitioned tableau: the whole solve behind one handle ----------------------------
+// The driver of the per-shard steps above, in the library (include/mi355x_simplex.h,
+// mi355x_colpart_*): per pivot  price -> exchange A -> la_contribute -> exchange B -> la_pivot,
+// after 16 pivots (or before the host looks) sweep.  Exchanges: RCCL on the shards' streams when
+// every shard has its own device (one host thread per shard in the one-process form, so the
+// enqueue work of N shards runs in parallel; in the one-process-per-GPU form the single local
+// shard is driven inline), device-local kernels with the same semantics when the shards are
+// logical shards of one device.
+}  // extern "C"
+
+namespace {
+
+#define RCCL_TRY(expr)                                                                         \
+    do {                                                                                       \
+        ncclResult_t r_ = (expr);                                                              \
+        if (r_ != ncclSuccess)                                                                 \
+            return fail(MI_RCCL_ERROR, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+// exchange B on one device: out[r] = sum over the shards of their contributions (owner's bit
+// patterns + zeros), exactly what the int64 SUM all-reduce delivers to every rank
+__global__ __launch_bounds__(256) void k_local_sum(const long long *all, long long *out, int64_t rows, int n)
+{
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < rows;
+         r += (int64_t)gridDim.x * blockDim.x) {
+        long long acc = 0;
+        for (int s = 0; s < n; ++s) acc += all[(int64_t)s * rows + r];
+        out[r] = acc;
+    }
+}
+
+struct CpShard {
+    mi355x_tab *t = nullptr;
+    int         device = 0, index = 0;        // physical device, global shard index
+    int64_t     col_begin = 0, col_end = 0;   // global logical columns (dense) / initial columns (compact)
+    double     *send = nullptr, *gathered = nullptr;
+    long long  *bits = nullptr, *bits_in = nullptr;   // contribution / exchanged column
+    int64_t    *ec = nullptr;
+    ncclComm_t  comm = nullptr;
+};
+
+}  // namespace
+
+struct mi355x_colpart {
+    int     world = 1;                       // shards in total
+    bool    rccl = false, multi_process = false, compact = false;
+    int64_t rows = 0, var_count = 0;
+    int     block = kMaxBlock, j = 0;        // pivots per sweep, steps of the current block enqueued
+    int     is_max = 1;
+    std::vector<CpShard> sh;                 // the shards of THIS process
+    // logical shards: one allocation each, shared by all of them
+    double    *l_gathered = nullptr;
+    long long *l_bits_all = nullptr, *l_bits_sum = nullptr;
+    std::vector<int> thread_rc;
+};
+
+namespace {
+
+void cp_free(mi355x_colpart *p)
+{
+    if (!p) return;
+    for (CpShard &s : p->sh) {
+        if (s.t) { (void)hipSetDevice(s.device); (void)hipStreamSynchronize(s.t->stream); }
+        if (s.comm) (void)ncclCommDestroy(s.comm);
+    }
+    for (CpShard &s : p->sh) {
+        (void)hipSetDevice(s.device);
+        if (p->rccl) { (void)hipFree(s.send); (void)hipFree(s.gathered); (void)hipFree(s.bits); }
+        (void)hipFree(s.ec);
+        if (s.t) free_tab(s.t);
+    }
+    if (!p->sh.empty()) (void)hipSetDevice(p->sh[0].device);
+    (void)hipFree(p->l_gathered);
+    (void)hipFree(p->l_bits_all);
+    (void)hipFree(p->l_bits_sum);
+    delete p;
+}
+
+// [begin, end) of shard r of n over `count` columns, sizes differing by at most one
+void cp_partition(int64_t count, int n, int r, int64_t *b, int64_t *e)
+{
+    const int64_t base = count / n, extra = count % n;
+    *b = r * base + std::min<int64_t>(r, extra);
+    *e = *b + base + (r < extra ? 1 : 0);
+}
+
+// exchange buffers (+ communicators) once the shards' handles exist
+int cp_finish_setup(mi355x_colpart *p, const void *id128, int rank)
+{
+    const int nl = (int)p->sh.size();
+    if (!p->rccl) {
+        HIP_TRY(hipSetDevice(p->sh[0].device));
+        HIP_TRY(hipMalloc((void **)&p->l_gathered, 2 * p->world * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&p->l_bits_all, (size_t)p->world * p->rows * sizeof(long long)));
+        HIP_TRY(hipMalloc((void **)&p->l_bits_sum, p->rows * sizeof(long long)));
+        HIP_TRY(hipMemset(p->l_gathered, 0, 2 * p->world * sizeof(double)));
+        for (CpShard &s : p->sh) {
+            s.send = p->l_gathered + 2 * s.index;           // "all-gather" = everyone writes its slot
+            s.gathered = p->l_gathered;
+            s.bits = p->l_bits_all + (int64_t)s.index * p->rows;
+            s.bits_in = p->l_bits_sum;
+            HIP_TRY(hipMalloc((void **)&s.ec, sizeof(int64_t)));
+        }
+        // the logical shards run one after the other on ONE stream (that of the first)
+        for (CpShard &s : p->sh) s.t->stream = p->sh[0].t->own_stream;
+        return MI_OK;
+    }
+    for (CpShard &s : p->sh) {
+        HIP_TRY(hipSetDevice(s.device));
+        HIP_TRY(hipMalloc((void **)&s.send, 2 * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&s.gathered, 2 * p->world * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&s.bits, p->rows * sizeof(long long)));
+        HIP_TRY(hipMalloc((void **)&s.ec, sizeof(int64_t)));
+        s.bits_in = s.bits;                                  // all-reduce in place
+    }
+    if (p->multi_process) {
+        ncclUniqueId id;
+        memcpy(&id, id128, sizeof id);
+        HIP_TRY(hipSetDevice(p->sh[0].device));
+        RCCL_TRY(ncclCommInitRank(&p->sh[0].comm, p->world, id, rank));
+    } else {
+        std::vector<ncclComm_t> comms((size_t)nl);
+        std::vector<int> devs((size_t)nl);
+        for (int i = 0; i < nl; ++i) devs[(size_t)i] = p->sh[(size_t)i].device;
+        RCCL_TRY(ncclCommInitAll(comms.data(), nl, devs.data()));
+        for (int i = 0; i < nl; ++i) p->sh[(size_t)i].comm = comms[(size_t)i];
+    }
+    return MI_OK;
+}
+
+// ---- one pivot, as the three local steps of shard s with the exchanges between them
+int cp_price(mi355x_colpart *p, CpShard &s)
+{
+    return mi355x_shard_price(s.t, p->is_max, s.col_begin, s.send);
+}
+int cp_contribute(mi355x_colpart *p, CpShard &s, double f)
+{
+    if (p->block > 1)
+        return mi355x_shard_la_contribute(s.t, p->j, s.gathered, p->world, s.col_begin, f,
+                                          (int64_t *)s.bits, s.ec);
+    return mi355x_shard_contribute(s.t, s.gathered, p->world, s.col_begin, f, (int64_t *)s.bits, s.ec);
+}
+int cp_pivot(mi355x_colpart *p, CpShard &s, double f)
+{
+    if (p->block > 1) return mi355x_shard_la_pivot(s.t, p->j, (const int64_t *)s.bits_in, s.ec, f);
+    return mi355x_shard_pivot(s.t, (const int64_t *)s.bits_in, s.ec, f);
+}
+
+// n iterations of shard s over RCCL (its own thread in the one-process form).  j0 = step of the
+// block the first iteration is; every shard runs the same sequence, so they meet in the collectives.
+int cp_run_rccl(mi355x_colpart *p, CpShard &s, double f, int64_t n, int j0)
+{
+    HIP_TRY(hipSetDevice(s.device));
+    int j = j0;
+    for (int64_t i = 0; i < n; ++i) {
+        int rc = mi355x_shard_price(s.t, p->is_max, s.col_begin, s.send);
+        if (rc != MI_OK) return rc;
+        RCCL_TRY(ncclAllGather(s.send, s.gathered, 2, ncclDouble, s.comm, s.t->stream));
+        if (p->block > 1) rc = mi355x_shard_la_contribute(s.t, j, s.gathered, p->world, s.col_begin, f, (int64_t *)s.bits, s.ec);
+        else              rc = mi355x_shard_contribute(s.t, s.gathered, p->world, s.col_begin, f, (int64_t *)s.bits, s.ec);
+        if (rc != MI_OK) return rc;
+        RCCL_TRY(ncclAllReduce(s.bits, s.bits, (size_t)p->rows, ncclInt64, ncclSum, s.comm, s.t->stream));
+        if (p->block > 1) rc = mi355x_shard_la_pivot(s.t, j, (const int64_t *)s.bits, s.ec, f);
+        else              rc = mi355x_shard_pivot(s.t, (const int64_t *)s.bits, s.ec, f);
+        if (rc != MI_OK) return rc;
+        if (p->block > 1 && ++j == p->block) {
+            rc = mi355x_shard_sweep(s.t);
+            if (rc != MI_OK) return rc;
+            j = 0;
+        }
+    }
+    return MI_OK;
+}
+
+// enqueue n iterations on every local shard; no host synchronisation
+int cp_run(mi355x_colpart *p, double f, int64_t n)
+{
+    if (n <= 0) return MI_OK;
+    if (p->rccl) {
+        const int j0 = p->j;
+        if (p->sh.size() == 1) {
+            int rc = cp_run_rccl(p, p->sh[0], f, n, j0);
+            if (rc != MI_OK) return rc;
+        } else {
+            // one host thread per shard: the shards' launches are enqueued in parallel and every
+            // thread issues its own rank's collectives (the standard one-process multi-GPU form)
+            p->thread_rc.assign(p->sh.size(), MI_OK);
+            std::vector<std::string> errs(p->sh.size());
+            std::vector<std::thread> th;
+            for (size_t i = 0; i < p->sh.size(); ++i)
+                th.emplace_back([p, f, n, j0, i, &errs]() {
+                    p->thread_rc[i] = cp_run_rccl(p, p->sh[i], f, n, j0);
+                    if (p->thread_rc[i] != MI_OK) errs[i] = g_err;       // g_err is thread-local
+                });
+            for (auto &x : th) x.join();
+            for (size_t i = 0; i < p->sh.size(); ++i)
+                if (p->thread_rc[i] != MI_OK) { g_err = errs[i]; return p->thread_rc[i]; }
+        }
+        if (p->block > 1) p->j = (int)((j0 + n) % p->block);
+        return MI_OK;
+    }
+    // logical shards on one device, one stream: step by step over all of them
+    HIP_TRY(hipSetDevice(p->sh[0].device));
+    hipStream_t st = p->sh[0].t->stream;
+    for (int64_t i = 0; i < n; ++i) {
+        int rc;
+        for (CpShard &s : p->sh) if ((rc = cp_price(p, s)) != MI_OK) return rc;
+        for (CpShard &s : p->sh) if ((rc = cp_contribute(p, s, f)) != MI_OK) return rc;
+        int blocks = (int)((p->rows + 255) / 256);
+        if (blocks > 256) blocks = 256;
+        hipLaunchKernelGGL(k_local_sum, dim3(blocks), dim3(256), 0, st, p->l_bits_all, p->l_bits_sum, p->rows, p->world);
+        for (CpShard &s : p->sh) if ((rc = cp_pivot(p, s, f)) != MI_OK) return rc;
+        if (p->block > 1 && ++p->j == p->block) {
+            for (CpShard &s : p->sh) if ((rc = mi355x_shard_sweep(s.t)) != MI_OK) return rc;
+            p->j = 0;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+// apply the pending pivots of an unfinished block (the tableau is whole whenever the host looks)
+int cp_flush(mi355x_colpart *p)
+{
+    if (p->block > 1 && p->j > 0) {
+        for (CpShard &s : p->sh) {
+            int rc = mi355x_shard_sweep(s.t);
+            if (rc != MI_OK) return rc;
+        }
+        p->j = 0;
+    }
+    return MI_OK;
+}
+
+int cp_status(mi355x_colpart *p, int64_t *n_pivots)
+{
+    int rc = cp_flush(p);
+    if (rc != MI_OK) return rc;
+    int st0 = 0;
+    int64_t n0 = 0;
+    for (size_t i = 0; i < p->sh.size(); ++i) {
+        int64_t n = 0;
+        const int st = mi355x_tab_sync(p->sh[i].t, &n);
+        if (st < 0) return st;
+        if (i == 0) { st0 = st; n0 = n; }
+        else if (st != st0 || n != n0)
+            return fail(MI_HIP_ERROR, "shards disagree: (%d, %lld) vs (%d, %lld)", st0, (long long)n0, st, (long long)n);
+    }
+    if (n_pivots) *n_pivots = n0;
+    return st0;
+}
+
+// devices for `world` shards of one process: one each when enough are visible, else all logical on 0.
+// MI355X_COLPART_FORCE_RCCL=1 (test hook): a single shard also goes through its RCCL communicator
+// (all-gather / all-reduce over one rank), so the collective code path runs on a one-GPU box.
+bool cp_one_device_each(int world)
+{
+    if (world == 1) { const char *e = getenv("MI355X_COLPART_FORCE_RCCL"); return e && e[0] == '1'; }
+    return device_count_checked() >= world;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355x_rccl_unique_id(void *id128)
+{
+    if (!id128) return fail(MI_BAD_ARG, "id128 is NULL");
+    ncclUniqueId id;
+    RCCL_TRY(ncclGetUniqueId(&id));
+    static_assert(sizeof id == 128, "ncclUniqueId is 128 bytes");
+    memcpy(id128, &id, sizeof id);
+    return MI_OK;
+}
+
+static int cp_create_synthetic(mi355x_colpart **out, int64_t n_vars, int64_t n_cons, uint64_t seed,
+                               int world, int rank, int device, const void *id128)
+{
+    if (!out) return fail(MI_BAD_ARG, "out is NULL");
+    *out = nullptr;
+    if (world < 1 || n_vars < world || n_cons < 1) return fail(MI_BAD_ARG, "need 1 <= shards <= n_vars and n_cons >= 1");
+    const bool mp = rank >= 0;
+    if (mp && (rank >= world || !id128)) return fail(MI_BAD_ARG, "bad rank / id");
+    if (device_count_checked() <= 0) return fail(MI_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    mi355x_colpart *p = new (std::nothrow) mi355x_colpart;
+    if (!p) return fail(MI_NO_MEMORY, "host allocation failed");
+    p->world = world;
+    p->multi_process = mp;
+    p->rccl = mp ? world > 1 : cp_one_device_each(world);
+    p->compact = true;
+    p->rows = n_cons + 1;
+    p->var_count = n_vars + n_cons;
+    const int first = mp ? rank : 0, last = mp ? rank + 1 : world;
+    for (int r = first; r < last; ++r) {
+        CpShard s;
+        s.index = r;
+        s.device = mp ? device : (p->rccl ? r : 0);
+        cp_partition(n_vars, world, r, &s.col_begin, &s.col_end);      // compact: the structural columns
+        int rc = mi355x_tab_create_synthetic(&s.t, n_vars, n_cons, seed, s.col_begin, s.col_end, s.device);
+        if (rc == MI_OK) {
+            std::vector<int64_t> cols((size_t)(s.col_end - s.col_begin));
+            for (size_t k = 0; k < cols.size(); ++k) cols[k] = s.col_begin + (int64_t)k;
+            rc = mi355x_shard_set_compact(s.t, p->var_count, cols.data());
+        }
+        p->sh.push_back(s);
+        if (rc != MI_OK) { cp_free(p); return rc; }
+    }
+    int rc = cp_finish_setup(p, id128, rank);
+    if (rc != MI_OK) { cp_free(p); return rc; }
+    *out = p;
+    return MI_OK;
+}
+
+int mi355x_colpart_create_synthetic(mi355x_colpart **out, int64_t n_vars, int64_t n_cons, uint64_t seed,
+                                    int n_devices)
+{
+    return cp_create_synthetic(out, n_vars, n_cons, seed, n_devices, -1, 0, nullptr);
+}
+
+int mi355x_colpart_create_synthetic_rank(mi355x_colpart **out, int64_t n_vars, int64_t n_cons, uint64_t seed,
+                                         int world, int rank, int device, const void *id128)
+{
+    if (rank < 0) return fail(MI_BAD_ARG, "rank < 0");
+    return cp_create_synthetic(out, n_vars, n_cons, seed, world, rank, device, id128);
+}
+
+int mi355x_colpart_create(mi355x_colpart **out, int64_t rows, int64_t cols, const double *hm,
+                          const int64_t *hb, int n_devices)
+{
+    if (!out) return fail(MI_BAD_ARG, "out is NULL");
+    *out = nullptr;
+    const int64_t m = rows - 1, vc = cols - 1;
+    if (!hm || !hb || m < 1 || vc < 1 || n_devices < 1) return fail(MI_BAD_ARG, "bad arguments");
+    if (device_count_checked() <= 0) return fail(MI_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    // compact shards when the basis is a set of exact unit columns (+0.0 in the objective row)
+    std::vector<char> basic((size_t)vc, 0);
+    bool compact = true;
+    for (int64_t i = 0; i < m && compact; ++i) {
+        const int64_t b = hb[i];
+        if (b < 0 || b >= vc || basic[(size_t)b]) { compact = false; break; }
+        basic[(size_t)b] = 1;
+        for (int64_t r = 0; r < rows && compact; ++r) {
+            double v = hm[r * cols + b];
+            uint64_t bits;
+            memcpy(&bits, &v, 8);
+            if (bits != (r == i ? 0x3FF0000000000000ull : 0ull)) compact = false;
+        }
+    }
+    std::vector<int64_t> dist;                                   // the columns that are distributed
+    for (int64_t c = 0; c < vc; ++c)
+        if (!compact || !basic[(size_t)c]) dist.push_back(c);
+    if ((int64_t)dist.size() < n_devices) return fail(MI_BAD_ARG, "more shards (%d) than columns to distribute (%lld)", n_devices, (long long)dist.size());
+    mi355x_colpart *p = new (std::nothrow) mi355x_colpart;
+    if (!p) return fail(MI_NO_MEMORY, "host allocation failed");
+    p->world = n_devices;
+    p->rccl = cp_one_device_each(n_devices);
+    p->compact = compact;
+    p->rows = rows;
+    p->var_count = vc;
+    std::vector<double> loc;
+    for (int r = 0; r < n_devices; ++r) {
+        CpShard s;
+        s.index = r;
+        s.device = p->rccl ? r : 0;
+        int64_t b, e;
+        cp_partition((int64_t)dist.size(), n_devices, r, &b, &e);
+        const int64_t nloc = e - b;
+        s.col_begin = dist[(size_t)b];                           // dense shards: a contiguous block of columns
+        s.col_end = s.col_begin + nloc;
+        loc.assign((size_t)(rows * (nloc + 1)), 0.0);
+        for (int64_t rr = 0; rr < rows; ++rr) {
+            for (int64_t k = 0; k < nloc; ++k) loc[(size_t)(rr * (nloc + 1) + k)] = hm[rr * cols + dist[(size_t)(b + k)]];
+            loc[(size_t)(rr * (nloc + 1) + nloc)] = hm[rr * cols + vc];   // own copy of the RHS column
+        }
+        int rc = mi355x_tab_create(&s.t, rows, nloc + 1, loc.data(), hb, s.device);
+        if (rc == MI_OK && compact) rc = mi355x_shard_set_compact(s.t, vc, dist.data() + b);
+        p->sh.push_back(s);
+        if (rc != MI_OK) { cp_free(p); return rc; }
+    }
+    int rc = cp_finish_setup(p, nullptr, -1);
+    if (rc != MI_OK) { cp_free(p); return rc; }
+    *out = p;
+    return MI_OK;
+}
+
+int mi355x_colpart_info(const mi355x_colpart *p, int *n_shards, int *n_devices_used, int *uses_rccl)
+{
+    if (!p) return fail(MI_BAD_ARG, "handle is NULL");
+    if (n_shards) *n_shards = p->world;
+    if (n_devices_used) *n_devices_used = p->rccl ? p->world : 1;
+    if (uses_rccl) *uses_rccl = p->rccl ? 1 : 0;
+    return MI_OK;
+}
+
+int mi355x_colpart_solve_async(mi355x_colpart *p, int is_max, double f, int64_t n_pivots, int reset)
+{
+    if (!p) return fail(MI_BAD_ARG, "handle is NULL");
+    if (n_pivots < 0) return fail(MI_BAD_ARG, "n_pivots < 0");
+    p->is_max = is_max ? 1 : 0;
+    if (reset) {
+        int rc = cp_flush(p);
+        if (rc != MI_OK) return rc;
+        for (CpShard &s : p->sh)
+            if ((rc = mi355x_tab_reset(s.t, 0)) != MI_OK) return rc;
+    }
+    return cp_run(p, f, n_pivots);
+}
+
+int mi355x_colpart_sync(mi355x_colpart *p, int64_t *n_pivots)
+{
+    if (!p) return fail(MI_BAD_ARG, "handle is NULL");
+    return cp_status(p, n_pivots);
+}
+
+int mi355x_colpart_solve(mi355x_colpart *p, int is_max, double f, int64_t max_pivots, int64_t *n_pivots)
+{
+    if (!p) return fail(MI_BAD_ARG, "handle is NULL");
+    if (max_pivots < 0) return fail(MI_BAD_ARG, "max_pivots < 0");
+    p->is_max = is_max ? 1 : 0;
+    int rc = cp_flush(p);
+    if (rc != MI_OK) return rc;
+    for (CpShard &s : p->sh)
+        if ((rc = mi355x_tab_reset(s.t, max_pivots)) != MI_OK) return rc;
+    // blind enqueue in chunks (an iteration after termination is a no-op on the device), one
+    // status read-back per chunk -- the same decision on every shard / rank
+    int64_t chunk = 64;
+    for (;;) {
+        rc = cp_run(p, f, chunk);
+        if (rc != MI_OK) return rc;
+        const int st = cp_status(p, n_pivots);
+        if (st != MI_RUNNING) return st;
+        if (chunk < 256) chunk *= 2;
+    }
+}
+
+int mi355x_colpart_trace(mi355x_colpart *p, int64_t *ecs, int64_t *crs, int64_t cap, int64_t *n)
+{
+    if (!p) return fail(MI_BAD_ARG, "handle is NULL");
+    int rc = cp_flush(p);
+    if (rc != MI_OK) return rc;
+    return mi355x_tab_trace(p->sh[0].t, ecs, crs, cap, n);
+}
+
+int mi355x_colpart_download(mi355x_colpart *p, double *hm, int64_t *hb, double *last_row, double *last_col)
+{
+    if (!p) return fail(MI_BAD_ARG, "handle is NULL");
+    int rc = cp_flush(p);
+    if (rc != MI_OK) return rc;
+    const int64_t rows = p->rows, vc = p->var_count, cols = vc + 1, m = rows - 1;
+    const bool whole = (int)p->sh.size() == p->world;
+    if ((hm || last_row) && !whole)
+        return fail(MI_UNSUPPORTED, "the logical tableau / objective row need every shard in this process");
+    std::vector<int64_t> basis((size_t)std::max<int64_t>(m, 1));
+    std::vector<double> loc;
+    std::vector<int64_t> gcols;
+    if (hm) std::fill(hm, hm + rows * cols, 0.0);
+    if (last_row) std::fill(last_row, last_row + cols, 0.0);
+    for (size_t si = 0; si < p->sh.size(); ++si) {
+        CpShard &s = p->sh[si];
+        const int64_t nloc = s.t->v.cols - 1;
+        const bool first = si == 0;
+        if (hm || last_row) {
+            gcols.resize((size_t)nloc);
+            if (p->compact) { if ((rc = mi355x_shard_columns(s.t, gcols.data())) != MI_OK) return rc; }
+            else for (int64_t k = 0; k < nloc; ++k) gcols[(size_t)k] = s.col_begin + k;
+        }
+        if (hm) {
+            loc.resize((size_t)(rows * (nloc + 1)));
+            rc = mi355x_tab_download(s.t, loc.data(), first ? basis.data() : nullptr, nullptr, nullptr);
+            if (rc != MI_OK) return rc;
+            for (int64_t r = 0; r < rows; ++r) {
+                for (int64_t k = 0; k < nloc; ++k) hm[r * cols + gcols[(size_t)k]] = loc[(size_t)(r * (nloc + 1) + k)];
+                if (first) hm[r * cols + vc] = loc[(size_t)(r * (nloc + 1) + nloc)];
+            }
+            if (last_row) for (int64_t k = 0; k < nloc; ++k) last_row[gcols[(size_t)k]] = loc[(size_t)(m * (nloc + 1) + k)];
+            if (last_row && first) last_row[vc] = loc[(size_t)(m * (nloc + 1) + nloc)];
+        } else if (last_row) {
+            loc.resize((size_t)(nloc + 1));
+            rc = mi355x_tab_download(s.t, nullptr, first ? basis.data() : nullptr, loc.data(), nullptr);
+            if (rc != MI_OK) return rc;
+            for (int64_t k = 0; k < nloc; ++k) last_row[gcols[(size_t)k]] = loc[(size_t)k];
+            if (first) last_row[vc] = loc[(size_t)nloc];
+        } else if (first && (hb || last_col)) {
+            rc = mi355x_tab_download(s.t, nullptr, basis.data(), nullptr, nullptr);
+            if (rc != MI_OK) return rc;
+        }
+    }
+    if (hm && p->compact)                                        // basic columns are stored nowhere: unit vectors
+        for (int64_t i = 0; i < m; ++i) hm[i * cols + basis[(size_t)i]] = 1.0;
+    if (hb) std::copy(basis.begin(), basis.begin() + m, hb);
+    if (last_col) {
+        rc = mi355x_tab_download(p->sh[0].t, nullptr, nullptr, nullptr, last_col);   // every shard holds the RHS column
+        if (rc != MI_OK) return rc;
+    }
+    return MI_OK;
+}
+
+void mi355x_colpart_destroy(mi355x_colpart *p) { cp_free(p); }
 
 // tuning hooks, used by bench.py / the microbenchmark only (not part of the reference boundary)
 int         mi355x_tune_variant_count(void) { return update_variant_count(); }

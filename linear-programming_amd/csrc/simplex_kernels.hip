@@ -1365,7 +1365,7 @@ __device__ __forceinline__ bool la_exchange(ValIdx mine, unsigned myflag, ExchRe
         const double bw = lane_value_dyn(fsel, rec_from & 63);
         // do all records carry the same first double?  (the XCC ids of the first exchange)
         const unsigned long long ref = dbits(lane_value(u0, 0));
-        const unsigned same = __all(((dbits(u0) == ref) | !v0) & ((dbits(u1) == ref) | !v1)) ? 1u : 0u;
+        const unsigned same = __all(((dbits(u0) == ref) || !v0) && ((dbits(u1) == ref) || !v1)) ? 1u : 0u;
         if (lane == 0) {
             s_res->c.v = x.v; s_res->c.i = x.i; s_res->c.s = bs;
             s_res->flag = fine ? fl : 2u; s_res->same = same; s_res->u = bu; s_res->w = bw;
@@ -1413,7 +1413,7 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
     BlockCtl *blk = t.blk;
     const int tid = threadIdx.x;
     const bool leader = w == 0 && tid == 0;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
     const int64_t m = t.rows - 1, vc = t.cols - 1, ld = t.ld, ldv = ld >> 1;
     const int64_t g = (int64_t)w * kLaThreads + tid;
     const bool has_row = g < t.rows, has_pair = g < ldv;

@@ -264,3 +264,79 @@ def test_lost_exchange_falls_back_to_two_launch_lookahead(fault_step):
     M2, b2 = M0.copy(), b0.copy()
     so2, no2, _ = oracle.solve(M2, b2)
     assert rc == so2 and np.array_equal(t.matrix.view(np.int64), M2.view(np.int64))
+
+
+# =========================================================================== multi-device C ABI
+@pytest.mark.parametrize("n_devices", [1, 2, 3, 8])
+@pytest.mark.parametrize("n,m,seed", [(96, 64, 1), (700, 333, 2)])
+def test_colpart_c_abi_logical_shards_bitwise(n, m, seed, n_devices):
+    """mi355x_colpart_*: the whole column-partitioned solve behind the C ABI (per-pivot loop and
+    both exchanges in C++).  This box has one GPU, so n_devices > 1 means logical shards on it with
+    device-local exchanges of the collectives' semantics: pivots and every bit as the oracle's."""
+    import importlib
+    cp = importlib.import_module("linear-programming_amd.colpart")
+    M0, b0 = lp.synth.tableau(n, m, lp.synth.seed_for(5, seed))
+    M, b = M0.copy(), b0.copy()
+    st_o, npiv, trace = oracle.solve(M, b, trace_cap=1 << 14)
+    tab = cp.NativeColumnPartition.from_arrays(M0, b0, n_devices)
+    info = tab.info()
+    assert info["n_shards"] == n_devices
+    st, k = tab.solve()
+    assert (st, k) == (st_o, npiv)
+    assert np.array_equal(tab.trace(npiv), trace)
+    G, bg, last_row, last_col = tab.download()
+    assert np.array_equal(G.view(np.int64), M.view(np.int64)) and np.array_equal(bg, b)
+    assert np.array_equal(last_row.view(np.int64), M[m].view(np.int64))
+    assert np.array_equal(last_col.view(np.int64), M[:, -1].view(np.int64))
+    tab.close()
+
+
+def test_colpart_c_abi_cap_resume_synthetic_and_dense_fallback():
+    import importlib
+    cp = importlib.import_module("linear-programming_amd.colpart")
+    n, m = 300, 120
+    seed = lp.synth.seed_for(5, 7)
+    M, b = lp.synth.tableau(n, m, seed)
+    tab = cp.NativeColumnPartition.synthetic(n, m, seed, 4)
+    st, k = tab.solve(max_pivots=37)                             # stops inside a block
+    assert (st, k) == (lp.capi.MI_MAX_PIVOTS, 37)
+    oracle.solve(M, b, max_pivots=37)
+    G, bg, _, _ = tab.download()
+    assert np.array_equal(G.view(np.int64), M.view(np.int64)) and np.array_equal(bg, b)
+    st, k2 = tab.solve()                                         # resume to optimality
+    so, no, _ = oracle.solve(M, b)
+    assert (st, k2) == (so, no)
+    G, bg, _, _ = tab.download()
+    assert np.array_equal(G.view(np.int64), M.view(np.int64)) and np.array_equal(bg, b)
+    tab.close()
+    # a basis that is not a set of unit columns: dense shards (every logical column distributed)
+    M0, b0 = lp.synth.tableau(40, 25, 3)
+    M0[:25, 40:65] *= 2.0                                        # slack "identity" scaled: basis columns != e_i
+    M, b = M0.copy(), b0.copy()
+    so, no, trace = oracle.solve(M, b, trace_cap=4096)
+    tab = cp.NativeColumnPartition.from_arrays(M0, b0, 3)
+    st, k = tab.solve()
+    assert (st, k) == (so, no) and np.array_equal(tab.trace(no), trace)
+    G, bg, _, _ = tab.download()
+    assert np.array_equal(G.view(np.int64), M.view(np.int64)) and np.array_equal(bg, b)
+    tab.close()
+
+
+def test_colpart_c_abi_over_rccl_single_rank(monkeypatch):
+    """The RCCL code path itself (ncclCommInitAll, ncclAllGather / ncclAllReduce on the shard's
+    stream, communicator teardown) on the one GPU this box has: a single shard forced through its
+    one-rank communicator.  (Two ranks need two devices: RCCL refuses two ranks on one GPU.)"""
+    import importlib
+    cp = importlib.import_module("linear-programming_amd.colpart")
+    monkeypatch.setenv("MI355X_COLPART_FORCE_RCCL", "1")
+    n, m = 500, 260
+    seed = lp.synth.seed_for(5, 11)
+    M, b = lp.synth.tableau(n, m, seed)
+    so, no, trace = oracle.solve(M, b, trace_cap=1 << 14)
+    tab = cp.NativeColumnPartition.synthetic(n, m, seed, 1)
+    assert tab.info() == {"n_shards": 1, "n_devices_used": 1, "uses_rccl": True}
+    st, k = tab.solve()
+    assert (st, k) == (so, no) and np.array_equal(tab.trace(no), trace)
+    G, bg, _, _ = tab.download()
+    assert np.array_equal(G.view(np.int64), M.view(np.int64)) and np.array_equal(bg, b)
+    tab.close()
