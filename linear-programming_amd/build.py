@@ -43,7 +43,7 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
     """extra_flags / out: instrumented builds next to the product library (tools/la_timing.py)."""
     if out is None and not force and not needs_build():
         return LIB
-    cmd = [_hipcc()] + FLAGS + list(extra_flags) + ["-shared", "-o", out or LIB] + sources() + ["-lrccl"]
+    cmd = [_hipcc()] + FLAGS + list(extra_flags) + ["-shared", "-o", out or LIB] + sources() + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

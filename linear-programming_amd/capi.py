@@ -138,10 +138,11 @@ def _share_hip_runtime_with_torch():
         spec = importlib.util.find_spec("torch")
         if spec is None or not spec.origin:
             return
-        for name in ("libamdhip64.so", "librccl.so"):        # same story for the RCCL the library links
-            cand = os.path.join(os.path.dirname(spec.origin), "lib", name)
-            if os.path.exists(cand):
-                ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        # (RCCL: the library binds it at run time and takes the copy the process already holds --
+        # torch's once torch is imported -- so there is never a second one; simplex_capi.hip)
     except Exception:
         pass
 

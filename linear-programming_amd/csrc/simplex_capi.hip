@@ -9,7 +9,9 @@
 #include "../../include/mi355x_simplex_tune.h"
 #include "simplex_kernels.h"
 
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>                    // types and prototypes only: the library is bound at run time
+#include <dlfcn.h>
+#include <link.h>
 
 #include <algorithm>
 #include <atomic>
@@ -1358,11 +1360,68 @@ int mi355x_shard_columns(mi355x_tab *t, int64_t *global_cols)
 
 namespace {
 
+// RCCL is bound at run time, to exactly ONE copy per process: a process that already holds a
+// librccl (PyTorch wheels bundle their own, built against their own HIP runtime; two copies in one
+// process interpose each other's symbols and corrupt the heap) uses that one, any other process
+// (the Lisp host) gets librccl.so.1 of the ROCm installation.  No RCCL at all = MI_RCCL_ERROR from
+// the entry points that need it; everything else in the library is unaffected.
+struct RcclApi {
+    decltype(&ncclGetUniqueId)    GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank)   CommInitRank = nullptr;
+    decltype(&ncclCommInitAll)    CommInitAll = nullptr;
+    decltype(&ncclCommDestroy)    CommDestroy = nullptr;
+    decltype(&ncclAllGather)      AllGather = nullptr;
+    decltype(&ncclAllReduce)      AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string path, error;
+    bool ok = false;
+};
+
+int rccl_find_loaded(struct dl_phdr_info *info, size_t, void *out)
+{
+    const char *name = info->dlpi_name ? info->dlpi_name : "";
+    const char *base = strrchr(name, '/');
+    base = base ? base + 1 : name;
+    if (strncmp(base, "librccl.so", 10) == 0) { *static_cast<std::string *>(out) = name; return 1; }
+    return 0;
+}
+
+const RcclApi &rccl()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void *h = nullptr;
+        std::string loaded;
+        dl_iterate_phdr(rccl_find_loaded, &loaded);
+        if (!loaded.empty()) { h = dlopen(loaded.c_str(), RTLD_NOW | RTLD_NOLOAD); api.path = loaded; }
+        for (const char *cand : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
+            if (h) break;
+            h = dlopen(cand, RTLD_NOW | RTLD_LOCAL);
+            if (h) api.path = cand;
+        }
+        if (!h) { api.error = "no librccl found (dlopen: " + std::string(dlerror() ? dlerror() : "?") + ")"; return; }
+#define MI_RCCL_SYM(name)                                                              \
+        api.name = reinterpret_cast<decltype(api.name)>(dlsym(h, "nccl" #name));        \
+        if (!api.name) { api.error = "nccl" #name " missing in " + api.path; return; }
+        MI_RCCL_SYM(GetUniqueId) MI_RCCL_SYM(CommInitRank) MI_RCCL_SYM(CommInitAll) MI_RCCL_SYM(CommDestroy)
+        MI_RCCL_SYM(AllGather) MI_RCCL_SYM(AllReduce) MI_RCCL_SYM(GetErrorString)
+#undef MI_RCCL_SYM
+        api.ok = true;
+    });
+    return api;
+}
+
+#define RCCL_NEED()                                                                            \
+    do {                                                                                       \
+        if (!rccl().ok) return fail(MI_RCCL_ERROR, "RCCL unavailable: %s", rccl().error.c_str()); \
+    } while (0)
+
 #define RCCL_TRY(expr)                                                                         \
     do {                                                                                       \
         ncclResult_t r_ = (expr);                                                              \
         if (r_ != ncclSuccess)                                                                 \
-            return fail(MI_RCCL_ERROR, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), \
+            return fail(MI_RCCL_ERROR, "%s failed: %s (%s:%d)", #expr, rccl().GetErrorString(r_), \
                         __FILE__, __LINE__);                                                   \
     } while (0)
 
@@ -1410,7 +1469,7 @@ void cp_free(mi355x_colpart *p)
     if (!p) return;
     for (CpShard &s : p->sh) {
         if (s.t) { (void)hipSetDevice(s.device); (void)hipStreamSynchronize(s.t->stream); }
-        if (s.comm) (void)ncclCommDestroy(s.comm);
+        if (s.comm && rccl().ok) (void)rccl().CommDestroy(s.comm);
     }
     for (CpShard &s : p->sh) {
         (void)hipSetDevice(s.device);
@@ -1454,6 +1513,7 @@ int cp_finish_setup(mi355x_colpart *p, const void *id128, int rank)
         for (CpShard &s : p->sh) s.t->stream = p->sh[0].t->own_stream;
         return MI_OK;
     }
+    RCCL_NEED();
     for (CpShard &s : p->sh) {
         HIP_TRY(hipSetDevice(s.device));
         HIP_TRY(hipMalloc((void **)&s.send, 2 * sizeof(double)));
@@ -1466,12 +1526,12 @@ int cp_finish_setup(mi355x_colpart *p, const void *id128, int rank)
         ncclUniqueId id;
         memcpy(&id, id128, sizeof id);
         HIP_TRY(hipSetDevice(p->sh[0].device));
-        RCCL_TRY(ncclCommInitRank(&p->sh[0].comm, p->world, id, rank));
+        RCCL_TRY(rccl().CommInitRank(&p->sh[0].comm, p->world, id, rank));
     } else {
         std::vector<ncclComm_t> comms((size_t)nl);
         std::vector<int> devs((size_t)nl);
         for (int i = 0; i < nl; ++i) devs[(size_t)i] = p->sh[(size_t)i].device;
-        RCCL_TRY(ncclCommInitAll(comms.data(), nl, devs.data()));
+        RCCL_TRY(rccl().CommInitAll(comms.data(), nl, devs.data()));
         for (int i = 0; i < nl; ++i) p->sh[(size_t)i].comm = comms[(size_t)i];
     }
     return MI_OK;
@@ -1504,11 +1564,11 @@ int cp_run_rccl(mi355x_colpart *p, CpShard &s, double f, int64_t n, int j0)
     for (int64_t i = 0; i < n; ++i) {
         int rc = mi355x_shard_price(s.t, p->is_max, s.col_begin, s.send);
         if (rc != MI_OK) return rc;
-        RCCL_TRY(ncclAllGather(s.send, s.gathered, 2, ncclDouble, s.comm, s.t->stream));
+        RCCL_TRY(rccl().AllGather(s.send, s.gathered, 2, ncclDouble, s.comm, s.t->stream));
         if (p->block > 1) rc = mi355x_shard_la_contribute(s.t, j, s.gathered, p->world, s.col_begin, f, (int64_t *)s.bits, s.ec);
         else              rc = mi355x_shard_contribute(s.t, s.gathered, p->world, s.col_begin, f, (int64_t *)s.bits, s.ec);
         if (rc != MI_OK) return rc;
-        RCCL_TRY(ncclAllReduce(s.bits, s.bits, (size_t)p->rows, ncclInt64, ncclSum, s.comm, s.t->stream));
+        RCCL_TRY(rccl().AllReduce(s.bits, s.bits, (size_t)p->rows, ncclInt64, ncclSum, s.comm, s.t->stream));
         if (p->block > 1) rc = mi355x_shard_la_pivot(s.t, j, (const int64_t *)s.bits, s.ec, f);
         else              rc = mi355x_shard_pivot(s.t, (const int64_t *)s.bits, s.ec, f);
         if (rc != MI_OK) return rc;
@@ -1615,8 +1675,9 @@ extern "C" {
 int mi355x_rccl_unique_id(void *id128)
 {
     if (!id128) return fail(MI_BAD_ARG, "id128 is NULL");
+    RCCL_NEED();
     ncclUniqueId id;
-    RCCL_TRY(ncclGetUniqueId(&id));
+    RCCL_TRY(rccl().GetUniqueId(&id));
     static_assert(sizeof id == 128, "ncclUniqueId is 128 bytes");
     memcpy(id128, &id, sizeof id);
     return MI_OK;

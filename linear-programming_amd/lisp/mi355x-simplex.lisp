@@ -68,6 +68,16 @@
 (cffi:defcfun ("mi355x_tab_download" %tab-download) :int
   (tab :pointer) (host-matrix :pointer) (host-basis :pointer) (last-row :pointer)
   (last-col :pointer))
+;; one tableau column-partitioned over several GPUs (include/mi355x_simplex.h, mi355x_colpart_*)
+(cffi:defcfun ("mi355x_colpart_create" %colpart-create) :int
+  (out :pointer) (rows :int64) (cols :int64) (host-matrix :pointer) (host-basis :pointer)
+  (n-devices :int))
+(cffi:defcfun ("mi355x_colpart_solve" %colpart-solve) :int
+  (handle :pointer) (is-max :int) (fp-factor :double) (max-pivots :int64) (n-pivots :pointer))
+(cffi:defcfun ("mi355x_colpart_download" %colpart-download) :int
+  (handle :pointer) (host-matrix :pointer) (host-basis :pointer) (last-row :pointer)
+  (last-col :pointer))
+(cffi:defcfun ("mi355x_colpart_destroy" %colpart-destroy) :void (handle :pointer))
 
 (define-condition mi355x-error (solver-error)
   ((code :initarg :code :reader mi355x-error-code)
@@ -164,6 +174,44 @@ the interior of the matrix keeps its pre-solve contents."
       (setf (aref basis-dst i) (aref basis i)))
     tableau))
 
+;;; ------------------------------------------------------------------ several GPUs
+(defun solve-column-partitioned (tableau devices factor max-pivots full-tableau n-pivots)
+  "Single-phase n-solve-tableau (src/simplex.lisp:453-461) with the tableau's non-basic columns
+distributed over DEVICES GPUs of this node (RCCL over xGMI inside the library; logical shards on
+one GPU when fewer are visible).  Same pivots, same bits as on one device."
+  (multiple-value-bind (flat basis rows cols) (tableau->vectors tableau)
+    (let ((handle
+            (cffi:with-foreign-object (out :pointer)
+              (cffi:with-pointer-to-vector-data (pm flat)
+                (cffi:with-pointer-to-vector-data (pb basis)
+                  (check (with-foreign-fp-mode
+                           (%colpart-create out rows cols pm pb devices)))))
+              (cffi:mem-ref out :pointer))))
+      (unwind-protect
+           (let ((status (check (with-foreign-fp-mode
+                                  (%colpart-solve handle (max-problem-p tableau) factor
+                                                  max-pivots n-pivots)))))
+             (signal-outcome status)
+             (let* ((matrix (tableau-matrix tableau))
+                    (last-row (make-array cols :element-type 'double-float))
+                    (last-col (make-array rows :element-type 'double-float))
+                    (basis-dst (tableau-basis-columns tableau)))
+               (cffi:with-pointer-to-vector-data (pr last-row)
+                 (cffi:with-pointer-to-vector-data (pc last-col)
+                   (cffi:with-pointer-to-vector-data (pb basis)
+                     (if full-tableau
+                         (cffi:with-pointer-to-vector-data (pm flat)
+                           (check (%colpart-download handle pm pb pr pc)))
+                         (check (%colpart-download handle (cffi:null-pointer) pb pr pc))))))
+               (if full-tableau
+                   (vectors->tableau tableau flat basis)
+                   (progn
+                     (dotimes (r rows) (setf (aref matrix r (1- cols)) (aref last-col r)))
+                     (dotimes (c cols) (setf (aref matrix (1- rows) c) (aref last-row c)))
+                     (dotimes (i (length basis-dst)) (setf (aref basis-dst i) (aref basis i)))
+                     tableau))))
+        (%colpart-destroy handle)))))
+
 (defun signal-outcome (status)
   "C outcome -> the reference's conditions (src/conditions.lisp:43-60)."
   (cond
@@ -181,13 +229,17 @@ the interior of the matrix keeps its pre-solve contents."
 
 ;;; ------------------------------------------------------------------ the *solver* value
 (defun mi355x-simplex-solver (problem &rest args
-                              &key (fp-tolerance 1024) (device 0) (max-pivots 0) full-tableau
+                              &key (fp-tolerance 1024) (device 0) (devices 1) (max-pivots 0)
+                                full-tableau
                               &allow-other-keys)
   "Solver interface function for the MI355X backend (the value of
 linear-programming:*solver*, src/solver.lisp:39-49).  Takes a problem and backend keyword
 arguments -- :fp-tolerance (as the built-in solver, src/simplex.lisp:506-511), :device,
-:max-pivots, :full-tableau (write every entry of the solved tableau back instead of only what
-the solution-* generics read) -- and returns a solved `tableau`."
+:devices (> 1: the tableau of a single-phase problem is column-partitioned over that many GPUs
+of the node; two-phase problems run on :device), :max-pivots, :full-tableau (write every entry
+of the solved tableau back instead of only what the solution-* generics read) -- and returns a
+solved `tableau`.  solve-problem forwards these keywords (src/solver.lisp:53-56):
+  (solve-problem problem :devices 8)"
   (declare (ignore args))
   (when (problem-integer-vars problem)
     (error 'unsupported-constraint-error
@@ -216,6 +268,8 @@ the solution-* generics read) -- and returns a solved `tableau`."
                        (%tab-destroy main-handle)))
                 (%tab-destroy art-handle))))
           ;; single phase, src/simplex.lisp:453-461
+          (if (> devices 1)
+              (solve-column-partitioned tableaus devices factor max-pivots full-tableau n-pivots)
           (multiple-value-bind (handle flat basis) (upload-tableau tableaus device)
             (unwind-protect
                  (let ((status (check (with-foreign-fp-mode
@@ -225,4 +279,4 @@ the solution-* generics read) -- and returns a solved `tableau`."
                    (if full-tableau
                        (download-tableau handle tableaus flat basis)
                        (download-solution handle tableaus basis)))
-              (%tab-destroy handle)))))))
+              (%tab-destroy handle))))))))

@@ -114,3 +114,46 @@ def test_mps_to_solution_on_gpu():
     assert abs(sol.objective_value() - 92.0 / 3.0) < 1e-12
     assert abs(sol.variable("X") - 8.0 / 3.0) < 1e-12 and sol.variable("Y") == 0.0
     assert abs(sol.variable("Z") - 3.5) < 1e-12
+
+
+def test_single_variable_rows_deliberate_deviation_from_the_reference():
+    """Single-variable rows become bounds.  The reference (src/external-formats.lisp:312-323)
+    writes a `<=` row's bound with lb-max into the UPPER-bound slot, a `>=` row's bound into the
+    INTEGER-flag slot, and ignores the coefficient's sign; this reader does what the row means
+    (documented in csrc/mps_reader.cpp and INTEGRATION.md): `<=` tightens the upper bound, `>=`
+    the lower bound, the sense flips for a negative coefficient, `=` fixes the variable."""
+    text = """NAME          t
+ROWS
+ N  cost
+ L  both
+ L  upx
+ G  loy
+ L  negz
+ G  negv
+ E  fixw
+COLUMNS
+    x         cost      1               both      1
+    x         upx       2
+    y         cost      1               both      1
+    y         loy       4
+    z         cost      1               both      1
+    z         negz      -2
+    v         cost      1               both      1
+    v         negv      -2
+    w         cost      1               both      1
+    w         fixw      5
+RHS
+    r         both      100             upx       6
+    r         loy       2               negz      8
+    r         fixw      10              negv      -8
+ENDATA
+"""
+    p = read_mps(text, "max", read_case="preserve")
+    b = dict(p.var_bounds)
+    assert b["v"] == (0.0, 4.0)            # -2v >= -8  <=>  v <= 4 (sense flipped by the sign)
+    assert b["x"] == (0.0, 3.0)            # 2x <= 6
+    assert b["y"] == (0.5, None)           # 4y >= 2
+    assert "z" not in b                    # -2z <= 8  <=>  z >= -4: the default z >= 0 is tighter
+    assert b["w"] == (2.0, 2.0)            # 5w = 10
+    assert p.integer_vars == []            # nothing leaks into the integer flags
+    assert _cset(p.constraints) == _cset([("<=", [("x", 1.0), ("y", 1.0), ("z", 1.0), ("v", 1.0), ("w", 1.0)], 100.0)])
