@@ -37,7 +37,8 @@ int         mi355x_tune_set_sweep_shape(int rows_per_workgroup, int nontemporal 
 int         mi355x_tune_set_sweep_impl(int impl);            /* 0 k_sweep16 for full blocks, 1 k_sweep
                                                                 always; 4 / 8: rows per step of k_sweep16 */
 int         mi355x_tune_set_handover_mode(int mode);         /* 0 auto, 1 sequential re-elimination */
-int         mi355x_tune_set_batch_mode(int mode);            /* 0 auto, 1 lockstep, 2 workgroup per LP */
+int         mi355x_tune_set_batch_mode(int mode);            /* 0 auto, 1 lockstep, 2 all in one workgroup
+                                                                per LP, 3 look-ahead per LP + sweeps over all LPs */
 int         mi355x_tune_set_batch_block(int k);              /* blocked per-LP kernel, 1 = off   */
 
 /* ---- persistent look-ahead (k_la_block) ------------------------------------------------ */

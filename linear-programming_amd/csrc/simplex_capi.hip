@@ -33,7 +33,8 @@ thread_local std::string g_err;
 int g_select_mode = 0;                    // 0 auto, 1 single workgroup, 2 split (tuning/test hook)
 int g_compact_enabled = 1;                // solve loops run on the compact representation
 int g_handover_mode = 0;                  // 0 auto, 1 always the sequential re-elimination
-int g_batch_mode = 0;                     // 0 auto, 1 lockstep launch pairs, 2 one workgroup per LP
+int g_batch_mode = 0;                     // 0 auto, 1 lockstep launch pairs, 2 one workgroup per LP,
+                                          // 3 blocked: look-ahead per LP + one sweep launch over all LPs
 int g_la_mode = 0;                        // look-ahead: 0 auto, 1 two launches per step, 2 one persistent launch per block
 int g_block_k = 16;                       // pivots selected ahead and applied per sweep (1 = off)
 
@@ -217,6 +218,18 @@ int alloc_tab(mi355x_tab **out, int64_t rows, int64_t cols, int device, int64_t 
     ALLOC(t->v.part_i, n_lps * part_cap * sizeof(int64_t));
     ALLOC(t->v.part_s, n_lps * part_cap * sizeof(int64_t));
     t->v.part_cap = part_cap;
+    if (n_lps > 1) {                                  // per-LP block state (look-ahead launch -> sweep launch)
+        t->v.bk_stride = (rows + kLdAlign - 1) / kLdAlign * kLdAlign;
+        t->v.zs_bk = (int64_t)kMaxBlock * t->v.bk_stride;
+        t->v.zs_bkp = (int64_t)kMaxBlock * t->v.ld;
+        t->v.zs_rm = t->v.bk_stride;
+        t->v.zs_sm = t->v.ld;
+        ALLOC(t->v.bk_col, (size_t)n_lps * t->v.zs_bk * sizeof(double));
+        ALLOC(t->v.bk_prow, (size_t)n_lps * t->v.zs_bkp * sizeof(double));
+        ALLOC(t->v.bk_rmask, (size_t)n_lps * t->v.zs_rm * sizeof(uint32_t));
+        ALLOC(t->v.bk_smask, (size_t)n_lps * t->v.zs_sm * sizeof(uint32_t));
+        ALLOC(t->v.blk, (size_t)n_lps * sizeof(BlockCtl));
+    }
     if (n_lps == 1) {                                 // blocked pivoting
         t->v.bk_stride = (rows + kLdAlign - 1) / kLdAlign * kLdAlign;
         ALLOC(t->v.bk_col, (size_t)kMaxBlock * t->v.bk_stride * sizeof(double));
@@ -248,7 +261,15 @@ int alloc_tab(mi355x_tab **out, int64_t rows, int64_t cols, int device, int64_t 
         free_tab(t);
         return fail(MI_HIP_ERROR, "memset failed: %s", hipGetErrorString(e));
     }
-    if ((t->v.blk && ((e = hipMemsetAsync(t->v.blk, 0, sizeof(BlockCtl), t->stream)) != hipSuccess ||
+    if (n_lps > 1 && ((e = hipMemsetAsync(t->v.bk_col, 0, (size_t)n_lps * t->v.zs_bk * sizeof(double), t->stream)) != hipSuccess ||
+                      (e = hipMemsetAsync(t->v.bk_prow, 0, (size_t)n_lps * t->v.zs_bkp * sizeof(double), t->stream)) != hipSuccess ||
+                      (e = hipMemsetAsync(t->v.bk_rmask, 0, (size_t)n_lps * t->v.zs_rm * sizeof(uint32_t), t->stream)) != hipSuccess ||
+                      (e = hipMemsetAsync(t->v.bk_smask, 0, (size_t)n_lps * t->v.zs_sm * sizeof(uint32_t), t->stream)) != hipSuccess ||
+                      (e = hipMemsetAsync(t->v.blk, 0, (size_t)n_lps * sizeof(BlockCtl), t->stream)) != hipSuccess)) {
+        free_tab(t);
+        return fail(MI_HIP_ERROR, "memset failed: %s", hipGetErrorString(e));
+    }
+    if ((n_lps == 1 && ((e = hipMemsetAsync(t->v.blk, 0, sizeof(BlockCtl), t->stream)) != hipSuccess ||
                       (e = hipMemsetAsync(t->v.bk_rmask, 0, t->v.bk_stride * sizeof(uint32_t), t->stream)) != hipSuccess ||
                       (e = hipMemsetAsync(t->v.bk_smask, 0, t->v.ld * sizeof(uint32_t), t->stream)) != hipSuccess ||
                       (e = hipMemsetAsync(t->v.la_px, 0, kMaxLaRecords * sizeof(ExchRec), t->stream)) != hipSuccess ||
@@ -1108,6 +1129,45 @@ int mi355x_batch_solve(mi355x_batch *b, int is_max, double f, int64_t max_pivots
     // an LP is too large for the LDS budget (or when forced by the tuning hook)
     // measured (257x769 LPs, compact representation): one workgroup per LP 1.76 M pivots/s at
     // 128 LPs and 2.13 M at 1024 LPs; lockstep launch pairs 1.62 M and 1.25 M
+    // default: blocked, with the sweep of a block as ONE launch over all LPs (every CU busy in the
+    // part that moves the tableaux; the look-ahead of a block is one workgroup per LP): 128 LPs of
+    // 512 x 256 3.5 -> 7.2 M pivots/s, 1024 LPs 8.2 -> 11.4 M against the all-in-one-workgroup
+    // kernel.  Needs the compact representation and an LP whose block state fits the LDS.
+    if ((g_batch_mode == 0 || g_batch_mode == 3) && t->compact) {
+        bool split_ok = true;
+        int64_t blocks = 2;
+        for (;;) {
+            for (int64_t i = 0; i < blocks && split_ok; ++i)
+                split_ok = launch_batch_block_split(t->c, is_max, f, t->stream);
+            if (!split_ok) break;
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(t->h_ctl, t->v.ctl, n * sizeof(Ctl), hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            bool running = false, need_dense = false;
+            for (int64_t i = 0; i < n; ++i) {
+                running |= t->h_ctl[i].status == kRunning;
+                need_dense |= t->h_ctl[i].status == kNeedDense;
+            }
+            if (need_dense) { split_ok = false; break; }      // finish below on the dense tableaux
+            if (!running) {
+                t->n_part = 0;
+                for (int64_t i = 0; i < n; ++i) {
+                    if (status) status[i] = t->h_ctl[i].status;
+                    if (n_pivots) n_pivots[i] = t->h_ctl[i].n_pivots;
+                }
+                return MI_OK;
+            }
+            if (blocks < 8) blocks *= 2;
+        }
+        if (t->compact) {                                      // an LP met an inf / NaN: the established path
+            bool need_dense = false;
+            for (int64_t i = 0; i < n; ++i) need_dense |= t->h_ctl[i].status == kNeedDense;
+            if (need_dense) {
+                rc = fall_back_to_dense(t);
+                if (rc != MI_OK) return rc;
+            }
+        }
+    }
     const bool want_persistent = g_batch_mode != 1;
     bool persistent = want_persistent && launch_batch_solve(cur(t), is_max, f, t->stream);
     if (persistent) t->n_part = 0;
@@ -1920,8 +1980,9 @@ int         mi355x_tune_set_alternate_sweep(int on) { set_alternate_sweep(on); r
 int         mi355x_tab_block_size(mi355x_tab *t) { return (t && block_mode(t)) ? g_block_k : 1; }
 int         mi355x_debug_rhs(mi355x_tab *t, double *out, int64_t n, int clear)
 {
-    if (hipMemcpy(out, t->v.rhs, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    if (clear) (void)hipMemset(t->v.rhs, 0, n * sizeof(double));
+    double *buf = t->v.rhs ? t->v.rhs : t->v.col;          // batches have no rhs buffer: their col buffer
+    if (hipMemcpy(out, buf, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (clear) (void)hipMemset(buf, 0, n * sizeof(double));
     return 0;
 }
 int         mi355x_tune_set_batch_block(int k) { set_batch_block(k); return k; }

@@ -91,6 +91,7 @@ struct TabView {
     // batch of n_lps same-shape LPs: per-LP element strides (all zero for a single tableau)
     int64_t  n_lps;
     int64_t  zs_M, zs_basis, zs_col, zs_prow, zs_part, zs_p2l, zs_l2p;
+    int64_t  zs_bk, zs_bkp, zs_rm, zs_sm;       // per-LP block state: bk_col, bk_prow, bk_rmask, bk_smask (blk: one BlockCtl each)
 };
 
 struct UpdateShape {
@@ -153,6 +154,9 @@ int  launch_shard_la_prepare(const TabView &t, int j, const double *col, const i
 void launch_handover(const TabView &art, const TabView &main_tab, bool unit_basis, hipStream_t s);
 // whole-batch solve, one workgroup per LP (false: an LP does not fit the LDS budget)
 bool launch_batch_solve(const TabView &t, int is_max, double fp_factor, hipStream_t s);
+// one block of every LP of a batch: look-ahead (one workgroup per LP, 16 pivots selected ahead)
+// then ONE sweep launch over all LPs (grid.z = LP); false: not available for this shape
+bool launch_batch_block_split(const TabView &t, int is_max, double fp_factor, hipStream_t s);
 void set_batch_block(int k);       // tuning hook: pivots per pass of the blocked per-LP kernel (1 = off)
 // dense logical tableau <-> compact representation
 void launch_verify_basis(const TabView &t, int *flag, hipStream_t s);

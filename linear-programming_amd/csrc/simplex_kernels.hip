@@ -325,6 +325,11 @@ __device__ __forceinline__ TabView lp_slice(TabView t)
     t.part_s += z * t.zs_part;
     t.ctl    += z;
     if (t.p2l) { t.p2l += z * t.zs_p2l; t.l2p += z * t.zs_l2p; }
+    if (t.blk && t.n_lps > 1) {                     // per-LP block state of a batch
+        t.blk += z;
+        t.bk_col += z * t.zs_bk; t.bk_prow += z * t.zs_bkp;
+        t.bk_rmask += z * t.zs_rm; t.bk_smask += z * t.zs_sm;
+    }
     return t;
 }
 
@@ -1678,6 +1683,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(TabView t, const int tr, const 
 {
     constexpr int U = 4;                                       // rows per step
     constexpr int CH = KMAX < 4 ? KMAX : 4;                    // pivots per SGPR chunk (32 SGPRs: more would spill)
+    t = lp_slice(t);                                           // batch: grid.z = LP
     const BlockCtl *__restrict__ blk = t.blk;
     const int k = (int)blk->n_pending;
     if (k == 0) return;
@@ -1869,6 +1875,7 @@ __global__ __launch_bounds__(256) void k_sweep16(TabView t, const int tr, const 
                                                  const double sgn, const int price, const unsigned stamp)
 {
     constexpr int K = kSweepK, CP = ColChunk<U>::CP, NCH = K / CP;
+    t = lp_slice(t);                                           // batch: grid.z = LP
     const BlockCtl *__restrict__ blk = t.blk;
     const int k = (int)blk->n_pending;
     if (k == 0) return;
@@ -2180,35 +2187,71 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_solve(TabView t, double sg
 // wants 256 VGPRs per thread (16 prow pairs + four rows in flight; at 1024 threads it spilled).
 constexpr int kBbThreads = 512, kRowPhases = kBbThreads / 256;
 
+// Reduction of the per-LP kernel: wave arg-min (wave_argmin: v_min_f64 butterfly, the tree when a
+// NaN or a tie is involved), one LDS slot per wave, ONE barrier, then every thread folds the
+// wave winners in wave order -- the order of block_reduce_min.  `buf` alternates between the
+// pricing and the ratio reduction of a step, so the slots of one are never rewritten before every
+// thread has passed the other's barrier.
+struct BbMsg { ValIdx c; unsigned flag; unsigned pad; };
+__device__ __forceinline__ ValIdx bb_reduce(ValIdx mine, unsigned myflag, BbMsg *buf, unsigned &flag)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    Cand c; c.v = mine.v; c.i = (int)mine.i;
+    int src;
+    c = wave_argmin(c, src);
+    const int64_t cs = lane_pick(mine.s, src);
+    const unsigned wf = __any(myflag != 0u) ? 1u : 0u;
+    if (lane == 0) { buf[wave].c.v = c.v; buf[wave].c.i = c.i; buf[wave].c.s = cs; buf[wave].flag = wf; }
+    __syncthreads();
+    ValIdx r = buf[0].c;
+    flag = buf[0].flag;
+#pragma unroll
+    for (int w = 1; w < kBbThreads / 64; ++w) { r = vi_min(r, buf[w].c); flag |= buf[w].flag; }
+    return r;
+}
+
 template <int KB>
 __global__ __launch_bounds__(kBbThreads) void k_batch_block(TabView t, double sgn, double price_tol,
-                                                           double ratio_thr)
+                                                           double ratio_thr, const int split)
 {
+    // split == 0: the whole solve of the LP in this launch, look-ahead and sweeps alternating.
+    // split != 0: the look-ahead of ONE block only; col_i / prow_i / masks / pending list go to the
+    // LP's global block state and the sweep is a separate launch over ALL LPs (k_sweep with
+    // grid.z = LP), which uses every CU of the chip instead of one per LP.
+    static_assert(KB % 4 == 0 && KB <= 16, "chains in groups of four links; 16 + 16 mask bits per pair");
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    __shared__ double    s_v[kBbThreads / 64];
-    __shared__ long long s_i[kBbThreads / 64];
-    __shared__ long long s_cr[KB], s_sl[KB];
+    __shared__ BbMsg s_wp[kBbThreads / 64], s_wr[kBbThreads / 64];
     t = lp_slice(t);
     Ctl *ctl = t.ctl;
     const Ctl c0 = *ctl;
-    if (c0.status != kRunning) return;
-    const int tid = threadIdx.x;
+    if (c0.status != kRunning) {
+        if (split && threadIdx.x == 0) t.blk->n_pending = 0;   // nothing for the sweep that follows
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
     const int64_t rows = t.rows, m = rows - 1, vc = t.cols - 1, ld = t.ld, ldv = ld >> 1;
     const int64_t rp = (rows + 1) & ~(int64_t)1;
     double    *s_prow = lds;                                   // KB x ld
     double    *s_col  = s_prow + (int64_t)KB * ld;             // KB x rp
     double    *s_z    = s_col + (int64_t)KB * rp;              // ld: objective row through all pending pivots
-    double    *s_b    = s_z + ld;                              // rp: RHS column, likewise
+    double    *s_b    = s_z + ld;                              // rp: RHS column, through all but the last one
     long long *s_p2l  = reinterpret_cast<long long *>(s_b + rp);   // ld: logical column of a slot
-    unsigned  *s_rm   = reinterpret_cast<unsigned *>(s_p2l + ld);  // rp: row -> pending pivots whose row it is
+    long long *s_bas  = s_p2l + ld;                            // rp: basis (the leaving column of a pivot)
+    unsigned  *s_rm   = reinterpret_cast<unsigned *>(s_bas + rp);  // rp: row -> pending pivots whose row it is
     unsigned  *s_sm   = s_rm + rp;                             // ldv: pair -> pending pivots whose slot it holds
     vec2d *M2 = reinterpret_cast<vec2d *>(t.M);
 
+    // Ownership, fixed for the whole solve: a thread owns the rows r = tid, tid + T, ... (their
+    // s_b / s_col / s_rm entries) and the column pairs p = tid, tid + T, ... (their s_z / s_prow /
+    // s_p2l / s_sm entries): what a thread writes of these only it reads before the next barrier.
     for (int64_t c = tid; c < ld; c += kBbThreads) {
         s_z[c] = t.M[m * ld + c];
         s_p2l[c] = c < vc ? t.p2l[c] : -1;
     }
-    for (int64_t r = tid; r < rows; r += kBbThreads) s_b[r] = t.M[r * ld + vc];
+    for (int64_t r = tid; r < rp; r += kBbThreads) {
+        s_b[r] = r < rows ? t.M[r * ld + vc] : 0.0;
+        s_bas[r] = r < m ? t.basis[r] : -1;
+    }
     int64_t n_pivots = c0.n_pivots, trace_n = c0.trace_n;
     int term = -1;                                             // status that ends the solve
     __syncthreads();
@@ -2216,73 +2259,168 @@ __global__ __launch_bounds__(kBbThreads) void k_batch_block(TabView t, double sg
     while (term < 0) {
         for (int64_t r = tid; r < rp; r += kBbThreads) s_rm[r] = 0u;
         for (int64_t p = tid; p < ldv; p += kBbThreads) s_sm[p] = 0u;
-        int k = 0;
+        int k = 0, b_done = 0;                                 // pending pivots; how many of them s_b has seen
+        int64_t v_cr = -1, v_sl = -1;                          // lane i: pivot row / slot of pending pivot i
         for (int J = 0; J < KB && term < 0; ++J) {
-            // ---- find-entering-column on the running objective row
+#ifdef MI355X_LA_TIMING
+            const bool tm = blockIdx.z == 0 && tid == 0;
+            unsigned long long T0 = wall_clock64(), T1 = T0, T2 = T0, T3 = T0, T4 = T0, T5 = T0;
+#endif
+            // ---- find-entering-column on the running objective row (my pairs)
             ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
-            for (int64_t c = tid; c < vc; c += kBbThreads) {
-                ValIdx x; x.v = s_z[c] * sgn; x.i = s_p2l[c]; x.s = c;
-                best = vi_min(best, x);
+            for (int64_t p = tid; p < ldv; p += kBbThreads) {
+                const double2 z = reinterpret_cast<const double2 *>(s_z)[p];
+                if (2 * p < vc)     { ValIdx x; x.v = z.x * sgn; x.i = s_p2l[2 * p];     x.s = 2 * p;     best = vi_min(best, x); }
+                if (2 * p + 1 < vc) { ValIdx x; x.v = z.y * sgn; x.i = s_p2l[2 * p + 1]; x.s = 2 * p + 1; best = vi_min(best, x); }
             }
-            const ValIdx e = block_reduce_min<kBbThreads>(best, s_v, s_i);
+            unsigned fl;
+#ifdef MI355X_LA_TIMING
+            T1 = wall_clock64();
+#endif
+            const ValIdx e = bb_reduce(best, 0u, s_wp, fl);     // barrier: prow_{J-1}, s_z, masks of step J-1 complete
+#ifdef MI355X_LA_TIMING
+            T2 = wall_clock64();
+#endif
             if (e.i < 0 || !(e.v < 0.0 - price_tol)) { term = 0; break; }          // MI_OPTIMAL
             if (c0.max_pivots > 0 && n_pivots >= c0.max_pivots) { term = 3; break; }   // MI_MAX_PIVOTS
-            const int64_t ec = e.i, slot = e.s;
-            // ---- entering column through the pending chain, ratio test
+            const int64_t ec = e.i, slot = uniform64(e.s);
+            // ---- entering column through the pending chain, ratio test.  Uniform operands of the
+            // chain: lane i holds prow_i[slot]; bit i of slmask: pending pivot i gave up this slot
+            const double v_pa = lane < J ? s_prow[(int64_t)lane * ld + slot] : 0.0;
+            const unsigned slmask = (unsigned)__ballot((lane < J) & (v_sl == slot));
+            const double pb = J > 0 ? s_prow[(int64_t)(J - 1) * ld + vc] : 0.0;   // RHS entry of prow_{J-1}
             ValIdx q; q.v = 0.0; q.i = -1; q.s = 0;
-            int bad = 0;
+            unsigned bad = 0u;
             for (int64_t r = tid; r < rows; r += kBbThreads) {
                 double a = t.M[r * ld + slot];
-                for (int i = 0; i < J; ++i)
-                    a = pend(a, slot == s_sl[i], r == s_cr[i], s_col[(int64_t)i * rp + r], s_prow[(int64_t)i * ld + slot]);
+                const unsigned rmb = s_rm[r];
+                double b = s_b[r];
+                if (J > 0) {                                   // RHS entry brought up to date with pivot J-1
+                    b = pend(b, false, (rmb >> (J - 1)) & 1u, s_col[(int64_t)(J - 1) * rp + r], pb);
+                    s_b[r] = b;
+                }
+#pragma unroll
+                for (int i0 = 0; i0 < KB; i0 += 4) {
+                    if (i0 < J) {
+                        double prod[4], pa[4];
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const double ci = (i0 + kk < J) ? s_col[(int64_t)(i0 + kk) * rp + r] : 0.0;
+                            pa[kk] = lane_value(v_pa, i0 + kk);
+                            prod[kk] = ci * pa[kk];                    // rounded product
+                        }
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const bool is_cr = (rmb >> (i0 + kk)) & 1u;
+                            if ((slmask >> (i0 + kk)) & 1u) a = is_cr ? 1.0 : 0.0;
+                            const double d = a - prod[kk];             // rounded difference
+                            a = is_cr ? pa[kk] : d;
+                        }
+                    }
+                }
                 s_col[(int64_t)J * rp + r] = a;
+                if (split) t.bk_col[(int64_t)J * t.bk_stride + r] = a;   // for the sweep launch
                 bad |= !(fabs(a) <= 1.7976931348623157e308);
                 if (r < m && ratio_thr < a) {
-                    ValIdx x; x.v = s_b[r] / a; x.i = r; x.s = __double_as_longlong(a);
+                    ValIdx x; x.v = b / a; x.i = r; x.s = __double_as_longlong(a);
                     q = vi_min(q, x);
                 }
             }
-            q = block_reduce_min<kBbThreads>(q, s_v, s_i);     // barriers: s_col[J] complete
-            if (__syncthreads_or(bad)) { term = kNeedDense; break; }
+            b_done = J;
+#ifdef MI355X_LA_TIMING
+            T3 = wall_clock64();
+#endif
+            q = bb_reduce(q, bad, s_wr, fl);                   // barrier: s_col[J] complete
+#ifdef MI355X_LA_TIMING
+            T4 = wall_clock64();
+#endif
+            if (fl) { term = kNeedDense; break; }
             if (q.i < 0) { term = 1; break; }                  // MI_UNBOUNDED
-            const int64_t cr = q.i;
+            const int64_t cr = uniform64(q.i);
             const double piv = __longlong_as_double(q.s);
             // ---- pivot row through the chain -> prow_J; objective row through pivot J
             const double cmj = s_col[(int64_t)J * rp + m];
+            const double v_ccr = lane < J ? s_col[(int64_t)lane * rp + cr] : 0.0;
+            const unsigned crmask = (unsigned)__ballot((lane < J) & (v_cr == cr));
             for (int64_t p = tid; p < ldv; p += kBbThreads) {
                 const vec2d y0 = M2[cr * ldv + p];
                 double2 y = make_double2(y0.x, y0.y);
-                for (int i = 0; i < J; ++i) {
-                    const bool   is_cr = cr == s_cr[i];
-                    const double ccr = s_col[(int64_t)i * rp + cr];
-                    const double2 pi = reinterpret_cast<const double2 *>(s_prow + (int64_t)i * ld)[p];
-                    y.x = pend(y.x, 2 * p     == s_sl[i], is_cr, ccr, pi.x);
-                    y.y = pend(y.y, 2 * p + 1 == s_sl[i], is_cr, ccr, pi.y);
+                const unsigned smb = s_sm[p];
+#pragma unroll
+                for (int i0 = 0; i0 < KB; i0 += 4) {
+                    if (i0 < J) {
+                        double2 pii[4], prod[4];
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            pii[kk] = (i0 + kk < J) ? reinterpret_cast<const double2 *>(s_prow + (int64_t)(i0 + kk) * ld)[p]
+                                                    : make_double2(0.0, 0.0);
+                            const double ccr = lane_value(v_ccr, i0 + kk);
+                            prod[kk].x = ccr * pii[kk].x;              // rounded products
+                            prod[kk].y = ccr * pii[kk].y;
+                        }
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const bool is_cr = (crmask >> (i0 + kk)) & 1u;
+                            if ((smb >> (i0 + kk)) & 1u)      y.x = is_cr ? 1.0 : 0.0;
+                            if ((smb >> (16 + i0 + kk)) & 1u) y.y = is_cr ? 1.0 : 0.0;
+                            const double dx = y.x - prod[kk].x, dy = y.y - prod[kk].y;
+                            y.x = is_cr ? pii[kk].x : dx;
+                            y.y = is_cr ? pii[kk].y : dy;
+                        }
+                    }
                 }
                 const double2 pr = scale_pair(t, p, y, piv, slot);
                 reinterpret_cast<double2 *>(s_prow + (int64_t)J * ld)[p] = pr;
+                if (split) reinterpret_cast<double2 *>(t.bk_prow + (int64_t)J * ld)[p] = pr;
                 double2 z = reinterpret_cast<double2 *>(s_z)[p];
                 z.x = pend(z.x, 2 * p     == slot, false, cmj, pr.x);
                 z.y = pend(z.y, 2 * p + 1 == slot, false, cmj, pr.y);
                 reinterpret_cast<double2 *>(s_z)[p] = z;
+                if (p == (slot >> 1)) {                        // the slot changes hands: its owner keeps the books
+                    const int64_t leaving = s_bas[cr];
+                    s_p2l[slot] = leaving;
+                    s_sm[p] = smb | (1u << (J + 16 * (int)(slot & 1)));
+                    t.p2l[slot] = leaving;
+                    t.l2p[leaving] = slot;
+                    t.l2p[ec] = -1;
+                    t.basis[cr] = ec;                          // src/simplex.lisp:358
+                    s_bas[cr] = ec;                            // (next read: after the next barrier)
+                }
             }
-            __syncthreads();                                   // prow_J complete
-            const double pbj = s_prow[(int64_t)J * ld + vc];
             for (int64_t r = tid; r < rows; r += kBbThreads)
-                s_b[r] = pend(s_b[r], false, r == cr, s_col[(int64_t)J * rp + r], pbj);
-            if (tid == 0) {                                    // bookkeeping of pivot J
-                const int64_t leaving = t.basis[cr];
-                t.p2l[slot] = leaving;  s_p2l[slot] = leaving;
-                t.l2p[leaving] = slot;  t.l2p[ec] = -1;
-                t.basis[cr] = ec;                              // src/simplex.lisp:358
+                if (r == cr) s_rm[r] |= 1u << J;
+            if (tid == 0) {
+                if (split) { t.blk->cr[J] = cr; t.blk->slot[J] = slot; }
                 if (t.trace_ec && trace_n < t.trace_cap) { t.trace_ec[trace_n] = ec; t.trace_cr[trace_n] = cr; }
-                s_cr[J] = cr;  s_sl[J] = slot;
-                s_rm[cr] |= 1u << J;
-                s_sm[slot >> 1] |= 1u << (J + 16 * (int)(slot & 1));
             }
+            if (lane == J) { v_cr = cr; v_sl = slot; }
             n_pivots += 1; trace_n += 1;
             k = J + 1;
-            __syncthreads();
+#ifdef MI355X_LA_TIMING
+            T5 = wall_clock64();
+            if (tm) {
+                double *d = t.col;                              // (unused by this kernel)
+                d[0] += 1.0; d[1] += (double)(T1 - T0); d[2] += (double)(T2 - T1); d[3] += (double)(T3 - T2);
+                d[4] += (double)(T4 - T3); d[5] += (double)(T5 - T4);
+            }
+#endif
+        }
+        __syncthreads();                                       // prow / col / masks of the block complete
+        if (split) {                                           // hand the block over to the sweep launch
+            for (int64_t r = tid; r < t.bk_stride; r += kBbThreads) t.bk_rmask[r] = r < rp ? s_rm[r] : 0u;
+            for (int64_t p = tid; p < ldv; p += kBbThreads) t.bk_smask[p] = s_sm[p];
+            if (tid == 0) {
+                t.blk->n_pending = k;
+                if (term >= 0) ctl->status = term;
+                ctl->n_pivots = n_pivots;
+                ctl->trace_n = trace_n;
+            }
+            return;
+        }
+        if (k > b_done) {                                      // RHS column through the last pending pivot
+            const double pb = s_prow[(int64_t)(k - 1) * ld + vc];
+            for (int64_t r = tid; r < rows; r += kBbThreads)
+                s_b[r] = pend(s_b[r], false, (s_rm[r] >> (k - 1)) & 1u, s_col[(int64_t)(k - 1) * rp + r], pb);
         }
         // ---- the sweep: the k pending pivots applied to every stored element.  Full strips of
         // 256 column pairs: a thread owns one pair (its prow entries of the pending pivots in
@@ -2682,10 +2820,10 @@ static int g_batch_block = 0;                                  // 0 = default (1
 void set_batch_block(int k) { g_batch_block = k; }
 
 template <int KB>
-static bool launch_batch_block_t(const TabView &t, int is_max, double f, hipStream_t s)
+static bool launch_batch_block_t(const TabView &t, int is_max, double f, hipStream_t s, int split = 0)
 {
     const int64_t rp = (t.rows + 1) & ~(int64_t)1, ldv = t.ld >> 1;
-    const size_t bytes = (size_t)((int64_t)KB * (t.ld + rp) + t.ld + rp + t.ld) * 8 + (size_t)(rp + ldv) * 4;
+    const size_t bytes = (size_t)((int64_t)KB * (t.ld + rp) + t.ld + rp + t.ld + rp) * 8 + (size_t)(rp + ldv) * 4;
     if (bytes > 150 * 1024) return false;
     static bool attr_set = false;
     if (!attr_set) {
@@ -2695,7 +2833,7 @@ static bool launch_batch_block_t(const TabView &t, int is_max, double f, hipStre
         attr_set = true;
     }
     hipLaunchKernelGGL(k_batch_block<KB>, dim3(1, 1, (unsigned)t.n_lps), dim3(kBbThreads), bytes, s, t,
-                       sgn_of(is_max), (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon);
+                       sgn_of(is_max), (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon, split);
     return true;
 }
 
@@ -2715,6 +2853,30 @@ bool launch_batch_solve(const TabView &t, int is_max, double f, hipStream_t s)
     if (lds > 96 * 1024 || t.ld / 2 < 1) return false;
     hipLaunchKernelGGL(k_batch_solve, dim3(1, 1, (unsigned)t.n_lps), dim3(kLpThreads), lds, s, t,
                        sgn_of(is_max), (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon);
+    return true;
+}
+static int g_sweep_tr = 0, g_sweep_nt = -1;                     // 0 / -1: by size
+static int g_sweep_impl = 0;                                    // 0: k_sweep16 for full blocks, 1: k_sweep always
+bool launch_batch_block_split(const TabView &t, int is_max, double f, hipStream_t s)
+{
+    if (!t.p2l || !t.blk || !t.bk_col || !t.bk_prow || t.n_lps < 2 || t.rows < 2) return false;
+    if (!launch_batch_block_t<16>(t, is_max, f, s, /*split=*/1)) return false;
+    // the sweep of every LP's pending pivots: k_sweep copes with any number of pending pivots per
+    // LP (an LP that has finished has none), grid.z = LP
+    constexpr int block = 256;
+    const int64_t ldv = t.ld >> 1;
+    int strips = (int)((ldv + block - 1) / block);
+    int64_t sp = (ldv + strips - 1) / strips;
+    sp = (sp + 7) / 8 * 8;
+    if (sp > block) sp = block;
+    strips = (int)((ldv + sp - 1) / sp);
+    // measured (tools/batch_sweep_ab.py, 257 x 513 stored per LP): k_sweep with 16-row tiles 7.2 /
+    // 11.4 M pivots/s at 128 / 1024 LPs (32 rows 6.8 / 11.3); k_sweep16, whose partial-block form is
+    // a slow one and every LP ends on a partial block, 6.7 / 10.2
+    int64_t tr = g_sweep_tr ? g_sweep_tr : 16;
+    while (tr > 4 && ((t.rows + tr - 1) / tr) * strips * t.n_lps < 2048) tr /= 2;
+    const dim3 grid((unsigned)strips, (unsigned)((t.rows + tr - 1) / tr), (unsigned)t.n_lps);
+    hipLaunchKernelGGL((k_sweep<256, 16, false>), grid, dim3(256), 0, s, t, (int)tr, (int)sp, sgn_of(is_max), 0, 0u);
     return true;
 }
 void launch_verify_basis(const TabView &t, int *flag, hipStream_t s)
@@ -2926,8 +3088,6 @@ void launch_la_block(const TabView &t, int ksteps, int is_max, double f, unsigne
                        g_la_max_spins, one_xcd, g_la_fault);
 }
 
-static int g_sweep_tr = 0, g_sweep_nt = -1;                     // 0 / -1: by size
-static int g_sweep_impl = 0;                                    // 0: k_sweep16 for full blocks, 1: k_sweep always
 static int g_sweep_u = 4;                                       // rows per step of k_sweep16: 4, or 8 (measured
                                                                 // slower: 199 VGPRs, 2 waves per SIMD, 125 vs 103 us)
 void set_sweep_shape(int tr, int nt) { g_sweep_tr = tr >= 4 ? tr / 4 * 4 : 0; g_sweep_nt = nt; }

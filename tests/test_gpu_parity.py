@@ -696,7 +696,8 @@ def test_async_enqueue_matches_blocking_solve():
 
 
 # =========================================================================== batches (config 4)
-@pytest.fixture(params=[2, 1], ids=["one-workgroup-per-LP", "lockstep-launch-pairs"])
+@pytest.fixture(params=[3, 2, 1], ids=["lookahead-per-LP+sweep-over-all-LPs", "one-workgroup-per-LP",
+                                        "lockstep-launch-pairs"])
 def batch_mode(request):
     L = lp.capi.lib()
     L.mi355x_tune_set_batch_mode(request.param)
