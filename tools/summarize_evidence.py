@@ -1,7 +1,7 @@
 """Copy the judged summaries from gpurun_out/evidence/ (scratch) into profiles/ and derive the
-corrected per-launch HBM traffic of the tableau-update kernel (k_sweep / k_update) from the two PMC passes.
+corrected per-launch HBM traffic of every profiled kernel from the two PMC passes.
 
-    python tools/summarize_evidence.py r01
+    python tools/summarize_evidence.py r02
 
 FETCH_SIZE / WRITE_SIZE are KiB.  On gfx950 FETCH_SIZE reports half of the bytes of a wide
 coalesced read (MI355X_MICROARCH.md, HBM section): the factor is re-measured here on the
@@ -18,59 +18,86 @@ EV = os.path.join(ROOT, "gpurun_out", "evidence")
 PR = os.path.join(ROOT, "profiles")
 
 
-def one(pattern):
+def one(pattern, required=True):
     g = glob.glob(os.path.join(EV, pattern))
     if not g:
-        raise SystemExit("missing " + pattern)
+        if required:
+            raise SystemExit("missing " + pattern)
+        return None
     return max(g, key=os.path.getmtime)       # gpurun merges runs: take the newest
 
 
 def counter(path, kernel_sub):
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if kernel_sub in r["Kernel_Name"]]
-    return v
+    return [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if kernel_sub in r["Kernel_Name"]]
+
+
+def last_json(path):
+    with open(path) as f:
+        return [l for l in f.read().splitlines() if l.startswith("{")][-1]
 
 
 def main(tag):
     os.makedirs(PR, exist_ok=True)
-    shutil.copy(one("kernel_stats/*/*kernel_stats.csv"), os.path.join(PR, tag + "_cfg3_kernel_stats.csv"))
-    fpath = os.path.join(PR, tag + "_cfg3_pmc_FETCH_SIZE.csv")
-    wpath = os.path.join(PR, tag + "_cfg3_pmc_WRITE_SIZE.csv")
-    shutil.copy(one("pmc_FETCH_SIZE/*/*counter_collection.csv"), fpath)
-    shutil.copy(one("pmc_WRITE_SIZE/*/*counter_collection.csv"), wpath)
-    with open(one("bench.log")) as f:
-        bench = [l for l in f.read().splitlines() if l.startswith("{")][-1]
-    open(os.path.join(PR, tag + "_bench_cfg3.json"), "w").write(bench + "\n")
-    layout = {}
-    for l in open(one("pmc_FETCH_SIZE.log")):
-        if l.startswith("layout"):
-            layout = dict(kv.split("=") for kv in l.split()[1:])
-    rows, cols, ld = int(layout["rows"]), int(layout["stored_cols"]), int(layout["stored_ld"])
-    kernel = json.loads(bench)["roofline"]["kernel"]          # k_sweep (blocked) or k_update
-    f = counter(fpath, kernel)
-    w = counter(wpath, kernel)
-    cf, cw = max(counter(fpath, "copyBuffer")), max(counter(wpath, "copyBuffer"))
+    for src, dst in (("kernel_stats/*/*kernel_stats.csv", "_cfg3_kernel_stats.csv"),
+                     ("kernel_stats_cfg4/*/*kernel_stats.csv", "_cfg4_kernel_stats.csv"),
+                     ("kernel_stats_perpivot/*/*kernel_stats.csv", "_perpivot_cfg3_kernel_stats.csv"),
+                     ("pmc_SQ/*/*counter_collection.csv", "_cfg3_pmc_SQ.csv")):
+        f = one(src, required=False)
+        if f:
+            shutil.copy(f, os.path.join(PR, tag + dst))
+    for log, dst in (("bench.log", "_bench_cfg3.json"), ("bench_driver_flags.log", "_bench_cfg3_driver_flags.json"),
+                     ("bench_cfg4.log", "_bench_cfg4_128lps.json"), ("bench_cfg4_1024.log", "_bench_cfg4_1024lps.json"),
+                     ("bench_cfg2.log", "_bench_cfg2.json"), ("bench_colpart_1gpu.log", "_bench_cfg5_colpart_1gpu.json")):
+        f = one(log, required=False)
+        if f:
+            try:
+                open(os.path.join(PR, tag + dst), "w").write(last_json(f) + "\n")
+            except IndexError:
+                print("no JSON line in", log)
+    out = {"workload": "cfg3", "kernels": {}}
     dense_ld = (8192 + 4096 + 1 + 15) // 16 * 16
-    copy_kib = rows * dense_ld * 8 / 1024.0           # mi355x_tab_copy copies the DENSE padded buffer
-    favg, wavg = sum(f) / len(f), sum(w) / len(w)
-    traffic = (2 * favg + wavg) * 1024
-    alg = 2 * rows * cols * 8
-    d = {"workload": "cfg3", "kernel": kernel, "launches": len(f),
-         "pivots_per_launch": json.loads(bench)["roofline"].get("pivots_per_launch", 1),
-         "representation": "compact" if int(layout["compact"]) else "dense",
-         "stored_rows_cols_ld": [rows, cols, ld],
-         "FETCH_SIZE_KiB_avg": favg, "WRITE_SIZE_KiB_avg": wavg,
-         "calibration": {"what": "__amd_rocclr_copyBuffer (mi355x_tab_copy) of the dense padded "
-                                 "tableau: reads and writes rows*ld*8 bytes",
-                         "KiB_each_way": copy_kib, "FETCH_SIZE_reported_KiB": cf,
-                         "WRITE_SIZE_reported_KiB": cw, "fetch_factor_measured": copy_kib / cf,
-                         "write_factor_measured": copy_kib / cw,
-                         "correction_applied": "FETCH x2 (gfx950), WRITE x1"},
-         "hbm_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": alg,
-         "traffic_over_algorithmic": traffic / alg}
-    json.dump(d, open(os.path.join(PR, tag + "_cfg3_pmc_traffic.json"), "w"), indent=1)
-    print(json.dumps(d, indent=1))
-    print(open(os.path.join(PR, tag + "_cfg3_kernel_stats.csv")).read()[:1500])
+    for variant, kernels in (("", ("k_sweep16", "k_la_block")), ("perpivot_", ("k_update", "k_select_gather", "k_select_scale"))):
+        fp = one("pmc_%sFETCH_SIZE/*/*counter_collection.csv" % variant, required=False)
+        wp = one("pmc_%sWRITE_SIZE/*/*counter_collection.csv" % variant, required=False)
+        lg = one("pmc_%sFETCH_SIZE.log" % variant, required=False)
+        if not (fp and wp and lg):
+            continue
+        shutil.copy(fp, os.path.join(PR, "%s_%scfg3_pmc_FETCH_SIZE.csv" % (tag, variant)))
+        shutil.copy(wp, os.path.join(PR, "%s_%scfg3_pmc_WRITE_SIZE.csv" % (tag, variant)))
+        layout = {}
+        for l in open(lg):
+            if l.startswith("layout"):
+                layout = dict(kv.split("=") for kv in l.split()[1:])
+        rows, cols, ld = int(layout["rows"]), int(layout["stored_cols"]), int(layout["stored_ld"])
+        cf, cw = max(counter(fp, "copyBuffer")), max(counter(wp, "copyBuffer"))
+        copy_kib = rows * dense_ld * 8 / 1024.0           # mi355x_tab_copy copies the DENSE padded buffer
+        out["calibration"] = {"what": "__amd_rocclr_copyBuffer (mi355x_tab_copy) of the dense padded tableau: reads "
+                                      "and writes rows*ld*8 bytes", "KiB_each_way": copy_kib,
+                              "FETCH_SIZE_reported_KiB": cf, "WRITE_SIZE_reported_KiB": cw,
+                              "fetch_factor_measured": copy_kib / cf, "write_factor_measured": copy_kib / cw,
+                              "correction_applied": "FETCH x2 (gfx950), WRITE x1"}
+        for k in kernels:
+            f, w = counter(fp, k), counter(wp, k)
+            if not f or not w:
+                continue
+            if k in ("k_sweep16", "k_update"):           # steady state: drop launches that did nothing
+                f = [x for x in f if x > 0.5 * max(f)]
+                w = [x for x in w if x > 0.5 * max(w)]
+            favg, wavg = sum(f) / len(f), sum(w) / len(w)
+            rec = {"launches": len(f), "FETCH_SIZE_KiB_avg": favg, "WRITE_SIZE_KiB_avg": wavg,
+                   "hbm_bytes_per_launch": (2 * favg + wavg) * 1024,
+                   "representation": "compact" if int(layout["compact"]) else "dense",
+                   "stored_rows_cols_ld": [rows, cols, ld]}
+            if k in ("k_sweep16", "k_update"):
+                rec["algorithmic_bytes_per_launch"] = 2 * rows * cols * 8
+                rec["traffic_over_algorithmic"] = rec["hbm_bytes_per_launch"] / rec["algorithmic_bytes_per_launch"]
+            out["kernels"][k] = rec
+    json.dump(out, open(os.path.join(PR, tag + "_cfg3_pmc_traffic.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+    for f in sorted(glob.glob(os.path.join(PR, tag + "*kernel_stats.csv"))):
+        print(f)
+        print(open(f).read()[:900])
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r02")
