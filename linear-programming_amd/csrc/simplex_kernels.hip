@@ -1276,6 +1276,10 @@ __device__ __forceinline__ Cand wave_argmin(Cand x, int &src)
 // PRICE: granules v v i s u u w w   (s = slot: 32 bits)      RATIO: v v i|flag s s u u -
 // false: a record did not arrive within max_spins polls.
 constexpr int kLaWaves = kLaThreads / 64;
+// true: every wave collects the records itself (no LDS hop, no workgroup barrier left in the
+// kernel; four times the poll traffic on the one L2) -- measured 149 us per block of 16 at config 3
+// against 122 us for false: the first wave of a workgroup collects and broadcasts through LDS
+constexpr bool kLaEveryWavePolls = false;
 
 template <bool PRICE>
 __device__ __forceinline__ void decode_rec(const unsigned long long (&g)[8], bool valid, Cand &x, int64_t &xs,
@@ -1327,7 +1331,7 @@ __device__ __forceinline__ bool la_exchange(ValIdx mine, unsigned myflag, ExchRe
 #ifdef MI355X_LA_TIMING
     if (ts) ts[0] = wall_clock64();
 #endif
-    if (tid < 64) {
+    if (kLaEveryWavePolls || tid < 64) {
         // ---- collect: lane l <- records l and l + 64
         const bool v0 = lane < nrec, v1 = lane + 64 < nrec;
         const ExchRec *r0 = recs + (v0 ? lane : 0), *r1 = recs + (v1 ? lane + 64 : 0);
@@ -1371,16 +1375,21 @@ __device__ __forceinline__ bool la_exchange(ValIdx mine, unsigned myflag, ExchRe
         // do all records carry the same first double?  (the XCC ids of the first exchange)
         const unsigned long long ref = dbits(lane_value(u0, 0));
         const unsigned same = __all(((dbits(u0) == ref) || !v0) && ((dbits(u1) == ref) || !v1)) ? 1u : 0u;
-        if (lane == 0) {
+        if (kLaEveryWavePolls) {                                 // every wave has the result in registers
+            out.c.v = x.v; out.c.i = x.i; out.c.s = bs;
+            out.flag = fine ? fl : 2u; out.same = same; out.u = bu; out.w = bw;
+        } else if (lane == 0) {
             s_res->c.v = x.v; s_res->c.i = x.i; s_res->c.s = bs;
             s_res->flag = fine ? fl : 2u; s_res->same = same; s_res->u = bu; s_res->w = bw;
         }
     }
-    __syncthreads();
+    if (!kLaEveryWavePolls) {
+        __syncthreads();
+        out = *s_res;
+    }
 #ifdef MI355X_LA_TIMING
     if (ts) ts[2] = wall_clock64();
 #endif
-    out = *s_res;
     return out.flag != 2u;
 }
 
