@@ -1452,6 +1452,7 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
     int64_t l0 = (has_pair && 2 * p < vc) ? t.p2l[2 * p] : -1;   // logical columns of my pair
     int64_t l1 = (has_pair && 2 * p + 1 < vc) ? t.p2l[2 * p + 1] : -1;
     int64_t v_cr = -1, v_sl = -1;                                // lane i: pivot row / slot of pivot i
+    unsigned wave_rm = 0u, wave_sm = 0u;                         // bit i: SOME lane of my wave is on pivot row i / holds slot i
     double2 pr = make_double2(0.0, 0.0);                         // my pair of the last normalised pivot row
     bool local = false;                                          // all workgroups on one XCD (verified)
     const double my_xcc = (double)xcc_id();
@@ -1506,7 +1507,7 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
         {
             // pending pivots whose given-up slot is the entering column's slot (uniform); lanes on a pending pivot row
             const unsigned slmask = (unsigned)__ballot((lane < J) & (v_sl == slot));
-            const bool bare = slmask == 0u && !__any(my_rm != 0u);
+            const unsigned gen = slmask | wave_rm;                         // links that need the general form
 #pragma unroll
             for (int i0 = 0; i0 < KMAX; i0 += 4) {
                 if (i0 < J) {
@@ -1517,16 +1518,15 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
                         pa[k] = lane_value(v_pa, i0 + k);
                         prod[k] = ci * pa[k];                          // rounded product
                     }
-                    if (bare) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) a = a - prod[k];   // rounded difference
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < 4; ++k) {
+                        if ((gen >> (i0 + k)) & 1u) {                  // (uniform; rare)
                             const bool is_cr = (my_rm >> (i0 + k)) & 1u;
                             if ((slmask >> (i0 + k)) & 1u) a = is_cr ? 1.0 : 0.0;
                             const double d = a - prod[k];
                             a = is_cr ? pa[k] : d;
+                        } else {
+                            a = a - prod[k];                           // rounded difference
                         }
                     }
                 }
@@ -1574,7 +1574,7 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
         {
             // pending pivots whose pivot row is the new pivot row (uniform); lanes holding a given-up slot
             const unsigned crmask = (unsigned)__ballot((lane < J) & (v_cr == cr));
-            const bool bare = crmask == 0u && !__any(my_sm != 0u);
+            const unsigned gen = crmask | wave_sm;                         // links that need the general form
 #pragma unroll
             for (int i0 = 0; i0 < KMAX; i0 += 4) {
                 if (i0 < J) {
@@ -1586,18 +1586,18 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
                         prod[k].x = ccr * pii[k].x;                    // rounded products
                         prod[k].y = ccr * pii[k].y;
                     }
-                    if (bare) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) { y.x = y.x - prod[k].x; y.y = y.y - prod[k].y; }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const bool is_cr = (crmask >> (i0 + k)) & 1u;          // uniform
+                    for (int k = 0; k < 4; ++k) {
+                        if ((gen >> (i0 + k)) & 1u) {                  // (uniform; rare)
+                            const bool is_cr = (crmask >> (i0 + k)) & 1u;
                             if ((my_sm >> (i0 + k)) & 1u)      y.x = is_cr ? 1.0 : 0.0;
                             if ((my_sm >> (16 + i0 + k)) & 1u) y.y = is_cr ? 1.0 : 0.0;
                             const double dx = y.x - prod[k].x, dy = y.y - prod[k].y;
                             y.x = is_cr ? pii[k].x : dx;
                             y.y = is_cr ? pii[k].y : dy;
+                        } else {
+                            y.x = y.x - prod[k].x;
+                            y.y = y.y - prod[k].y;
                         }
                     }
                 }
@@ -1625,6 +1625,8 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
             my_rm |= 1u << J;
             t.bk_rmask[r] = my_rm;
         }
+        if (__any(has_row && r == cr)) wave_rm |= 1u << J;
+        if (__any(own))                wave_sm |= 1u << J;
         if (leader) {                                            // the one writer of these words
             const int64_t tn = c0.trace_n + J;
             ctl->ec = ec;
