@@ -1301,7 +1301,7 @@ template <bool PRICE, class Extra>
 __device__ __forceinline__ bool la_exchange(ValIdx mine, unsigned myflag, ExchRec *recs, int nw, int w,
                                             unsigned tag, unsigned max_spins, bool mute, bool local,
                                             int rec_from, LaMsg *s_res, LaMsg &out, Extra extra,
-                                            unsigned long long *ts)
+                                            unsigned long long *ts, double *dbg = nullptr)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nrec = nw * kLaWaves;
@@ -1327,6 +1327,9 @@ __device__ __forceinline__ bool la_exchange(ValIdx mine, unsigned myflag, ExchRe
             for (int k = 1; k < 8; ++k) val = lane == k ? word[k] : val;
             if (lane < 8) st_x(&recs[w * kLaWaves + wave].g[lane], ((unsigned long long)tag << 32) | val, local);
         }
+#ifdef MI355X_LA_TIMING
+        if (dbg && lane == 0) dbg[w * kLaWaves + wave] = (double)wall_clock64();   // when this wave published
+#endif
     }
 #ifdef MI355X_LA_TIMING
     if (ts) ts[0] = wall_clock64();
@@ -1466,8 +1469,11 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
     for (int J = 0; J < ksteps; ++J) {
         const unsigned e_price = epoch_base + 2 * J + 1, e_ratio = epoch_base + 2 * J + 2;
         const bool mute = fault > 0 && J >= fault - 1 && w == nw - 1;
+        double *dbg_p = nullptr, *dbg_r = nullptr;
 #ifdef MI355X_LA_TIMING
         unsigned long long T0 = wall_clock64(), T2, T3, T5, T6;
+        dbg_p = t.rhs + 512 + (2 * J) * 72;                      // publish times of the last block, per record
+        dbg_r = t.rhs + 512 + (2 * J + 1) * 72;
 #endif
         // ---- pricing: my pair's candidates -> wave winner -> record -> everybody's winner.
         // The record also carries the winner's entry of prow_{J-1} and (from its owner) the RHS
@@ -1481,7 +1487,7 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
                     if (J == 0) { u = my_xcc; return; }
                     u = lane_pick((c.s & 1) ? pr.y : pr.x, src);            // prow_{J-1}[winner's slot]
                     if (wave_has_vc) x2 = lane_value_dyn((vc & 1) ? pr.y : pr.x, g_vc & 63);
-                }, ts_p)) {
+                }, ts_p, dbg_p)) {
             if (tid == 0) st_wt(&ctl->status, kSyncLost);        // same word, same value from everyone
             return;
         }
@@ -1547,7 +1553,7 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
         LaMsg qq;
         if (!la_exchange<false>(q, bad, t.la_rx, nw, w, e_ratio, max_spins, mute, local, rec_m, &s_res, qq,
                 [&](const ValIdx &, int, double &u, double &) { if (wave_has_m) u = lane_value_dyn(a, g_m & 63); },
-                ts_r)) {
+                ts_r, dbg_r)) {
             if (tid == 0) st_wt(&ctl->status, kSyncLost);
             return;
         }
@@ -1640,7 +1646,7 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
             blk->n_pending = J + 1;
         }
         if (lane == J) { v_cr = cr; v_sl = slot; }
-#ifdef MI355X_LA_TIMING
+#if defined(MI355X_LA_TIMING) && MI355X_LA_TIMING != 2       // (2: publish stamps only, the leader is not slowed down)
         T6 = wall_clock64();
         if (leader) {
             double *d = t.rhs + J * 24;

@@ -35,6 +35,11 @@ int main(void)
         rc = mi355x_tab_create(&t, rows, cols, M, basis, 0);
         if (rc != MI_NO_DEVICE || t != NULL) return 10;
         if (mi355x_simplex_solver(p, 1024.0, 0, &s) != MI_NO_DEVICE || s != NULL) return 11;
+        {   /* the multi-device entry points fail the same way (and never touch RCCL) */
+            mi355x_colpart *cp = NULL;
+            if (mi355x_colpart_create(&cp, rows, cols, M, basis, 8) != MI_NO_DEVICE || cp != NULL) return 14;
+            if (mi355x_colpart_solve(NULL, 1, 1024.0, 0, NULL) != MI_BAD_ARG) return 15;
+        }
         printf("no device: %s\n", mi355x_last_error());
     } else {
         mi355x_solution *s = NULL;
@@ -44,6 +49,17 @@ int main(void)
         mi355x_solution_variable(s, 0, &x);
         if (w != 28.5 || x != 0.5) return 13;                                                /* README.md:58-62 */
         mi355x_solution_destroy(s);
+        {   /* the same tableau column-partitioned over 2 shards (logical shards on one GPU),
+             * what the Lisp glue does for :devices 2 -- t/simplex.lisp:170-194: objective 57/2 */
+            mi355x_colpart *cp = NULL;
+            double last_col[3];
+            int64_t b2[2], np = 0;
+            if (mi355x_colpart_create(&cp, rows, cols, M, basis, 2) != MI_OK) return 16;
+            if (mi355x_colpart_solve(cp, 1, 1024.0, 0, &np) != MI_OPTIMAL || np != 2) return 17;
+            if (mi355x_colpart_download(cp, NULL, b2, NULL, last_col) != MI_OK) return 18;
+            if (last_col[2] != 28.5 || b2[0] != 0 || b2[1] != 1) return 19;
+            mi355x_colpart_destroy(cp);
+        }
         printf("solved on the GPU: w = %g, x = %g\n", w, x);
     }
     mi355x_problem_destroy(p);

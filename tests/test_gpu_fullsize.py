@@ -340,3 +340,18 @@ def test_colpart_c_abi_over_rccl_single_rank(monkeypatch):
     G, bg, _, _ = tab.download()
     assert np.array_equal(G.view(np.int64), M.view(np.int64)) and np.array_equal(bg, b)
     tab.close()
+
+
+def test_plain_c_client_on_the_gpu(tmp_path):
+    """tests/c_abi_check.c with a device present: the native solver and the column-partitioned
+    entry points (2 logical shards) from a plain C program, the way a non-Python host binds them."""
+    import os
+    import subprocess
+    from tests.helpers import ROOT
+    exe = str(tmp_path / "c_abi_check")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_abi_check.c"), "-o", exe,
+                           "-L", os.path.dirname(lp.capi.LIB_PATH), "-lmi355x_simplex",
+                           "-Wl,-rpath," + os.path.dirname(lp.capi.LIB_PATH)])
+    out = subprocess.check_output([exe], text=True)
+    assert "solved on the GPU: w = 28.5, x = 0.5" in out and "c abi ok" in out
