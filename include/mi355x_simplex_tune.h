@@ -36,6 +36,8 @@ int         mi355x_tune_set_lookahead_mode(int mode);        /* 0 auto, 1 two la
 int         mi355x_tune_set_sweep_shape(int rows_per_workgroup, int nontemporal /* -1 by size */);
 int         mi355x_tune_set_sweep_impl(int impl);            /* 0 k_sweep16 for full blocks, 1 k_sweep
                                                                 always; 4 / 8: rows per step of k_sweep16 */
+int         mi355x_tune_set_shard_la_split(int mode);        /* column shards, local look-ahead step:
+                                                                0 by size, 1 one workgroup, 2 many */
 int         mi355x_tune_set_handover_mode(int mode);         /* 0 auto, 1 sequential re-elimination */
 int         mi355x_tune_set_batch_mode(int mode);            /* 0 auto, 1 lockstep, 2 all in one workgroup
                                                                 per LP, 3 look-ahead per LP + sweeps over all LPs */

@@ -97,6 +97,7 @@ SIGNATURES = {
 # tuning / measurement / test hooks: include/mi355x_simplex_tune.h (not the drop-in boundary)
 _EXTRA = {
     "mi355x_tune_set_sweep_impl": (_int, [_int]),
+    "mi355x_tune_set_shard_la_split": (_int, [_int]),
     "mi355x_tune_set_la_one_xcd": (_int, [_int]),
     "mi355x_tune_set_la_max_spins": (_int, [ctypes.c_uint]),
     "mi355x_tune_set_la_fault": (_int, [_int]),

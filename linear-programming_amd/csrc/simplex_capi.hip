@@ -1991,6 +1991,7 @@ int         mi355x_tune_set_block(int k) { g_block_k = k < 1 ? 1 : (k > kMaxBloc
 int         mi355x_tune_set_sweep_shape(int tr, int nt) { set_sweep_shape(tr, nt); return tr; }
 int         mi355x_tune_set_compact(int on) { g_compact_enabled = on ? 1 : 0; return g_compact_enabled; }
 int         mi355x_tune_set_sweep_impl(int impl) { set_sweep_impl(impl); return impl; }
+int         mi355x_tune_set_shard_la_split(int mode) { set_shard_la_split(mode); return mode; }
 // persistent look-ahead: all workgroups on one XCD (1, default) or spread (0); polls before a
 // workgroup gives up on a record (0 = default 2^21); test hook: the last workgroup stops
 // publishing from step `step_plus_1 - 1` of every block on (0 = off)

@@ -148,6 +148,7 @@ void launch_shard_la_contribute(const TabView &t, int j, const double *gathered,
                                 int64_t *ec_out, hipStream_t s);
 int  launch_shard_la_prepare(const TabView &t, int j, const double *col, const int64_t *ec_dev,
                              double fp_factor, int is_max, hipStream_t s);
+void set_shard_la_split(int mode);         // tuning / test hook: 0 by size, 1 one workgroup, 2 split over many
 // two-phase hand-over (src/simplex.lisp:437-451)
 // unit_basis: the basic columns of `art` are known to be exact unit vectors (column-parallel
 // re-elimination); otherwise the sequential form

@@ -1077,6 +1077,151 @@ __global__ __launch_bounds__(kSelThreads) void k_shard_la_prepare(TabView t, int
     }
 }
 
+// ---- the same local step spread over many workgroups (large shards) -----------------------------
+// k_shard_la_prepare is ONE workgroup: fine for a shard of a few thousand rows / column pairs, a
+// hundred microseconds for a shard that holds tens of thousands (config 5 on few GPUs).  The split
+// form is the k_la_gather / k_la_scale pair of the single-tableau path with the shard's inputs:
+//   k_shard_la_ratio     the exchanged column is col_J: store it, ratio-test it against the
+//                        shard's RHS copy (brought up to date by k_shard_la_contribute), one
+//                        partial per workgroup;
+//   k_shard_la_scale<J>  every workgroup reduces the partials to the same pivot row, chains its
+//                        slice of that row and of the objective row through the J pending pivots
+//                        (J a template parameter: all operands requested up front), prow_J, the
+//                        objective row through pivot J priced on the way out (per-wave partials).
+__global__ __launch_bounds__(kGatherThreads) void k_shard_la_ratio(TabView t, int j, const double *col_src,
+                                                                   const int64_t *ec_dev, double ratio_thr)
+{
+    __shared__ double    s_v[kGatherThreads / 64];
+    __shared__ long long s_i[kGatherThreads / 64];
+    double  *rp_v = t.part_v + t.part_cap / 2;      // ratio partials: upper half of the buffers
+    int64_t *rp_i = t.part_i + t.part_cap / 2;
+    int64_t *rp_s = t.part_s + t.part_cap / 2;
+    Ctl *ctl = t.ctl;
+    const Ctl c0 = *ctl;
+    const int64_t m = t.rows - 1;
+    const int64_t r = (int64_t)blockIdx.x * kGatherThreads + threadIdx.x;
+    const bool live = c0.status == kRunning && *ec_dev >= 0 &&
+                      !(c0.max_pivots > 0 && c0.n_pivots >= c0.max_pivots);
+    ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
+    if (live && r < t.rows) {
+        const double a = col_src[r];
+        const double b = r < m ? t.rhs[r] : 0.0;
+        t.bk_col[(int64_t)j * t.bk_stride + r] = a;
+        if (t.p2l && !(fabs(a) <= 1.7976931348623157e308)) atomicOr(&ctl->poison, 1);   // compact shard: MI_NONFINITE
+        if (r < m && ratio_thr < a) { best.v = b / a; best.i = r; best.s = __double_as_longlong(a); }
+    }
+    best = block_reduce_min<kGatherThreads>(best, s_v, s_i);
+    if (threadIdx.x == 0) { rp_v[blockIdx.x] = best.v; rp_i[blockIdx.x] = best.i; rp_s[blockIdx.x] = best.s; }
+}
+
+template <int J>
+__global__ __launch_bounds__(kScaleThreads) void k_shard_la_scale(TabView t, int n_rp, const int64_t *ec_dev,
+                                                                 double sgn)
+{
+    __shared__ double    s_v[kScaleThreads / 64];
+    __shared__ long long s_i[kScaleThreads / 64];
+    constexpr int JJ = J > 0 ? J : 1;
+    const double  *rp_v = t.part_v + t.part_cap / 2;
+    const int64_t *rp_i = t.part_i + t.part_cap / 2;
+    const int64_t *rp_s = t.part_s + t.part_cap / 2;
+    Ctl *ctl = t.ctl;
+    const Ctl c0 = *ctl;
+    BlockCtl *blk = t.blk;
+    const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+    const int64_t m = t.rows - 1, vcl = t.cols - 1, ldv = t.ld >> 1;
+    const int64_t p = (int64_t)blockIdx.x * kScaleThreads + threadIdx.x;
+    const bool in = p < ldv;
+    const double2 *M2 = reinterpret_cast<const double2 *>(t.M);
+    double2 *P2 = reinterpret_cast<double2 *>(t.bk_prow);
+    // independent of the pivot row: the objective row, the pending pivots' rows / slots / prow
+    // entries / objective-row col entries, this step's objective-row col entry, the column map
+    double2 z = in ? M2[m * ldv + p] : make_double2(0.0, 0.0);
+    double2 pi[JJ];
+    const int lane = threadIdx.x & 63;
+    const bool  lj = lane < J;
+    const double  v_cm = lj ? t.bk_col[(int64_t)lane * t.bk_stride + m] : 0.0;
+    const int64_t v_cr = lj ? blk->cr[lane] : -1;
+    const int64_t v_sl = lj ? blk->slot[lane] : -1;
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+        pi[i] = in ? P2[(int64_t)i * ldv + p] : make_double2(0.0, 0.0);
+    const int64_t global_ec = *ec_dev;
+    const int64_t c0i = 2 * p;
+    const int64_t l0 = (in && c0i < vcl) ? (t.p2l ? t.p2l[c0i] : c0i) : -1;
+    const int64_t l1 = (in && c0i + 1 < vcl) ? (t.p2l ? t.p2l[c0i + 1] : c0i + 1) : -1;
+    const int64_t slot = (t.p2l && global_ec >= 0) ? t.l2p[global_ec] : -1;   // compact owner: the slot the leaving column takes
+    const ValIdx q = block_price_partials<kScaleThreads>(rp_v, rp_i, rp_s, n_rp, s_v, s_i);
+    if (c0.status != kRunning) return;
+    if (global_ec < 0) {
+        if (leader) ctl->status = 0;                // MI_OPTIMAL
+        return;
+    }
+    if (c0.max_pivots > 0 && c0.n_pivots >= c0.max_pivots) {
+        if (leader) ctl->status = 3;                // MI_MAX_PIVOTS
+        return;
+    }
+    if (c0.poison) {
+        if (leader) ctl->status = 6;                // MI_NONFINITE (compact shard)
+        return;
+    }
+    if (q.i < 0) {
+        if (leader) ctl->status = 1;                // MI_UNBOUNDED
+        return;
+    }
+    const int64_t cr = uniform64(q.i);
+    const double piv = __longlong_as_double(q.s);   // == col_J[cr], carried by the winner
+    const double cmj = t.bk_col[(int64_t)J * t.bk_stride + m];
+    ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
+    const double v_ccr = lj ? t.bk_col[(int64_t)lane * t.bk_stride + cr] : 0.0;
+    double2 y = in ? M2[cr * ldv + p] : make_double2(0.0, 0.0);   // row cr
+#pragma unroll
+    for (int i = 0; i < J; ++i) {                   // (all lanes: v_readlane ignores exec)
+        const bool    is_cr = cr == lane_value(v_cr, i);
+        const int64_t sl = lane_value(v_sl, i);
+        const double  ccr = lane_value(v_ccr, i), cm = lane_value(v_cm, i);
+        y.x = pend(y.x, 2 * p     == sl, is_cr, ccr, pi[i].x);
+        y.y = pend(y.y, 2 * p + 1 == sl, is_cr, ccr, pi[i].y);
+        z.x = pend(z.x, 2 * p     == sl, false, cm, pi[i].x);
+        z.y = pend(z.y, 2 * p + 1 == sl, false, cm, pi[i].y);
+    }
+    if (in) {
+        const bool own = slot >= 0 && (p == (slot >> 1));
+        const int64_t leaving = own ? t.basis[cr] : -1;
+        const double2 pr = scale_pair(t, p, y, piv, slot);
+        P2[(int64_t)J * ldv + p] = pr;
+        z.x = pend(z.x, 2 * p     == slot, false, cmj, pr.x);
+        z.y = pend(z.y, 2 * p + 1 == slot, false, cmj, pr.y);
+        if (c0i < vcl) {
+            ValIdx c; c.v = z.x * sgn; c.i = (c0i == slot) ? leaving : l0; c.s = c0i;
+            best = vi_min(best, c);
+        }
+        if (c0i + 1 < vcl) {
+            ValIdx c; c.v = z.y * sgn; c.i = (c0i + 1 == slot) ? leaving : l1; c.s = c0i + 1;
+            best = vi_min(best, c);
+        }
+        // bookkeeping: the owner of the slot where there is one (it alone reads basis[cr] before
+        // it changes), the leader otherwise -- one writer either way
+        if (slot >= 0 ? own : leader) {
+            if (own) {
+                swap_columns(t, global_ec, cr, slot);
+                t.bk_smask[slot >> 1] |= 1u << (J + 16 * (int)(slot & 1));
+            }
+            record_pivot(t, c0, global_ec, cr);      // basis holds GLOBAL column indices
+            blk->cr[J] = cr;
+            blk->slot[J] = slot;
+            blk->n_pending = J + 1;
+            t.bk_rmask[cr] |= 1u << J;
+        }
+    }
+    best = wave_reduce_min(best);
+    if ((threadIdx.x & 63) == 0) {
+        const int w = blockIdx.x * (kScaleThreads / 64) + (threadIdx.x >> 6);
+        t.part_v[w] = best.v;
+        t.part_i[w] = best.i;
+        t.part_s[w] = best.s;
+    }
+}
+
 // ---- the look-ahead of a whole block as ONE launch ------------------------------------------
 // Two launches per look-ahead step are two kernel boundaries (2.5 us each) plus cold caches at
 // every start.  For tableaux whose rows and column pairs fit a few workgroups (config 3: 17 x 256
@@ -2809,12 +2954,38 @@ void launch_shard_la_contribute(const TabView &t, int j, const double *gathered,
     hipLaunchKernelGGL(k_shard_la_contribute, dim3(blocks), dim3(kSelThreads), 0, s, t, j, gathered,
                        n_shards, col_offset, (f / 8.0) * kClEpsilon, (long long *)bits_out, ec_out);
 }
+static int g_shard_la_split = 0;                     // 0 by size, 1 always one workgroup, 2 always split
+void set_shard_la_split(int mode) { g_shard_la_split = mode; }
+
+template <int J>
+static void launch_shard_la_scale_t(const TabView &t, int g2, int g1, const int64_t *ec_dev, int is_max, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_shard_la_scale<J>, dim3(g2), dim3(kScaleThreads), 0, s, t, g1, ec_dev, sgn_of(is_max));
+}
+
 int launch_shard_la_prepare(const TabView &t, int j, const double *col, const int64_t *ec_dev, double f,
                             int is_max, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_shard_la_prepare, dim3(1), dim3(kSelThreads), 0, s, t, j, col, ec_dev,
-                       0.0 + (f / 2.0) * kClEpsilon, sgn_of(is_max));
-    return kSelWaves;                                // pricing partials left for the next step
+    // one workgroup for small shards (one launch, ~10 us), the split pair for large ones (rows or
+    // column pairs in the tens of thousands: config 5 on one GPU 1 536 -> see DESIGN.md pivots/s)
+    const int g1 = (int)((t.rows + kGatherThreads - 1) / kGatherThreads);
+    const int g2 = (int)(((t.ld >> 1) + kScaleThreads - 1) / kScaleThreads);
+    const bool fits = g1 <= t.part_cap / 2 && g2 * (kScaleThreads / 64) <= t.part_cap / 2;
+    const bool split = fits && (g_shard_la_split == 2 || (g_shard_la_split == 0 && (t.rows > 4096 || t.ld > 8192)));
+    if (!split) {
+        hipLaunchKernelGGL(k_shard_la_prepare, dim3(1), dim3(kSelThreads), 0, s, t, j, col, ec_dev,
+                           0.0 + (f / 2.0) * kClEpsilon, sgn_of(is_max));
+        return kSelWaves;                            // pricing partials left for the next step
+    }
+    hipLaunchKernelGGL(k_shard_la_ratio, dim3(g1), dim3(kGatherThreads), 0, s, t, j, col, ec_dev,
+                       0.0 + (f / 2.0) * kClEpsilon);
+    switch (j) {
+#define MI_SLA(J) case J: launch_shard_la_scale_t<J>(t, g2, g1, ec_dev, is_max, s); break;
+        MI_SLA(0) MI_SLA(1) MI_SLA(2) MI_SLA(3) MI_SLA(4) MI_SLA(5) MI_SLA(6) MI_SLA(7)
+        MI_SLA(8) MI_SLA(9) MI_SLA(10) MI_SLA(11) MI_SLA(12) MI_SLA(13) MI_SLA(14) MI_SLA(15)
+#undef MI_SLA
+    }
+    return g2 * (kScaleThreads / 64);
 }
 void launch_handover(const TabView &art, const TabView &mt, bool unit_basis, hipStream_t s)
 {

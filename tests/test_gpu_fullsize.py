@@ -355,3 +355,30 @@ def test_plain_c_client_on_the_gpu(tmp_path):
                            "-Wl,-rpath," + os.path.dirname(lp.capi.LIB_PATH)])
     out = subprocess.check_output([exe], text=True)
     assert "solved on the GPU: w = 28.5, x = 0.5" in out and "c abi ok" in out
+
+
+@pytest.mark.parametrize("n_shards", [1, 3])
+@pytest.mark.parametrize("dense", [False, True], ids=["compact-shards", "dense-shards"])
+def test_colpart_split_lookahead_step_bitwise(n_shards, dense):
+    """The local look-ahead step of a shard spread over many workgroups (k_shard_la_ratio +
+    k_shard_la_scale<J>: what large shards -- config 5 on few GPUs -- run), forced on at a size
+    the oracle can follow: pivots and bits as the oracle's, compact and dense shards."""
+    import importlib
+    cp = importlib.import_module("linear-programming_amd.colpart")
+    L = lp.capi.lib()
+    n, m = 900, 420
+    M0, b0 = lp.synth.tableau(n, m, lp.synth.seed_for(5, 21))
+    if dense:
+        M0[:m, n:n + m] *= 2.0                                   # basis columns != e_i: every column is distributed
+    M, b = M0.copy(), b0.copy()
+    so, no, trace = oracle.solve(M, b, max_pivots=150, trace_cap=150)
+    try:
+        L.mi355x_tune_set_shard_la_split(2)
+        tab = cp.NativeColumnPartition.from_arrays(M0, b0, n_shards)
+        st, k = tab.solve(max_pivots=150)
+    finally:
+        L.mi355x_tune_set_shard_la_split(0)
+    assert (st, k) == (so, no) and np.array_equal(tab.trace(no), trace)
+    G, bg, _, _ = tab.download()
+    assert np.array_equal(G.view(np.int64), M.view(np.int64)) and np.array_equal(bg, b)
+    tab.close()
