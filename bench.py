@@ -316,16 +316,6 @@ def main():
             dist.destroy_process_group()
         return
 
-    # N > 1 with the default workload: the north star's multi-GPU claim is about ONE large tableau
-    # column-partitioned over the GPUs with the pivot column travelling over RCCL / xGMI -- that
-    # strong-scaling record is the headline; independent LPs (weak scaling, no collective) follow
-    # below and are attached to it as a secondary field.
-    rec_colpart = None
-    if N > 1 and args.workload == "cfg3" and args.multi_gpu == "colpart":
-        from importlib import import_module
-        rec_colpart = import_module("linear-programming_amd.colpart").bench(args, rank, local_rank, N)
-        torch.cuda.empty_cache()
-
     n, m, cfg = WORKLOADS[args.workload]
     R, C = m + 1, n + m + 1
     bytes_per_pivot = 2 * R * C * 8            # dense tableau: every element read once + written once
@@ -416,7 +406,7 @@ def main():
     if not args.no_events:
         upd_n, upd_avg_ms, upd_min_ms = read_events(0)
         la_n, la_avg_ms, la_min_ms = read_events(1)
-        if upd_n < 8 and block > 1 and N == 1:
+        if upd_n < 8 and block > 1:
             # a short run (the driver's 20 steps are ONE full block): more event samples from full
             # blocks run right AFTER the timed region on the same tableau -- kernel statistics
             # only, not part of `value`
@@ -540,15 +530,49 @@ def main():
         if N == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"], state = cpu_baseline(lp, n, m, seed, args.cpu_pivots)
             rec["parity_in_run"] = parity_in_run(lp, L, n, m, seed, local_rank, state)
-        if rec_colpart is not None:
-            rec_colpart["independent_lps_weak_scaling"] = {
-                "what": "every rank iterating on its own 8192 x 4096 LP, no collective (BASELINE config 3 per GPU)",
-                "value": rec["value"], "unit": "pivots/s", "ms_per_step": rec["ms_per_step"],
-                "scaling": "weak", "roofline": rec["roofline"]}
-            rec = rec_colpart
-        print(json.dumps(rec), flush=True)
     for hk in handles:
         L.mi355x_tab_destroy(hk)
+    handles = []
+    torch.cuda.empty_cache()
+
+    # N > 1 with the default workload: the north star's multi-GPU claim is about ONE large tableau
+    # column-partitioned over the GPUs with the pivot column travelling over RCCL / xGMI -- that
+    # strong-scaling record is the headline; the independent LPs above (weak scaling, no
+    # collective) are attached to it as a secondary field.  The leg runs under a watchdog: should
+    # a rank fail or a collective never complete, the weak-scaling record is printed with the
+    # reason instead of no line at all.
+    if N > 1 and args.workload == "cfg3" and args.multi_gpu == "colpart":
+        import threading
+        limit = float(os.environ.get("BENCH_COLPART_TIMEOUT", "420"))
+
+        def give_up():
+            if rank == 0:
+                rec["colpart_error"] = "column-partition leg did not finish within %.0f s" % limit
+                print(json.dumps(rec), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(limit, give_up)
+        dog.daemon = True
+        dog.start()
+        rec_colpart, err = None, None
+        try:
+            rec_colpart = importlib.import_module("linear-programming_amd.colpart").bench(args, rank, local_rank, N)
+        except BaseException as e:           # SystemExit included: a line is owed whatever happens
+            err = "%s: %s" % (type(e).__name__, e)
+        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=red_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)   # the ranks agree (a lone failure parks the others in a collective: watchdog)
+        dog.cancel()
+        if rank == 0:
+            if int(flag.item()) == 0 and rec_colpart is not None:
+                rec_colpart["independent_lps_weak_scaling"] = {
+                    "what": "every rank iterating on its own 8192 x 4096 LP, no collective (BASELINE config 3 per GPU)",
+                    "value": rec["value"], "unit": "pivots/s", "ms_per_step": rec["ms_per_step"],
+                    "scaling": "weak", "roofline": rec["roofline"]}
+                rec = rec_colpart
+            else:
+                rec["colpart_error"] = err or "the column-partition leg failed on another rank"
+    if rank == 0:
+        print(json.dumps(rec), flush=True)
     if N > 1:
         dist.destroy_process_group()
 

@@ -60,6 +60,12 @@ int         mi355x_tab_la_lost(const mi355x_tab *t);
  * 0 update / sweep, 1 look-ahead (select) */
 int         mi355x_tab_timing_read_kind(mi355x_tab *t, int which, int64_t *n_launches,
                                         double *sum_ms, double *min_ms);
+/* column partition over RCCL: HIP-event brackets around the two per-pivot collectives of every
+ * `stride`-th pivot (at most max_samples per shard and per solve call; 0 = off); _read waits for
+ * the shards' streams and returns the averages over this process's shards since the last read */
+int         mi355x_colpart_exchange_timing_enable(mi355x_colpart *p, int stride, int max_samples);
+int         mi355x_colpart_exchange_timing_read(mi355x_colpart *p, int64_t *n_samples,
+                                                double *allgather_us, double *allreduce_us);
 /* debugging aid: copies n doubles of the handle's scratch `rhs` buffer (the per-phase clocks of
  * a -DMI355X_LA_TIMING build); clear != 0 zeroes it afterwards */
 int         mi355x_debug_rhs(mi355x_tab *t, double *out, int64_t n, int clear);

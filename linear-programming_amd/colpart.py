@@ -365,6 +365,17 @@ class NativeColumnPartition:
         capi.check(capi.lib().mi355x_colpart_solve_async(self._h, int(bool(is_max)), float(fp_tolerance),
                                                          int(n_pivots), int(bool(reset))), "mi355x_colpart_solve_async")
 
+    def exchange_timing(self, stride, max_samples=256):
+        """HIP-event brackets around the two collectives of every stride-th pivot (RCCL shards)."""
+        capi.check(capi.lib().mi355x_colpart_exchange_timing_enable(self._h, int(stride), int(max_samples)),
+                   "mi355x_colpart_exchange_timing_enable")
+
+    def exchange_timing_read(self):
+        n, ag, ar = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+        capi.check(capi.lib().mi355x_colpart_exchange_timing_read(
+            self._h, ctypes.byref(n), ctypes.byref(ag), ctypes.byref(ar)), "mi355x_colpart_exchange_timing_read")
+        return n.value, ag.value, ar.value
+
     def sync(self):
         n = ctypes.c_int64(0)
         rc = capi.check(capi.lib().mi355x_colpart_sync(self._h, ctypes.byref(n)), "mi355x_colpart_sync")
@@ -428,6 +439,8 @@ def bench(args, rank, local_rank, world):
         info = tab.info()
         tab.solve_async(args.warmup, reset=True)
         st, done = tab.sync()
+        if info["uses_rccl"]:
+            tab.exchange_timing(max(1, args.steps // 64), 128)
     else:
         shards = synthetic_shards(torch, n, m, seed, [rank], world, local_rank, compact=not dense)
         comm = DistComm(dist, stage_through_host=staged) if world > 1 else LocalComm(torch)
@@ -458,6 +471,15 @@ def bench(args, rank, local_rank, world):
         elapsed = float(tt.item())
     R, C = m + 1, n + m + 1
     value = args.steps / elapsed
+    exchange = None
+    if native and info["uses_rccl"]:
+        ns, ag_us, ar_us = tab.exchange_timing_read()
+        if ns:
+            exchange = {"samples": ns, "allgather_us": ag_us, "allreduce_us": ar_us,
+                        "us_per_pivot": ag_us + ar_us,
+                        "what": "HIP events on rank 0's stream around ncclAllGather (16 B/rank) and "
+                                "ncclAllReduce (int64 x %d rows) of sampled pivots; includes waiting "
+                                "for the slowest rank" % R}
     stored_bytes = 2.0 * R * ((n + m if dense else n) + world) * 8 / block   # per pivot, all shards
     rec = {
         "metric": "simplex pivots/sec, one column-partitioned dense tableau",
@@ -475,6 +497,7 @@ def bench(args, rank, local_rank, world):
                              else "Python protocol driver (torch.distributed)"},
         "rccl_ranks": world if info["uses_rccl"] else 0,
         "exchange_bytes_per_pivot_per_rank": 16 * world + 8 * R,
+        "exchange": exchange,
         "us_per_pivot": elapsed / args.steps * 1e6,
         "per_gpu_physical_GBps": stored_bytes * value / 1e9 / world,
         "aggregate_GBps": stored_bytes * value / 1e9,

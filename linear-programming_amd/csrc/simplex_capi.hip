@@ -1505,6 +1505,10 @@ struct CpShard {
     long long  *bits = nullptr, *bits_in = nullptr;   // contribution / exchanged column
     int64_t    *ec = nullptr;
     ncclComm_t  comm = nullptr;
+    // exchange timing (mi355x_colpart_exchange_timing): event quads around the two collectives of
+    // sampled pivots -- [before all-gather, after, before all-reduce, after]
+    std::vector<hipEvent_t> ev;
+    int ev_used = 0;
 };
 
 }  // namespace
@@ -1515,6 +1519,7 @@ struct mi355x_colpart {
     int64_t rows = 0, var_count = 0;
     int     block = kMaxBlock, j = 0;        // pivots per sweep, steps of the current block enqueued
     int     is_max = 1;
+    int     timing_stride = 0;               // 0 = no exchange timing, k = every k-th pivot
     std::vector<CpShard> sh;                 // the shards of THIS process
     // logical shards: one allocation each, shared by all of them
     double    *l_gathered = nullptr;
@@ -1530,6 +1535,7 @@ void cp_free(mi355x_colpart *p)
     for (CpShard &s : p->sh) {
         if (s.t) { (void)hipSetDevice(s.device); (void)hipStreamSynchronize(s.t->stream); }
         if (s.comm && rccl().ok) (void)rccl().CommDestroy(s.comm);
+        for (hipEvent_t e : s.ev) (void)hipEventDestroy(e);
     }
     for (CpShard &s : p->sh) {
         (void)hipSetDevice(s.device);
@@ -1622,13 +1628,20 @@ int cp_run_rccl(mi355x_colpart *p, CpShard &s, double f, int64_t n, int j0)
     HIP_TRY(hipSetDevice(s.device));
     int j = j0;
     for (int64_t i = 0; i < n; ++i) {
+        const bool timed = p->timing_stride > 0 && i % p->timing_stride == 0 &&
+                           (size_t)s.ev_used + 4 <= s.ev.size();
+        hipEvent_t *e = timed ? &s.ev[(size_t)s.ev_used] : nullptr;
         int rc = mi355x_shard_price(s.t, p->is_max, s.col_begin, s.send);
         if (rc != MI_OK) return rc;
+        if (timed) HIP_TRY(hipEventRecord(e[0], s.t->stream));
         RCCL_TRY(rccl().AllGather(s.send, s.gathered, 2, ncclDouble, s.comm, s.t->stream));
+        if (timed) HIP_TRY(hipEventRecord(e[1], s.t->stream));
         if (p->block > 1) rc = mi355x_shard_la_contribute(s.t, j, s.gathered, p->world, s.col_begin, f, (int64_t *)s.bits, s.ec);
         else              rc = mi355x_shard_contribute(s.t, s.gathered, p->world, s.col_begin, f, (int64_t *)s.bits, s.ec);
         if (rc != MI_OK) return rc;
+        if (timed) HIP_TRY(hipEventRecord(e[2], s.t->stream));
         RCCL_TRY(rccl().AllReduce(s.bits, s.bits, (size_t)p->rows, ncclInt64, ncclSum, s.comm, s.t->stream));
+        if (timed) { HIP_TRY(hipEventRecord(e[3], s.t->stream)); s.ev_used += 4; }
         if (p->block > 1) rc = mi355x_shard_la_pivot(s.t, j, (const int64_t *)s.bits, s.ec, f);
         else              rc = mi355x_shard_pivot(s.t, (const int64_t *)s.bits, s.ec, f);
         if (rc != MI_OK) return rc;
@@ -1874,6 +1887,47 @@ int mi355x_colpart_solve_async(mi355x_colpart *p, int is_max, double f, int64_t 
             if ((rc = mi355x_tab_reset(s.t, 0)) != MI_OK) return rc;
     }
     return cp_run(p, f, n_pivots);
+}
+
+int mi355x_colpart_exchange_timing_enable(mi355x_colpart *p, int stride, int max_samples)
+{
+    if (!p || stride < 0 || max_samples < 0 || max_samples > 4096) return fail(MI_BAD_ARG, "bad exchange-timing arguments");
+    p->timing_stride = stride;
+    for (CpShard &s : p->sh) {
+        HIP_TRY(hipSetDevice(s.device));
+        HIP_TRY(hipStreamSynchronize(s.t->stream));
+        s.ev_used = 0;
+        while (s.ev.size() < (size_t)max_samples * 4) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            s.ev.push_back(e);
+        }
+    }
+    return MI_OK;
+}
+
+int mi355x_colpart_exchange_timing_read(mi355x_colpart *p, int64_t *n_samples, double *allgather_us, double *allreduce_us)
+{
+    if (!p) return fail(MI_BAD_ARG, "handle is NULL");
+    int64_t n = 0;
+    double ag = 0.0, ar = 0.0;
+    for (CpShard &s : p->sh) {                       // averages over the local shards' samples
+        HIP_TRY(hipSetDevice(s.device));
+        HIP_TRY(hipStreamSynchronize(s.t->stream));
+        for (int k = 0; k + 4 <= s.ev_used; k += 4) {
+            float a = 0.f, b = 0.f;
+            HIP_TRY(hipEventElapsedTime(&a, s.ev[(size_t)k], s.ev[(size_t)k + 1]));
+            HIP_TRY(hipEventElapsedTime(&b, s.ev[(size_t)k + 2], s.ev[(size_t)k + 3]));
+            ag += a * 1e3;
+            ar += b * 1e3;
+            ++n;
+        }
+        s.ev_used = 0;
+    }
+    if (n_samples) *n_samples = n;
+    if (allgather_us) *allgather_us = n ? ag / n : 0.0;
+    if (allreduce_us) *allreduce_us = n ? ar / n : 0.0;
+    return MI_OK;
 }
 
 int mi355x_colpart_sync(mi355x_colpart *p, int64_t *n_pivots)

@@ -14,12 +14,13 @@ look-ahead kernel under load -- the round-1 review's list:
     publishes) must end in a correct solve, not in an error.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
 
 import oracle
-from tests.helpers import lp_amd
+from tests.helpers import ROOT, lp_amd
 
 pytestmark = pytest.mark.gpu
 lp = lp_amd()
@@ -335,8 +336,11 @@ def test_colpart_c_abi_over_rccl_single_rank(monkeypatch):
     so, no, trace = oracle.solve(M, b, trace_cap=1 << 14)
     tab = cp.NativeColumnPartition.synthetic(n, m, seed, 1)
     assert tab.info() == {"n_shards": 1, "n_devices_used": 1, "uses_rccl": True}
+    tab.exchange_timing(4, 64)
     st, k = tab.solve()
     assert (st, k) == (so, no) and np.array_equal(tab.trace(no), trace)
+    ns, ag_us, ar_us = tab.exchange_timing_read()
+    assert 0 < ns <= 64 and 0.0 < ag_us < 1e5 and 0.0 < ar_us < 1e5      # both collectives were bracketed
     G, bg, _, _ = tab.download()
     assert np.array_equal(G.view(np.int64), M.view(np.int64)) and np.array_equal(bg, b)
     tab.close()
@@ -382,3 +386,41 @@ def test_colpart_split_lookahead_step_bitwise(n_shards, dense):
     G, bg, _, _ = tab.download()
     assert np.array_equal(G.view(np.int64), M.view(np.int64)) and np.array_equal(bg, b)
     tab.close()
+
+
+def _bench_two_ranks(extra_env, extra_args=()):
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, BENCH_SHARE_DEVICE="1", BENCH_DIST_BACKEND="gloo", **extra_env)
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+         "--gpus", "2", "--steps", "20", "--warmup", "5", "--colpart-vars", "2048", *extra_args],
+        env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_headline_is_the_column_partition():
+    """`bench.py --gpus 2` as the driver launches it (two ranks; here both on the one GPU with the
+    scalar reductions over gloo, where the shards' exchanges are staged through the host): ONE JSON
+    line, the strong-scaling column-partition record with the independent LPs attached."""
+    rec = _bench_two_ranks({})
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["steps"] == 20
+    assert rec["value"] > 0 and "column-partitioned" in rec["config"]["workload"]
+    weak = rec["independent_lps_weak_scaling"]
+    assert weak["scaling"] == "weak" and weak["value"] > 0 and weak["roofline"]["frac"] > 0
+
+
+def test_bench_two_ranks_watchdog_still_prints_a_line():
+    """The column-partition leg under a watchdog that fires at once: the weak-scaling record is
+    printed with the reason (a run that hangs in a collective must not end without a line)."""
+    rec = _bench_two_ranks({"BENCH_COLPART_TIMEOUT": "0.001"})
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and "did not finish" in rec["colpart_error"]
