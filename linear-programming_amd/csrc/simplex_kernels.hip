@@ -2213,6 +2213,318 @@ __global__ __launch_bounds__(256) void k_sweep16(TabView t, const int tr, const 
     }
 }
 
+// ---- the same sweep with the tableau rows AND the col values arriving by LDS-DMA -----------------
+// What holds k_sweep16 at ~5.3 TB/s is not the f64 work and not the bytes in flight
+// (tools/microbench/sweep_stream.hip: the same tile streams at 68-80 us without the links, 88 us with
+// 16 links whose col operands are already in registers, 121 us with col operands from scalar loads):
+// it is the scalar loads.  Every chunk of 4 pivots x 4 rows waits for an s_load that was issued
+// 64 f64 instructions earlier -- 0.13 us of cover for a round trip to an L2 that is busy streaming
+// the tableau -- so a wave's step is four exposed L2 latencies long whatever else is in flight.
+// Here nothing in the row loop is a scalar load and nothing is waited for that was not requested a
+// whole step earlier:
+//   * every wave owns a ring of P groups of 4 tableau rows in LDS (1 KB per row: 64 lanes x 16 B,
+//     lane-linear, exactly what `global_load_lds_dwordx4` writes); the rows of step s+P are
+//     requested as soon as step s has read its own out of the ring -- no register holds a row that
+//     is not being computed, and the step needs ONE register set;
+//   * the col values travel the same way: one DMA instruction brings the 16 pivots x 8 rows of TWO
+//     steps (lane l: pivot l % 16, rows 2*(l / 16), +1), requested two steps ahead; a step reads
+//     its 4 rows x 16 pivots with two ds_read_b128 (lane l then holds col[l % 16][row]), and link i
+//     takes its operand from lane i of every row of 16 lanes with `v_mov_b64_dpp row_newbcast:i`
+//     (one VALU instruction per col value and wave -- a quarter of the four f64 instructions that
+//     use it);
+//   * completion is counted, never drained: VMEM operations of a wave retire in issue order on
+//     gfx9-class hardware, so "the DMAs of step s have landed" is `s_waitcnt vmcnt(n)` with n = the
+//     operations the wave has issued after them (`issued` / `mark_*`: uniform integers).  Operations
+//     the count does not know about (the prow loads of the prologue, the loads of a slow step) only
+//     make a wait stricter.
+// Arithmetic: the statements of k_sweep16 (rounded product, rounded difference, pivot order).
+template <bool NT>
+__device__ __forceinline__ void dma_row16(const void *row_base, unsigned lane_off, unsigned lds_byte)
+{
+    unsigned keep;
+    if constexpr (NT)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane_off), "s"(row_base), "s"(lds_byte) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane_off), "s"(row_base), "s"(lds_byte) : "memory");
+}
+
+// the same with ALL 64 lanes enabled (the col values are for the whole wave, whichever of its lanes
+// own a column pair)
+__device__ __forceinline__ void dma_all_lanes16(const void *base, unsigned lane_off, unsigned lds_byte)
+{
+    unsigned keep;
+    unsigned long long ex;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_or_saveexec_b64 %1, -1\n\t"
+                 "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep), "=&s"(ex) : "v"(lane_off), "s"(base), "s"(lds_byte) : "memory", "scc");
+}
+
+__device__ __forceinline__ void wait_vm_at_most(int n)       // the largest immediate <= n
+{
+    if      (n >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (n >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (n >= 9)  asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if (n >= 8)  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n >= 5)  asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (n >= 4)  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// lane I of every row of 16 lanes, to all lanes of that row
+template <int I> __device__ __forceinline__ double lane16_bcast(double v)
+{
+    double c;
+    asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(c) : "v"(v), "n"(I));
+    return c;
+}
+
+// links I..15 applied to U rows; cv[u]: lane l holds col_{l % 16}[row u]
+template <int I, int U> struct SweepLinks {
+    static __device__ __forceinline__ void run(vec2d (&cur)[U], const double (&cv)[U], const vec2d (&p)[kSweepK])
+    {
+        if constexpr (I < kSweepK) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double c  = lane16_bcast<I>(cv[u]);
+                const double m0 = c * p[I].x;                  // rounded products
+                const double m1 = c * p[I].y;
+                cur[u].x = cur[u].x - m0;                      // rounded differences
+                cur[u].y = cur[u].y - m1;
+            }
+            SweepLinks<I + 1, U>::run(cur, cv, p);
+        }
+    }
+};
+
+template <bool NT, int P>
+__global__ __launch_bounds__(256) void k_sweep16d(TabView t, const int tr, const int strip_pairs,
+                                                  const double sgn, const int price, const unsigned stamp)
+{
+    constexpr int K = kSweepK, U = 4;
+    constexpr int kWaveVec = P * U * 64 + 2 * 64;              // vec2d per wave: row ring + two col groups
+    extern __shared__ __attribute__((aligned(16))) double ring_lds[];
+    t = lp_slice(t);
+    const BlockCtl *__restrict__ blk = t.blk;
+    const int k = (int)blk->n_pending;
+    if (k == 0) return;
+    if (stamp != 0u && (unsigned)blk->stamp != stamp) return;
+    double *__restrict__ M = t.M;
+    const int64_t ld = t.ld, rows = t.rows, vc = t.cols - 1;
+    const int64_t ldv  = ld >> 1;
+    const int64_t pair = (int64_t)blockIdx.x * strip_pairs + threadIdx.x;
+    const bool active  = (int)threadIdx.x < strip_pairs && pair < ldv;
+    const int64_t r0 = (int64_t)blockIdx.y * tr;               // tr is a multiple of 8, at most 64
+    const int64_t r1 = (r0 + tr < rows) ? r0 + tr : rows;
+    double  *__restrict__ part_v = price ? t.part_v : nullptr;
+    const bool prices = (r1 == rows) && part_v != nullptr;
+    // rows of this tile that are the pivot row of a pending pivot: bit per row
+    const int lane = (int)(threadIdx.x & 63);
+    const unsigned long long hot = __ballot(r0 + lane < r1 && lane < tr && t.bk_rmask[r0 + lane] != 0u);
+    // col DMA: lane l fetches pivot l % 16, rows 2 * (l / 16), +1 of a group of 8 rows
+    unsigned col_off = (unsigned)(((int64_t)(lane & 15) * t.bk_stride + 2 * (lane >> 4)) * 8);
+    asm volatile("" : "+v"(col_off));                          // computed HERE, while every lane is enabled
+    // A wave with at least one column pair runs with ALL its lanes enabled (the col values are
+    // broadcast from lanes 0..15 of every row of 16, whoever owns a pair): a lane without a pair
+    // works on the strip's first pair and stores nothing.
+    const bool wave_on = __any(active);
+    if (!wave_on && !prices) return;                           // no workgroup barrier below
+    const int64_t pair_ld = active ? pair : (int64_t)blockIdx.x * strip_pairs;
+
+    vec2d *Mp = reinterpret_cast<vec2d *>(M) + pair_ld;
+    auto ld2 = [&](int64_t r) -> vec2d {
+        if constexpr (NT) return __builtin_nontemporal_load(Mp + r * ldv);
+        else              return Mp[r * ldv];
+    };
+    auto st2 = [&](int64_t r, vec2d v) {
+        if (active) {
+            if constexpr (NT) __builtin_nontemporal_store(v, Mp + r * ldv);
+            else              Mp[r * ldv] = v;
+        }
+    };
+    vec2d last; last.x = 0.0; last.y = 0.0;
+    if (wave_on) {
+        const unsigned sm = t.bk_smask[pair_ld];
+        if (k != K) {
+            // a partial block (the look-ahead terminated inside it): one row at a time, operands
+            // from memory -- runs once per solve
+            const unsigned sx = sm & 0xffffu, sy = sm >> 16;
+            for (int64_t r = r0; r < r1; ++r) {
+                vec2d x = ld2(r);
+                const unsigned rm = t.bk_rmask[r];
+                for (int i = 0; i < k; ++i) {
+                    const double cv = t.bk_col[(int64_t)i * t.bk_stride + r];
+                    const vec2d pi = reinterpret_cast<const vec2d *>(t.bk_prow)[(int64_t)i * ldv + pair_ld];
+                    const bool is_cr = (rm >> i) & 1u;
+                    x.x = pend(x.x, (sx >> i) & 1u, is_cr, cv, pi.x);
+                    x.y = pend(x.y, (sy >> i) & 1u, is_cr, cv, pi.y);
+                }
+                st2(r, x);
+                last = x;
+            }
+        } else {
+            const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            const unsigned ring_byte =
+                (unsigned)(unsigned long long)(__attribute__((address_space(3))) double *)ring_lds +
+                (unsigned)wv * (unsigned)(kWaveVec * 16);
+            const unsigned colring_byte = ring_byte + (unsigned)(P * U * 1024);
+            const vec2d *ring = reinterpret_cast<const vec2d *>(ring_lds) + wv * kWaveVec + lane;
+            const vec2d *colring = reinterpret_cast<const vec2d *>(ring_lds) + wv * kWaveVec + P * U * 64 + (lane & 15);
+            const unsigned lane_off = active ? threadIdx.x * 16u : 0u;
+            const unsigned rb = (unsigned)(ld * 8);            // bytes per tableau row (< 2^31)
+            // uniform row pointer of the step being computed, advanced by 4 rows per step
+            const char *grow = reinterpret_cast<const char *>(M) + (int64_t)blockIdx.x * strip_pairs * 16 + r0 * (int64_t)rb;
+            const char *gcol = reinterpret_cast<const char *>(t.bk_col + r0);   // col values of the group being computed
+            const int nrows = (int)(r1 - r0);
+            const int SF = nrows / U, rem = nrows - SF * U;    // full steps, rows of a last partial step
+            const int NG = (SF + 1) / 2;                       // col groups (8 rows each) the full steps read
+            int issued = 0;                                    // VMEM operations this wave has issued (that it counts)
+            int mark_row[P], mark_col[2];                      // `issued` right after the DMAs into that ring slot
+            auto request_rows = [&](const int g, const char *rowp) {   // 4 rows at rowp -> row group g
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    dma_row16<NT>(rowp + (size_t)u * rb, lane_off, ring_byte + (unsigned)((g * U + u) * 1024));
+                issued += U;
+                mark_row[g] = issued;
+            };
+            auto request_col = [&](const int cg, const char *colp) {   // 16 pivots x 8 rows at colp -> col group cg
+                dma_all_lanes16(colp, col_off, colring_byte + (unsigned)(cg * 1024));
+                issued += 1;
+                mark_col[cg] = issued;
+            };
+            mark_col[0] = mark_col[1] = 0;
+            if (NG > 0) request_col(0, gcol);
+#pragma unroll
+            for (int g = 0; g < P; ++g) {
+                mark_row[g] = 0;
+                if (g < SF) request_rows(g, grow + (size_t)(g * U) * rb);
+            }
+            if (NG > 1) request_col(1, gcol + 64);
+            vec2d p[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i)
+                p[i] = reinterpret_cast<const vec2d *>(t.bk_prow)[(int64_t)i * ldv + pair_ld];
+            const unsigned sx = sm & 0xffffu, sy = sm >> 16;
+            // slot columns: chain starts at the last pivot that handed the slot over
+            const bool wave_slots = __any(sm != 0u);
+            unsigned crx = 0x80000000u, cry = 0x80000000u;     // unit row relative to r0 (far away: not in this tile)
+            bool hasx = false, hasy = false;
+            if (wave_slots) {
+                const int lx = sx ? 31 - __clz((int)sx) : -1, ly = sy ? 31 - __clz((int)sy) : -1;
+                if (lx >= 0) { hasx = true; const int64_t d = blk->cr[lx] - r0; if (d >= 0 && d < nrows) crx = (unsigned)d; }
+                if (ly >= 0) { hasy = true; const int64_t d = blk->cr[ly] - r0; if (d >= 0 && d < nrows) cry = (unsigned)d; }
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    if (i < lx) p[i].x = 0.0;
+                    if (i < ly) p[i].y = 0.0;
+                }
+            }
+
+            // Rows one at a time, operands from memory (the rings are not used): the steps that hold
+            // the pivot row of a pending pivot (16 of ~1000) and the last rows of the tableau.  Such
+            // a row takes the pivot's normalised row at link i (what pend() returns there); a slot
+            // lane's p[i] was zeroed for i < its last hand-over, and +0 is exactly what its chain
+            // restarts from at the hand-over.
+            auto slow_rows = [&](const int rr, const int nv) {
+#pragma unroll 1
+                for (int u = 0; u < nv; ++u) {
+                    const int64_t r = r0 + rr + u;
+                    vec2d x = ld2(r);
+                    if (hasx) x.x = (crx == (unsigned)(rr + u)) ? 1.0 : 0.0;
+                    if (hasy) x.y = (cry == (unsigned)(rr + u)) ? 1.0 : 0.0;
+                    const unsigned rm = __builtin_amdgcn_readfirstlane(t.bk_rmask[r]);
+#pragma unroll
+                    for (int i = 0; i < K; ++i) {
+                        const double cv = t.bk_col[(int64_t)i * t.bk_stride + r];
+                        const double m0 = cv * p[i].x;
+                        const double m1 = cv * p[i].y;
+                        x.x = x.x - m0;
+                        x.y = x.y - m1;
+                        if ((rm >> i) & 1u) x = p[i];
+                    }
+                    st2(r, x);
+                    last = x;
+                }
+                issued += nv;                                  // (its loads are waited for by the compiler)
+            };
+            // one full step: rows [rr, rr + 4) of the tile; g = its row group, half = which half of col group cg
+            auto step = [&](const int g, const int cg, const int half, const int sidx) {
+                const int rr = sidx * U;
+                const int mk = mark_row[g] > mark_col[cg] ? mark_row[g] : mark_col[cg];
+                wait_vm_at_most(issued - mk);                  // this step's rows and col values have landed
+                const bool slow = ((hot >> (unsigned)rr) & 0xfull) != 0ull;
+                vec2d cur[U], cpair[2];
+                if (!slow) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) cur[u] = ring[(g * U + u) * 64];
+                    cpair[0] = colring[cg * 64 + (half * 2) * 16];
+                    cpair[1] = colring[cg * 64 + (half * 2 + 1) * 16];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read out: the slots are free again
+                }
+                if (sidx + P < SF) request_rows(g, grow + (size_t)(P * U) * rb);
+                if (half == 1 && sidx / 2 + 2 < NG) request_col(cg, gcol + 2 * 64);
+                if (slow) {
+                    slow_rows(rr, U);
+                } else {
+                    if (wave_slots) {
+                        const unsigned dx = crx - (unsigned)rr, dy = cry - (unsigned)rr;   // == u on the unit row
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            if (hasx) cur[u].x = (dx == (unsigned)u) ? 1.0 : 0.0;
+                            if (hasy) cur[u].y = (dy == (unsigned)u) ? 1.0 : 0.0;
+                        }
+                    }
+                    const double cv[U] = {cpair[0].x, cpair[0].y, cpair[1].x, cpair[1].y};
+                    SweepLinks<0, U>::run(cur, cv, p);
+                    char *wrow = const_cast<char *>(grow);
+                    if (active) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            vec2d *dst = reinterpret_cast<vec2d *>(wrow + (size_t)u * rb + lane_off);
+                            if constexpr (NT) __builtin_nontemporal_store(cur[u], dst);
+                            else              *dst = cur[u];
+                        }
+                    }
+                    issued += U;
+                    last = cur[U - 1];
+                }
+                grow += (size_t)U * rb;
+                if (half == 1) gcol += 64;
+            };
+            static_assert(P == 2, "the step loop is written for two row groups");
+            for (int s0 = 0; s0 < SF; s0 += 4) {               // 4 steps = both row groups x both halves x ... col groups alternate
+                if (s0 + 0 < SF) step(0, 0, 0, s0 + 0);
+                if (s0 + 1 < SF) step(1, 0, 1, s0 + 1);
+                if (s0 + 2 < SF) step(0, 1, 0, s0 + 2);
+                if (s0 + 3 < SF) step(1, 1, 1, s0 + 3);
+            }
+            if (rem > 0) slow_rows(SF * U, rem);               // the last rows of the tableau
+        }
+    }
+    if (prices) {                                              // `last` = new objective-row entries
+        ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
+        const int64_t c0 = 2 * pair;
+        if (active && c0 < vc) {
+            ValIdx c; c.v = last.x * sgn; c.i = t.p2l ? t.p2l[c0] : c0; c.s = c0;
+            best = vi_min(best, c);
+        }
+        if (active && c0 + 1 < vc) {
+            ValIdx c; c.v = last.y * sgn; c.i = t.p2l ? t.p2l[c0 + 1] : c0 + 1; c.s = c0 + 1;
+            best = vi_min(best, c);
+        }
+        best = wave_reduce_min(best);
+        if ((threadIdx.x & 63) == 0) {
+            const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+            part_v[w]   = best.v;
+            t.part_i[w] = best.i;
+            t.part_s[w] = best.s;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ batch: one workgroup per LP
 // BASELINE config 4 is many SMALL independent LPs (257 x 769 doubles = 1.6 MB each).  Advancing
 // them in lockstep with the launch pairs above makes every LP wait for the slowest one (78..199
@@ -3044,6 +3356,7 @@ bool launch_batch_solve(const TabView &t, int is_max, double f, hipStream_t s)
     return true;
 }
 static int g_sweep_tr = 0, g_sweep_nt = -1;                     // 0 / -1: by size
+static int g_sweep_dma = 0;                                     // >0: k_sweep16d with that many ring groups
 static int g_sweep_impl = 0;                                    // 0: k_sweep16 for full blocks, 1: k_sweep always
 bool launch_batch_block_split(const TabView &t, int is_max, double f, hipStream_t s)
 {
@@ -3279,7 +3592,13 @@ void launch_la_block(const TabView &t, int ksteps, int is_max, double f, unsigne
 static int g_sweep_u = 4;                                       // rows per step of k_sweep16: 4, or 8 (measured
                                                                 // slower: 199 VGPRs, 2 waves per SIMD, 125 vs 103 us)
 void set_sweep_shape(int tr, int nt) { g_sweep_tr = tr >= 4 ? tr / 4 * 4 : 0; g_sweep_nt = nt; }
-void set_sweep_impl(int impl) { g_sweep_impl = impl == 1 ? 1 : 0; if (impl == 4 || impl == 8) g_sweep_u = impl; }
+void set_sweep_impl(int impl)
+{
+    g_sweep_impl = impl == 1 ? 1 : 0;
+    if (impl == 4 || impl == 8) g_sweep_u = impl;
+    if (impl == 0 || impl == 1 || impl == 4 || impl == 8) g_sweep_dma = 0;
+    if (impl == 22) g_sweep_dma = 2;                         // k_sweep16d: rows and col values by LDS-DMA
+}
 
 template <int KMAX>
 static void launch_sweep_t(const TabView &t, dim3 grid, int tr, int sp, double sgn, bool nt, unsigned stamp,
@@ -3310,6 +3629,13 @@ int launch_sweep(const TabView &t, int kmax, double sgn, hipStream_t s, unsigned
     const dim3 grid((unsigned)strips, (unsigned)((t.rows + tr - 1) / tr));
     const double bytes = (double)t.rows * (double)t.ld * 8.0;
     const bool nt = g_sweep_nt < 0 ? bytes > kNtThresholdBytes : g_sweep_nt != 0;
+    if (kmax == kSweepK && g_sweep_impl == 0 && g_sweep_dma > 0 && tr <= 64 && tr % 8 == 0) {
+        // rows and col values by LDS-DMA: per wave a ring of 2 groups of 4 rows + 2 col groups
+        const size_t lds = 4 * (2 * 4 + 2) * 1024;
+        if (nt) hipLaunchKernelGGL((k_sweep16d<true, 2>),  grid, dim3(256), lds, s, t, (int)tr, (int)sp, sgn, 1, stamp);
+        else    hipLaunchKernelGGL((k_sweep16d<false, 2>), grid, dim3(256), lds, s, t, (int)tr, (int)sp, sgn, 1, stamp);
+        return strips * (block / 64);
+    }
     if (kmax == kSweepK && g_sweep_impl == 0) {
         // rows in flight per thread and step: 8 when the tile is a multiple of 8 rows (bk_rmask is
         // padded to a multiple of 16 rows, so the uint4 mask loads of the last tile stay inside)

@@ -7,6 +7,8 @@ lp = lp_amd(); L = lp.capi.lib()
 n, m = 8192, 4096
 if len(sys.argv) > 2:                                     # pivots per sweep (blocked pivoting)
     L.mi355x_tune_set_block(int(sys.argv[2]))
+if len(sys.argv) > 3:                                     # sweep implementation (mi355x_tune_set_sweep_impl)
+    L.mi355x_tune_set_sweep_impl(int(sys.argv[3]))
 h = ctypes.c_void_p()
 lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h), n, m, lp.synth.seed_for(3), 0, -1, 0), "create")
 h2 = ctypes.c_void_p()

@@ -1,14 +1,17 @@
 """k_sweep16 / k_sweep launch-shape sweep on config 3: rows per workgroup x non-temporal x implementation.
-    python tools/sweep_shapes.py"""
+    python tools/sweep_shapes.py [rows,rows,...] [impl,...] [nt,...]"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tests.helpers import lp_amd
 lp = lp_amd(); L = lp.capi.lib()
 n, m, K = 8192, 4096, 800
-for impl in (8, 4):
-    for nt in (0, 1):
-        for tr in (16, 32, 64):
+TRS = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else (16, 32, 64)
+IMPLS = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else (8, 4)
+NTS = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else (0, 1)
+for impl in IMPLS:
+    for nt in NTS:
+        for tr in TRS:
             L.mi355x_tune_set_sweep_impl(0); L.mi355x_tune_set_sweep_impl(impl)
             L.mi355x_tune_set_sweep_shape(tr, nt)
             h = ctypes.c_void_p()
