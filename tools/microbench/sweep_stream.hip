@@ -155,8 +155,8 @@ int main(int argc, char **argv)
 {
     const int64_t rows = argc > 1 ? atoll(argv[1]) : 4097, ld = argc > 2 ? atoll(argv[2]) : 8208;
     double *M, *prow, *col;
-    CK(hipMalloc(&M, rows * ld * 8)); CK(hipMalloc(&prow, 16 * ld * 8)); CK(hipMalloc(&col, 16 * (rows + 64) * 8));
-    CK(hipMemset(M, 0, rows * ld * 8)); CK(hipMemset(prow, 0, 16 * ld * 8)); CK(hipMemset(col, 0, 16 * (rows + 64) * 8));
+    CK(hipMalloc(&M, rows * ld * 8)); CK(hipMalloc(&prow, 32 * ld * 8)); CK(hipMalloc(&col, 32 * (rows + 64) * 8));
+    CK(hipMemset(M, 0, rows * ld * 8)); CK(hipMemset(prow, 0, 32 * ld * 8)); CK(hipMemset(col, 0, 32 * (rows + 64) * 8));
     const double gb = 2.0 * rows * ld * 8 / 1e9;
     auto show = [&](const char *what, int K, int U, int pro, int tr, int occ, int order, double us) {
         printf("%-22s K=%2d U=%d prologue=%d tr=%3d occ=%d order=%d : %7.1f us  %5.2f TB/s\n", what, K, U, pro, tr, occ, order, us, gb / us * 1e3 / 1e3 * 1e-3 * 1e3);
@@ -177,6 +177,15 @@ int main(int argc, char **argv)
     show("K=16 sgpr col", 16, 4, 1, 32, 4, 0, run<16, 4, true, 0>(M, prow, col, ld, rows, 32, 4, 0));
     show("K=0", 0, 4, 0, 32, 4, 0, run<0, 4, false>(M, prow, col, ld, rows, 32, 4, 0));
     show("K=0 + sleep", 0, 4, 0, 32, 4, 0, run<0, 4, false, 1>(M, prow, col, ld, rows, 32, 4, 0));
+    if (argc > 3 && argv[3][0] == 'k') {      // links per pass: 16 vs 32 (two look-ahead blocks per sweep)
+        for (int occ : {2, 3}) {
+            show("K=16 f64, no s_load", 16, 4, 1, 32, occ, 0, run<16, 4, true, 3>(M, prow, col, ld, rows, 32, occ, 0));
+            show("K=24 f64, no s_load", 24, 4, 1, 32, occ, 0, run<24, 4, true, 3>(M, prow, col, ld, rows, 32, occ, 0));
+            show("K=32 f64, no s_load", 32, 4, 1, 32, occ, 0, run<32, 4, true, 3>(M, prow, col, ld, rows, 32, occ, 0));
+            show("K=32 f64, no s_load U=2", 32, 2, 1, 32, occ, 0, run<32, 2, true, 3>(M, prow, col, ld, rows, 32, occ, 0));
+        }
+        return 0;
+    }
     if (argc > 3 && argv[3][0] == 'p') {      // pacing study
         for (int occ : {1, 2, 3, 4, 6, 8}) show("K=16 f64, no s_load", 16, 4, 1, 32, occ, 0, run<16, 4, true, 3>(M, prow, col, ld, rows, 32, occ, 0));
         for (int occ : {1, 2, 4, 8}) {
