@@ -38,9 +38,8 @@ int         mi355x_tune_set_sweep_impl(int impl);            /* 0 k_sweep16 for 
                                                                 always; 4 / 8: rows per step of k_sweep16 */
 int         mi355x_tune_set_shard_la_split(int mode);        /* column shards, local look-ahead step:
                                                                 0 by size, 1 one workgroup, 2 many */
-int         mi355x_tune_set_double_block(int on);            /* 1 (default): two look-ahead blocks (16 + 16
-                                                                pivots) per sweep where the persistent
-                                                                look-ahead runs; 0: one */
+int         mi355x_tune_set_tail_policy(int p);              /* n pivots, n not a multiple of the block:
+                                                                0 spread evenly, 1 full blocks + remainder */
 int         mi355x_tune_set_handover_mode(int mode);         /* 0 auto, 1 sequential re-elimination */
 int         mi355x_tune_set_batch_mode(int mode);            /* 0 auto, 1 lockstep, 2 all in one workgroup
                                                                 per LP, 3 look-ahead per LP + sweeps over all LPs */

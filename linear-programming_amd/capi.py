@@ -98,7 +98,7 @@ SIGNATURES = {
 _EXTRA = {
     "mi355x_tune_set_sweep_impl": (_int, [_int]),
     "mi355x_tune_set_shard_la_split": (_int, [_int]),
-    "mi355x_tune_set_double_block": (_int, [_int]),
+    "mi355x_tune_set_tail_policy": (_int, [_int]),
     "mi355x_colpart_exchange_timing_enable": (_int, [_p, _int, _int]),
     "mi355x_colpart_exchange_timing_read": (_int, [_p, _p, _p, _p]),
     "mi355x_tune_set_la_one_xcd": (_int, [_int]),

@@ -35,6 +35,7 @@ int g_compact_enabled = 1;                // solve loops run on the compact repr
 int g_handover_mode = 0;                  // 0 auto, 1 always the sequential re-elimination
 int g_batch_mode = 0;                     // 0 auto, 1 lockstep launch pairs, 2 one workgroup per LP,
                                           // 3 blocked: look-ahead per LP + one sweep launch over all LPs
+int g_tail_policy = 1;                    // a request that is not a whole number of blocks: 0 spread evenly, 1 full blocks + remainder
 int g_la_mode = 0;                        // look-ahead: 0 auto, 1 two launches per step, 2 one persistent launch per block
 int g_block_k = 16;                       // pivots selected ahead and applied per sweep (1 = off)
 
@@ -111,10 +112,6 @@ struct mi355x_tab {
     std::vector<hipEvent_t> ev0, ev1;     // around the update / sweep launches
     int         n_timed_la = 0;
     std::vector<hipEvent_t> la0, la1;     // around the look-ahead of the same blocks
-    // two blocks per sweep: the second pending list
-    double     *bk2_col = nullptr, *bk2_prow = nullptr;
-    BlockCtl   *blk2 = nullptr;
-    uint32_t   *bk2_rmask = nullptr, *bk2_smask = nullptr;
 };
 
 struct mi355x_batch {
@@ -128,6 +125,7 @@ int use_device(const mi355x_tab *t)
     HIP_TRY(hipSetDevice(t->device));
     return MI_OK;
 }
+
 void free_tab(mi355x_tab *t)
 {
     if (!t) return;
@@ -137,11 +135,6 @@ void free_tab(mi355x_tab *t)
     for (auto e : t->ev1) (void)hipEventDestroy(e);
     for (auto e : t->la0) (void)hipEventDestroy(e);
     for (auto e : t->la1) (void)hipEventDestroy(e);
-    (void)hipFree(t->bk2_col);
-    (void)hipFree(t->bk2_prow);
-    (void)hipFree(t->blk2);
-    (void)hipFree(t->bk2_rmask);
-    (void)hipFree(t->bk2_smask);
     (void)hipFree(t->v.M);
     (void)hipFree(t->v.basis);
     (void)hipFree(t->v.col);
@@ -522,98 +515,6 @@ int enqueue_block(mi355x_tab *t, int is_max, double f, int k)
     return MI_OK;
 }
 
-// ---- two blocks per sweep -----------------------------------------------------
-// The look-ahead is 54 % of a block of 16 and the sweep moves the whole tableau for it.  Selecting
-// a SECOND block before sweeping halves the sweeps: la(A) as ever, la(B) on the still untouched
-// tableau with A's list as "previous" (k_la_block<.., true>: chains of 16 + J links, A's
-// per-thread operands in registers), then ONE pass that applies A's and B's links in order to every
-// element (k_sweep32).  Same operands, same roundings, same order => same bits.
-static int g_double = 1;
-
-bool double_mode(const mi355x_tab *t)
-{
-    return g_double && t->compact && t->c.n_lps == 1 && !t->la_lost && g_la_mode != 1 &&
-           g_block_k == kMaxBlock && la_block_supported(t->c);
-}
-
-int second_list(mi355x_tab *t)
-{
-    const TabView &c = t->c;
-    if (!t->bk2_col) {
-        HIP_TRY(hipMalloc((void **)&t->bk2_col, (size_t)kMaxBlock * c.bk_stride * sizeof(double)));
-        HIP_TRY(hipMemsetAsync(t->bk2_col, 0, (size_t)kMaxBlock * c.bk_stride * sizeof(double), t->stream));
-    }
-    if (!t->bk2_prow) {                               // sized for the dense view's ld, like bk_prow
-        HIP_TRY(hipMalloc((void **)&t->bk2_prow, (size_t)kMaxBlock * t->v.ld * sizeof(double)));
-        HIP_TRY(hipMemsetAsync(t->bk2_prow, 0, (size_t)kMaxBlock * t->v.ld * sizeof(double), t->stream));
-    }
-    if (!t->blk2) {
-        HIP_TRY(hipMalloc((void **)&t->blk2, sizeof(BlockCtl)));
-        HIP_TRY(hipMemsetAsync(t->blk2, 0, sizeof(BlockCtl), t->stream));
-    }
-    if (!t->bk2_rmask) {
-        HIP_TRY(hipMalloc((void **)&t->bk2_rmask, (size_t)c.bk_stride * sizeof(uint32_t)));
-        HIP_TRY(hipMemsetAsync(t->bk2_rmask, 0, (size_t)c.bk_stride * sizeof(uint32_t), t->stream));
-    }
-    if (!t->bk2_smask) {
-        HIP_TRY(hipMalloc((void **)&t->bk2_smask, (size_t)t->v.ld * sizeof(uint32_t)));
-        HIP_TRY(hipMemsetAsync(t->bk2_smask, 0, (size_t)t->v.ld * sizeof(uint32_t), t->stream));
-    }
-    return MI_OK;
-}
-
-// kMaxBlock pivots selected, then kb more (1 <= kb <= kMaxBlock), then one sweep for all of them
-int enqueue_double_block(mi355x_tab *t, int is_max, double f, int kb)
-{
-    int rc = second_list(t);
-    if (rc != MI_OK) return rc;
-    const TabView &va = t->c;                         // list A = the handle's first list
-    TabView vb = t->c;                                // list B, with A as the previous block
-    vb.bk_col = t->bk2_col; vb.bk_prow = t->bk2_prow; vb.blk = t->blk2; vb.bk_rmask = t->bk2_rmask; vb.bk_smask = t->bk2_smask;
-    vb.pv_col = va.bk_col; vb.pv_prow = va.bk_prow; vb.pv_blk = va.blk; vb.pv_rmask = va.bk_rmask; vb.pv_smask = va.bk_smask;
-    const bool timed = t->timing_stride > 0 && t->n_timed < kTimingCap && kb == kMaxBlock &&
-                       (t->update_launches++ % t->timing_stride) == 0;
-    auto ensure_events = [](std::vector<hipEvent_t> &a, std::vector<hipEvent_t> &b, int n) -> hipError_t {
-        while ((int)a.size() <= n) {
-            hipEvent_t x, y;
-            hipError_t e = hipEventCreate(&x);
-            if (e != hipSuccess) return e;
-            if ((e = hipEventCreate(&y)) != hipSuccess) { (void)hipEventDestroy(x); return e; }
-            a.push_back(x);
-            b.push_back(y);
-        }
-        return hipSuccess;
-    };
-    if (timed) {
-        HIP_TRY(ensure_events(t->la0, t->la1, t->n_timed_la));
-        HIP_TRY(ensure_events(t->ev0, t->ev1, t->n_timed));
-        HIP_TRY(hipEventRecord(t->la0[t->n_timed_la], t->stream));
-    }
-    if (t->la_epoch > 0x7fff0000u) {                  // 32-bit tags: start over on clean records
-        HIP_TRY(hipMemsetAsync(va.la_px, 0, kMaxLaRecords * sizeof(ExchRec), t->stream));
-        HIP_TRY(hipMemsetAsync(va.la_rx, 0, kMaxLaRecords * sizeof(ExchRec), t->stream));
-        t->la_epoch = 1;
-    }
-    const unsigned stamp_a = t->la_epoch;
-    launch_la_block(va, kMaxBlock, is_max, f, stamp_a, t->stream);
-    t->la_epoch += 2 * kMaxBlock + 2;
-    const unsigned stamp_b = t->la_epoch;
-    launch_la_block(vb, kb, is_max, f, stamp_b, t->stream);
-    t->la_epoch += 2 * kMaxBlock + 2;
-    if (timed) {
-        HIP_TRY(hipEventRecord(t->la1[t->n_timed_la], t->stream));
-        t->n_timed_la++;
-        HIP_TRY(hipEventRecord(t->ev0[t->n_timed], t->stream));
-    }
-    t->n_part = launch_sweep32(vb, is_max ? 1.0 : -1.0, t->stream, stamp_a, stamp_b);
-    t->part_is_max = is_max ? 1 : 0;
-    if (timed) {
-        HIP_TRY(hipEventRecord(t->ev1[t->n_timed], t->stream));
-        t->n_timed++;
-    }
-    return MI_OK;
-}
-
 // The persistent look-ahead gave up waiting for a workgroup's record (status kSyncLost): its
 // workgroups were not all resident at the same time -- a GPU shared with other work.  Nothing is
 // lost: the pivots selected before that exchange have been applied by the sweep that followed,
@@ -844,27 +745,13 @@ int mi355x_tab_solve_async(mi355x_tab *t, int is_max, double f, int64_t n_pivots
     if (rc != MI_OK) return rc;
     if (reset) launch_ctl_reset(t->v, 0, 0, t->stream);
     if (block_mode(t)) {
-        // whole blocks; a remainder is spread evenly over the blocks (every sweep costs one pass
-        // over the tableau however few pivots it applies: 20 pivots are two blocks of 10, not 16 + 4)
-        if (double_mode(t) && n_pivots > g_block_k) {
-            // double blocks of 16 + 16, the remainder as 16 + r or as a single block of r
-            int64_t left = n_pivots;
-            while (left > g_block_k) {
-                const int kb = (int)(left - g_block_k < g_block_k ? left - g_block_k : g_block_k);
-                rc = enqueue_double_block(t, is_max, f, kb);
-                if (rc != MI_OK) return rc;
-                left -= g_block_k + kb;
-            }
-            if (left > 0) {
-                rc = enqueue_block(t, is_max, f, (int)left);
-                if (rc != MI_OK) return rc;
-            }
-            HIP_TRY(hipGetLastError());
-            return MI_OK;
-        }
+        // whole blocks, then the remainder as one shorter block (k_sweep16 for the full ones, a
+        // k_sweep with as few links as the remainder needs: 20 pivots 371 us, 40 pivots 627 us), or
+        // (g_tail_policy 0) the remainder spread evenly over the blocks (378 / 656 us)
         const int64_t nblk = (n_pivots + g_block_k - 1) / g_block_k;
         for (int64_t b = 0; b < nblk; ++b) {
-            const int64_t k = n_pivots / nblk + (b < n_pivots % nblk ? 1 : 0);
+            int64_t k = n_pivots / nblk + (b < n_pivots % nblk ? 1 : 0);
+            if (g_tail_policy == 1) k = (b + 1 < nblk || n_pivots % g_block_k == 0) ? g_block_k : n_pivots % g_block_k;
             rc = enqueue_block(t, is_max, f, (int)k);
             if (rc != MI_OK) return rc;
         }
@@ -925,16 +812,9 @@ int mi355x_tab_solve(mi355x_tab *t, int is_max, double f, int64_t max_pivots, in
         // look-ahead terminates the solve still sweeps (applies what was selected before)
         int64_t blocks = 2;
         for (;;) {
-            if (double_mode(t)) {
-                for (int64_t i = 0; i < blocks; i += 2) {
-                    rc = enqueue_double_block(t, is_max, f, g_block_k);
-                    if (rc != MI_OK) return rc;
-                }
-            } else {
-                for (int64_t i = 0; i < blocks; ++i) {
-                    rc = enqueue_block(t, is_max, f, g_block_k);
-                    if (rc != MI_OK) return rc;
-                }
+            for (int64_t i = 0; i < blocks; ++i) {
+                rc = enqueue_block(t, is_max, f, g_block_k);
+                if (rc != MI_OK) return rc;
             }
             HIP_TRY(hipGetLastError());
             rc = read_ctl(t);
@@ -2154,11 +2034,7 @@ int         mi355x_tune_set_handover_mode(int mode) { g_handover_mode = mode; re
 int         mi355x_tune_set_batch_mode(int mode) { g_batch_mode = mode; return g_batch_mode; }
 int         mi355x_tune_set_alternate_sweep(int on) { set_alternate_sweep(on); return on; }
 // pivots one tableau-update launch of this handle applies in its current representation
-int         mi355x_tab_block_size(mi355x_tab *t)           // pivots per pass over the tableau
-{
-    if (!t || !block_mode(t)) return 1;
-    return double_mode(t) ? 2 * g_block_k : g_block_k;
-}
+int         mi355x_tab_block_size(mi355x_tab *t) { return (t && block_mode(t)) ? g_block_k : 1; }
 int         mi355x_debug_rhs(mi355x_tab *t, double *out, int64_t n, int clear)
 {
     double *buf = t->v.rhs ? t->v.rhs : t->v.col;          // batches have no rhs buffer: their col buffer
@@ -2173,7 +2049,7 @@ int         mi355x_tune_set_sweep_shape(int tr, int nt) { set_sweep_shape(tr, nt
 int         mi355x_tune_set_compact(int on) { g_compact_enabled = on ? 1 : 0; return g_compact_enabled; }
 int         mi355x_tune_set_sweep_impl(int impl) { set_sweep_impl(impl); return impl; }
 int         mi355x_tune_set_shard_la_split(int mode) { set_shard_la_split(mode); return mode; }
-int         mi355x_tune_set_double_block(int on) { g_double = on ? 1 : 0; return MI_OK; }
+int         mi355x_tune_set_tail_policy(int p) { g_tail_policy = p == 1 ? 1 : 0; return g_tail_policy; }
 // persistent look-ahead: all workgroups on one XCD (1, default) or spread (0); polls before a
 // workgroup gives up on a record (0 = default 2^21); test hook: the last workgroup stops
 // publishing from step `step_plus_1 - 1` of every block on (0 = off)

@@ -88,12 +88,6 @@ struct TabView {
     // bk_smask[pair]: the even / odd column of that pair is the slot pending pivot i gave up
     uint32_t *bk_rmask, *bk_smask;
     ExchRec  *la_px, *la_rx;      // kMaxLaRecords pricing / ratio records (persistent look-ahead)
-    // two blocks per sweep: the look-ahead of the second block runs on the
-    // untouched tableau and treats the first block -- selected, not yet in M -- as pending too;
-    // pv_* are that block's list (null: none), and k_sweep32 applies both lists in one pass
-    const double   *pv_col, *pv_prow;
-    const BlockCtl *pv_blk;
-    const uint32_t *pv_rmask, *pv_smask;
     // batch of n_lps same-shape LPs: per-LP element strides (all zero for a single tableau)
     int64_t  n_lps;
     int64_t  zs_M, zs_basis, zs_col, zs_prow, zs_part, zs_p2l, zs_l2p;
@@ -125,9 +119,6 @@ bool block_supported(const TabView &t);
 int  launch_lookahead(const TabView &t, int j, int is_max, double fp_factor, int n_part, hipStream_t s);
 // stamp != 0: apply the pending list only if the look-ahead launch with that epoch base wrote it
 int  launch_sweep(const TabView &t, int kmax, double sgn, hipStream_t s, unsigned stamp = 0);
-// the lists of TWO blocks (t.pv_*: selected first, then t.bk_*: selected with the first one pending)
-// applied in one pass over the tableau
-int  launch_sweep32(const TabView &t, double sgn, hipStream_t s, unsigned stamp_a, unsigned stamp_b);
 // the whole look-ahead of a block (steps 0 .. ksteps-1) as ONE launch of a few persistent
 // workgroups that exchange their reduction candidates through la_px / la_rx; epoch_base (> 0)
 // must grow by at least 2*kMaxBlock+2 from launch to launch on the same tableau (the records

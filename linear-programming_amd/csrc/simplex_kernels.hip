@@ -1555,15 +1555,7 @@ __device__ __forceinline__ bool la_exchange(ValIdx mine, unsigned myflag, ExchRe
 // x - (+0.0) == x bit for bit).
 // one_xcd: see above.  fault > 0 (test hook): the last workgroup stops publishing from step
 // `fault - 1` on, as a workgroup that is not resident would.
-// PREV (two blocks per sweep): t.M is the tableau BEFORE the previous block -- its
-// pivots are selected but not swept in yet -- and t.pv_* is that block's list.  Every value read
-// from t.M is therefore brought forward through the previous block's links first (same general /
-// bare link forms, same operands and order as the sweep applies them), then through this
-// block's: the chains are kB + J links long instead of J.  The previous block's
-// per-thread operands (col_i[my row], prow_i[my pair], i < kB) are loaded once, into registers;
-// its wave-uniform operands (prow_i[slot], col_i[cr]) arrive in lanes 16.. of the same vector
-// loads that fetch this block's.
-template <int KMAX, bool PREV>
+template <int KMAX>
 __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, double sgn,
                                                         double price_tol, double ratio_thr,
                                                         unsigned epoch_base, unsigned max_spins,
@@ -1605,42 +1597,6 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
 
     double  b = (has_row && r < m) ? t.M[r * ld + vc] : 0.0;     // RHS entry of my row
     double2 z = has_pair ? M2[m * ldv + p] : make_double2(0.0, 0.0);   // objective row, my pair
-    // ---- the previous block (selected, not swept into t.M yet)
-    constexpr int KB = PREV ? KMAX : 1;
-    double  ciB[KB];                                             // col_i[my row]
-    double2 piB[KB];                                             // prow_i[my pair]
-    unsigned my_rmB = 0u, my_smB = 0u, wave_rmB = 0u, wave_smB = 0u;
-    int64_t v_crB = -1, v_slB = -1;                              // lane i: pivot row / slot of its pivot i
-    int kB = 0;
-    if constexpr (PREV) {
-        kB = (int)t.pv_blk->n_pending;
-        if (g < t.bk_stride) my_rmB = t.pv_rmask[g];
-        if (g < ldv)         my_smB = t.pv_smask[g];
-        if (lane < kB) { v_crB = t.pv_blk->cr[lane]; v_slB = t.pv_blk->slot[lane]; }
-        const double vB_pvc = (lane < kB) ? t.pv_prow[(int64_t)lane * ld + vc] : 0.0;          // prow_i[RHS column]
-        const double vB_cm  = (lane < kB) ? t.pv_col[(int64_t)lane * t.bk_stride + m] : 0.0;   // col_i[objective row]
-#pragma unroll
-        for (int i = 0; i < KB; ++i) {
-            ciB[i] = (i < kB && has_row) ? t.pv_col[(int64_t)i * t.bk_stride + r] : 0.0;
-            piB[i] = (i < kB && has_pair) ? reinterpret_cast<const double2 *>(t.pv_prow)[(int64_t)i * ldv + p]
-                                          : make_double2(0.0, 0.0);
-        }
-        unsigned orr = my_rmB, ors = (my_smB | (my_smB >> 16)) & 0xffffu;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { orr |= __shfl_xor(orr, off, 64); ors |= __shfl_xor(ors, off, 64); }
-        wave_rmB = __builtin_amdgcn_readfirstlane(orr);
-        wave_smB = __builtin_amdgcn_readfirstlane(ors);
-        // RHS entry and objective-row pair through the previous block, as its sweep computes them
-#pragma unroll
-        for (int i = 0; i < KB; ++i) {
-            if (i < kB) {
-                b = pend(b, false, (my_rmB >> i) & 1u, ciB[i], lane_value(vB_pvc, i));
-                const double cm = lane_value(vB_cm, i);
-                z.x = pend(z.x, (my_smB >> i) & 1u, false, cm, piB[i].x);
-                z.y = pend(z.y, (my_smB >> (16 + i)) & 1u, false, cm, piB[i].y);
-            }
-        }
-    }
     int64_t l0 = (has_pair && 2 * p < vc) ? t.p2l[2 * p] : -1;   // logical columns of my pair
     int64_t l1 = (has_pair && 2 * p + 1 < vc) ? t.p2l[2 * p + 1] : -1;
     int64_t v_cr = -1, v_sl = -1;                                // lane i: pivot row / slot of pivot i
@@ -1696,38 +1652,9 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
         // ---- entering column through the pending chain; RHS entry brought up to date
         double a = has_row ? t.M[r * ld + slot] : 0.0;
         double v_pa = (lane < J - 1) ? ld_l2(&t.bk_prow[(int64_t)lane * ld + slot]) : 0.0;
-        if constexpr (PREV) {                                      // lanes 16.. : the previous block's prow_i[slot]
-            if (lane >= 16 && lane < 16 + kB) v_pa = t.pv_prow[(int64_t)(lane - 16) * ld + slot];
-        }
         drain_vmem();                  // the loads -- and what this wave stored in the previous half-step
         if (lane == J - 1) v_pa = e.u;
         if (J > 0) b = pend(b, false, (my_rm >> (J - 1)) & 1u, s_ci[J - 1][tid], e.w);
-        if constexpr (PREV) {
-            const unsigned slmask = (unsigned)__ballot((lane < kB) & (v_slB == slot));
-            const unsigned gen = slmask | wave_rmB;
-#pragma unroll
-            for (int i0 = 0; i0 < KB; i0 += 4) {
-                if (i0 < kB) {
-                    double prod[4], pa[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        pa[k] = lane_value(v_pa, 16 + i0 + k);         // (0.0 beyond kB, and so is ciB)
-                        prod[k] = ciB[i0 + k] * pa[k];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if ((gen >> (i0 + k)) & 1u) {
-                            const bool is_cr = (my_rmB >> (i0 + k)) & 1u;
-                            if ((slmask >> (i0 + k)) & 1u) a = is_cr ? 1.0 : 0.0;
-                            const double d = a - prod[k];
-                            a = is_cr ? pa[k] : d;
-                        } else {
-                            a = a - prod[k];
-                        }
-                    }
-                }
-            }
-        }
         {
             // pending pivots whose given-up slot is the entering column's slot (uniform); lanes on a pending pivot row
             const unsigned slmask = (unsigned)__ballot((lane < J) & (v_sl == slot));
@@ -1791,43 +1718,10 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
         const double cmj = qq.w;                                 // col_J[m]
         // ---- pivot row through the chain -> prow_J; objective row through pivot J
         double2 y = has_pair ? M2[cr * ldv + p] : make_double2(0.0, 0.0);
-        double v_ccr = (lane < J) ? ld_l2(&t.bk_col[(int64_t)lane * t.bk_stride + cr]) : 0.0;
-        if constexpr (PREV) {                                      // lanes 16.. : the previous block's col_i[cr]
-            if (lane >= 16 && lane < 16 + kB) v_ccr = t.pv_col[(int64_t)(lane - 16) * t.bk_stride + cr];
-        }
+        const double v_ccr = (lane < J) ? ld_l2(&t.bk_col[(int64_t)lane * t.bk_stride + cr]) : 0.0;
         const bool own = has_pair && (p == (slot >> 1));
         const int64_t leaving = own ? ld_l2(&t.basis[cr]) : -1;
         drain_vmem();                  // the loads -- and the col_J entry stored above
-        if constexpr (PREV) {
-            const unsigned crmask = (unsigned)__ballot((lane < kB) & (v_crB == cr));
-            const unsigned gen = crmask | wave_smB;
-#pragma unroll
-            for (int i0 = 0; i0 < KB; i0 += 4) {
-                if (i0 < kB) {
-                    double2 prod[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const double ccr = lane_value(v_ccr, 16 + i0 + k);
-                        prod[k].x = ccr * piB[i0 + k].x;
-                        prod[k].y = ccr * piB[i0 + k].y;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if ((gen >> (i0 + k)) & 1u) {
-                            const bool is_cr = (crmask >> (i0 + k)) & 1u;
-                            if ((my_smB >> (i0 + k)) & 1u)      y.x = is_cr ? 1.0 : 0.0;
-                            if ((my_smB >> (16 + i0 + k)) & 1u) y.y = is_cr ? 1.0 : 0.0;
-                            const double dx = y.x - prod[k].x, dy = y.y - prod[k].y;
-                            y.x = is_cr ? piB[i0 + k].x : dx;
-                            y.y = is_cr ? piB[i0 + k].y : dy;
-                        } else {
-                            y.x = y.x - prod[k].x;
-                            y.y = y.y - prod[k].y;
-                        }
-                    }
-                }
-            }
-        }
         {
             // pending pivots whose pivot row is the new pivot row (uniform); lanes holding a given-up slot
             const unsigned crmask = (unsigned)__ballot((lane < J) & (v_cr == cr));
@@ -2296,786 +2190,6 @@ __global__ __launch_bounds__(256) void k_sweep16(TabView t, const int tr, const 
                 step(xa, xb, r);
                 if (r + U < r1) step(xb, xa, r + U);
             }
-        }
-    }
-    if (prices) {                                              // `last` = new objective-row entries
-        ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
-        const int64_t c0 = 2 * pair;
-        if (active && c0 < vc) {
-            ValIdx c; c.v = last.x * sgn; c.i = t.p2l ? t.p2l[c0] : c0; c.s = c0;
-            best = vi_min(best, c);
-        }
-        if (active && c0 + 1 < vc) {
-            ValIdx c; c.v = last.y * sgn; c.i = t.p2l ? t.p2l[c0 + 1] : c0 + 1; c.s = c0 + 1;
-            best = vi_min(best, c);
-        }
-        best = wave_reduce_min(best);
-        if ((threadIdx.x & 63) == 0) {
-            const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-            part_v[w]   = best.v;
-            t.part_i[w] = best.i;
-            t.part_s[w] = best.s;
-        }
-    }
-}
-
-// ---- the sweep of TWO blocks (up to 32 pending pivots) in one pass over the tableau ---------------
-// The look-ahead of the second block ran on the untouched tableau with the first block's list as
-// "previous" (k_la_block<.., true>), so both lists are pending here: list A = t.pv_* (kA pivots,
-// applied first), list B = t.bk_* (kB pivots).  Same tile, same operands, same roundings and the
-// same link order as two k_sweep16 launches -- but the tableau is read and written once for 32
-// pivots.  Per thread: the prow pairs of all 32 pivots (128 VGPRs), two register sets of four rows;
-// 2 waves per SIMD, which the stream tolerates (tools/microbench/sweep_stream.hip: 32 links cost
-// 113 us against 2 x 88 us for 16 + 16).  Links beyond a list's length are skipped by wave-uniform
-// branches (never multiplied by stale operands); a step that holds a pivot row of either list, or
-// the rows of the last partial step, go through pend() one link at a time.
-template <bool NT>
-__global__ __launch_bounds__(256) void k_sweep32(TabView t, const int tr, const int strip_pairs, const double sgn,
-                                                 const int price, const unsigned stamp_a, const unsigned stamp_b)
-{
-    constexpr int KL = kSweepK, K = 2 * kSweepK, U = 4, CP = ColChunk<U>::CP, NCH = K / CP;
-    const BlockCtl *__restrict__ blkA = t.pv_blk, *__restrict__ blkB = t.blk;
-    int kA = (int)blkA->n_pending, kB = (int)blkB->n_pending;
-    if (stamp_a != 0u && (unsigned)blkA->stamp != stamp_a) kA = 0;   // not this launch pair's list
-    if (stamp_b != 0u && (unsigned)blkB->stamp != stamp_b) kB = 0;
-    if (kA < KL) kB = 0;                                       // (B was selected behind a full A only)
-    if (kA == 0) return;
-    double *__restrict__ M = t.M;
-    const int64_t ld = t.ld, rows = t.rows, vc = t.cols - 1;
-    const int64_t ldv  = ld >> 1;
-    const int64_t pair = (int64_t)blockIdx.x * strip_pairs + threadIdx.x;
-    const bool active  = (int)threadIdx.x < strip_pairs && pair < ldv;
-    const int64_t r0 = (int64_t)blockIdx.y * tr;
-    const int64_t r1 = (r0 + tr < rows) ? r0 + tr : rows;
-    double  *__restrict__ part_v = price ? t.part_v : nullptr;
-    const bool prices = (r1 == rows) && part_v != nullptr;
-    if (!active && !prices) return;                            // no workgroup barrier below
-
-    vec2d *Mp = reinterpret_cast<vec2d *>(M) + pair;
-    auto ld2 = [&](int64_t r) -> vec2d {
-        if constexpr (NT) return __builtin_nontemporal_load(Mp + r * ldv);
-        else              return Mp[r * ldv];
-    };
-    auto st2 = [&](int64_t r, vec2d v) {
-        if constexpr (NT) __builtin_nontemporal_store(v, Mp + r * ldv);
-        else              Mp[r * ldv] = v;
-    };
-    vec2d last; last.x = 0.0; last.y = 0.0;
-    if (active) {
-        vec2d xa[U], xb[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {                          // the first step's rows, requested first
-            xa[u].x = 0.0; xa[u].y = 0.0; xb[u] = xa[u];
-            if (r0 + u < r1) xa[u] = ld2(r0 + u);
-        }
-        // link i < 16: pivot i of list A; link 16 + i: pivot i of list B
-        const unsigned smA = t.pv_smask[pair], smB = kB > 0 ? t.bk_smask[pair] : 0u;
-        const unsigned sx = (smA & 0xffffu) | (smB << 16), sy = (smA >> 16) | (smB & 0xffff0000u);
-        vec2d p[K];
-#pragma unroll
-        for (int i = 0; i < KL; ++i) {
-            p[i].x = 0.0; p[i].y = 0.0; p[KL + i] = p[i];
-            if (i < kA) p[i] = reinterpret_cast<const vec2d *>(t.pv_prow)[(int64_t)i * ldv + pair];
-            if (i < kB) p[KL + i] = reinterpret_cast<const vec2d *>(t.bk_prow)[(int64_t)i * ldv + pair];
-        }
-        // slot columns: the chain starts at the last pivot (of either list) that handed the slot over
-        const bool wave_slots = __any((sx | sy) != 0u);
-        int64_t crx = -1, cry = -1;
-        bool hasx = false, hasy = false;
-        if (wave_slots) {
-            const int lx = sx ? 31 - __clz((int)sx) : -1, ly = sy ? 31 - __clz((int)sy) : -1;
-            if (lx >= 0) { hasx = true; crx = lx < KL ? blkA->cr[lx] : blkB->cr[lx - KL]; }
-            if (ly >= 0) { hasy = true; cry = ly < KL ? blkA->cr[ly] : blkB->cr[ly - KL]; }
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                if (i < lx) p[i].x = 0.0;
-                if (i < ly) p[i].y = 0.0;
-            }
-        }
-        const unsigned o1 = (unsigned)(t.bk_stride * 8);
-        const int64_t chunk_stride = (int64_t)CP * t.bk_stride;
-        const int nlinks = kA + kB;                            // (kB > 0 only behind kA == 16)
-
-        // Rows one at a time, operands from memory: the steps that hold a pivot row of either list
-        // (32 of ~1000) and the last rows of the tableau.  Such a row takes the pivot's normalised
-        // row at its link (what pend() returns there); a slot lane's p[i] was zeroed for i < its last
-        // hand-over, and +0 is exactly what its chain restarts from at the hand-over.
-        auto slow_row = [&](const int64_t r, vec2d x) -> vec2d {
-            if (hasx) x.x = (r == crx) ? 1.0 : 0.0;
-            if (hasy) x.y = (r == cry) ? 1.0 : 0.0;
-            const unsigned rm = __builtin_amdgcn_readfirstlane(t.pv_rmask[r] | (kB > 0 ? t.bk_rmask[r] << 16 : 0u));
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                if (i < (i < KL ? kA : KL + kB)) {             // (uniform)
-                    const double cv = i < KL ? t.pv_col[(int64_t)i * t.bk_stride + r]
-                                             : t.bk_col[(int64_t)(i - KL) * t.bk_stride + r];
-                    const double m0 = cv * p[i].x;
-                    const double m1 = cv * p[i].y;
-                    x.x = x.x - m0;
-                    x.y = x.y - m1;
-                    if ((rm >> i) & 1u) x = p[i];
-                }
-            }
-            return x;
-        };
-        auto step = [&](vec2d (&cur)[U], vec2d (&nxt)[U], const int64_t r) {
-#pragma unroll
-            for (int u = 0; u < U; ++u)                       // next step's rows travel during this one
-                if (r + U + u < r1) nxt[u] = ld2(r + U + u);
-            const uint4 rmA = *reinterpret_cast<const uint4 *>(t.pv_rmask + r);   // uniform (padded to 16 rows)
-            unsigned rm_any = rmA.x | rmA.y | rmA.z | rmA.w;
-            if (kB > 0) {
-                const uint4 rmB = *reinterpret_cast<const uint4 *>(t.bk_rmask + r);
-                rm_any |= rmB.x | rmB.y | rmB.z | rmB.w;
-            }
-            if (rm_any == 0u && r + U <= r1) {
-                if (wave_slots) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        if (hasx) cur[u].x = (r + u == crx) ? 1.0 : 0.0;
-                        if (hasy) cur[u].y = (r + u == cry) ? 1.0 : 0.0;
-                    }
-                }
-                // chunk c: 4 pivots of list A (c < 4) or B, rows r .. r+3
-                auto chunk_base = [&](const int c) -> const double * {
-                    return (c < NCH / 2 ? t.pv_col + (int64_t)c * chunk_stride
-                                        : t.bk_col + (int64_t)(c - NCH / 2) * chunk_stride) + r;
-                };
-                ColChunk<U> A, B;
-                auto apply = [&](const ColChunk<U> &c, const int i0) {
-                    const int lim = i0 < KL ? kA : KL + kB;    // (uniform) links of this chunk's list that are pending
-                    if (i0 + CP <= lim) {
-#pragma unroll
-                        for (int i = 0; i < CP; ++i) {
-                            const vec2d pi = p[i0 + i];
-#pragma unroll
-                            for (int u = 0; u < U; ++u) {
-                                const double cv = c.col(i, u);
-                                const double m0 = cv * pi.x;      // rounded products
-                                const double m1 = cv * pi.y;
-                                cur[u].x = cur[u].x - m0;         // rounded differences
-                                cur[u].y = cur[u].y - m1;
-                            }
-                        }
-                    } else if (i0 < lim) {
-#pragma unroll
-                        for (int i = 0; i < CP; ++i) {
-                            if (i0 + i < lim) {
-                                const vec2d pi = p[i0 + i];
-#pragma unroll
-                                for (int u = 0; u < U; ++u) {
-                                    const double cv = c.col(i, u);
-                                    const double m0 = cv * pi.x;
-                                    const double m1 = cv * pi.y;
-                                    cur[u].x = cur[u].x - m0;
-                                    cur[u].y = cur[u].y - m1;
-                                }
-                            }
-                        }
-                    }
-                };
-                A.issue(chunk_base(0), o1);
-                A.wait();
-#pragma unroll
-                for (int c = 0; c < NCH; c += 2) {            // two SGPR sets, alternating
-                    B.issue(chunk_base(c + 1), o1);
-                    apply(A, c * CP);
-                    B.wait();
-                    if (c + 2 < NCH) A.issue(chunk_base(c + 2), o1);
-                    apply(B, (c + 1) * CP);
-                    if (c + 2 < NCH) A.wait();
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) st2(r + u, cur[u]);
-                last = cur[U - 1];
-            } else {
-#pragma unroll 1
-                for (int u = 0; u < U; ++u) {
-                    if (r + u < r1) {
-                        const vec2d x = slow_row(r + u, ld2(r + u));   // (read again: no run-time index into cur)
-                        st2(r + u, x);
-                        last = x;
-                    }
-                }
-            }
-        };
-        (void)nlinks;
-        for (int64_t r = r0; r < r1; r += 2 * U) {
-            step(xa, xb, r);
-            if (r + U < r1) step(xb, xa, r + U);
-        }
-    }
-    if (prices) {                                              // `last` = new objective-row entries
-        ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
-        const int64_t c0 = 2 * pair;
-        if (active && c0 < vc) {
-            ValIdx c; c.v = last.x * sgn; c.i = t.p2l ? t.p2l[c0] : c0; c.s = c0;
-            best = vi_min(best, c);
-        }
-        if (active && c0 + 1 < vc) {
-            ValIdx c; c.v = last.y * sgn; c.i = t.p2l ? t.p2l[c0 + 1] : c0 + 1; c.s = c0 + 1;
-            best = vi_min(best, c);
-        }
-        best = wave_reduce_min(best);
-        if ((threadIdx.x & 63) == 0) {
-            const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-            part_v[w]   = best.v;
-            t.part_i[w] = best.i;
-            t.part_s[w] = best.s;
-        }
-    }
-}
-
-// ---- the same sweep with the tableau rows AND the col values arriving by LDS-DMA -----------------
-// What holds k_sweep16 at ~5.3 TB/s is not the f64 work and not the bytes in flight
-// (tools/microbench/sweep_stream.hip: the same tile streams at 68-80 us without the links, 88 us with
-// 16 links whose col operands are already in registers, 121 us with col operands from scalar loads):
-// it is the scalar loads.  Every chunk of 4 pivots x 4 rows waits for an s_load that was issued
-// 64 f64 instructions earlier -- 0.13 us of cover for a round trip to an L2 that is busy streaming
-// the tableau -- so a wave's step is four exposed L2 latencies long whatever else is in flight.
-// Here nothing in the row loop is a scalar load and nothing is waited for that was not requested a
-// whole step earlier:
-//   * every wave owns a ring of P groups of 4 tableau rows in LDS (1 KB per row: 64 lanes x 16 B,
-//     lane-linear, exactly what `global_load_lds_dwordx4` writes); the rows of step s+P are
-//     requested as soon as step s has read its own out of the ring -- no register holds a row that
-//     is not being computed, and the step needs ONE register set;
-//   * the col values travel the same way: one DMA instruction brings the 16 pivots x 8 rows of TWO
-//     steps (lane l: pivot l % 16, rows 2*(l / 16), +1), requested two steps ahead; a step reads
-//     its 4 rows x 16 pivots with two ds_read_b128 (lane l then holds col[l % 16][row]), and link i
-//     takes its operand from lane i of every row of 16 lanes with `v_mov_b64_dpp row_newbcast:i`
-//     (one VALU instruction per col value and wave -- a quarter of the four f64 instructions that
-//     use it);
-//   * completion is counted, never drained: VMEM operations of a wave retire in issue order on
-//     gfx9-class hardware, so "the DMAs of step s have landed" is `s_waitcnt vmcnt(n)` with n = the
-//     operations the wave has issued after them (`issued` / `mark_*`: uniform integers).  Operations
-//     the count does not know about (the prow loads of the prologue, the loads of a slow step) only
-//     make a wait stricter.
-// Arithmetic: the statements of k_sweep16 (rounded product, rounded difference, pivot order).
-template <bool NT>
-__device__ __forceinline__ void dma_row16(const void *row_base, unsigned lane_off, unsigned lds_byte)
-{
-    unsigned keep;
-    if constexpr (NT)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(lane_off), "s"(row_base), "s"(lds_byte) : "memory");
-    else
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(lane_off), "s"(row_base), "s"(lds_byte) : "memory");
-}
-
-// the same with ALL 64 lanes enabled (the col values are for the whole wave, whichever of its lanes
-// own a column pair)
-__device__ __forceinline__ void dma_all_lanes16(const void *base, unsigned lane_off, unsigned lds_byte)
-{
-    unsigned keep;
-    unsigned long long ex;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_or_saveexec_b64 %1, -1\n\t"
-                 "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep), "=&s"(ex) : "v"(lane_off), "s"(base), "s"(lds_byte) : "memory", "scc");
-}
-
-__device__ __forceinline__ void wait_vm_at_most(int n)       // the largest immediate <= n
-{
-    if      (n >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else if (n >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-    else if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (n >= 9)  asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    else if (n >= 8)  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (n >= 5)  asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if (n >= 4)  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// lane I of every row of 16 lanes, to all lanes of that row
-template <int I> __device__ __forceinline__ double lane16_bcast(double v)
-{
-    double c;
-    asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(c) : "v"(v), "n"(I));
-    return c;
-}
-
-// links I..15 applied to U rows; cv[u]: lane l holds col_{l % 16}[row u]
-template <int I, int U> struct SweepLinks {
-    static __device__ __forceinline__ void run(vec2d (&cur)[U], const double (&cv)[U], const vec2d (&p)[kSweepK])
-    {
-        if constexpr (I < kSweepK) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const double c  = lane16_bcast<I>(cv[u]);
-                const double m0 = c * p[I].x;                  // rounded products
-                const double m1 = c * p[I].y;
-                cur[u].x = cur[u].x - m0;                      // rounded differences
-                cur[u].y = cur[u].y - m1;
-            }
-            SweepLinks<I + 1, U>::run(cur, cv, p);
-        }
-    }
-};
-
-template <bool NT, int P>
-__global__ __launch_bounds__(256) void k_sweep16d(TabView t, const int tr, const int strip_pairs,
-                                                  const double sgn, const int price, const unsigned stamp)
-{
-    constexpr int K = kSweepK, U = 4;
-    constexpr int kWaveVec = P * U * 64 + 2 * 64;              // vec2d per wave: row ring + two col groups
-    extern __shared__ __attribute__((aligned(16))) double ring_lds[];
-    t = lp_slice(t);
-    const BlockCtl *__restrict__ blk = t.blk;
-    const int k = (int)blk->n_pending;
-    if (k == 0) return;
-    if (stamp != 0u && (unsigned)blk->stamp != stamp) return;
-    double *__restrict__ M = t.M;
-    const int64_t ld = t.ld, rows = t.rows, vc = t.cols - 1;
-    const int64_t ldv  = ld >> 1;
-    const int64_t pair = (int64_t)blockIdx.x * strip_pairs + threadIdx.x;
-    const bool active  = (int)threadIdx.x < strip_pairs && pair < ldv;
-    const int64_t r0 = (int64_t)blockIdx.y * tr;               // tr is a multiple of 8, at most 64
-    const int64_t r1 = (r0 + tr < rows) ? r0 + tr : rows;
-    double  *__restrict__ part_v = price ? t.part_v : nullptr;
-    const bool prices = (r1 == rows) && part_v != nullptr;
-    // rows of this tile that are the pivot row of a pending pivot: bit per row
-    const int lane = (int)(threadIdx.x & 63);
-    const unsigned long long hot = __ballot(r0 + lane < r1 && lane < tr && t.bk_rmask[r0 + lane] != 0u);
-    // col DMA: lane l fetches pivot l % 16, rows 2 * (l / 16), +1 of a group of 8 rows
-    unsigned col_off = (unsigned)(((int64_t)(lane & 15) * t.bk_stride + 2 * (lane >> 4)) * 8);
-    asm volatile("" : "+v"(col_off));                          // computed HERE, while every lane is enabled
-    // A wave with at least one column pair runs with ALL its lanes enabled (the col values are
-    // broadcast from lanes 0..15 of every row of 16, whoever owns a pair): a lane without a pair
-    // works on the strip's first pair and stores nothing.
-    const bool wave_on = __any(active);
-    if (!wave_on && !prices) return;                           // no workgroup barrier below
-    const int64_t pair_ld = active ? pair : (int64_t)blockIdx.x * strip_pairs;
-
-    vec2d *Mp = reinterpret_cast<vec2d *>(M) + pair_ld;
-    auto ld2 = [&](int64_t r) -> vec2d {
-        if constexpr (NT) return __builtin_nontemporal_load(Mp + r * ldv);
-        else              return Mp[r * ldv];
-    };
-    auto st2 = [&](int64_t r, vec2d v) {
-        if (active) {
-            if constexpr (NT) __builtin_nontemporal_store(v, Mp + r * ldv);
-            else              Mp[r * ldv] = v;
-        }
-    };
-    vec2d last; last.x = 0.0; last.y = 0.0;
-    if (wave_on) {
-        const unsigned sm = t.bk_smask[pair_ld];
-        if (k != K) {
-            // a partial block (the look-ahead terminated inside it): one row at a time, operands
-            // from memory -- runs once per solve
-            const unsigned sx = sm & 0xffffu, sy = sm >> 16;
-            for (int64_t r = r0; r < r1; ++r) {
-                vec2d x = ld2(r);
-                const unsigned rm = t.bk_rmask[r];
-                for (int i = 0; i < k; ++i) {
-                    const double cv = t.bk_col[(int64_t)i * t.bk_stride + r];
-                    const vec2d pi = reinterpret_cast<const vec2d *>(t.bk_prow)[(int64_t)i * ldv + pair_ld];
-                    const bool is_cr = (rm >> i) & 1u;
-                    x.x = pend(x.x, (sx >> i) & 1u, is_cr, cv, pi.x);
-                    x.y = pend(x.y, (sy >> i) & 1u, is_cr, cv, pi.y);
-                }
-                st2(r, x);
-                last = x;
-            }
-        } else {
-            const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-            const unsigned ring_byte =
-                (unsigned)(unsigned long long)(__attribute__((address_space(3))) double *)ring_lds +
-                (unsigned)wv * (unsigned)(kWaveVec * 16);
-            const unsigned colring_byte = ring_byte + (unsigned)(P * U * 1024);
-            const vec2d *ring = reinterpret_cast<const vec2d *>(ring_lds) + wv * kWaveVec + lane;
-            const vec2d *colring = reinterpret_cast<const vec2d *>(ring_lds) + wv * kWaveVec + P * U * 64 + (lane & 15);
-            const unsigned lane_off = active ? threadIdx.x * 16u : 0u;
-            const unsigned rb = (unsigned)(ld * 8);            // bytes per tableau row (< 2^31)
-            // uniform row pointer of the step being computed, advanced by 4 rows per step
-            const char *grow = reinterpret_cast<const char *>(M) + (int64_t)blockIdx.x * strip_pairs * 16 + r0 * (int64_t)rb;
-            const char *gcol = reinterpret_cast<const char *>(t.bk_col + r0);   // col values of the group being computed
-            const int nrows = (int)(r1 - r0);
-            const int SF = nrows / U, rem = nrows - SF * U;    // full steps, rows of a last partial step
-            const int NG = (SF + 1) / 2;                       // col groups (8 rows each) the full steps read
-            int issued = 0;                                    // VMEM operations this wave has issued (that it counts)
-            int mark_row[P], mark_col[2];                      // `issued` right after the DMAs into that ring slot
-            auto request_rows = [&](const int g, const char *rowp) {   // 4 rows at rowp -> row group g
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    dma_row16<NT>(rowp + (size_t)u * rb, lane_off, ring_byte + (unsigned)((g * U + u) * 1024));
-                issued += U;
-                mark_row[g] = issued;
-            };
-            auto request_col = [&](const int cg, const char *colp) {   // 16 pivots x 8 rows at colp -> col group cg
-                dma_all_lanes16(colp, col_off, colring_byte + (unsigned)(cg * 1024));
-                issued += 1;
-                mark_col[cg] = issued;
-            };
-            mark_col[0] = mark_col[1] = 0;
-            if (NG > 0) request_col(0, gcol);
-#pragma unroll
-            for (int g = 0; g < P; ++g) {
-                mark_row[g] = 0;
-                if (g < SF) request_rows(g, grow + (size_t)(g * U) * rb);
-            }
-            if (NG > 1) request_col(1, gcol + 64);
-            vec2d p[K];
-#pragma unroll
-            for (int i = 0; i < K; ++i)
-                p[i] = reinterpret_cast<const vec2d *>(t.bk_prow)[(int64_t)i * ldv + pair_ld];
-            const unsigned sx = sm & 0xffffu, sy = sm >> 16;
-            // slot columns: chain starts at the last pivot that handed the slot over
-            const bool wave_slots = __any(sm != 0u);
-            unsigned crx = 0x80000000u, cry = 0x80000000u;     // unit row relative to r0 (far away: not in this tile)
-            bool hasx = false, hasy = false;
-            if (wave_slots) {
-                const int lx = sx ? 31 - __clz((int)sx) : -1, ly = sy ? 31 - __clz((int)sy) : -1;
-                if (lx >= 0) { hasx = true; const int64_t d = blk->cr[lx] - r0; if (d >= 0 && d < nrows) crx = (unsigned)d; }
-                if (ly >= 0) { hasy = true; const int64_t d = blk->cr[ly] - r0; if (d >= 0 && d < nrows) cry = (unsigned)d; }
-#pragma unroll
-                for (int i = 0; i < K; ++i) {
-                    if (i < lx) p[i].x = 0.0;
-                    if (i < ly) p[i].y = 0.0;
-                }
-            }
-
-            // Rows one at a time, operands from memory (the rings are not used): the steps that hold
-            // the pivot row of a pending pivot (16 of ~1000) and the last rows of the tableau.  Such
-            // a row takes the pivot's normalised row at link i (what pend() returns there); a slot
-            // lane's p[i] was zeroed for i < its last hand-over, and +0 is exactly what its chain
-            // restarts from at the hand-over.
-            auto slow_rows = [&](const int rr, const int nv) {
-#pragma unroll 1
-                for (int u = 0; u < nv; ++u) {
-                    const int64_t r = r0 + rr + u;
-                    vec2d x = ld2(r);
-                    if (hasx) x.x = (crx == (unsigned)(rr + u)) ? 1.0 : 0.0;
-                    if (hasy) x.y = (cry == (unsigned)(rr + u)) ? 1.0 : 0.0;
-                    const unsigned rm = __builtin_amdgcn_readfirstlane(t.bk_rmask[r]);
-#pragma unroll
-                    for (int i = 0; i < K; ++i) {
-                        const double cv = t.bk_col[(int64_t)i * t.bk_stride + r];
-                        const double m0 = cv * p[i].x;
-                        const double m1 = cv * p[i].y;
-                        x.x = x.x - m0;
-                        x.y = x.y - m1;
-                        if ((rm >> i) & 1u) x = p[i];
-                    }
-                    st2(r, x);
-                    last = x;
-                }
-                issued += nv;                                  // (its loads are waited for by the compiler)
-            };
-            // one full step: rows [rr, rr + 4) of the tile; g = its row group, half = which half of col group cg
-            auto step = [&](const int g, const int cg, const int half, const int sidx) {
-                const int rr = sidx * U;
-                const int mk = mark_row[g] > mark_col[cg] ? mark_row[g] : mark_col[cg];
-                wait_vm_at_most(issued - mk);                  // this step's rows and col values have landed
-                const bool slow = ((hot >> (unsigned)rr) & 0xfull) != 0ull;
-                vec2d cur[U], cpair[2];
-                if (!slow) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) cur[u] = ring[(g * U + u) * 64];
-                    cpair[0] = colring[cg * 64 + (half * 2) * 16];
-                    cpair[1] = colring[cg * 64 + (half * 2 + 1) * 16];
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read out: the slots are free again
-                }
-                if (sidx + P < SF) request_rows(g, grow + (size_t)(P * U) * rb);
-                if (half == 1 && sidx / 2 + 2 < NG) request_col(cg, gcol + 2 * 64);
-                if (slow) {
-                    slow_rows(rr, U);
-                } else {
-                    if (wave_slots) {
-                        const unsigned dx = crx - (unsigned)rr, dy = cry - (unsigned)rr;   // == u on the unit row
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            if (hasx) cur[u].x = (dx == (unsigned)u) ? 1.0 : 0.0;
-                            if (hasy) cur[u].y = (dy == (unsigned)u) ? 1.0 : 0.0;
-                        }
-                    }
-                    const double cv[U] = {cpair[0].x, cpair[0].y, cpair[1].x, cpair[1].y};
-                    SweepLinks<0, U>::run(cur, cv, p);
-                    char *wrow = const_cast<char *>(grow);
-                    if (active) {
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            vec2d *dst = reinterpret_cast<vec2d *>(wrow + (size_t)u * rb + lane_off);
-                            if constexpr (NT) __builtin_nontemporal_store(cur[u], dst);
-                            else              *dst = cur[u];
-                        }
-                    }
-                    issued += U;
-                    last = cur[U - 1];
-                }
-                grow += (size_t)U * rb;
-                if (half == 1) gcol += 64;
-            };
-            static_assert(P == 2, "the step loop is written for two row groups");
-            for (int s0 = 0; s0 < SF; s0 += 4) {               // 4 steps = both row groups x both halves x ... col groups alternate
-                if (s0 + 0 < SF) step(0, 0, 0, s0 + 0);
-                if (s0 + 1 < SF) step(1, 0, 1, s0 + 1);
-                if (s0 + 2 < SF) step(0, 1, 0, s0 + 2);
-                if (s0 + 3 < SF) step(1, 1, 1, s0 + 3);
-            }
-            if (rem > 0) slow_rows(SF * U, rem);               // the last rows of the tableau
-        }
-    }
-    if (prices) {                                              // `last` = new objective-row entries
-        ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
-        const int64_t c0 = 2 * pair;
-        if (active && c0 < vc) {
-            ValIdx c; c.v = last.x * sgn; c.i = t.p2l ? t.p2l[c0] : c0; c.s = c0;
-            best = vi_min(best, c);
-        }
-        if (active && c0 + 1 < vc) {
-            ValIdx c; c.v = last.y * sgn; c.i = t.p2l ? t.p2l[c0 + 1] : c0 + 1; c.s = c0 + 1;
-            best = vi_min(best, c);
-        }
-        best = wave_reduce_min(best);
-        if ((threadIdx.x & 63) == 0) {
-            const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-            part_v[w]   = best.v;
-            t.part_i[w] = best.i;
-            t.part_s[w] = best.s;
-        }
-    }
-}
-
-// links of ONE list applied to U rows: link I of the list is p[OFF + I]; cv[u]: lane l holds that
-// list's col_{l % 16}[row u].  run_some: only the first n links (wave-uniform n)
-template <int I, int N, int OFF, int U> struct SweepLinks2 {
-    static __device__ __forceinline__ void link(vec2d (&cur)[U], const double (&cv)[U], const vec2d (&p)[2 * kSweepK])
-    {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const double c  = lane16_bcast<I>(cv[u]);
-            const double m0 = c * p[OFF + I].x;                // rounded products
-            const double m1 = c * p[OFF + I].y;
-            cur[u].x = cur[u].x - m0;                          // rounded differences
-            cur[u].y = cur[u].y - m1;
-        }
-    }
-    static __device__ __forceinline__ void run(vec2d (&cur)[U], const double (&cv)[U], const vec2d (&p)[2 * kSweepK])
-    {
-        if constexpr (I < N) {
-            link(cur, cv, p);
-            SweepLinks2<I + 1, N, OFF, U>::run(cur, cv, p);
-        }
-    }
-    static __device__ __forceinline__ void run_some(vec2d (&cur)[U], const double (&cv)[U], const vec2d (&p)[2 * kSweepK], const int n)
-    {
-        if constexpr (I < N) {
-            if (I < n) {
-                link(cur, cv, p);
-                SweepLinks2<I + 1, N, OFF, U>::run_some(cur, cv, p, n);
-            }
-        }
-    }
-};
-
-// ---- k_sweep32 with everything arriving by LDS-DMA (the form of k_sweep16d above): list A = t.pv_*
-// (kA pivots, applied first), list B = t.bk_* (kB pivots).  At 32 links a step is 128 + 512 VALU
-// instructions between two memory phases and only two or three waves share a SIMD: the scalar
-// col loads of k_sweep32 (eight dependent chunk waits per step) are what that kernel spends its
-// time on; here every operand of a step was requested a step earlier.
-template <bool NT, int P>
-__global__ __launch_bounds__(256) void k_sweep32d(TabView t, const int tr, const int strip_pairs, const double sgn,
-                                                  const int price, const unsigned stamp_a, const unsigned stamp_b)
-{
-    constexpr int KL = kSweepK, K = 2 * kSweepK, U = 4;
-    constexpr int kWaveVec = P * U * 64 + 4 * 64;              // vec2d per wave: row ring + two col groups x two lists
-    extern __shared__ __attribute__((aligned(16))) double ring_lds[];
-    const BlockCtl *__restrict__ blkA = t.pv_blk, *__restrict__ blkB = t.blk;
-    int kA = (int)blkA->n_pending, kB = (int)blkB->n_pending;
-    if (stamp_a != 0u && (unsigned)blkA->stamp != stamp_a) kA = 0;   // not this launch pair's list
-    if (stamp_b != 0u && (unsigned)blkB->stamp != stamp_b) kB = 0;
-    if (kA < KL) kB = 0;                                       // (B was selected behind a full A only)
-    if (kA == 0) return;
-    double *__restrict__ M = t.M;
-    const int64_t ld = t.ld, rows = t.rows, vc = t.cols - 1;
-    const int64_t ldv  = ld >> 1;
-    const int64_t pair = (int64_t)blockIdx.x * strip_pairs + threadIdx.x;
-    const bool active  = (int)threadIdx.x < strip_pairs && pair < ldv;
-    const int64_t r0 = (int64_t)blockIdx.y * tr;               // tr is a multiple of 8, at most 64
-    const int64_t r1 = (r0 + tr < rows) ? r0 + tr : rows;
-    double  *__restrict__ part_v = price ? t.part_v : nullptr;
-    const bool prices = (r1 == rows) && part_v != nullptr;
-    // rows of this tile that are the pivot row of a pending pivot: bit per row
-    const int lane = (int)(threadIdx.x & 63);
-    const unsigned long long hot = __ballot(r0 + lane < r1 && lane < tr &&
-                                            (t.pv_rmask[r0 + lane] | (kB > 0 ? t.bk_rmask[r0 + lane] : 0u)) != 0u);
-    // col DMA: lane l fetches pivot l % 16, rows 2 * (l / 16), +1 of a group of 8 rows
-    unsigned col_off = (unsigned)(((int64_t)(lane & 15) * t.bk_stride + 2 * (lane >> 4)) * 8);
-    asm volatile("" : "+v"(col_off));                          // computed HERE, while every lane is enabled
-    // A wave with at least one column pair runs with ALL its lanes enabled (the col values are
-    // broadcast from lanes 0..15 of every row of 16, whoever owns a pair): a lane without a pair
-    // works on the strip's first pair and stores nothing.
-    const bool wave_on = __any(active);
-    if (!wave_on && !prices) return;                           // no workgroup barrier below
-    const int64_t pair_ld = active ? pair : (int64_t)blockIdx.x * strip_pairs;
-
-    vec2d *Mp = reinterpret_cast<vec2d *>(M) + pair_ld;
-    auto ld2 = [&](int64_t r) -> vec2d {
-        if constexpr (NT) return __builtin_nontemporal_load(Mp + r * ldv);
-        else              return Mp[r * ldv];
-    };
-    auto st2 = [&](int64_t r, vec2d v) {
-        if (active) {
-            if constexpr (NT) __builtin_nontemporal_store(v, Mp + r * ldv);
-            else              Mp[r * ldv] = v;
-        }
-    };
-    vec2d last; last.x = 0.0; last.y = 0.0;
-    if (wave_on) {
-        // link i < 16: pivot i of list A; link 16 + i: pivot i of list B
-        const unsigned smA = t.pv_smask[pair_ld], smB = kB > 0 ? t.bk_smask[pair_ld] : 0u;
-        const unsigned sx = (smA & 0xffffu) | (smB << 16), sy = (smA >> 16) | (smB & 0xffff0000u);
-        {
-            const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-            const unsigned ring_byte =
-                (unsigned)(unsigned long long)(__attribute__((address_space(3))) double *)ring_lds +
-                (unsigned)wv * (unsigned)(kWaveVec * 16);
-            const unsigned colring_byte = ring_byte + (unsigned)(P * U * 1024);   // [group][list] x 1 KB
-            const vec2d *ring = reinterpret_cast<const vec2d *>(ring_lds) + wv * kWaveVec + lane;
-            const vec2d *colring = reinterpret_cast<const vec2d *>(ring_lds) + wv * kWaveVec + P * U * 64 + (lane & 15);
-            const unsigned lane_off = active ? threadIdx.x * 16u : 0u;
-            const unsigned rb = (unsigned)(ld * 8);            // bytes per tableau row (< 2^31)
-            // uniform row pointer of the step being computed, advanced by 4 rows per step
-            const char *grow = reinterpret_cast<const char *>(M) + (int64_t)blockIdx.x * strip_pairs * 16 + r0 * (int64_t)rb;
-            const char *gcolA = reinterpret_cast<const char *>(t.pv_col + r0);   // col values of the group being computed
-            const char *gcolB = reinterpret_cast<const char *>(t.bk_col + r0);
-            const int nrows = (int)(r1 - r0);
-            const int SF = nrows / U, rem = nrows - SF * U;    // full steps, rows of a last partial step
-            const int NG = (SF + 1) / 2;                       // col groups (8 rows each) the full steps read
-            int issued = 0;                                    // VMEM operations this wave has issued (that it counts)
-            int mark_row[P], mark_col[2];                      // `issued` right after the DMAs into that ring slot
-            auto request_rows = [&](const int g, const char *rowp) {   // 4 rows at rowp -> row group g
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    dma_row16<NT>(rowp + (size_t)u * rb, lane_off, ring_byte + (unsigned)((g * U + u) * 1024));
-                issued += U;
-                mark_row[g] = issued;
-            };
-            auto request_col = [&](const int cg, const int64_t byte_off) {   // 2 x 16 pivots x 8 rows -> col group cg
-                dma_all_lanes16(gcolA + byte_off, col_off, colring_byte + (unsigned)(cg * 2048));
-                dma_all_lanes16(gcolB + byte_off, col_off, colring_byte + (unsigned)(cg * 2048 + 1024));
-                issued += 2;
-                mark_col[cg] = issued;
-            };
-            mark_col[0] = mark_col[1] = 0;
-            if (NG > 0) request_col(0, 0);
-#pragma unroll
-            for (int g = 0; g < P; ++g) {
-                mark_row[g] = 0;
-                if (g < SF) request_rows(g, grow + (size_t)(g * U) * rb);
-            }
-            if (NG > 1) request_col(1, 64);
-            vec2d p[K];
-#pragma unroll
-            for (int i = 0; i < KL; ++i) {
-                p[i].x = 0.0; p[i].y = 0.0; p[KL + i] = p[i];
-                if (i < kA) p[i] = reinterpret_cast<const vec2d *>(t.pv_prow)[(int64_t)i * ldv + pair_ld];
-                if (i < kB) p[KL + i] = reinterpret_cast<const vec2d *>(t.bk_prow)[(int64_t)i * ldv + pair_ld];
-            }
-            // slot columns: the chain starts at the last pivot (of either list) that handed the slot over
-            const bool wave_slots = __any((sx | sy) != 0u);
-            unsigned crx = 0x80000000u, cry = 0x80000000u;     // unit row relative to r0 (far away: not in this tile)
-            bool hasx = false, hasy = false;
-            if (wave_slots) {
-                const int lx = sx ? 31 - __clz((int)sx) : -1, ly = sy ? 31 - __clz((int)sy) : -1;
-                if (lx >= 0) { hasx = true; const int64_t d = (lx < KL ? blkA->cr[lx] : blkB->cr[lx - KL]) - r0; if (d >= 0 && d < nrows) crx = (unsigned)d; }
-                if (ly >= 0) { hasy = true; const int64_t d = (ly < KL ? blkA->cr[ly] : blkB->cr[ly - KL]) - r0; if (d >= 0 && d < nrows) cry = (unsigned)d; }
-#pragma unroll
-                for (int i = 0; i < K; ++i) {
-                    if (i < lx) p[i].x = 0.0;
-                    if (i < ly) p[i].y = 0.0;
-                }
-            }
-
-            // Rows one at a time, operands from memory (the rings are not used): the steps that hold
-            // the pivot row of a pending pivot (16 of ~1000) and the last rows of the tableau.  Such
-            // a row takes the pivot's normalised row at link i (what pend() returns there); a slot
-            // lane's p[i] was zeroed for i < its last hand-over, and +0 is exactly what its chain
-            // restarts from at the hand-over.
-            auto slow_rows = [&](const int rr, const int nv) {
-#pragma unroll 1
-                for (int u = 0; u < nv; ++u) {
-                    const int64_t r = r0 + rr + u;
-                    vec2d x = ld2(r);
-                    if (hasx) x.x = (crx == (unsigned)(rr + u)) ? 1.0 : 0.0;
-                    if (hasy) x.y = (cry == (unsigned)(rr + u)) ? 1.0 : 0.0;
-                    const unsigned rm = __builtin_amdgcn_readfirstlane(t.pv_rmask[r] | (kB > 0 ? t.bk_rmask[r] << 16 : 0u));
-#pragma unroll
-                    for (int i = 0; i < K; ++i) {
-                        if (i < (i < KL ? kA : KL + kB)) {     // (uniform)
-                            const double cv = i < KL ? t.pv_col[(int64_t)i * t.bk_stride + r]
-                                                     : t.bk_col[(int64_t)(i - KL) * t.bk_stride + r];
-                            const double m0 = cv * p[i].x;
-                            const double m1 = cv * p[i].y;
-                            x.x = x.x - m0;
-                            x.y = x.y - m1;
-                            if ((rm >> i) & 1u) x = p[i];
-                        }
-                    }
-                    st2(r, x);
-                    last = x;
-                }
-                issued += nv;                                  // (its loads are waited for by the compiler)
-            };
-            // one full step: rows [rr, rr + 4) of the tile; g = its row group, half = which half of col group cg
-            auto step = [&](const int g, const int cg, const int half, const int sidx) {
-                const int rr = sidx * U;
-                const int mk = mark_row[g] > mark_col[cg] ? mark_row[g] : mark_col[cg];
-                wait_vm_at_most(issued - mk);                  // this step's rows and col values have landed
-                const bool slow = ((hot >> (unsigned)rr) & 0xfull) != 0ull;
-                vec2d cur[U], cpa[2], cpb[2];
-                if (!slow) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) cur[u] = ring[(g * U + u) * 64];
-                    cpa[0] = colring[cg * 128 + (half * 2) * 16];
-                    cpa[1] = colring[cg * 128 + (half * 2 + 1) * 16];
-                    cpb[0] = colring[cg * 128 + 64 + (half * 2) * 16];
-                    cpb[1] = colring[cg * 128 + 64 + (half * 2 + 1) * 16];
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read out: the slots are free again
-                }
-                if (sidx + P < SF) request_rows(g, grow + (size_t)(P * U) * rb);
-                if (half == 1 && sidx / 2 + 2 < NG) request_col(cg, (int64_t)(sidx / 2 + 2) * 64);
-                if (slow) {
-                    slow_rows(rr, U);
-                } else {
-                    if (wave_slots) {
-                        const unsigned dx = crx - (unsigned)rr, dy = cry - (unsigned)rr;   // == u on the unit row
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            if (hasx) cur[u].x = (dx == (unsigned)u) ? 1.0 : 0.0;
-                            if (hasy) cur[u].y = (dy == (unsigned)u) ? 1.0 : 0.0;
-                        }
-                    }
-                    const double cva[U] = {cpa[0].x, cpa[0].y, cpa[1].x, cpa[1].y};
-                    const double cvb[U] = {cpb[0].x, cpb[0].y, cpb[1].x, cpb[1].y};
-                    if (kA == KL) SweepLinks2<0, KL, 0, U>::run(cur, cva, p);
-                    else          SweepLinks2<0, KL, 0, U>::run_some(cur, cva, p, kA);
-                    if (kB == KL) SweepLinks2<0, KL, KL, U>::run(cur, cvb, p);
-                    else if (kB > 0) SweepLinks2<0, KL, KL, U>::run_some(cur, cvb, p, kB);
-                    char *wrow = const_cast<char *>(grow);
-                    if (active) {
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            vec2d *dst = reinterpret_cast<vec2d *>(wrow + (size_t)u * rb + lane_off);
-                            if constexpr (NT) __builtin_nontemporal_store(cur[u], dst);
-                            else              *dst = cur[u];
-                        }
-                    }
-                    issued += U;
-                    last = cur[U - 1];
-                }
-                grow += (size_t)U * rb;
-            };
-            static_assert(P == 2, "the step loop is written for two row groups");
-            for (int s0 = 0; s0 < SF; s0 += 4) {               // 4 steps = both row groups x both halves x ... col groups alternate
-                if (s0 + 0 < SF) step(0, 0, 0, s0 + 0);
-                if (s0 + 1 < SF) step(1, 0, 1, s0 + 1);
-                if (s0 + 2 < SF) step(0, 1, 0, s0 + 2);
-                if (s0 + 3 < SF) step(1, 1, 1, s0 + 3);
-            }
-            if (rem > 0) slow_rows(SF * U, rem);               // the last rows of the tableau
         }
     }
     if (prices) {                                              // `last` = new objective-row entries
@@ -3930,8 +3044,6 @@ bool launch_batch_solve(const TabView &t, int is_max, double f, hipStream_t s)
     return true;
 }
 static int g_sweep_tr = 0, g_sweep_nt = -1;                     // 0 / -1: by size
-static int g_sweep32_impl = 0;                                  // two lists: 0 k_sweep32d (LDS-DMA), 1 k_sweep32 (scalar col loads)
-static int g_sweep_dma = 0;                                     // >0: k_sweep16d with that many ring groups
 static int g_sweep_impl = 0;                                    // 0: k_sweep16 for full blocks, 1: k_sweep always
 bool launch_batch_block_split(const TabView &t, int is_max, double f, hipStream_t s)
 {
@@ -4159,28 +3271,15 @@ void launch_la_block(const TabView &t, int ksteps, int is_max, double f, unsigne
     const int nw = (int)((need + kLaThreads - 1) / kLaThreads);
     // one-XCD mode: 8 x nw blocks, every eighth takes part (the kernel verifies where they run)
     const int one_xcd = g_la_one_xcd && nw > 1;
-    if (t.pv_blk)
-        hipLaunchKernelGGL((k_la_block<kMaxBlock, true>), dim3(one_xcd ? 8 * nw : nw), dim3(kLaThreads), 0, s, t, ksteps,
-                           sgn_of(is_max), (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon, epoch_base,
-                           g_la_max_spins, one_xcd, g_la_fault);
-    else
-        hipLaunchKernelGGL((k_la_block<kMaxBlock, false>), dim3(one_xcd ? 8 * nw : nw), dim3(kLaThreads), 0, s, t, ksteps,
-                           sgn_of(is_max), (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon, epoch_base,
-                           g_la_max_spins, one_xcd, g_la_fault);
+    hipLaunchKernelGGL(k_la_block<kMaxBlock>, dim3(one_xcd ? 8 * nw : nw), dim3(kLaThreads), 0, s, t, ksteps,
+                       sgn_of(is_max), (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon, epoch_base,
+                       g_la_max_spins, one_xcd, g_la_fault);
 }
 
 static int g_sweep_u = 4;                                       // rows per step of k_sweep16: 4, or 8 (measured
                                                                 // slower: 199 VGPRs, 2 waves per SIMD, 125 vs 103 us)
 void set_sweep_shape(int tr, int nt) { g_sweep_tr = tr >= 4 ? tr / 4 * 4 : 0; g_sweep_nt = nt; }
-void set_sweep_impl(int impl)
-{
-    g_sweep_impl = impl == 1 ? 1 : 0;
-    if (impl == 4 || impl == 8) g_sweep_u = impl;
-    if (impl == 0 || impl == 1 || impl == 4 || impl == 8) g_sweep_dma = 0;
-    if (impl == 32) g_sweep32_impl = 0;
-    if (impl == 33) g_sweep32_impl = 1;
-    if (impl == 22) g_sweep_dma = 2;                         // k_sweep16d: rows and col values by LDS-DMA
-}
+void set_sweep_impl(int impl) { g_sweep_impl = impl == 1 ? 1 : 0; if (impl == 4 || impl == 8) g_sweep_u = impl; }
 
 template <int KMAX>
 static void launch_sweep_t(const TabView &t, dim3 grid, int tr, int sp, double sgn, bool nt, unsigned stamp,
@@ -4211,13 +3310,6 @@ int launch_sweep(const TabView &t, int kmax, double sgn, hipStream_t s, unsigned
     const dim3 grid((unsigned)strips, (unsigned)((t.rows + tr - 1) / tr));
     const double bytes = (double)t.rows * (double)t.ld * 8.0;
     const bool nt = g_sweep_nt < 0 ? bytes > kNtThresholdBytes : g_sweep_nt != 0;
-    if (kmax == kSweepK && g_sweep_impl == 0 && g_sweep_dma > 0 && tr <= 64 && tr % 8 == 0) {
-        // rows and col values by LDS-DMA: per wave a ring of 2 groups of 4 rows + 2 col groups
-        const size_t lds = 4 * (2 * 4 + 2) * 1024;
-        if (nt) hipLaunchKernelGGL((k_sweep16d<true, 2>),  grid, dim3(256), lds, s, t, (int)tr, (int)sp, sgn, 1, stamp);
-        else    hipLaunchKernelGGL((k_sweep16d<false, 2>), grid, dim3(256), lds, s, t, (int)tr, (int)sp, sgn, 1, stamp);
-        return strips * (block / 64);
-    }
     if (kmax == kSweepK && g_sweep_impl == 0) {
         // rows in flight per thread and step: 8 when the tile is a multiple of 8 rows (bk_rmask is
         // padded to a multiple of 16 rows, so the uint4 mask loads of the last tile stay inside)
@@ -4235,36 +3327,6 @@ int launch_sweep(const TabView &t, int kmax, double sgn, hipStream_t s, unsigned
     else if (kmax <= 4) launch_sweep_t<4>(t, grid, (int)tr, (int)sp, sgn, nt, stamp, s);
     else if (kmax <= 8) launch_sweep_t<8>(t, grid, (int)tr, (int)sp, sgn, nt, stamp, s);
     else                launch_sweep_t<16>(t, grid, (int)tr, (int)sp, sgn, nt, stamp, s);
-    return strips * (block / 64);
-}
-
-// Two pending lists (t.pv_* then t.bk_*) applied in one pass: see k_sweep32.
-int launch_sweep32(const TabView &t, double sgn, hipStream_t s, unsigned stamp_a, unsigned stamp_b)
-{
-    const int block = 256;
-    const int64_t ldv = t.ld >> 1;
-    int strips = (int)((ldv + block - 1) / block);
-    int64_t sp = (ldv + strips - 1) / strips;
-    sp = (sp + 7) / 8 * 8;
-    if (sp > block) sp = block;
-    strips = (int)((ldv + sp - 1) / sp);
-    int64_t tr = g_sweep_tr;
-    if (tr == 0) {
-        tr = 32;
-        while (tr > 4 && ((t.rows + tr - 1) / tr) * strips < 2048) tr /= 2;
-    }
-    while ((t.rows + tr - 1) / tr > 65535) tr *= 2;            // grid.y limit
-    const dim3 grid((unsigned)strips, (unsigned)((t.rows + tr - 1) / tr));
-    const double bytes = (double)t.rows * (double)t.ld * 8.0;
-    const bool nt = g_sweep_nt < 0 ? bytes > kNtThresholdBytes : g_sweep_nt != 0;
-    if (g_sweep32_impl == 0 && tr <= 64 && tr % 8 == 0) {      // rows and col values by LDS-DMA
-        const size_t lds = 4 * (2 * 4 + 4) * 1024;
-        if (nt) hipLaunchKernelGGL((k_sweep32d<true, 2>),  grid, dim3(256), lds, s, t, (int)tr, (int)sp, sgn, 1, stamp_a, stamp_b);
-        else    hipLaunchKernelGGL((k_sweep32d<false, 2>), grid, dim3(256), lds, s, t, (int)tr, (int)sp, sgn, 1, stamp_a, stamp_b);
-        return strips * (block / 64);
-    }
-    if (nt) hipLaunchKernelGGL((k_sweep32<true>),  grid, dim3(256), 0, s, t, (int)tr, (int)sp, sgn, 1, stamp_a, stamp_b);
-    else    hipLaunchKernelGGL((k_sweep32<false>), grid, dim3(256), 0, s, t, (int)tr, (int)sp, sgn, 1, stamp_a, stamp_b);
     return strips * (block / 64);
 }
 
