@@ -351,11 +351,14 @@ def main():
         lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, args.warmup, 1), "warmup")
         L.mi355x_tab_sync(h, ctypes.byref(npv))
         if not args.no_events:
-            # every launch of a short run (the driver's 20-step run is two blocks), every k-th of a
-            # long one (~50 event pairs per kernel class: the event records are host work inside the timed region)
+            # every k-th launch of a long run (~50 event pairs per kernel class: the event records are
+            # host work inside the timed region); a short run (the driver's 20 steps are one full
+            # block + 4) records nothing inside the timed region -- its kernel statistics come from
+            # the full blocks run right AFTER it (below)
             launches = max(1, args.steps // max(L.mi355x_tab_block_size(h), 1))
             stride = args.event_stride if args.event_stride > 0 else max(1, launches // 50)
-            L.mi355x_tab_timing_enable(h, stride)
+            if launches >= 8 or args.event_stride > 0:
+                L.mi355x_tab_timing_enable(h, stride)
         handles.append(h)
     seed = lp.synth.seed_for(cfg, rank)
     h = handles[0]
@@ -410,6 +413,7 @@ def main():
             # a short run (the driver's 20 steps are ONE full block): more event samples from full
             # blocks run right AFTER the timed region on the same tableau -- kernel statistics
             # only, not part of `value`
+            L.mi355x_tab_timing_enable(handles[-1], 1)
             lp.capi.check(L.mi355x_tab_solve_async(handles[-1], 1, 1024.0, 12 * block, 0), "extra event samples")
             L.mi355x_tab_sync(handles[-1], ctypes.byref(npv))
             n2, a2, m2 = read_events(0)
