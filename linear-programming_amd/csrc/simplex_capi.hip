@@ -1274,6 +1274,7 @@ int mi355x_shard_price(mi355x_tab *t, int is_max, int64_t col_offset, double *de
     rc = ensure_dense(t);
     if (rc != MI_OK) return rc;
     t->shard_is_max = is_max ? 1 : 0;
+    t->v.col_bias = t->v.p2l ? 0 : col_offset;        // a dense shard's column 0 is global column col_offset
     const int np = (t->n_part > 0 && t->part_is_max == (is_max ? 1 : 0)) ? t->n_part : 0;
     launch_shard_price(t->v, is_max, col_offset, dev_out2, np, t->stream);
     HIP_TRY(hipGetLastError());

@@ -79,6 +79,7 @@ struct TabView {
     // maps; both null for the dense logical layout
     int64_t *p2l;         // cols-1 entries: logical column stored in physical slot j
     int64_t *l2p;         // logical var_count entries: slot of a logical column, -1 if basic
+    int64_t  col_bias;    // dense column shard: global index of its column 0 (0 everywhere else)
     // blocked pivoting: entering-column snapshots (kMaxBlock x bk_stride), normalised pivot rows
     // (kMaxBlock x ld of the view in use) and the pending list; null when not available
     double   *bk_col, *bk_prow;

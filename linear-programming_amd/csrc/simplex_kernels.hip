@@ -85,6 +85,34 @@ __device__ __forceinline__ ValIdx vi_min(ValIdx a, ValIdx b)
     return r;
 }
 
+// A pricing candidate (key = objective-row entry in key space, LOGICAL column, physical slot).
+// find-entering-column (src/simplex.lisp:362-379) starts from column 0 and replaces the incumbent
+// only by a strictly smaller entry.  With NaNs in the objective row (inf - inf after an overflow)
+// that is: a NaN entry never replaces anything -- it is no candidate at all --, and a NaN in
+// column 0 is never replaced: the winner is then column 0, (fp< NaN 0) fails, and the tableau
+// counts as optimal.  Every reduction below is order-independent under exactly these rules: a NaN
+// key leaves the candidate empty, except in logical column 0, where it becomes the unbeatable
+// candidate (-inf, 0) whose payload is kNanColumn0; whoever consumes a pricing winner tests
+// price_says_optimal().
+constexpr int64_t kNanColumn0 = 0xffffffffll;       // (fits the 32 payload bits of an exchange record)
+
+// (bias: a dense column shard numbers its columns from 0; its first GLOBAL column is t.col_bias)
+__device__ __forceinline__ ValIdx price_cand(double key, int64_t logical, int64_t slot, int64_t bias = 0)
+{
+    ValIdx c; c.v = key; c.i = logical; c.s = slot;
+    if (key != key) {
+        if (logical + bias == 0) { c.v = -__builtin_inf(); c.s = kNanColumn0; }
+        else              c.i = -1;
+    }
+    return c;
+}
+
+// (fp< v 0 factor/8) on the winner: nothing to enter <=> the tableau is optimal
+__device__ __forceinline__ bool price_says_optimal(const ValIdx &e, double price_tol)
+{
+    return e.i < 0 || e.s == kNanColumn0 || !(e.v < 0.0 - price_tol);
+}
+
 // Wave-wide lexicographic minimum, result valid in lane 0.  A fixed binary tree -- lane l takes
 // lane l+32, then l+16, l+8, ... -- because with NaN candidates vi_min is not associative and the
 // tree order is part of the (tested) behaviour.  The two steps that cross rows of 16 lanes use
@@ -163,7 +191,8 @@ constexpr int kBatch = 8;
 template <int THREADS = kSelThreads>
 __device__ __forceinline__ ValIdx block_price(const double *__restrict__ obj, int64_t ncols,
                                               double sgn, double *s_v, long long *s_i,
-                                              const int64_t *__restrict__ p2l = nullptr)
+                                              const int64_t *__restrict__ p2l = nullptr,
+                                              const int64_t bias = 0)
 {
     // p2l != nullptr (compact representation): physical slot -> logical column; the winner is
     // the lexicographic (key, LOGICAL column) minimum, i.e. still the reference's lowest-index
@@ -182,15 +211,14 @@ __device__ __forceinline__ ValIdx block_price(const double *__restrict__ obj, in
         for (int g = 0; g < kBatch; ++g) {
             const int64_t p = base + (int64_t)g * THREADS + threadIdx.x;
             if (p < npair) {
-                ValIdx c0, c1;
-                c0.v = v[g].x * sgn; c0.i = p2l ? p2l[2 * p] : 2 * p;         c0.s = 2 * p;
-                c1.v = v[g].y * sgn; c1.i = p2l ? p2l[2 * p + 1] : 2 * p + 1; c1.s = 2 * p + 1;
+                const ValIdx c0 = price_cand(v[g].x * sgn, p2l ? p2l[2 * p] : 2 * p, 2 * p, p2l ? 0 : bias);
+                const ValIdx c1 = price_cand(v[g].y * sgn, p2l ? p2l[2 * p + 1] : 2 * p + 1, 2 * p + 1, p2l ? 0 : bias);
                 best = vi_min(vi_min(best, c0), c1);
             }
         }
     }
     if ((ncols & 1) && threadIdx.x == 0) {          // odd tail element
-        ValIdx t; t.v = obj[ncols - 1] * sgn; t.i = p2l ? p2l[ncols - 1] : ncols - 1; t.s = ncols - 1;
+        ValIdx t = price_cand(obj[ncols - 1] * sgn, p2l ? p2l[ncols - 1] : ncols - 1, ncols - 1, p2l ? 0 : bias);
         best = vi_min(best, t);
     }
     return block_reduce_min<THREADS>(best, s_v, s_i);
@@ -223,8 +251,9 @@ __device__ __forceinline__ ValIdx block_gather_ratio(const TabView &t, int64_t e
                                                      int *nonfinite = nullptr)
 {
     const int64_t m = t.rows - 1, vc = t.cols - 1;
-    int bad = 0;
+    int bad = 0, nanq = 0;
     ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
+    ValIdx first; first.v = 0.0; first.i = -1; first.s = 0;   // this thread's first eligible row (all keys equal: lowest row wins)
     for (int64_t base = 0; base < t.rows; base += (int64_t)kBatch * THREADS) {
         double a[kBatch], b[kBatch];
 #pragma unroll
@@ -239,12 +268,53 @@ __device__ __forceinline__ ValIdx block_gather_ratio(const TabView &t, int64_t e
             if (r < t.rows) { t.col[r] = a[g]; bad |= !(fabs(a[g]) <= 1.7976931348623157e308); }
             if (r < m && ratio_thr < a[g]) {         // (fp< 0 a factor/2) -> (< (+ 0 thr) a)
                 const double q = b[g] / a[g];
-                if (best.i < 0 || q < best.v) { best.v = q; best.i = r; best.s = __double_as_longlong(a[g]); }
+                if (first.i < 0) { first.i = r; first.s = __double_as_longlong(a[g]); }
+                if (q != q) nanq = 1;              // no candidate (unless it is the FIRST eligible row: below)
+                else if (best.i < 0 || q < best.v) { best.v = q; best.i = r; best.s = __double_as_longlong(a[g]); }
             }
         }
     }
     if (nonfinite) *nonfinite = bad;               // this thread's entries only
-    return block_reduce_min<THREADS>(best, s_v, s_i);
+    best = block_reduce_min<THREADS>(best, s_v, s_i);
+    // find-pivoting-row takes the first eligible row and replaces it only by a strictly smaller
+    // quotient: a NaN quotient (inf / inf, NaN / x after an overflow) wins iff its row is the
+    // FIRST eligible one, and is no candidate otherwise.
+    if (__syncthreads_or(nanq)) {
+        first = block_reduce_min<THREADS>(first, s_v, s_i);
+        if (first.i >= 0) {
+            const double a0 = __longlong_as_double(first.s);
+            const double b0 = rhs_src ? rhs_src[first.i] : t.M[first.i * t.ld + vc];
+            const double q0 = b0 / a0;
+            if (q0 != q0) { best.v = q0; best.i = first.i; best.s = first.s; }
+        }
+    }
+    return best;
+}
+
+// The same decision from a contiguous snapshot of the entering column (col[r], r < rows) -- what the
+// split select falls back to when one of its workgroups met a NaN quotient (see above).
+template <int THREADS>
+__device__ __forceinline__ ValIdx block_ratio_from_snapshot(const TabView &t, const double *__restrict__ col,
+                                                            double ratio_thr, double *s_v, long long *s_i)
+{
+    const int64_t m = t.rows - 1, vc = t.cols - 1;
+    ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
+    ValIdx first; first.v = 0.0; first.i = -1; first.s = 0;
+    for (int64_t r = threadIdx.x; r < m; r += THREADS) {
+        const double a = col[r];
+        if (ratio_thr < a) {
+            const double q = t.M[r * t.ld + vc] / a;
+            if (first.i < 0) { first.i = r; first.s = __double_as_longlong(a); }
+            if (q == q && (best.i < 0 || q < best.v)) { best.v = q; best.i = r; best.s = __double_as_longlong(a); }
+        }
+    }
+    best  = block_reduce_min<THREADS>(best, s_v, s_i);
+    first = block_reduce_min<THREADS>(first, s_v, s_i);
+    if (first.i >= 0) {
+        const double q0 = t.M[first.i * t.ld + vc] / __longlong_as_double(first.s);
+        if (q0 != q0) { best.v = q0; best.i = first.i; best.s = first.s; }
+    }
+    return best;
 }
 
 // prow[c] = M[cr][c] / M[cr][ec]  (src/simplex.lisp:343-348), padding columns zeroed.
@@ -347,10 +417,10 @@ __global__ __launch_bounds__(THREADS) void k_select(TabView t, double sgn, doubl
 
     // n_part > 0: the preceding k_update of this tableau priced the new objective row
     const ValIdx e = n_part > 0 ? block_price_partials<THREADS>(t.part_v, t.part_i, t.part_s, n_part, s_v, s_i)
-                                : block_price<THREADS>(t.M + m * t.ld, vc, sgn, s_v, s_i, t.p2l);
+                                : block_price<THREADS>(t.M + m * t.ld, vc, sgn, s_v, s_i, t.p2l, t.col_bias);
     if (c0.status != kRunning) return;
     // (fp< v 0 factor/8): v < 0 - tol ; min problems: (fp> v 0 factor/8) <=> -v < 0 - tol
-    if (e.i < 0 || !(e.v < 0.0 - price_tol)) {
+    if (price_says_optimal(e, price_tol)) {
         if (threadIdx.x == 0) ctl->status = 0;      // MI_OPTIMAL
         return;
     }
@@ -411,9 +481,9 @@ __global__ __launch_bounds__(kGatherThreads) void k_select_gather(TabView t, dou
     // reads a few values it does not use)
     const ValIdx e = n_part > 0
         ? block_price_partials<kGatherThreads>(t.part_v, t.part_i, t.part_s, n_part, s_v, s_i)
-        : block_price<kGatherThreads>(t.M + m * t.ld, vc, sgn, s_v, s_i, t.p2l);
+        : block_price<kGatherThreads>(t.M + m * t.ld, vc, sgn, s_v, s_i, t.p2l, t.col_bias);
     if (c0.status != kRunning) return;
-    if (e.i < 0 || !(e.v < 0.0 - price_tol)) {
+    if (price_says_optimal(e, price_tol)) {
         if (leader) ctl->status = 0;                // MI_OPTIMAL
         return;
     }
@@ -430,14 +500,18 @@ __global__ __launch_bounds__(kGatherThreads) void k_select_gather(TabView t, dou
         const double b = r < m ? t.M[r * t.ld + vc] : 0.0;
         t.col[r] = a;
         if (t.p2l && !(fabs(a) <= 1.7976931348623157e308)) atomicOr(&ctl->poison, 1);   // see kNeedDense
-        if (r < m && ratio_thr < a) { best.v = b / a; best.i = r; best.s = __double_as_longlong(a); }
+        if (r < m && ratio_thr < a) {
+            const double q = b / a;
+            if (q != q) atomicOr(&ctl->poison, 2);   // a NaN quotient: k_select_scale decides from the snapshot
+            else { best.v = q; best.i = r; best.s = __double_as_longlong(a); }
+        }
     }
     best = block_reduce_min<kGatherThreads>(best, s_v, s_i);
     if (threadIdx.x == 0) { rp_v[blockIdx.x] = best.v; rp_i[blockIdx.x] = best.i; rp_s[blockIdx.x] = best.s; }
     if (leader) { ctl->ec = ec; ctl->slot = slot; }
 }
 
-__global__ __launch_bounds__(kScaleThreads) void k_select_scale(TabView t, int n_rp)
+__global__ __launch_bounds__(kScaleThreads) void k_select_scale(TabView t, int n_rp, double ratio_thr)
 {
     __shared__ double    s_v[kScaleThreads / 64];
     __shared__ long long s_i[kScaleThreads / 64];
@@ -448,12 +522,16 @@ __global__ __launch_bounds__(kScaleThreads) void k_select_scale(TabView t, int n
     Ctl *ctl = t.ctl;
     const Ctl c0 = *ctl;                            // in flight together with the ratio partials
     const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
-    const ValIdx q = block_price_partials<kScaleThreads>(rp_v, rp_i, rp_s, n_rp, s_v, s_i);
+    ValIdx q = block_price_partials<kScaleThreads>(rp_v, rp_i, rp_s, n_rp, s_v, s_i);
     if (c0.status != kRunning) return;
-    if (c0.poison) {                                // the gather met an inf / NaN: see kNeedDense
+    if (c0.poison && t.p2l) {                       // the gather met an inf / NaN: see kNeedDense
         if (leader) ctl->status = kNeedDense;
         return;
     }
+    // dense tableau, a NaN quotient somewhere (now or earlier in this solve: the flag stays up):
+    // every workgroup takes the decision again from the snapshot of the column, with the
+    // reference's first-eligible-row rule (block_gather_ratio)
+    if (c0.poison & 2) q = block_ratio_from_snapshot<kScaleThreads>(t, t.col, ratio_thr, s_v, s_i);
     if (q.i < 0) {
         if (leader) ctl->status = 1;                // MI_UNBOUNDED
         return;
@@ -491,13 +569,14 @@ __global__ __launch_bounds__(kSelThreads) void k_price_only(TabView t, double sg
     __shared__ long long s_i[kSelWaves];
     const int64_t m = t.rows - 1, vc = t.cols - 1;
     const ValIdx e = n_part > 0 ? block_price_partials(t.part_v, t.part_i, t.part_s, n_part, s_v, s_i)
-                                : block_price(t.M + m * t.ld, vc, sgn, s_v, s_i, t.p2l);
+                                : block_price(t.M + m * t.ld, vc, sgn, s_v, s_i, t.p2l, t.col_bias);
     if (threadIdx.x == 0) {
         if (out2) {                                 // compact shards price GLOBAL columns already
             out2[0] = e.i < 0 ? 0.0 : e.v;
-            out2[1] = e.i < 0 ? -1.0 : (double)(e.i + (t.p2l ? 0 : col_offset));
+            // (-2: the objective entry of GLOBAL column 0 is a NaN -- see price_cand: everybody stops)
+            out2[1] = e.i < 0 ? -1.0 : (e.s == kNanColumn0 ? -2.0 : (double)(e.i + (t.p2l ? 0 : col_offset)));
         } else {
-            t.ctl->ec = (e.i >= 0 && e.v < 0.0 - price_tol) ? e.i : -1;
+            t.ctl->ec = price_says_optimal(e, price_tol) ? -1 : e.i;
         }
     }
 }
@@ -541,11 +620,13 @@ __global__ __launch_bounds__(kSelThreads) void k_shard_contribute(TabView t, con
     // nor index with it.
     const bool running = t.ctl->status == kRunning;
     ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
+    bool nan0 = false;                              // some shard holds a NaN in global column 0's objective entry
     for (int k = 0; k < n_shards; ++k) {
         ValIdx c; c.v = gathered[2 * k]; c.i = (int64_t)gathered[2 * k + 1]; c.s = 0;
+        nan0 |= gathered[2 * k + 1] == -2.0;
         best = vi_min(best, c);
     }
-    const int64_t ec = (running && best.i >= 0 && best.v < 0.0 - price_tol) ? best.i : -1;
+    const int64_t ec = (running && !nan0 && !price_says_optimal(best, price_tol)) ? best.i : -1;
     // dense shard: a fixed block of logical columns; compact shard: whatever non-basic columns
     // currently live in its slots (l2p: global logical column -> local slot, -1 = not here)
     const int64_t lc = ec < 0 ? -1 : (t.l2p ? t.l2p[ec] : ec - col_offset);
@@ -691,11 +772,11 @@ __global__ __launch_bounds__(BLOCK) void k_update(TabView t, const int tr, const
         ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
         const int64_t c0 = 2 * pair;
         if (active && c0 < vc) {
-            ValIdx c; c.v = last.x * sgn; c.i = t.p2l ? t.p2l[c0] : c0; c.s = c0;
+            ValIdx c = price_cand(last.x * sgn, t.p2l ? t.p2l[c0] : c0, c0, t.p2l ? 0 : t.col_bias);
             best = vi_min(best, c);
         }
         if (active && c0 + 1 < vc) {
-            ValIdx c; c.v = last.y * sgn; c.i = t.p2l ? t.p2l[c0 + 1] : c0 + 1; c.s = c0 + 1;
+            ValIdx c = price_cand(last.y * sgn, t.p2l ? t.p2l[c0 + 1] : c0 + 1, c0 + 1, t.p2l ? 0 : t.col_bias);
             best = vi_min(best, c);
         }
         best = wave_reduce_min(best);
@@ -811,10 +892,10 @@ __global__ __launch_bounds__(kGatherThreads) void k_la_gather(TabView t, double 
     }
     // J > 0: the partials were left by k_la_scale<J-1> (objective row after pivot J-1)
     ValIdx e;
-    if (J == 0 && n_part <= 0) e = block_price<kGatherThreads>(t.M + m * ld, vc, sgn, s_v, s_i, t.p2l);
+    if (J == 0 && n_part <= 0) e = block_price<kGatherThreads>(t.M + m * ld, vc, sgn, s_v, s_i, t.p2l, t.col_bias);
     else e = block_price_partials<kGatherThreads>(t.part_v, t.part_i, t.part_s, n_part, s_v, s_i);
     if (c0.status != kRunning) return;
-    if (e.i < 0 || !(e.v < 0.0 - price_tol)) {
+    if (price_says_optimal(e, price_tol)) {
         if (leader) ctl->status = 0;                // MI_OPTIMAL
         return;
     }
@@ -835,7 +916,11 @@ __global__ __launch_bounds__(kGatherThreads) void k_la_gather(TabView t, double 
     if (r < t.rows) {
         t.bk_col[(int64_t)J * t.bk_stride + r] = a;
         if (!(fabs(a) <= 1.7976931348623157e308)) atomicOr(&ctl->poison, 1);   // see kNeedDense
-        if (r < m && ratio_thr < a) { best.v = b / a; best.i = r; best.s = __double_as_longlong(a); }
+        if (r < m && ratio_thr < a) {
+            const double q = b / a;
+            if (q != q) atomicOr(&ctl->poison, 1);   // a NaN quotient: decided on the dense path (block_gather_ratio)
+            else { best.v = q; best.i = r; best.s = __double_as_longlong(a); }
+        }
     }
     best = block_reduce_min<kGatherThreads>(best, s_v, s_i);
     if (threadIdx.x == 0) { rp_v[blockIdx.x] = best.v; rp_i[blockIdx.x] = best.i; rp_s[blockIdx.x] = best.s; }
@@ -915,11 +1000,11 @@ __global__ __launch_bounds__(kScaleThreads) void k_la_scale(TabView t, int n_rp,
         z.x = pend(z.x, 2 * p     == slot, false, cmj, pr.x);
         z.y = pend(z.y, 2 * p + 1 == slot, false, cmj, pr.y);
         if (c0i < vc) {
-            ValIdx c; c.v = z.x * sgn; c.i = (c0i == slot) ? leaving : l0; c.s = c0i;
+            ValIdx c = price_cand(z.x * sgn, (c0i == slot) ? leaving : l0, c0i);
             best = vi_min(best, c);
         }
         if (c0i + 1 < vc) {
-            ValIdx c; c.v = z.y * sgn; c.i = (c0i + 1 == slot) ? leaving : l1; c.s = c0i + 1;
+            ValIdx c = price_cand(z.y * sgn, (c0i + 1 == slot) ? leaving : l1, c0i + 1);
             best = vi_min(best, c);
         }
         if (own) {
@@ -966,11 +1051,13 @@ __global__ __launch_bounds__(kSelThreads) void k_shard_la_contribute(TabView t, 
         }
     }
     ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
+    bool nan0 = false;                              // some shard holds a NaN in global column 0's objective entry
     for (int k = 0; k < n_shards; ++k) {
         ValIdx c; c.v = gathered[2 * k]; c.i = (int64_t)gathered[2 * k + 1]; c.s = 0;
+        nan0 |= gathered[2 * k + 1] == -2.0;
         best = vi_min(best, c);
     }
-    const int64_t ec = (running && best.i >= 0 && best.v < 0.0 - price_tol) ? best.i : -1;
+    const int64_t ec = (running && !nan0 && !price_says_optimal(best, price_tol)) ? best.i : -1;
     const int64_t lc = ec < 0 ? -1 : (t.l2p ? t.l2p[ec] : ec - col_offset);
     const bool mine = ec >= 0 && lc >= 0 && lc < vcl;
     for (int64_t r = gid; r < t.rows; r += gsz) {
@@ -1048,11 +1135,11 @@ __global__ __launch_bounds__(kSelThreads) void k_shard_la_prepare(TabView t, int
         z.y = pend(z.y, 2 * p + 1 == slot, false, cmj, pr.y);
         const int64_t c0i = 2 * p;
         if (c0i < vcl) {
-            ValIdx c; c.v = z.x * sgn; c.i = (c0i == slot) ? leaving : (t.p2l ? t.p2l[c0i] : c0i); c.s = c0i;
+            ValIdx c = price_cand(z.x * sgn, (c0i == slot) ? leaving : (t.p2l ? t.p2l[c0i] : c0i), c0i);
             best = vi_min(best, c);
         }
         if (c0i + 1 < vcl) {
-            ValIdx c; c.v = z.y * sgn; c.i = (c0i + 1 == slot) ? leaving : (t.p2l ? t.p2l[c0i + 1] : c0i + 1); c.s = c0i + 1;
+            ValIdx c = price_cand(z.y * sgn, (c0i + 1 == slot) ? leaving : (t.p2l ? t.p2l[c0i + 1] : c0i + 1), c0i + 1);
             best = vi_min(best, c);
         }
     }
@@ -1108,7 +1195,11 @@ __global__ __launch_bounds__(kGatherThreads) void k_shard_la_ratio(TabView t, in
         const double b = r < m ? t.rhs[r] : 0.0;
         t.bk_col[(int64_t)j * t.bk_stride + r] = a;
         if (t.p2l && !(fabs(a) <= 1.7976931348623157e308)) atomicOr(&ctl->poison, 1);   // compact shard: MI_NONFINITE
-        if (r < m && ratio_thr < a) { best.v = b / a; best.i = r; best.s = __double_as_longlong(a); }
+        if (r < m && ratio_thr < a) {
+            const double q = b / a;
+            if (q != q) atomicOr(&ctl->poison, 1);   // a NaN quotient: MI_NONFINITE as well (the first-eligible-row rule is not reproduced here)
+            else { best.v = q; best.i = r; best.s = __double_as_longlong(a); }
+        }
     }
     best = block_reduce_min<kGatherThreads>(best, s_v, s_i);
     if (threadIdx.x == 0) { rp_v[blockIdx.x] = best.v; rp_i[blockIdx.x] = best.i; rp_s[blockIdx.x] = best.s; }
@@ -1192,11 +1283,11 @@ __global__ __launch_bounds__(kScaleThreads) void k_shard_la_scale(TabView t, int
         z.x = pend(z.x, 2 * p     == slot, false, cmj, pr.x);
         z.y = pend(z.y, 2 * p + 1 == slot, false, cmj, pr.y);
         if (c0i < vcl) {
-            ValIdx c; c.v = z.x * sgn; c.i = (c0i == slot) ? leaving : l0; c.s = c0i;
+            ValIdx c = price_cand(z.x * sgn, (c0i == slot) ? leaving : l0, c0i);
             best = vi_min(best, c);
         }
         if (c0i + 1 < vcl) {
-            ValIdx c; c.v = z.y * sgn; c.i = (c0i + 1 == slot) ? leaving : l1; c.s = c0i + 1;
+            ValIdx c = price_cand(z.y * sgn, (c0i + 1 == slot) ? leaving : l1, c0i + 1);
             best = vi_min(best, c);
         }
         // bookkeeping: the owner of the slot where there is one (it alone reads basis[cr] before
@@ -1624,8 +1715,8 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
         // The record also carries the winner's entry of prow_{J-1} and (from its owner) the RHS
         // entry of prow_{J-1}: what the chain below needs of the row that was stored last.
         ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
-        if (has_pair && 2 * p < vc)     { ValIdx c; c.v = z.x * sgn; c.i = l0; c.s = 2 * p;     best = vi_min(best, c); }
-        if (has_pair && 2 * p + 1 < vc) { ValIdx c; c.v = z.y * sgn; c.i = l1; c.s = 2 * p + 1; best = vi_min(best, c); }
+        if (has_pair && 2 * p < vc)     { ValIdx c = price_cand(z.x * sgn, l0, 2 * p);     best = vi_min(best, c); }
+        if (has_pair && 2 * p + 1 < vc) { ValIdx c = price_cand(z.y * sgn, l1, 2 * p + 1); best = vi_min(best, c); }
         LaMsg e;
         if (!la_exchange<true>(best, 0u, t.la_px, nw, w, e_price, max_spins, mute, local, rec_vc, &s_res, e,
                 [&](const ValIdx &c, int src, double &u, double &x2) {
@@ -1640,7 +1731,7 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
 #ifdef MI355X_LA_TIMING
         T2 = wall_clock64();
 #endif
-        if (e.c.i < 0 || !(e.c.v < 0.0 - price_tol)) {
+        if (price_says_optimal(e.c, price_tol)) {
             if (leader) ctl->status = 0;                         // MI_OPTIMAL
             return;
         }
@@ -1689,7 +1780,11 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
         if (has_row) {
             st_x(&t.bk_col[(int64_t)J * t.bk_stride + r], a, local);
             bad = !(fabs(a) <= 1.7976931348623157e308);
-            if (r < m && ratio_thr < a) { q.v = b / a; q.i = r; q.s = __double_as_longlong(a); }
+            if (r < m && ratio_thr < a) {
+                const double qv = b / a;
+                if (qv != qv) bad = 1u;                        // a NaN quotient: decided on the dense path (kNeedDense)
+                else { q.v = qv; q.i = r; q.s = __double_as_longlong(a); }
+            }
         }
 #ifdef MI355X_LA_TIMING
         T3 = wall_clock64();
@@ -1963,11 +2058,11 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(TabView t, const int tr, const 
         ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
         const int64_t c0 = 2 * pair;
         if (active && c0 < vc) {
-            ValIdx c; c.v = last.x * sgn; c.i = t.p2l ? t.p2l[c0] : c0; c.s = c0;
+            ValIdx c = price_cand(last.x * sgn, t.p2l ? t.p2l[c0] : c0, c0, t.p2l ? 0 : t.col_bias);
             best = vi_min(best, c);
         }
         if (active && c0 + 1 < vc) {
-            ValIdx c; c.v = last.y * sgn; c.i = t.p2l ? t.p2l[c0 + 1] : c0 + 1; c.s = c0 + 1;
+            ValIdx c = price_cand(last.y * sgn, t.p2l ? t.p2l[c0 + 1] : c0 + 1, c0 + 1, t.p2l ? 0 : t.col_bias);
             best = vi_min(best, c);
         }
         best = wave_reduce_min(best);
@@ -2196,11 +2291,11 @@ __global__ __launch_bounds__(256) void k_sweep16(TabView t, const int tr, const 
         ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
         const int64_t c0 = 2 * pair;
         if (active && c0 < vc) {
-            ValIdx c; c.v = last.x * sgn; c.i = t.p2l ? t.p2l[c0] : c0; c.s = c0;
+            ValIdx c = price_cand(last.x * sgn, t.p2l ? t.p2l[c0] : c0, c0, t.p2l ? 0 : t.col_bias);
             best = vi_min(best, c);
         }
         if (active && c0 + 1 < vc) {
-            ValIdx c; c.v = last.y * sgn; c.i = t.p2l ? t.p2l[c0 + 1] : c0 + 1; c.s = c0 + 1;
+            ValIdx c = price_cand(last.y * sgn, t.p2l ? t.p2l[c0 + 1] : c0 + 1, c0 + 1, t.p2l ? 0 : t.col_bias);
             best = vi_min(best, c);
         }
         best = wave_reduce_min(best);
@@ -2245,9 +2340,9 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_solve(TabView t, double sg
     int64_t n_pivots = c0.n_pivots;
     const int64_t max_pivots = c0.max_pivots;
 
-    ValIdx e = block_price(t.M + m * ld, vc, sgn, s_v, s_i, t.p2l);
+    ValIdx e = block_price(t.M + m * ld, vc, sgn, s_v, s_i, t.p2l, t.col_bias);
     for (;;) {
-        if (e.i < 0 || !(e.v < 0.0 - price_tol)) {
+        if (price_says_optimal(e, price_tol)) {
             if (threadIdx.x == 0) ctl->status = 0;  // MI_OPTIMAL
             break;
         }
@@ -2259,17 +2354,27 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_solve(TabView t, double sg
         const int64_t slot = e.s;                   // its physical column
         // gather the entering column into LDS + ratio test
         ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
-        int bad = 0;
+        ValIdx first; first.v = 0.0; first.i = -1; first.s = 0;   // this thread's first eligible row
+        int bad = 0, nanq = 0;
         for (int64_t r = threadIdx.x; r < rows; r += kLpThreads) {
             const double a = t.M[r * ld + slot];
             s_col[r] = a;
             bad |= !(fabs(a) <= 1.7976931348623157e308);
             if (r < m && ratio_thr < a) {
                 ValIdx c; c.v = t.M[r * ld + vc] / a; c.i = r; c.s = 0;
-                best = vi_min(best, c);
+                if (first.i < 0) first.i = r;
+                if (c.v != c.v) nanq = 1;            // no candidate, unless its row is the first eligible one
+                else best = vi_min(best, c);
             }
         }
-        const ValIdx q = block_reduce_min(best, s_v, s_i);     // barriers: s_col complete
+        ValIdx q = block_reduce_min(best, s_v, s_i);           // barriers: s_col complete
+        if (__syncthreads_or(nanq)) {                          // the first-eligible-row rule: see block_gather_ratio
+            first = block_reduce_min(first, s_v, s_i);
+            if (first.i >= 0) {
+                const double q0 = t.M[first.i * ld + vc] / s_col[first.i];
+                if (q0 != q0) { q.v = q0; q.i = first.i; }
+            }
+        }
         if (t.p2l && __syncthreads_or(bad)) {                  // see kNeedDense
             if (threadIdx.x == 0) ctl->status = kNeedDense;
             break;
@@ -2325,8 +2430,8 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_solve(TabView t, double sg
                     M2[ii[u]] = o;
                     if (ri[u] == m) {
                         const int64_t c0 = 2 * pi[u];
-                        if (c0 < vc)     { ValIdx c; c.v = o.x * sgn; c.i = t.p2l ? t.p2l[c0] : c0;         c.s = c0;     best = vi_min(best, c); }
-                        if (c0 + 1 < vc) { ValIdx c; c.v = o.y * sgn; c.i = t.p2l ? t.p2l[c0 + 1] : c0 + 1; c.s = c0 + 1; best = vi_min(best, c); }
+                        if (c0 < vc)     { ValIdx c = price_cand(o.x * sgn, t.p2l ? t.p2l[c0] : c0, c0, t.p2l ? 0 : t.col_bias);     best = vi_min(best, c); }
+                        if (c0 + 1 < vc) { ValIdx c = price_cand(o.y * sgn, t.p2l ? t.p2l[c0 + 1] : c0 + 1, c0 + 1, t.p2l ? 0 : t.col_bias); best = vi_min(best, c); }
                     }
                 }
             }
@@ -2432,8 +2537,8 @@ __global__ __launch_bounds__(kBbThreads) void k_batch_block(TabView t, double sg
             ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
             for (int64_t p = tid; p < ldv; p += kBbThreads) {
                 const double2 z = reinterpret_cast<const double2 *>(s_z)[p];
-                if (2 * p < vc)     { ValIdx x; x.v = z.x * sgn; x.i = s_p2l[2 * p];     x.s = 2 * p;     best = vi_min(best, x); }
-                if (2 * p + 1 < vc) { ValIdx x; x.v = z.y * sgn; x.i = s_p2l[2 * p + 1]; x.s = 2 * p + 1; best = vi_min(best, x); }
+                if (2 * p < vc)     { ValIdx x = price_cand(z.x * sgn, s_p2l[2 * p], 2 * p);     best = vi_min(best, x); }
+                if (2 * p + 1 < vc) { ValIdx x = price_cand(z.y * sgn, s_p2l[2 * p + 1], 2 * p + 1); best = vi_min(best, x); }
             }
             unsigned fl;
 #ifdef MI355X_LA_TIMING
@@ -2443,7 +2548,7 @@ __global__ __launch_bounds__(kBbThreads) void k_batch_block(TabView t, double sg
 #ifdef MI355X_LA_TIMING
             T2 = wall_clock64();
 #endif
-            if (e.i < 0 || !(e.v < 0.0 - price_tol)) { term = 0; break; }          // MI_OPTIMAL
+            if (price_says_optimal(e, price_tol)) { term = 0; break; }          // MI_OPTIMAL
             if (c0.max_pivots > 0 && n_pivots >= c0.max_pivots) { term = 3; break; }   // MI_MAX_PIVOTS
             const int64_t ec = e.i, slot = uniform64(e.s);
             // ---- entering column through the pending chain, ratio test.  Uniform operands of the
@@ -2485,7 +2590,8 @@ __global__ __launch_bounds__(kBbThreads) void k_batch_block(TabView t, double sg
                 bad |= !(fabs(a) <= 1.7976931348623157e308);
                 if (r < m && ratio_thr < a) {
                     ValIdx x; x.v = b / a; x.i = r; x.s = __double_as_longlong(a);
-                    q = vi_min(q, x);
+                    if (x.v != x.v) bad = 1;         // a NaN quotient: decided by the lockstep select (kNeedDense)
+                    else q = vi_min(q, x);
                 }
             }
             b_done = J;
@@ -2904,7 +3010,8 @@ void launch_select_split(const TabView &t, int is_max, double f, int n_part, hip
     const int g2 = (int)(((t.ld >> 1) + kScaleThreads - 1) / kScaleThreads);
     hipLaunchKernelGGL(k_select_gather, dim3(g1, 1, (unsigned)t.n_lps), dim3(kGatherThreads), 0, s, t,
                        sgn_of(is_max), (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon, n_part);
-    hipLaunchKernelGGL(k_select_scale, dim3(g2, 1, (unsigned)t.n_lps), dim3(kScaleThreads), 0, s, t, g1);
+    hipLaunchKernelGGL(k_select_scale, dim3(g2, 1, (unsigned)t.n_lps), dim3(kScaleThreads), 0, s, t, g1,
+                       0.0 + (f / 2.0) * kClEpsilon);
 }
 bool select_split_supported(const TabView &t)
 {

@@ -2,7 +2,8 @@
 # Runs on the GPU box (via gpurun): parity tests, the default bench line and the driver's short
 # one, the rocprofv3 kernel summary of the same bench command, the PMC passes (separate runs,
 # kernel-trace only -- never combined with a sys / runtime trace), config 4 and the per-pivot path.
-# Everything lands under gpurun_out/evidence/ ; tools/summarize_evidence.py copies what should be
+# Every rocprofv3 call runs under its own `timeout` (a profiler that dies can sit in its signal
+# handler for the rest of the lease).  Everything lands under gpurun_out/evidence/ ; tools/summarize_evidence.py copies what should be
 # judged into profiles/.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -17,11 +18,11 @@ python bench.py --workload cfg4 --batch-lps 1024 > $O/bench_cfg4_1024.log 2>&1; 
 python bench.py --workload cfg2 --steps 128 --no-cpu-baseline > $O/bench_cfg2.log 2>&1; echo "bench cfg2 rc=$?"
 python bench.py --workload colpart --steps 64 --warmup 16 > $O/bench_colpart_1gpu.log 2>&1; echo "bench colpart rc=$?"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats -- python $R/bench.py --no-cpu-baseline --no-per-pivot > $O/kernel_stats.log 2>&1; echo "rocprof stats rc=$?"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats_cfg4 -- python $R/bench.py --workload cfg4 > $O/kernel_stats_cfg4.log 2>&1; echo "rocprof stats cfg4 rc=$?"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats_perpivot -- python $R/bench.py --block 1 --steps 320 --no-cpu-baseline --no-per-pivot > $O/kernel_stats_perpivot.log 2>&1; echo "rocprof stats per-pivot rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats -- python $R/bench.py --no-cpu-baseline --no-per-pivot > $O/kernel_stats.log 2>&1; echo "rocprof stats rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats_cfg4 -- python $R/bench.py --workload cfg4 > $O/kernel_stats_cfg4.log 2>&1; echo "rocprof stats cfg4 rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats_perpivot -- python $R/bench.py --block 1 --steps 320 --no-cpu-baseline --no-per-pivot > $O/kernel_stats_perpivot.log 2>&1; echo "rocprof stats per-pivot rc=$?"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python $R/tools/pmc_probe.py 64 > $O/pmc_$c.log 2>&1; echo "pmc $c rc=$?"
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_perpivot_$c -- python $R/tools/pmc_probe.py 24 1 > $O/pmc_perpivot_$c.log 2>&1; echo "pmc per-pivot $c rc=$?"
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python $R/tools/pmc_probe.py 64 > $O/pmc_$c.log 2>&1; echo "pmc $c rc=$?"
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_perpivot_$c -- python $R/tools/pmc_probe.py 24 1 > $O/pmc_perpivot_$c.log 2>&1; echo "pmc per-pivot $c rc=$?"
 done
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --kernel-trace --output-format csv -d $O/pmc_SQ -- python $R/tools/pmc_probe.py 64 > $O/pmc_SQ.log 2>&1; echo "pmc SQ rc=$?"
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --kernel-trace --output-format csv -d $O/pmc_SQ -- python $R/tools/pmc_probe.py 64 > $O/pmc_SQ.log 2>&1; echo "pmc SQ rc=$?"
