@@ -114,8 +114,9 @@ __device__ __forceinline__ bool price_says_optimal(const ValIdx &e, double price
 }
 
 // Wave-wide lexicographic minimum, result valid in lane 0.  A fixed binary tree -- lane l takes
-// lane l+32, then l+16, l+8, ... -- because with NaN candidates vi_min is not associative and the
-// tree order is part of the (tested) behaviour.  The two steps that cross rows of 16 lanes use
+// lane l+32, then l+16, l+8, ...  (NaN keys never get here: price_cand and the ratio tests drop them
+// and apply the reference's scan-order rules for them separately, so the reduction is a plain
+// associative minimum and its shape does not matter for the result.)  The two steps that cross rows of 16 lanes use
 // __shfl_down (ds_bpermute: an LDS round trip per 32-bit word); the four steps inside a row use
 // DPP row shifts, a few cycles each.  (All six as ds_bpermute made one reduction 1.3 us.)
 template <int CTRL>
