@@ -1203,6 +1203,12 @@ int mi355x_batch_solve(mi355x_batch *b, int is_max, double f, int64_t max_pivots
             need_dense |= t->h_ctl[i].status == kNeedDense;
         }
         if (need_dense) {
+            // The chunk ended on a select: every LP that is still running has a pivot selected and
+            // HALF done (on the compact representation the select already moved the leaving column
+            // into the entering column's slot).  Finish those pivots before the representation
+            // changes -- the update is a no-op for the LP(s) that asked for the dense tableau.
+            rc = enqueue_update(t, is_max);
+            if (rc != MI_OK) return rc;
             rc = fall_back_to_dense(t);
             if (rc != MI_OK) return rc;
             enqueue_select(t, is_max, f);

@@ -149,3 +149,46 @@ def test_regression_extreme_magnitudes_case():
     b0 = np.arange(n, n + m, dtype=np.int64)
     st, npiv, trace = _check(M0, b0, cap=60)
     assert npiv == 5
+
+
+def test_batches_with_overflowing_members_every_mode():
+    """Batches whose members overflow at different pivots (each such member sends the whole batch
+    to the dense tableaux while the others are in the middle of theirs), in every batch mode:
+    every member ends where the oracle ends on it alone.  (Mode 1, the lockstep driver, used to
+    change the representation with the other members' pivots half done.)"""
+    L = lp.capi.lib()
+    meta = np.random.default_rng(123)
+    try:
+        for bi in range(160):
+            n = int(meta.integers(2, 61)); m = int(meta.integers(1, 41)); nl = int(meta.integers(2, 17))
+            lo = int(meta.choice([-300, -160, -20])); hi = int(meta.choice([20, 160, 300]))
+            mode = int(meta.choice([0, 1, 2, 3]))
+            Ms, Bs, ref = [], [], []
+            for k in range(nl):
+                rng = np.random.default_rng(int(meta.integers(0, 2 ** 31 - 1)))
+                mag = lambda shape: rng.uniform(0.5, 2.0, shape) * 10.0 ** rng.integers(lo, hi + 1, shape)   # noqa: E731
+                M0 = np.zeros((m + 1, n + m + 1))
+                M0[:m, :n] = mag((m, n)) * rng.choice([1.0, 1.0, -1.0], (m, n))
+                M0[np.arange(m), n + np.arange(m)] = 1.0
+                M0[:m, -1] = mag(m)
+                M0[m, :n] = -mag(n)
+                b0 = np.arange(n, n + m, dtype=np.int64)
+                Ms.append(M0); Bs.append(b0)
+                M, b = M0.copy(), b0.copy()
+                with np.errstate(all="ignore"):
+                    st_o, npiv, _ = oracle.solve(M, b, max_pivots=60)
+                ref.append((st_o, npiv, M, b))
+            L.mi355x_tune_set_batch_mode(mode)
+            batch = lp.TableauBatch.from_arrays(np.stack(Ms), np.stack(Bs))
+            st, npv = batch.solve(max_pivots=60)
+            for k in range(nl):
+                G, bg = batch.download(k)
+                so, no, M, b = ref[k]
+                where = "batch %d (mode %d, %d x %d, %d LPs) member %d" % (bi, mode, n, m, nl, k)
+                assert (int(st[k]), int(npv[k])) == (so, no), where
+                nan_o, nan_g = np.isnan(M), np.isnan(G)
+                assert np.array_equal(nan_o, nan_g), where
+                assert np.array_equal(G[~nan_g].view(np.int64), M[~nan_o].view(np.int64)), where
+                assert np.array_equal(bg, b), where
+    finally:
+        L.mi355x_tune_set_batch_mode(0)
