@@ -54,6 +54,7 @@
 (defconstant +mi-max-pivots+ 3)
 (defconstant +mi-art-nonzero+ 4)
 (defconstant +mi-art-stuck+ 5)
+(defconstant +mi-nonfinite+ 6)   ; column shards only: the tableau overflowed (see solve-column-partitioned)
 
 (cffi:defcfun ("mi355x_device_count" device-count) :int)
 (cffi:defcfun ("mi355x_last_error" %last-error) :string)
@@ -191,6 +192,12 @@ one GPU when fewer are visible).  Same pivots, same bits as on one device."
            (let ((status (check (with-foreign-fp-mode
                                   (%colpart-solve handle (max-problem-p tableau) factor
                                                   max-pivots n-pivots)))))
+             ;; A compact column shard cannot do what the reference does with an entering column
+             ;; that holds an infinity or a NaN (it would turn basic columns, which a shard does not
+             ;; store, into NaNs): the library stops with MI_NONFINITE and the caller, whose tableau
+             ;; has not been written to, solves it on one device, where that case is reproduced.
+             (when (= status +mi-nonfinite+)
+               (return-from solve-column-partitioned :overflowed))
              (signal-outcome status)
              (let* ((matrix (tableau-matrix tableau))
                     (last-row (make-array cols :element-type 'double-float))
@@ -268,8 +275,11 @@ solved `tableau`.  solve-problem forwards these keywords (src/solver.lisp:53-56)
                        (%tab-destroy main-handle)))
                 (%tab-destroy art-handle))))
           ;; single phase, src/simplex.lisp:453-461
-          (if (> devices 1)
-              (solve-column-partitioned tableaus devices factor max-pivots full-tableau n-pivots)
+          (if (and (> devices 1)
+                   (not (eq :overflowed
+                            (solve-column-partitioned tableaus devices factor max-pivots
+                                                      full-tableau n-pivots))))
+              tableaus
           (multiple-value-bind (handle flat basis) (upload-tableau tableaus device)
             (unwind-protect
                  (let ((status (check (with-foreign-fp-mode

@@ -122,3 +122,48 @@ def test_header_is_plain_c_and_a_c_program_links(tmp_path):
                            "-Wl,-rpath," + os.path.dirname(lp.capi.LIB_PATH)])
     out = subprocess.check_output([exe], text=True)
     assert "c abi ok" in out
+
+
+def test_lisp_glue_is_well_formed_and_binds_only_declared_entry_points():
+    """The CFFI glue cannot be executed here (no Common Lisp in the image): at least its forms
+    are balanced, every foreign function it binds is declared in the public header with the same
+    number of arguments, and every status constant it names has the header's value."""
+    import re
+    src = open(os.path.join(ROOT, "linear-programming_amd", "lisp", "mi355x-simplex.lisp")).read()
+    depth, i, in_str, in_comment = 0, 0, False, False
+    while i < len(src):
+        c = src[i]
+        if in_comment:
+            in_comment = c != "\n"
+        elif in_str:
+            if c == "\\":
+                i += 1
+            elif c == '"':
+                in_str = False
+        elif c == ";":
+            in_comment = True
+        elif c == '"':
+            in_str = True
+        elif c == "#" and src[i + 1] == "\\":
+            i += 2
+        elif c == "(":
+            depth += 1
+        elif c == ")":
+            depth -= 1
+            assert depth >= 0, "unbalanced ')' at offset %d" % i
+        i += 1
+    assert depth == 0 and not in_str
+    header = open(os.path.join(ROOT, "include", "mi355x_simplex.h")).read()
+    flat = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+    bound = list(re.finditer(r'\(cffi:defcfun \("(mi355x_\w+)" %?[\w-]+\)\s+\S+?((?:\s*\([\w-]+ [^()]+\))*)\)', src))
+    assert len(bound) == src.count("cffi:defcfun") >= 11          # (every binding is looked at)
+    for m in bound:
+        name, args = m.group(1), re.findall(r"\([\w-]+ [^()]+\)", m.group(2))
+        decl = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, flat, flags=re.S)
+        assert decl, "%s is bound by the glue but not declared in mi355x_simplex.h" % name
+        params = [p for p in decl.group(1).split(",") if p.strip() and p.strip() != "void"]
+        assert len(params) == len(args), "%s: the glue passes %d arguments, the header declares %d" % (name, len(args), len(params))
+    for m in re.finditer(r"\(defconstant \+mi-([\w-]+)\+ (-?\d+)\)", src):
+        macro = "MI_" + m.group(1).upper().replace("-", "_")
+        decl = re.search(r"#define\s+%s\s+(-?\d+)" % macro, header)
+        assert decl and int(decl.group(1)) == int(m.group(2)), "%s = %s in the glue" % (macro, m.group(2))
