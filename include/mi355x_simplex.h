@@ -315,7 +315,9 @@ int  mi355x_shard_sweep(mi355x_tab *t);
  * Shards are compact (only non-basic columns are distributed) whenever the basis columns of the
  * uploaded tableau are exact unit vectors, dense otherwise; pivoting is blocked (16 pivots per
  * sweep of a shard's slice).  A failing RCCL call returns MI_RCCL_ERROR.
- * n_devices >= 1.  Results are bit-identical to mi355x_tab_solve on one device. */
+ * n_devices >= 1; a tableau with fewer distributable columns than that gets one shard per column
+ * (mi355x_colpart_info reports the number in use).  Results are bit-identical to mi355x_tab_solve
+ * on one device. */
 typedef struct mi355x_colpart mi355x_colpart;
 int  mi355x_colpart_create(mi355x_colpart **out, int64_t rows, int64_t cols,
                            const double *host_matrix, const int64_t *host_basis, int n_devices);

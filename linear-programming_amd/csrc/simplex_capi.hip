@@ -1842,7 +1842,8 @@ int mi355x_colpart_create(mi355x_colpart **out, int64_t rows, int64_t cols, cons
     std::vector<int64_t> dist;                                   // the columns that are distributed
     for (int64_t c = 0; c < vc; ++c)
         if (!compact || !basic[(size_t)c]) dist.push_back(c);
-    if ((int64_t)dist.size() < n_devices) return fail(MI_BAD_ARG, "more shards (%d) than columns to distribute (%lld)", n_devices, (long long)dist.size());
+    if (dist.empty()) return fail(MI_BAD_ARG, "no column to distribute");
+    if ((int64_t)dist.size() < n_devices) n_devices = (int)dist.size();   // a shard needs a column: fewer shards (mi355x_colpart_info says how many)
     mi355x_colpart *p = new (std::nothrow) mi355x_colpart;
     if (!p) return fail(MI_NO_MEMORY, "host allocation failed");
     p->world = n_devices;

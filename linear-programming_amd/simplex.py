@@ -410,16 +410,50 @@ def solve_tableau(tableau):
 
 
 # ------------------------------------------------------------------ the *solver* hook value
-def mi355x_simplex_solver(problem, fp_tolerance=1024, device=0, **_ignored):
+def _solve_column_partitioned(tableau, devices, max_pivots=0):
+    """The glue's `solve-column-partitioned` (lisp/mi355x-simplex.lisp): the tableau of a
+    single-phase problem split over `devices` GPUs behind mi355x_colpart_create / _solve /
+    _download / _destroy.  Returns False when the library stopped with MI_NONFINITE (the tableau
+    overflowed; compact shards cannot reproduce that case): the caller's tableau is untouched."""
+    L = capi.lib()
+    M, b = tableau.matrix, tableau.basis_columns
+    h = ctypes.c_void_p()
+    capi.check(L.mi355x_colpart_create(ctypes.byref(h), M.shape[0], M.shape[1], _ptr(M), _ptr(b),
+                                       int(devices)), "mi355x_colpart_create")
+    try:
+        n = ctypes.c_int64(0)
+        rc = capi.check(L.mi355x_colpart_solve(h, int(tableau.is_max), float(tableau.fp_tolerance_factor),
+                                               int(max_pivots), ctypes.byref(n)), "mi355x_colpart_solve")
+        if rc == capi.MI_NONFINITE:
+            return False
+        tableau.n_pivots = int(n.value)
+        _raise_for(rc)
+        G, bg = np.empty_like(M), np.empty_like(b)
+        capi.check(L.mi355x_colpart_download(h, _ptr(G), _ptr(bg), None, None), "mi355x_colpart_download")
+    finally:
+        L.mi355x_colpart_destroy(h)
+    # the solved arrays become the tableau's host copy; its device handle (if any) is stale
+    old, tableau._handle = tableau._handle, None
+    if old:
+        L.mi355x_tab_destroy(old)
+    tableau._matrix, tableau._basis, tableau._stale, tableau._light = G, bg, False, None
+    return True
+
+
+def mi355x_simplex_solver(problem, fp_tolerance=1024, device=0, devices=1, **_ignored):
     """What the Lisp glue installs as `*solver*` (src/solver.lisp:39-56): takes a problem and
     backend keyword arguments, returns a solved tableau answering the four solution-*
     generics.  LP only: integer/binary variables are declined the way a backend must
     (unsupported-constraint-error, src/conditions.lisp:69-77); branch-and-bound
-    (src/simplex.lisp:506-542) stays with the reference's own solver."""
+    (src/simplex.lisp:506-542) stays with the reference's own solver.  devices > 1: the tableau
+    of a single-phase problem is column-partitioned over that many GPUs (logical shards of one
+    GPU when fewer are visible); two-phase problems and tableaux that overflow run on `device`."""
     if problem.integer_vars:
         raise UnsupportedConstraintError(("integer",) + tuple(problem.integer_vars),
                                          "mi355x-simplex")
     tabs = build_tableau(problem, problem, fp_tolerance_factor=fp_tolerance, device=device)
+    if devices > 1 and isinstance(tabs, Tableau) and _solve_column_partitioned(tabs, devices):
+        return tabs
     return n_solve_tableau(tabs)
 
 

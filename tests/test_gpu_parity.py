@@ -1037,3 +1037,77 @@ def test_config3_first_pivots_bitwise_and_full_solve_properties():
     obj = Mf[m, -1]
     assert abs(c @ x[:n] - obj) <= 1e-10 * abs(obj)
     assert (A @ x[:n] - rhs).max() <= 1e-8 * np.abs(rhs).max()
+
+
+# =========================================================================== :devices through the solver hook
+@pytest.mark.parametrize("devices", [2, 3, 8])
+def test_solver_hook_devices_keyword(devices):
+    """(solve-problem problem :devices n): the call sequence of the Lisp glue's
+    solve-column-partitioned (create -> solve -> download -> destroy) through the Python mirror.
+    Single-phase problems go through the column partition (logical shards on this one GPU) and
+    end with the same solution object as on one device; a two-phase problem ignores the keyword."""
+    p = lp.Problem(type="max", vars=["x", "y", "z"], objective_var="w",          # README.md:43-47
+                   objective_func=[("x", 1), ("y", 4), ("z", 3)],
+                   constraints=[("<=", [("x", 2), ("y", 1)], 8), ("<=", [("y", 1), ("z", 1)], 7)])
+    one = lp.solve_problem(p)
+    many = lp.solve_problem(p, devices=devices)
+    assert lp.solution_variable(many, "w") == 28.5 and lp.solution_variable(many, "x") == 0.5
+    assert np.array_equal(many.matrix.view(np.int64), one.matrix.view(np.int64))
+    assert np.array_equal(many.basis_columns, one.basis_columns)
+    for v in ("x", "y", "z"):
+        assert lp.solution_reduced_cost(many, v) == lp.solution_reduced_cost(one, v)
+    # a larger single-phase LP: same bits as the single-device solve
+    rng = np.random.default_rng(devices)
+    n, m = 60, 35
+    names = ["v%d" % i for i in range(n)]
+    A = rng.uniform(0.1, 1.0, (m, n))
+    cons = [("<=", list(zip(names, A[i].tolist())), float(rng.uniform(5, 9))) for i in range(m)]
+    q = lp.Problem(type="max", vars=names, objective_var="obj",
+                   objective_func=list(zip(names, rng.uniform(0.5, 1.5, n).tolist())), constraints=cons)
+    one, many = lp.solve_problem(q), lp.solve_problem(q, devices=devices)
+    assert np.array_equal(many.matrix.view(np.int64), one.matrix.view(np.int64))
+    assert lp.solution_objective_value(many) == lp.solution_objective_value(one)
+    # two-phase problem (a >= row): the keyword is ignored, the answer is the single-device one
+    from tests.helpers import random_mixed_problem
+    r = random_mixed_problem(lp, 12, 5, 3, 2, 77)
+    assert lp.solution_objective_value(lp.solve_problem(r, devices=devices)) == lp.solution_objective_value(lp.solve_problem(r))
+
+
+def test_solver_hook_devices_falls_back_when_the_tableau_overflows():
+    """Entries over hundreds of orders of magnitude: the partitioned solve stops with
+    MI_NONFINITE, the hook solves the untouched tableau on one device -- same result as without
+    the keyword, whatever the reference does with the infinities."""
+    import ctypes
+    found = 0
+    for seed in range(40):
+        rng = np.random.default_rng(seed)
+        n, m = 20, 8
+        names = ["v%d" % i for i in range(n)]
+        mag = lambda shape: rng.uniform(0.5, 2.0, shape) * 10.0 ** rng.integers(-300, 161, shape)   # noqa: E731
+        A = mag((m, n))
+        cons = [("<=", list(zip(names, A[i].tolist())), float(mag(1)[0])) for i in range(m)]
+        q = lp.Problem(type="max", vars=names, objective_var="obj",
+                       objective_func=list(zip(names, mag(n).tolist())), constraints=cons)
+        tab = lp.build_tableau(q, q)
+        L = lp.capi.lib()
+        h = ctypes.c_void_p()
+        M, b = tab.matrix, tab.basis_columns
+        lp.capi.check(L.mi355x_colpart_create(ctypes.byref(h), M.shape[0], M.shape[1], M.ctypes.data_as(ctypes.c_void_p),
+                                              b.ctypes.data_as(ctypes.c_void_p), 3), "create")
+        rc = L.mi355x_colpart_solve(h, 1, 1024.0, 0, None)
+        L.mi355x_colpart_destroy(h)
+        if rc != lp.capi.MI_NONFINITE:
+            continue
+        found += 1
+        outcomes = []
+        for kw in ({}, {"devices": 3}):
+            try:
+                s = lp.solve_problem(q, **kw)
+                G = s.matrix
+                outcomes.append(("solved", G[~np.isnan(G)].view(np.int64).tolist(), np.isnan(G).tolist(), s.basis_columns.tolist()))
+            except lp.SolverError as e:
+                outcomes.append((type(e).__name__,))
+        assert outcomes[0] == outcomes[1], seed
+        if found >= 3:
+            break
+    assert found >= 1, "no overflowing problem among the seeds: the fallback was not exercised"
