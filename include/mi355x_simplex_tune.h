@@ -68,6 +68,10 @@ int         mi355x_tab_timing_read_kind(mi355x_tab *t, int which, int64_t *n_lau
 int         mi355x_colpart_exchange_timing_enable(mi355x_colpart *p, int stride, int max_samples);
 int         mi355x_colpart_exchange_timing_read(mi355x_colpart *p, int64_t *n_samples,
                                                 double *allgather_us, double *allreduce_us);
+/* measurement aid: launches the sweep of the handle's CURRENT pending list n more times (a sweep
+ * does not consume the list) and returns the average launch duration (HIP events).  The tableau
+ * is meaningless afterwards. */
+int         mi355x_debug_repeat_sweep(mi355x_tab *t, int n, double *avg_us);
 /* debugging aid: copies n doubles of the handle's scratch `rhs` buffer (the per-phase clocks of
  * a -DMI355X_LA_TIMING build); clear != 0 zeroes it afterwards */
 int         mi355x_debug_rhs(mi355x_tab *t, double *out, int64_t n, int clear);

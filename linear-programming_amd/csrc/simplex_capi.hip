@@ -2058,6 +2058,25 @@ int         mi355x_tune_set_compact(int on) { g_compact_enabled = on ? 1 : 0; re
 int         mi355x_tune_set_sweep_impl(int impl) { set_sweep_impl(impl); return impl; }
 int         mi355x_tune_set_shard_la_split(int mode) { set_shard_la_split(mode); return mode; }
 int         mi355x_tune_set_tail_policy(int p) { g_tail_policy = p == 1 ? 1 : 0; return g_tail_policy; }
+/* measurement aid: the sweep of the CURRENT pending list launched n more times (the list is not
+ * consumed by a sweep); average launch duration by HIP events.  Leaves the tableau meaningless. */
+int         mi355x_debug_repeat_sweep(mi355x_tab *t, int n, double *avg_us)
+{
+    if (!t || n < 1 || !avg_us || !t->compact) return MI_BAD_ARG;
+    if (hipSetDevice(t->device) != hipSuccess) return MI_HIP_ERROR;
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return MI_HIP_ERROR;
+    for (int i = 0; i < 3; ++i) (void)launch_sweep(t->c, kMaxBlock, 1.0, t->stream, 0);
+    (void)hipEventRecord(a, t->stream);
+    for (int i = 0; i < n; ++i) (void)launch_sweep(t->c, kMaxBlock, 1.0, t->stream, 0);
+    (void)hipEventRecord(b, t->stream);
+    (void)hipEventSynchronize(b);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    *avg_us = ms * 1e3 / n;
+    return MI_OK;
+}
 // persistent look-ahead: all workgroups on one XCD (1, default) or spread (0); polls before a
 // workgroup gives up on a record (0 = default 2^21); test hook: the last workgroup stops
 // publishing from step `step_plus_1 - 1` of every block on (0 = off)

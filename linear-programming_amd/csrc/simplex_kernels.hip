@@ -2102,6 +2102,11 @@ template <int U> struct ColChunk;
 template <> struct ColChunk<4> {
     static constexpr int CP = 4;
     v8i c[4];
+#ifdef MI355X_SWEEP_FAKE_COL      // measurement only (tools/sweep_fake_col.py): no col loads, every col value +0.0
+    __device__ __forceinline__ void issue(const double *, unsigned) {}
+    __device__ __forceinline__ void wait() {}
+    __device__ __forceinline__ double col(int, int) const { return 0.0; }
+#else
     __device__ __forceinline__ void issue(const double *base, unsigned o1)
     {
         const unsigned o2 = 2u * o1, o3 = 3u * o1;
@@ -2115,6 +2120,7 @@ template <> struct ColChunk<4> {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(c[0]), "+s"(c[1]), "+s"(c[2]), "+s"(c[3]));
     }
     __device__ __forceinline__ double col(int i, int u) const { return __builtin_bit_cast(v4d, c[i])[u]; }
+#endif
 };
 template <> struct ColChunk<8> {
     static constexpr int CP = 2;
