@@ -16,9 +16,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, 32, 1), "two blocks")
     L.mi355x_tab_sync(h, ctypes.byref(npv))
     us = ctypes.c_double(0)
-    for rep in range(3):
-        lp.capi.check(L.mi355x_debug_repeat_sweep(h, 50, ctypes.byref(us)), "repeat")
-        print("%s: sweep back to back, 50 launches: %.1f us" % (sys.argv[2], us.value), flush=True)
+    for tr in (0, 16, 64):                      # rows per workgroup: 0 = the launcher's choice (32)
+        L.mi355x_tune_set_sweep_shape(tr, -1)
+        best = 1e9
+        for rep in range(3):
+            lp.capi.check(L.mi355x_debug_repeat_sweep(h, 50, ctypes.byref(us)), "repeat")
+            best = min(best, us.value)
+        print("%s: rows per workgroup %2d: sweep back to back, best of 3 x 50 launches: %.1f us" % (sys.argv[2], tr or 32, best), flush=True)
     sys.exit(0)
 import build as _build
 fake = os.path.join(ROOT, "gpurun_out", "libmi355x_simplex_fake_col.so")
