@@ -424,3 +424,29 @@ def test_bench_two_ranks_watchdog_still_prints_a_line():
     printed with the reason (a run that hangs in a collective must not end without a line)."""
     rec = _bench_two_ranks({"BENCH_COLPART_TIMEOUT": "0.001"})
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and "did not finish" in rec["colpart_error"]
+
+
+@pytest.mark.parametrize("n_devices", [2, 4, 8])
+def test_colpart_over_rccl_on_real_devices(n_devices):
+    """The column partition with one shard per PHYSICAL GPU (ncclCommInitAll, one host thread and one
+    RCCL rank per device, all-gather + all-reduce over xGMI per pivot).  Needs that many GPUs in
+    this process: skipped on the one-GPU test box, where the same code runs over a one-rank
+    communicator (test_colpart_c_abi_over_rccl_single_rank) and as logical shards."""
+    import importlib
+    if lp.capi.device_count() < n_devices:
+        pytest.skip("needs %d GPUs, %d visible" % (n_devices, lp.capi.device_count()))
+    cp = importlib.import_module("linear-programming_amd.colpart")
+    n, m = 1500, 700
+    seed = lp.synth.seed_for(5, 21)
+    M, b = lp.synth.tableau(n, m, seed)
+    so, no, trace = oracle.solve(M, b, trace_cap=1 << 14)
+    tab = cp.NativeColumnPartition.synthetic(n, m, seed, n_devices)
+    assert tab.info() == {"n_shards": n_devices, "n_devices_used": n_devices, "uses_rccl": True}
+    tab.exchange_timing(8, 64)
+    st, k = tab.solve()
+    assert (st, k) == (so, no) and np.array_equal(tab.trace(no), trace)
+    ns, ag_us, ar_us = tab.exchange_timing_read()
+    assert ns > 0 and ag_us > 0.0 and ar_us > 0.0
+    G, bg, _, _ = tab.download()
+    assert np.array_equal(G.view(np.int64), M.view(np.int64)) and np.array_equal(bg, b)
+    tab.close()
