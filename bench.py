@@ -83,6 +83,13 @@ def parse():
                          "block of a short run, ~50 samples of a long one)")
     ap.add_argument("--no-per-pivot", action="store_true",
                     help="skip the extra per-pivot (k_update) measurement after the timed region")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N = 1, cfg3: skip the `other_configs` records (configs 2, 4, 5 and the config-3 "
+                         "steady state measured after the timed region)")
+    ap.add_argument("--no-colpart-baseline", action="store_true",
+                    help="colpart, N > 1: skip the same-workload one-GPU figure measured on rank 0 first")
+    ap.add_argument("--no-colpart-ab", action="store_true",
+                    help="colpart over RCCL: skip the second leg with the rooted-broadcast exchange")
     return ap.parse_args()
 
 
@@ -178,6 +185,129 @@ def per_pivot_record(lp, L, n, m, seed, device, kernel_bytes, restore_block, piv
             "pivots_per_s_whole_iteration": pivots / dt}
 
 
+def _events(L, h, kind):
+    nl, sm, mn = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+    L.mi355x_tab_timing_read_kind(h, kind, ctypes.byref(nl), ctypes.byref(sm), ctypes.byref(mn))
+    return {"launches_timed": int(nl.value), "avg_us": sm.value / nl.value * 1e3 if nl.value else None,
+            "min_us": mn.value * 1e3 if nl.value else None}
+
+
+def other_configs(lp, L, device, block):
+    """The other BASELINE configurations, measured in the same run right AFTER the config-3 timed
+    region (never part of `value`), each with pivots/s, the per-kernel HIP-event averages and a
+    parity flag where the oracle can follow: config 2 (full solve), config 4 (128-LP batch, solved
+    to optimality), config 5 as ONE column shard (64 pivots), and config 3 in steady state
+    (1 600 pivots -- the driver's 20 timed steps are one block of 16 plus one of 4)."""
+    import numpy as np
+    import torch
+    import oracle
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)                                   # noqa: E731
+    out = {}
+
+    # ---- config 2: 1024 x 512, solved to optimality, bitwise against the oracle
+    n, m = 1024, 512
+    seed = lp.synth.seed_for(2)
+    hw = ctypes.c_void_p()
+    lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(hw), n, m, lp.synth.seed_for(2, 1), 0, -1, device), "cfg2 warm")
+    k = ctypes.c_int64(0)
+    L.mi355x_tab_solve(hw, 1, 1024.0, 0, ctypes.byref(k))                     # warm: same kernels, another LP
+    L.mi355x_tab_destroy(hw)
+    h = ctypes.c_void_p()
+    lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h), n, m, seed, 0, -1, device), "cfg2")
+    lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, 0, 1), "cfg2 prepare")   # representation change outside the timing
+    L.mi355x_tab_sync(h, ctypes.byref(k))
+    L.mi355x_tab_timing_enable(h, 4)          # every fourth block: the event records are host work inside the timing
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rc = L.mi355x_tab_solve(h, 1, 1024.0, 0, ctypes.byref(k))
+    dt = time.perf_counter() - t0
+    M, b = lp.synth.tableau(n, m, seed)
+    so, no, trace = oracle.solve(M, b, trace_cap=1 << 14)
+    ec = np.empty(max(no, 1), dtype=np.int64); cr = np.empty(max(no, 1), dtype=np.int64); cnt = ctypes.c_int64(0)
+    L.mi355x_tab_trace(h, vp(ec), vp(cr), no, ctypes.byref(cnt))
+    last_row = np.empty(n + m + 1); last_col = np.empty(m + 1); basis = np.empty(m, dtype=np.int64)
+    L.mi355x_tab_download(h, None, vp(basis), vp(last_row), vp(last_col))
+    ident = (int(rc) == so and int(k.value) == no and np.array_equal(np.stack([ec[:no], cr[:no]], axis=1), trace)
+             and np.array_equal(last_col.view(np.int64), M[:, -1].view(np.int64))
+             and np.array_equal(last_row.view(np.int64), M[m].view(np.int64)) and np.array_equal(basis, b))
+    out["cfg2_full_solve"] = {
+        "workload": "BASELINE config 2: dense random LP 1024 vars x 512 <=-constraints (513x1537 f64), solved to optimality",
+        "value": k.value / dt, "unit": "pivots/s", "pivots": int(k.value), "ms": dt * 1e3, "us_per_pivot": dt / max(k.value, 1) * 1e6,
+        "kernels": {"lookahead_per_block_of_%d" % block: _events(L, h, 1), "sweep_per_block": _events(L, h, 0)},
+        "parity": {"identical": bool(ident), "checked_against": "oracle, whole solve: status, pivot count, pivot "
+                   "sequence, RHS column, objective row, basis (bit for bit)"}}
+    L.mi355x_tab_destroy(h)
+
+    # ---- config 4: 128 independent 512 x 256 LPs on this GPU (1024 over 8), solved to optimality
+    n, m, nl = 512, 256, 128
+    seeds = np.array([lp.synth.seed_for(4, i) for i in range(nl)], dtype=np.uint64)
+    warm = lp.TableauBatch.synthetic(nl, n, m, seeds[::-1].copy(), device=device)
+    warm.solve()
+    del warm
+    batch = lp.TableauBatch.synthetic(nl, n, m, seeds, device=device)
+    lp.capi.check(L.mi355x_batch_prepare(batch._h), "mi355x_batch_prepare")
+    L.mi355x_batch_timing_enable(batch._h, 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st, npv = batch.solve()
+    dt = time.perf_counter() - t0
+    nlch, sm, mn = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+    L.mi355x_batch_timing_read(batch._h, ctypes.byref(nlch), ctypes.byref(sm), ctypes.byref(mn))
+    checked, same = 16, True
+    for i in range(checked):
+        Mi, bi = lp.synth.tableau(n, m, int(seeds[i]))
+        so, no, _ = oracle.solve(Mi, bi)
+        Gi, gb = batch.download(i)
+        same = same and int(st[i]) == so and int(npv[i]) == no and np.array_equal(Gi.view(np.int64), Mi.view(np.int64)) \
+            and np.array_equal(gb, bi)
+    out["cfg4_128_lp_batch"] = {
+        "workload": "BASELINE config 4, one GPU's share: 128 independent LPs of 512 vars x 256 <=-constraints "
+                    "(257x769 f64 each), every LP solved to optimality",
+        "value": float(npv.sum()) / dt, "unit": "pivots/s (aggregate)", "pivots_total": int(npv.sum()), "ms": dt * 1e3,
+        "pivots_per_lp_min_mean_max": [int(npv.min()), float(npv.mean()), int(npv.max())],
+        "all_optimal": bool((st == 0).all()),
+        "kernels": {"sweep_over_all_lps": {"launches_timed": int(nlch.value),
+                                           "avg_us": sm.value / nlch.value * 1e3 if nlch.value else None,
+                                           "min_us": mn.value * 1e3 if nlch.value else None}},
+        "parity": {"identical": bool(same), "checked_against": "oracle, LPs 0..%d of the batch: status, pivot count, "
+                   "every entry of the final tableau, basis (bit for bit)" % (checked - 1)}}
+    del batch
+    torch.cuda.empty_cache()
+
+    # ---- config 5 as ONE column shard on this GPU (the denominator of the 8-GPU claim)
+    try:
+        cp = importlib.import_module("linear-programming_amd.colpart")
+        base = cp.one_shard_baseline(65536, 32768, lp.synth.seed_for(5), device, 64, 16)
+        base["workload"] = ("BASELINE config 5 on ONE GPU: the 32769x98305 f64 tableau (25.8 GB dense, 17.2 GB stored) "
+                            "as one column shard through mi355x_colpart_*, 64 pivots after 16 warm-up pivots")
+        base["parity"] = {"identical": None, "checked_against": "nothing in this run: no CPU oracle follows 3.2e9 entries "
+                          "in bench time (tests/test_gpu_fullsize.py re-derives 64 pivots of this tableau in numpy)"}
+        out["cfg5_one_shard_64_pivots"] = base
+    except BaseException as e:                       # noqa: BLE001 -- a record is owed whatever happens here
+        out["cfg5_one_shard_64_pivots"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # ---- config 3, steady state: 1 600 pivots = 100 full blocks
+    n, m = 8192, 4096
+    h = ctypes.c_void_p()
+    lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h), n, m, lp.synth.seed_for(3, 500), 0, -1, device), "cfg3 steady")
+    lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, 64, 1), "cfg3 steady warm")
+    L.mi355x_tab_sync(h, ctypes.byref(k))
+    L.mi355x_tab_timing_enable(h, 4)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, 1600, 0), "cfg3 steady run")
+    rc = L.mi355x_tab_sync(h, ctypes.byref(k))
+    dt = time.perf_counter() - t0
+    out["cfg3_steady_state"] = {
+        "workload": "BASELINE config 3 over 1600 pivots (100 full blocks of %d) after 64 warm-up pivots" % block,
+        "value": 1600 / dt, "unit": "pivots/s", "ms": dt * 1e3, "us_per_pivot": dt / 1600 * 1e6,
+        "still_running": int(rc) == lp.capi.MI_RUNNING and k.value == 1664,
+        "kernels": {"lookahead_per_block_of_%d" % block: _events(L, h, 1), "sweep_per_block": _events(L, h, 0)}}
+    L.mi355x_tab_destroy(h)
+    torch.cuda.empty_cache()
+    return out
+
+
 def baseline_metric():
     """The metric string exactly as BASELINE.json spells it."""
     try:
@@ -192,7 +322,7 @@ def pmc_traffic(workload, kernel):
     WRITE_SIZE in separate runs, FETCH doubled per the gfx950 correction, calibrated on a copy of
     the same buffer -- profiles/rNN_cfg3_pmc_traffic.json).  PMC counters cannot be collected
     from inside this process, so the number is the last profiled one for this kernel, or None."""
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_%s_pmc_traffic.json" % (tag, workload))
         try:
             with open(path) as f:
@@ -538,6 +668,11 @@ def main():
         L.mi355x_tab_destroy(hk)
     handles = []
     torch.cuda.empty_cache()
+    if rank == 0 and N == 1 and args.workload == "cfg3" and not args.no_other_configs and not args.block:
+        rec["other_configs"] = other_configs(lp, L, local_rank, 16)
+        ss = rec["other_configs"].get("cfg3_steady_state", {})
+        if ss.get("value"):
+            rec["steady_state_pivots_per_s"] = ss["value"]
 
     # N > 1 with the default workload: the north star's multi-GPU claim is about ONE large tableau
     # column-partitioned over the GPUs with the pivot column travelling over RCCL / xGMI -- that

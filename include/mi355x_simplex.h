@@ -162,7 +162,10 @@ int  mi355x_tab_solve_async(mi355x_tab *t, int is_max, double fp_factor, int64_t
 int  mi355x_tab_reset(mi355x_tab *t, int64_t max_pivots);
 /* Wait for the stream; returns the device-side status (MI_OPTIMAL, MI_UNBOUNDED,
  * MI_MAX_PIVOTS, or MI_RUNNING when the enqueued iterations ran out first) and the number
- * of pivots done since the last reset. */
+ * of pivots done since the last reset.  That number can be smaller than what was enqueued even
+ * with MI_RUNNING: after a non-finite entering column (the handle moved to the dense tableau) or
+ * on a GPU shared with other work (the handle moved to the look-ahead form that needs no
+ * co-resident workgroups) the rest of the request was dropped -- enqueue the difference again. */
 int  mi355x_tab_sync(mi355x_tab *t, int64_t *n_pivots);
 /* Per-launch HIP-event timing of the rank-1 update kernel (the bandwidth kernel):
  * enable = k > 0 brackets every k-th update launch with an event pair on the launch stream
@@ -314,13 +317,20 @@ int  mi355x_shard_sweep(mi355x_tab *t);
  *     communicator comes from ncclCommInitRank, the per-pivot loop is still entirely in here.
  * Shards are compact (only non-basic columns are distributed) whenever the basis columns of the
  * uploaded tableau are exact unit vectors, dense otherwise; pivoting is blocked (16 pivots per
- * sweep of a shard's slice).  A failing RCCL call returns MI_RCCL_ERROR.
+ * sweep of a shard's slice).  A failing RCCL call returns MI_RCCL_ERROR; the communicators are then
+ * aborted (the other ranks' pending collectives could never complete) and the handle can only be
+ * destroyed.
  * n_devices >= 1; a tableau with fewer distributable columns than that gets one shard per column
  * (mi355x_colpart_info reports the number in use).  Results are bit-identical to mi355x_tab_solve
  * on one device. */
 typedef struct mi355x_colpart mi355x_colpart;
 int  mi355x_colpart_create(mi355x_colpart **out, int64_t rows, int64_t cols,
                            const double *host_matrix, const int64_t *host_basis, int n_devices);
+/* the same on chosen devices: device_ids[0 .. n_devices) (distinct), NULL = devices 0 .. n_devices-1.
+ * Logical shards (fewer visible devices than shards) all live on device_ids[0]. */
+int  mi355x_colpart_create_on(mi355x_colpart **out, int64_t rows, int64_t cols,
+                              const double *host_matrix, const int64_t *host_basis, int n_devices,
+                              const int *device_ids);
 /* the synthetic LP of mi355x_tab_create_synthetic generated shard by shard in HBM (benchmarks) */
 int  mi355x_colpart_create_synthetic(mi355x_colpart **out, int64_t n_vars, int64_t n_cons,
                                      uint64_t seed, int n_devices);

@@ -38,6 +38,13 @@ int         mi355x_tune_set_sweep_impl(int impl);            /* 0 k_sweep16 for 
                                                                 always; 4 / 8: rows per step of k_sweep16 */
 int         mi355x_tune_set_shard_la_split(int mode);        /* column shards, local look-ahead step:
                                                                 0 by size, 1 one workgroup, 2 many */
+int         mi355x_tune_set_colpart_exchange(int mode);      /* column partition over RCCL, how the
+                                                                entering column travels (read when a
+                                                                handle is created): 0 int64 SUM
+                                                                all-reduce of owner's bits + zeros
+                                                                (no host sync), 1 ncclBroadcast from
+                                                                the owner (root read back from the
+                                                                all-gather: one host sync per pivot) */
 int         mi355x_tune_set_tail_policy(int p);              /* n pivots, n not a multiple of the block:
                                                                 0 spread evenly, 1 full blocks + remainder */
 int         mi355x_tune_set_handover_mode(int mode);         /* 0 auto, 1 sequential re-elimination */
@@ -50,8 +57,12 @@ int         mi355x_tune_set_la_one_xcd(int on);              /* 1 (default): all
                                                                 one XCD, verified inside the launch */
 int         mi355x_tune_set_la_max_spins(unsigned polls);    /* polls before a workgroup gives up
                                                                 on a record; 0 = default (2^21)  */
-int         mi355x_tune_set_la_fault(int step_plus_1);       /* TEST: the last workgroup stops
-                                                                publishing from that step on     */
+int         mi355x_tune_set_la_fault(int step_plus_1);       /* TEST: > 0: the last workgroup stops
+                                                                publishing from that step on; < 0: it
+                                                                publishes its ratio record of step
+                                                                -step_plus_1 - 1 and then gives up
+                                                                alone (the leader commits a pivot
+                                                                that workgroup never stored)     */
 /* 1 once an exchange of the persistent look-ahead was lost on this handle: the solve carried on
  * (and stays) on the two-launch look-ahead */
 int         mi355x_tab_la_lost(const mi355x_tab *t);

@@ -83,6 +83,7 @@ SIGNATURES = {
     "mi355x_shard_la_pivot": (_int, [_p, _int, _p, _p, _dbl]),
     "mi355x_shard_sweep": (_int, [_p]),
     "mi355x_colpart_create": (_int, [_pp, _i64, _i64, _p, _p, _int]),
+    "mi355x_colpart_create_on": (_int, [_pp, _i64, _i64, _p, _p, _int, _p]),
     "mi355x_colpart_create_synthetic": (_int, [_pp, _i64, _i64, ctypes.c_uint64, _int]),
     "mi355x_rccl_unique_id": (_int, [_p]),
     "mi355x_colpart_create_synthetic_rank": (_int, [_pp, _i64, _i64, ctypes.c_uint64, _int, _int, _int, _p]),
@@ -99,6 +100,7 @@ _EXTRA = {
     "mi355x_tune_set_sweep_impl": (_int, [_int]),
     "mi355x_tune_set_shard_la_split": (_int, [_int]),
     "mi355x_tune_set_tail_policy": (_int, [_int]),
+    "mi355x_tune_set_colpart_exchange": (_int, [_int]),
     "mi355x_colpart_exchange_timing_enable": (_int, [_p, _int, _int]),
     "mi355x_colpart_exchange_timing_read": (_int, [_p, _p, _p, _p]),
     "mi355x_tune_set_la_one_xcd": (_int, [_int]),

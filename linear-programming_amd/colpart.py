@@ -411,14 +411,68 @@ class NativeColumnPartition:
 
 
 # ------------------------------------------------------------------ bench.py --workload colpart
+def _timed_pivots(tab, k, torch, dist, world, sync_ranks=True):
+    """k pivots through the library's loop, bracketed as bench.py's contract asks: barrier +
+    device synchronisation on both sides, MAX over ranks."""
+    if world > 1 and sync_ranks:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tab.solve_async(k)
+    st, done = tab.sync()
+    torch.cuda.synchronize()
+    if world > 1 and sync_ranks:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1 and sync_ranks:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt, st, done
+
+
+def one_shard_baseline(n, m, seed, device, steps, warmup, steady_pivots=0):
+    """The SAME tableau as ONE shard on ONE GPU through the same driver (mi355x_colpart_*, device-
+    local exchanges): the denominator of the north star's '>= 6 x pivots/sec at 8 GPUs vs 1'."""
+    import torch
+    tab = NativeColumnPartition.synthetic_rank(n, m, seed, 1, 0, device, bytes(128))
+    try:
+        tab.solve_async(warmup, reset=True)
+        tab.sync()
+        dt, st, done = _timed_pivots(tab, steps, torch, None, 1)
+        if st != capi.MI_RUNNING:
+            raise SystemExit("colpart baseline: LP terminated early (status %d after %d pivots)" % (st, done))
+        rec = {"what": "the same %d x %d tableau as ONE shard on one GPU, same driver (mi355x_colpart_*), "
+                       "same %d warm-up and %d timed pivots" % (m + 1, n + m + 1, warmup, steps),
+               "value": steps / dt, "unit": "pivots/s", "us_per_pivot": dt / steps * 1e6}
+        if steady_pivots:
+            dt2, st, done = _timed_pivots(tab, steady_pivots, torch, None, 1)
+            rec["steady_state_pivots_per_s"] = steady_pivots / dt2
+            rec["steady_state_pivots"] = steady_pivots
+    finally:
+        tab.close()
+    torch.cuda.empty_cache()
+    return rec
+
+
 def bench(args, rank, local_rank, world):
     """ONE dense LP (BASELINE config 5: 65536 vars x 32768 constraints, 32769 x 98305 f64 =
     25.8 GB) column-partitioned over `world` ranks, strong scaling: K pivots timed with both
     per-pivot exchanges in the timed region.  The per-pivot loop runs in the library
     (mi355x_colpart_*: RCCL collectives issued from C++ on the shard's stream); this function only
-    distributes the RCCL id, starts the K pivots and waits.  Test set-up (ranks sharing one GPU,
-    where RCCL refuses to run: BENCH_DIST_BACKEND=gloo): the Python protocol driver above with the
-    exchanges staged through the host."""
+    distributes the RCCL id, starts the K pivots and waits.  What one record holds beyond `value`
+    (so that it answers the north star's '>= 6 x at 8 GPUs vs 1' by itself, whatever the driver's
+    N = 1 line measured):
+      * `one_gpu_same_workload` -- the same tableau as one shard on rank 0's GPU, same run, before
+        the collective leg -- and `speedup_vs_one_gpu`;
+      * `steady_state_pivots_per_s` -- further FULL blocks timed right after the timed region when
+        the requested steps are fewer than four blocks (a 20-step region is one block of 16 plus one
+        of 4, each paying a full sweep);
+      * `exchange_modes` -- the same K pivots with the entering column travelling as a rooted
+        ncclBroadcast instead of the int64 all-reduce (mi355x_tune_set_colpart_exchange).
+    Test set-up (ranks sharing one GPU, where RCCL refuses to run: BENCH_DIST_BACKEND=gloo): the
+    Python protocol driver above with the exchanges staged through the host."""
+    import os
     import torch
     import torch.distributed as dist
     n, m = 65536, 32768
@@ -429,13 +483,33 @@ def bench(args, rank, local_rank, world):
     dense = getattr(args, "colpart_dense", False)
     block = getattr(args, "colpart_block", 0) or ColumnPartitionedTableau.MAX_BLOCK
     native = not staged and not dense and block == ColumnPartitionedTableau.MAX_BLOCK
+    # BENCH_COLPART_RANK_ENTRY=1 (test hook): also a single rank goes through the entry N > 1 uses --
+    # mi355x_rccl_unique_id -> mi355x_colpart_create_synthetic_rank -> ncclCommInitRank (with
+    # MI355X_COLPART_FORCE_RCCL=1 over a one-rank communicator)
+    rank_entry = world > 1 or os.environ.get("BENCH_COLPART_RANK_ENTRY") == "1"
+    steady_pivots = 8 * block if args.steps < 4 * block else 0
+    L = capi.lib()
+    baseline = None
+    exchange_modes = None
+
+    def make_native(exchange):
+        L.mi355x_tune_set_colpart_exchange(exchange)
+        try:
+            if rank_entry:
+                box = [NativeColumnPartition.rccl_unique_id() if rank == 0 else None]
+                if world > 1:
+                    dist.broadcast_object_list(box, src=0)
+                return NativeColumnPartition.synthetic_rank(n, m, seed, world, rank, local_rank, box[0])
+            return NativeColumnPartition.synthetic(n, m, seed, 1)
+        finally:
+            L.mi355x_tune_set_colpart_exchange(0)
+
     if native:
-        if world > 1:
-            box = [NativeColumnPartition.rccl_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            tab = NativeColumnPartition.synthetic_rank(n, m, seed, world, rank, local_rank, box[0])
-        else:
-            tab = NativeColumnPartition.synthetic(n, m, seed, 1)
+        if world > 1 and not getattr(args, "no_colpart_baseline", False):
+            if rank == 0:
+                baseline = one_shard_baseline(n, m, seed, local_rank, args.steps, args.warmup, steady_pivots)
+            dist.barrier()
+        tab = make_native(0)
         info = tab.info()
         tab.solve_async(args.warmup, reset=True)
         st, done = tab.sync()
@@ -449,37 +523,56 @@ def bench(args, rank, local_rank, world):
         tab.reset()
         tab.run(args.warmup)
         st, done = tab.status()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    steady = None
     if native:
-        tab.solve_async(args.steps)
-        st, done = tab.sync()
+        elapsed, st, done = _timed_pivots(tab, args.steps, torch, dist, world)
     else:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         tab.run(args.steps)
         st, done = tab.status()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if staged else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
     if st != capi.MI_RUNNING or done != args.warmup + args.steps:
         raise SystemExit("colpart: LP terminated early (status %d after %d pivots)" % (st, done))
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if staged else "cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
     R, C = m + 1, n + m + 1
     value = args.steps / elapsed
     exchange = None
     if native and info["uses_rccl"]:
         ns, ag_us, ar_us = tab.exchange_timing_read()
+        tab.exchange_timing(0, 0)
         if ns:
             exchange = {"samples": ns, "allgather_us": ag_us, "allreduce_us": ar_us,
                         "us_per_pivot": ag_us + ar_us,
                         "what": "HIP events on rank 0's stream around ncclAllGather (16 B/rank) and "
                                 "ncclAllReduce (int64 x %d rows) of sampled pivots; includes waiting "
                                 "for the slowest rank" % R}
+    if native and steady_pivots:
+        dt2, st, done2 = _timed_pivots(tab, steady_pivots, torch, dist, world)
+        if st == capi.MI_RUNNING:
+            steady = steady_pivots / dt2
+    if native and info["uses_rccl"] and not getattr(args, "no_colpart_ab", False):
+        # A/B of exchange B on a fresh handle of the same tableau: rooted broadcast (one host
+        # synchronisation per pivot for the root) against the sync-free int64 all-reduce above
+        tab.close()
+        tab = make_native(1)
+        tab.solve_async(args.warmup, reset=True)
+        tab.sync()
+        dtb, stb, doneb = _timed_pivots(tab, args.steps, torch, dist, world)
+        exchange_modes = {
+            "int64_sum_allreduce": {"value": value, "unit": "pivots/s", "headline": True,
+                                    "what": "owner's bit patterns + zeros, ncclAllReduce(int64, SUM): no host synchronisation"},
+            "rooted_broadcast": {"value": args.steps / dtb if stb == capi.MI_RUNNING else None, "unit": "pivots/s",
+                                 "what": "ncclBroadcast from the owner; the root is read back from the "
+                                         "all-gathered pricing winners: one stream synchronisation per pivot"}}
     stored_bytes = 2.0 * R * ((n + m if dense else n) + world) * 8 / block   # per pivot, all shards
     rec = {
         "metric": "simplex pivots/sec, one column-partitioned dense tableau",
@@ -493,11 +586,21 @@ def bench(args, rank, local_rank, world):
                    "parallelism": "column partition, per-pivot all-gather(16 B/rank) + int64 "
                                   "all-reduce(%d B) over RCCL; shards swept once per %d pivots"
                                   % (R * 8, block),
-                   "driver": "mi355x_colpart_* (C++ loop, RCCL from the library)" if native
+                   "driver": ("mi355x_colpart_* (C++ loop, RCCL from the library; entry: %s)"
+                              % ("mi355x_colpart_create_synthetic_rank / ncclCommInitRank" if rank_entry
+                                 else "mi355x_colpart_create_synthetic")) if native
                              else "Python protocol driver (torch.distributed)"},
         "rccl_ranks": world if info["uses_rccl"] else 0,
         "exchange_bytes_per_pivot_per_rank": 16 * world + 8 * R,
         "exchange": exchange,
+        "exchange_modes": exchange_modes,
+        "steady_state_pivots_per_s": steady,
+        "steady_state_what": ("%d further pivots (full blocks) timed right after the timed region, same "
+                              "bracketing" % steady_pivots) if steady else None,
+        "one_gpu_same_workload": baseline,
+        "speedup_vs_one_gpu": (value / baseline["value"]) if baseline else None,
+        "steady_state_speedup_vs_one_gpu": (steady / baseline["steady_state_pivots_per_s"])
+                                           if baseline and steady and baseline.get("steady_state_pivots_per_s") else None,
         "us_per_pivot": elapsed / args.steps * 1e6,
         "per_gpu_physical_GBps": stored_bytes * value / 1e9 / world,
         "aggregate_GBps": stored_bytes * value / 1e9,

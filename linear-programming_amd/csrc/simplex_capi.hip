@@ -38,6 +38,10 @@ int g_batch_mode = 0;                     // 0 auto, 1 lockstep launch pairs, 2 
 int g_tail_policy = 1;                    // a request that is not a whole number of blocks: 0 spread evenly, 1 full blocks + remainder
 int g_la_mode = 0;                        // look-ahead: 0 auto, 1 two launches per step, 2 one persistent launch per block
 int g_block_k = 16;                       // pivots selected ahead and applied per sweep (1 = off)
+int g_cp_exchange = 0;                    // column partition over RCCL, exchange B (the entering column):
+                                          // 0 int64 SUM all-reduce of (owner's bits + zeros), 1 rooted
+                                          // ncclBroadcast (root = the rank whose pricing winner won, read
+                                          // back from the all-gather: one host synchronisation per pivot)
 
 int fail(int code, const char *fmt, ...)
 {
@@ -105,6 +109,8 @@ struct mi355x_tab {
     int64_t     update_launches = 0;
     int64_t     sweeps = 0;               // update launches so far: odd ones sweep bottom-up
     unsigned    la_epoch = 1;             // next epoch base of the persistent look-ahead kernel
+    unsigned    la_last_stamp = 0;        // epoch base / workgroups of the persistent launch enqueued
+    int         la_last_nw = 0;           // last (what a recovery rolls back against)
     bool        la_lost = false;          // an exchange of the persistent look-ahead was lost once
                                           // (its workgroups were not co-resident): this handle
                                           // stays on the two-launch look-ahead
@@ -467,7 +473,10 @@ int enqueue_block(mi355x_tab *t, int is_max, double f, int k)
 {
     const TabView &v = t->c;
     int np = (t->n_part > 0 && t->part_is_max == (is_max ? 1 : 0)) ? t->n_part : 0;
-    const bool persistent = (g_la_mode == 2 || (g_la_mode == 0 && !t->la_lost)) && la_block_supported(v);
+    // (a handle that lost an exchange once stays on the two-launch form, forced mode 2 or not:
+    // re-launching the persistent kernel for ever on a GPU that cannot co-schedule its workgroups
+    // would never return)
+    const bool persistent = g_la_mode != 1 && !t->la_lost && la_block_supported(v);
     // event pairs around FULL blocks only: the statistics are per (look-ahead of g_block_k
     // pivots, sweep of g_block_k pivots), the partial last block of a run is left out
     const bool timed = t->timing_stride > 0 && t->n_timed < kTimingCap && k == g_block_k &&
@@ -489,6 +498,7 @@ int enqueue_block(mi355x_tab *t, int is_max, double f, int k)
         HIP_TRY(hipEventRecord(t->la0[t->n_timed_la], t->stream));
     }
     unsigned stamp = 0;
+    int la_nw = 0;
     if (persistent) {
         if (t->la_epoch > 0x7fff0000u) {              // 32-bit tags: start over on clean records
             HIP_TRY(hipMemsetAsync(v.la_px, 0, kMaxLaRecords * sizeof(ExchRec), t->stream));
@@ -496,7 +506,10 @@ int enqueue_block(mi355x_tab *t, int is_max, double f, int k)
             t->la_epoch = 1;
         }
         stamp = t->la_epoch;
+        la_nw = la_block_workgroups(v);
         launch_la_block(v, k, is_max, f, t->la_epoch, t->stream);
+        t->la_last_stamp = stamp;
+        t->la_last_nw = la_nw;
         t->la_epoch += 2 * kMaxBlock + 2;
     } else {
         for (int j = 0; j < k; ++j) np = launch_lookahead(v, j, is_max, f, np, t->stream);
@@ -506,7 +519,7 @@ int enqueue_block(mi355x_tab *t, int is_max, double f, int k)
         t->n_timed_la++;
         HIP_TRY(hipEventRecord(t->ev0[t->n_timed], t->stream));
     }
-    t->n_part = launch_sweep(v, k, is_max ? 1.0 : -1.0, t->stream, stamp);
+    t->n_part = launch_sweep(v, k, is_max ? 1.0 : -1.0, t->stream, stamp, la_nw);
     t->part_is_max = is_max ? 1 : 0;
     if (timed) {
         HIP_TRY(hipEventRecord(t->ev1[t->n_timed], t->stream));
@@ -516,14 +529,18 @@ int enqueue_block(mi355x_tab *t, int is_max, double f, int k)
 }
 
 // The persistent look-ahead gave up waiting for a workgroup's record (status kSyncLost): its
-// workgroups were not all resident at the same time -- a GPU shared with other work.  Nothing is
-// lost: the pivots selected before that exchange have been applied by the sweep that followed,
-// everything enqueued behind it was a no-op.  Continue on the two-launch look-ahead, which needs
-// no co-residency, for the rest of this handle's life.
+// workgroups were not all resident at the same time -- a GPU shared with other work.  Every
+// workgroup times out on its own, so the leader's workgroup may have committed one pivot more than
+// some other workgroup completed (that one gave up on the ratio exchange whose records the leader
+// still saw arrive).  The sweep that followed applied only the pivots EVERY workgroup completed
+// (BlockCtl::done); the bookkeeping of the one beyond is taken back here (k_la_rollback), and
+// everything enqueued behind the failed launch was a no-op.  Nothing is lost: continue on the
+// two-launch look-ahead, which needs no co-residency, for the rest of this handle's life.
 int recover_lost_exchange(mi355x_tab *t)
 {
     t->la_lost = true;
     t->n_part = 0;
+    if (t->la_last_stamp) launch_la_rollback(t->c, t->la_last_stamp, t->la_last_nw, t->stream);
     launch_ctl_resume(t->v, t->stream, kSyncLost);
     HIP_TRY(hipGetLastError());
     return MI_OK;
@@ -784,12 +801,15 @@ int mi355x_tab_sync(mi355x_tab *t, int64_t *n_pivots)
     if (rc != MI_OK) return rc;
     rc = read_ctl(t);
     if (rc != MI_OK) return rc;
-    if (n_pivots) *n_pivots = t->h_ctl->n_pivots;
-    if (t->h_ctl->status == kSyncLost) {              // see recover_lost_exchange
-        rc = recover_lost_exchange(t);
+    if (t->h_ctl->status == kSyncLost) {              // see recover_lost_exchange: the request may
+        rc = recover_lost_exchange(t);                // have been cut short (fewer pivots than asked
+        if (rc != MI_OK) return rc;                   // for); the count reported is what was applied
+        rc = read_ctl(t);
         if (rc != MI_OK) return rc;
+        if (n_pivots) *n_pivots = t->h_ctl->n_pivots;
         return MI_RUNNING;
     }
+    if (n_pivots) *n_pivots = t->h_ctl->n_pivots;
     if (t->h_ctl->status == kNeedDense) {             // see fall_back_to_dense: further
         rc = fall_back_to_dense(t);                   // iterations continue on the dense tableau
         if (rc != MI_OK) return rc;
@@ -1442,6 +1462,8 @@ struct RcclApi {
     decltype(&ncclCommDestroy)    CommDestroy = nullptr;
     decltype(&ncclAllGather)      AllGather = nullptr;
     decltype(&ncclAllReduce)      AllReduce = nullptr;
+    decltype(&ncclBroadcast)      Broadcast = nullptr;
+    decltype(&ncclCommAbort)      CommAbort = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string path, error;
     bool ok = false;
@@ -1475,7 +1497,8 @@ const RcclApi &rccl()
         api.name = reinterpret_cast<decltype(api.name)>(dlsym(h, "nccl" #name));        \
         if (!api.name) { api.error = "nccl" #name " missing in " + api.path; return; }
         MI_RCCL_SYM(GetUniqueId) MI_RCCL_SYM(CommInitRank) MI_RCCL_SYM(CommInitAll) MI_RCCL_SYM(CommDestroy)
-        MI_RCCL_SYM(AllGather) MI_RCCL_SYM(AllReduce) MI_RCCL_SYM(GetErrorString)
+        MI_RCCL_SYM(AllGather) MI_RCCL_SYM(AllReduce) MI_RCCL_SYM(Broadcast) MI_RCCL_SYM(CommAbort)
+        MI_RCCL_SYM(GetErrorString)
 #undef MI_RCCL_SYM
         api.ok = true;
     });
@@ -1515,6 +1538,8 @@ struct CpShard {
     long long  *bits = nullptr, *bits_in = nullptr;   // contribution / exchanged column
     int64_t    *ec = nullptr;
     ncclComm_t  comm = nullptr;
+    double     *h_gathered = nullptr;         // pinned: the all-gathered winners (exchange B as a rooted broadcast)
+    bool        aborted = false;              // its communicator was aborted after a failure: no stream syncs
     // exchange timing (mi355x_colpart_exchange_timing): event quads around the two collectives of
     // sampled pivots -- [before all-gather, after, before all-reduce, after]
     std::vector<hipEvent_t> ev;
@@ -1530,11 +1555,13 @@ struct mi355x_colpart {
     int     block = kMaxBlock, j = 0;        // pivots per sweep, steps of the current block enqueued
     int     is_max = 1;
     int     timing_stride = 0;               // 0 = no exchange timing, k = every k-th pivot
+    int     exchange = 0;                    // g_cp_exchange when the handle was created
     std::vector<CpShard> sh;                 // the shards of THIS process
     // logical shards: one allocation each, shared by all of them
     double    *l_gathered = nullptr;
     long long *l_bits_all = nullptr, *l_bits_sum = nullptr;
     std::vector<int> thread_rc;
+    bool    dead = false;                    // communicators aborted after a failure: only destroy is left
 };
 
 namespace {
@@ -1543,9 +1570,13 @@ void cp_free(mi355x_colpart *p)
 {
     if (!p) return;
     for (CpShard &s : p->sh) {
-        if (s.t) { (void)hipSetDevice(s.device); (void)hipStreamSynchronize(s.t->stream); }
+        // (a shard whose communicator had to be aborted may have collectives on its stream that
+        // can never complete: do not wait for them)
+        if (s.t && !s.aborted) { (void)hipSetDevice(s.device); (void)hipStreamSynchronize(s.t->stream); }
         if (s.comm && rccl().ok) (void)rccl().CommDestroy(s.comm);
         for (hipEvent_t e : s.ev) (void)hipEventDestroy(e);
+        if (s.h_gathered) (void)hipHostFree(s.h_gathered);
+        if (s.aborted && s.t) s.t->own_stream = nullptr;   // free_tab must not synchronise / destroy it either
     }
     for (CpShard &s : p->sh) {
         (void)hipSetDevice(s.device);
@@ -1596,7 +1627,8 @@ int cp_finish_setup(mi355x_colpart *p, const void *id128, int rank)
         HIP_TRY(hipMalloc((void **)&s.gathered, 2 * p->world * sizeof(double)));
         HIP_TRY(hipMalloc((void **)&s.bits, p->rows * sizeof(long long)));
         HIP_TRY(hipMalloc((void **)&s.ec, sizeof(int64_t)));
-        s.bits_in = s.bits;                                  // all-reduce in place
+        HIP_TRY(hipHostMalloc((void **)&s.h_gathered, 2 * p->world * sizeof(double)));
+        s.bits_in = s.bits;                                  // all-reduce / broadcast in place
     }
     if (p->multi_process) {
         ncclUniqueId id;
@@ -1631,6 +1663,20 @@ int cp_pivot(mi355x_colpart *p, CpShard &s, double f)
     return mi355x_shard_pivot(s.t, (const int64_t *)s.bits_in, s.ec, f);
 }
 
+// The rank whose (key, global column) pair wins the pricing -- vi_min's rule on the host: an empty
+// pair (column -1) loses against anything, a NaN-in-column-0 marker (-2) or no candidate at all
+// means nobody enters a column, and any root will do (everybody contributes zeros).
+int cp_winner_rank(const double *g, int world)
+{
+    int best = -1;
+    for (int k = 0; k < world; ++k) {
+        const double v = g[2 * k], c = g[2 * k + 1];
+        if (c < 0.0) continue;
+        if (best < 0 || v < g[2 * best] || (v == g[2 * best] && c < g[2 * best + 1])) best = k;
+    }
+    return best < 0 ? 0 : best;
+}
+
 // n iterations of shard s over RCCL (its own thread in the one-process form).  j0 = step of the
 // block the first iteration is; every shard runs the same sequence, so they meet in the collectives.
 int cp_run_rccl(mi355x_colpart *p, CpShard &s, double f, int64_t n, int j0)
@@ -1649,8 +1695,22 @@ int cp_run_rccl(mi355x_colpart *p, CpShard &s, double f, int64_t n, int j0)
         if (p->block > 1) rc = mi355x_shard_la_contribute(s.t, j, s.gathered, p->world, s.col_begin, f, (int64_t *)s.bits, s.ec);
         else              rc = mi355x_shard_contribute(s.t, s.gathered, p->world, s.col_begin, f, (int64_t *)s.bits, s.ec);
         if (rc != MI_OK) return rc;
+        int root = -1;
+        if (p->exchange == 1) {
+            // exchange B as a rooted broadcast: the root is the rank whose local pricing winner is
+            // the global one (lexicographic (key, column) minimum over the all-gathered pairs -- the
+            // decision every shard takes on the device).  The host has to look: one stream
+            // synchronisation per pivot, the price of a root RCCL wants as a host argument.
+            HIP_TRY(hipMemcpyAsync(s.h_gathered, s.gathered, 2 * p->world * sizeof(double),
+                                   hipMemcpyDeviceToHost, s.t->stream));
+            HIP_TRY(hipStreamSynchronize(s.t->stream));
+            root = cp_winner_rank(s.h_gathered, p->world);
+        }
         if (timed) HIP_TRY(hipEventRecord(e[2], s.t->stream));
-        RCCL_TRY(rccl().AllReduce(s.bits, s.bits, (size_t)p->rows, ncclInt64, ncclSum, s.comm, s.t->stream));
+        if (root >= 0)
+            RCCL_TRY(rccl().Broadcast(s.bits, s.bits, (size_t)p->rows, ncclInt64, root, s.comm, s.t->stream));
+        else
+            RCCL_TRY(rccl().AllReduce(s.bits, s.bits, (size_t)p->rows, ncclInt64, ncclSum, s.comm, s.t->stream));
         if (timed) { HIP_TRY(hipEventRecord(e[3], s.t->stream)); s.ev_used += 4; }
         if (p->block > 1) rc = mi355x_shard_la_pivot(s.t, j, (const int64_t *)s.bits, s.ec, f);
         else              rc = mi355x_shard_pivot(s.t, (const int64_t *)s.bits, s.ec, f);
@@ -1664,15 +1724,31 @@ int cp_run_rccl(mi355x_colpart *p, CpShard &s, double f, int64_t n, int j0)
     return MI_OK;
 }
 
+// A rank failed between two collectives: the other ranks' streams hold collectives that will never
+// complete.  Abort every local communicator (ncclCommAbort tears the kernels down) and mark the
+// shards, so that neither this call's caller nor the destroy path waits on those streams.
+void cp_abort(mi355x_colpart *p)
+{
+    if (!p->rccl || !rccl().ok) return;
+    const std::string keep = g_err;
+    for (CpShard &s : p->sh) {
+        if (s.comm) { (void)hipSetDevice(s.device); (void)rccl().CommAbort(s.comm); s.comm = nullptr; }
+        s.aborted = true;
+    }
+    p->dead = true;
+    g_err = keep;
+}
+
 // enqueue n iterations on every local shard; no host synchronisation
 int cp_run(mi355x_colpart *p, double f, int64_t n)
 {
+    if (p->dead) return fail(MI_RCCL_ERROR, "this handle's communicators were aborted after an earlier failure");
     if (n <= 0) return MI_OK;
     if (p->rccl) {
         const int j0 = p->j;
         if (p->sh.size() == 1) {
             int rc = cp_run_rccl(p, p->sh[0], f, n, j0);
-            if (rc != MI_OK) return rc;
+            if (rc != MI_OK) { cp_abort(p); return rc; }
         } else {
             // one host thread per shard: the shards' launches are enqueued in parallel and every
             // thread issues its own rank's collectives (the standard one-process multi-GPU form)
@@ -1686,7 +1762,12 @@ int cp_run(mi355x_colpart *p, double f, int64_t n)
                 });
             for (auto &x : th) x.join();
             for (size_t i = 0; i < p->sh.size(); ++i)
-                if (p->thread_rc[i] != MI_OK) { g_err = errs[i]; return p->thread_rc[i]; }
+                if (p->thread_rc[i] != MI_OK) {
+                    // the other ranks have enqueued collectives that can never complete now
+                    cp_abort(p);
+                    g_err = errs[i];
+                    return p->thread_rc[i];
+                }
         }
         if (p->block > 1) p->j = (int)((j0 + n) % p->block);
         return MI_OK;
@@ -1779,7 +1860,10 @@ static int cp_create_synthetic(mi355x_colpart **out, int64_t n_vars, int64_t n_c
     if (!p) return fail(MI_NO_MEMORY, "host allocation failed");
     p->world = world;
     p->multi_process = mp;
-    p->rccl = mp ? world > 1 : cp_one_device_each(world);
+    // (world == 1 in the one-process-per-GPU form: device-local exchanges, unless the test hook
+    // MI355X_COLPART_FORCE_RCCL=1 asks for the one-rank ncclCommInitRank communicator)
+    p->rccl = mp ? (world > 1 || cp_one_device_each(1)) : cp_one_device_each(world);
+    p->exchange = g_cp_exchange;
     p->compact = true;
     p->rows = n_cons + 1;
     p->var_count = n_vars + n_cons;
@@ -1820,11 +1904,26 @@ int mi355x_colpart_create_synthetic_rank(mi355x_colpart **out, int64_t n_vars, i
 int mi355x_colpart_create(mi355x_colpart **out, int64_t rows, int64_t cols, const double *hm,
                           const int64_t *hb, int n_devices)
 {
+    return mi355x_colpart_create_on(out, rows, cols, hm, hb, n_devices, nullptr);
+}
+
+int mi355x_colpart_create_on(mi355x_colpart **out, int64_t rows, int64_t cols, const double *hm,
+                             const int64_t *hb, int n_devices, const int *device_ids)
+{
     if (!out) return fail(MI_BAD_ARG, "out is NULL");
     *out = nullptr;
     const int64_t m = rows - 1, vc = cols - 1;
     if (!hm || !hb || m < 1 || vc < 1 || n_devices < 1) return fail(MI_BAD_ARG, "bad arguments");
-    if (device_count_checked() <= 0) return fail(MI_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    const int ndev = device_count_checked();
+    if (ndev <= 0) return fail(MI_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    if (device_ids) {
+        for (int i = 0; i < n_devices; ++i) {
+            if (device_ids[i] < 0 || device_ids[i] >= ndev)
+                return fail(MI_BAD_ARG, "device %d out of range [0,%d)", device_ids[i], ndev);
+            for (int k = 0; k < i; ++k)
+                if (device_ids[k] == device_ids[i]) return fail(MI_BAD_ARG, "device %d listed twice", device_ids[i]);
+        }
+    }
     // compact shards when the basis is a set of exact unit columns (+0.0 in the objective row)
     std::vector<char> basic((size_t)vc, 0);
     bool compact = true;
@@ -1848,6 +1947,7 @@ int mi355x_colpart_create(mi355x_colpart **out, int64_t rows, int64_t cols, cons
     if (!p) return fail(MI_NO_MEMORY, "host allocation failed");
     p->world = n_devices;
     p->rccl = cp_one_device_each(n_devices);
+    p->exchange = g_cp_exchange;
     p->compact = compact;
     p->rows = rows;
     p->var_count = vc;
@@ -1855,7 +1955,8 @@ int mi355x_colpart_create(mi355x_colpart **out, int64_t rows, int64_t cols, cons
     for (int r = 0; r < n_devices; ++r) {
         CpShard s;
         s.index = r;
-        s.device = p->rccl ? r : 0;
+        // one shard per listed device (default 0 .. n-1); logical shards all live on the first
+        s.device = device_ids ? device_ids[p->rccl ? r : 0] : (p->rccl ? r : 0);
         int64_t b, e;
         cp_partition((int64_t)dist.size(), n_devices, r, &b, &e);
         const int64_t nloc = e - b;
@@ -2058,6 +2159,7 @@ int         mi355x_tune_set_compact(int on) { g_compact_enabled = on ? 1 : 0; re
 int         mi355x_tune_set_sweep_impl(int impl) { set_sweep_impl(impl); return impl; }
 int         mi355x_tune_set_shard_la_split(int mode) { set_shard_la_split(mode); return mode; }
 int         mi355x_tune_set_tail_policy(int p) { g_tail_policy = p == 1 ? 1 : 0; return g_tail_policy; }
+int         mi355x_tune_set_colpart_exchange(int mode) { g_cp_exchange = mode == 1 ? 1 : 0; return g_cp_exchange; }
 /* measurement aid: the sweep of the CURRENT pending list launched n more times (the list is not
  * consumed by a sweep); average launch duration by HIP events.  Leaves the tableau meaningless. */
 int         mi355x_debug_repeat_sweep(mi355x_tab *t, int n, double *avg_us)

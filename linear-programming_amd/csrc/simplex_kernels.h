@@ -45,6 +45,12 @@ struct BlockCtl {
     int64_t stamp;                // persistent look-ahead: epoch base of the launch that wrote the list
     int64_t cr[kMaxBlock];        // their pivot rows ...
     int64_t slot[kMaxBlock];      // ... and the physical slots their entering columns gave up
+    // persistent look-ahead: (stamp << 8 | steps) -- how many steps of the launch with that stamp
+    // workgroup w completed (everything it owns of col_i / prow_i stored).  The leader raises
+    // n_pending on its own; a workgroup that gave up on an exchange (kSyncLost) may be one step
+    // behind it, so the sweep applies min(n_pending, min over w of steps) pivots and the host's
+    // recovery takes the bookkeeping of the pivot beyond that back (k_la_rollback).
+    int64_t done[32];             // kMaxLaWorkgroups entries
 };
 
 // Record one workgroup of the persistent look-ahead kernel publishes per exchange: eight
@@ -55,6 +61,7 @@ struct ExchRec {
     unsigned long long g[8];
 };
 constexpr int kMaxLaWorkgroups = 32;
+static_assert(sizeof(BlockCtl::done) / sizeof(int64_t) == kMaxLaWorkgroups, "BlockCtl::done");
 constexpr int kMaxLaRecords = 4 * kMaxLaWorkgroups;     // one record per wave of a 256-thread workgroup
 
 // One tableau in HBM.  Row-major, leading dimension ld (a multiple of 16 doubles so
@@ -118,8 +125,13 @@ void set_alternate_sweep(int on);
 // launch_lookahead returns the number of pricing partials it leaves for step j+1.
 bool block_supported(const TabView &t);
 int  launch_lookahead(const TabView &t, int j, int is_max, double fp_factor, int n_part, hipStream_t s);
-// stamp != 0: apply the pending list only if the look-ahead launch with that epoch base wrote it
-int  launch_sweep(const TabView &t, int kmax, double sgn, hipStream_t s, unsigned stamp = 0);
+// stamp != 0: apply the pending list only if the look-ahead launch with that epoch base wrote it,
+// and of it only the pivots all la_nw workgroups of that launch completed (BlockCtl::done)
+int  launch_sweep(const TabView &t, int kmax, double sgn, hipStream_t s, unsigned stamp = 0, int la_nw = 0);
+// after a lost exchange (kSyncLost): undo the bookkeeping (column maps, basis, pivot count, trace)
+// of the pivots the leader committed but the sweep did not apply
+void launch_la_rollback(const TabView &t, unsigned stamp, int la_nw, hipStream_t s);
+int  la_block_workgroups(const TabView &t);
 // the whole look-ahead of a block (steps 0 .. ksteps-1) as ONE launch of a few persistent
 // workgroups that exchange their reduction candidates through la_px / la_rx; epoch_base (> 0)
 // must grow by at least 2*kMaxBlock+2 from launch to launch on the same tableau (the records

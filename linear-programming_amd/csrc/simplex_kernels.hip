@@ -1136,11 +1136,11 @@ __global__ __launch_bounds__(kSelThreads) void k_shard_la_prepare(TabView t, int
         z.y = pend(z.y, 2 * p + 1 == slot, false, cmj, pr.y);
         const int64_t c0i = 2 * p;
         if (c0i < vcl) {
-            ValIdx c = price_cand(z.x * sgn, (c0i == slot) ? leaving : (t.p2l ? t.p2l[c0i] : c0i), c0i);
+            ValIdx c = price_cand(z.x * sgn, (c0i == slot) ? leaving : (t.p2l ? t.p2l[c0i] : c0i), c0i, t.p2l ? 0 : t.col_bias);
             best = vi_min(best, c);
         }
         if (c0i + 1 < vcl) {
-            ValIdx c = price_cand(z.y * sgn, (c0i + 1 == slot) ? leaving : (t.p2l ? t.p2l[c0i + 1] : c0i + 1), c0i + 1);
+            ValIdx c = price_cand(z.y * sgn, (c0i + 1 == slot) ? leaving : (t.p2l ? t.p2l[c0i + 1] : c0i + 1), c0i + 1, t.p2l ? 0 : t.col_bias);
             best = vi_min(best, c);
         }
     }
@@ -1284,11 +1284,11 @@ __global__ __launch_bounds__(kScaleThreads) void k_shard_la_scale(TabView t, int
         z.x = pend(z.x, 2 * p     == slot, false, cmj, pr.x);
         z.y = pend(z.y, 2 * p + 1 == slot, false, cmj, pr.y);
         if (c0i < vcl) {
-            ValIdx c = price_cand(z.x * sgn, (c0i == slot) ? leaving : l0, c0i);
+            ValIdx c = price_cand(z.x * sgn, (c0i == slot) ? leaving : l0, c0i, t.p2l ? 0 : t.col_bias);
             best = vi_min(best, c);
         }
         if (c0i + 1 < vcl) {
-            ValIdx c = price_cand(z.y * sgn, (c0i + 1 == slot) ? leaving : l1, c0i + 1);
+            ValIdx c = price_cand(z.y * sgn, (c0i + 1 == slot) ? leaving : l1, c0i + 1, t.p2l ? 0 : t.col_bias);
             best = vi_min(best, c);
         }
         // bookkeeping: the owner of the slot where there is one (it alone reads basis[cr] before
@@ -1538,7 +1538,8 @@ template <bool PRICE, class Extra>
 __device__ __forceinline__ bool la_exchange(ValIdx mine, unsigned myflag, ExchRec *recs, int nw, int w,
                                             unsigned tag, unsigned max_spins, bool mute, bool local,
                                             int rec_from, LaMsg *s_res, LaMsg &out, Extra extra,
-                                            unsigned long long *ts, double *dbg = nullptr)
+                                            unsigned long long *ts, double *dbg = nullptr,
+                                            bool give_up = false)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nrec = nw * kLaWaves;
@@ -1571,6 +1572,7 @@ __device__ __forceinline__ bool la_exchange(ValIdx mine, unsigned myflag, ExchRe
 #ifdef MI355X_LA_TIMING
     if (ts) ts[0] = wall_clock64();
 #endif
+    if (give_up) { out.flag = 2u; return false; }               // test hook (workgroup-uniform): published, then "timed out"
     if (kLaEveryWavePolls || tid < 64) {
         // ---- collect: lane l <- records l and l + 64
         const bool v0 = lane < nrec, v1 = lane + 64 < nrec;
@@ -1681,11 +1683,17 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
     // a new block starts (whatever the status): pending list, stamp (the sweep applies the list
     // only under this launch's stamp -- had the leader's workgroup never run, the list would be
     // the previous block's) and this thread's OWN mask words, which only it ever writes
-    if (leader) { blk->n_pending = 0; blk->stamp = epoch_base; }
+    // (not behind a launch that lost an exchange: the host's recovery reads that launch's list)
+    if (leader && c0.status != kSyncLost) { blk->n_pending = 0; blk->stamp = epoch_base; }
     unsigned my_rm = 0u, my_sm = 0u;     // bit i: my row is pivot row i / bits i, 16+i: my pair's columns are slot i
     if (g < t.bk_stride) t.bk_rmask[g] = 0u;
     if (g < ldv)         t.bk_smask[g] = 0u;
-    if (c0.status != kRunning) return;
+    // every way out of the launch records how many steps this workgroup COMPLETED (its col_i /
+    // prow_i entries stored): the sweep applies no pivot that some workgroup did not finish
+    auto leave = [&](int steps) {
+        if (tid == 0) st_wt(&blk->done[w], (int64_t)(((unsigned long long)epoch_base << 8) | (unsigned)steps));
+    };
+    if (c0.status != kRunning) { leave(0); return; }
 
     double  b = (has_row && r < m) ? t.M[r * ld + vc] : 0.0;     // RHS entry of my row
     double2 z = has_pair ? M2[m * ldv + p] : make_double2(0.0, 0.0);   // objective row, my pair
@@ -1706,6 +1714,10 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
     for (int J = 0; J < ksteps; ++J) {
         const unsigned e_price = epoch_base + 2 * J + 1, e_ratio = epoch_base + 2 * J + 2;
         const bool mute = fault > 0 && J >= fault - 1 && w == nw - 1;
+        // fault < 0 (test hook): the last workgroup publishes its ratio record of step -fault - 1 and
+        // then gives up as if its polls had run out -- while every other workgroup sees all records,
+        // the leader commits that pivot, and nobody gets past the next exchange
+        const bool quit = fault < 0 && J == -fault - 1 && w == nw - 1 && nw > 1;
         double *dbg_p = nullptr, *dbg_r = nullptr;
 #ifdef MI355X_LA_TIMING
         unsigned long long T0 = wall_clock64(), T2, T3, T5, T6;
@@ -1726,6 +1738,7 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
                     if (wave_has_vc) x2 = lane_value_dyn((vc & 1) ? pr.y : pr.x, g_vc & 63);
                 }, ts_p, dbg_p)) {
             if (tid == 0) st_wt(&ctl->status, kSyncLost);        // same word, same value from everyone
+            leave(J);
             return;
         }
         if (J == 0) local = one_xcd != 0 && e.same != 0u;        // same records, same decision everywhere
@@ -1734,10 +1747,12 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
 #endif
         if (price_says_optimal(e.c, price_tol)) {
             if (leader) ctl->status = 0;                         // MI_OPTIMAL
+            leave(J);
             return;
         }
         if (c0.max_pivots > 0 && c0.n_pivots + J >= c0.max_pivots) {
             if (leader) ctl->status = 3;                         // MI_MAX_PIVOTS
+            leave(J);
             return;
         }
         const int64_t ec = e.c.i, slot = uniform64(e.c.s);
@@ -1794,8 +1809,9 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
         LaMsg qq;
         if (!la_exchange<false>(q, bad, t.la_rx, nw, w, e_ratio, max_spins, mute, local, rec_m, &s_res, qq,
                 [&](const ValIdx &, int, double &u, double &) { if (wave_has_m) u = lane_value_dyn(a, g_m & 63); },
-                ts_r, dbg_r)) {
+                ts_r, dbg_r, quit)) {
             if (tid == 0) st_wt(&ctl->status, kSyncLost);
+            leave(J);
             return;
         }
 #ifdef MI355X_LA_TIMING
@@ -1803,10 +1819,12 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
 #endif
         if (qq.flag != 0u) {                                     // inf / NaN in the column: see kNeedDense
             if (leader) ctl->status = kNeedDense;
+            leave(J);
             return;
         }
         if (qq.c.i < 0) {
             if (leader) ctl->status = 1;                         // MI_UNBOUNDED
+            leave(J);
             return;
         }
         const int64_t cr = uniform64(qq.c.i);
@@ -1899,6 +1917,44 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
         }
 #endif
     }
+    leave(ksteps);
+}
+
+// Pivots of the pending list that a sweep may apply: those EVERY workgroup of the persistent
+// look-ahead launch `stamp` completed (BlockCtl::done).  All of n_pending in every run in which no
+// exchange was lost; one fewer when a workgroup gave up on the ratio exchange of the last step while
+// the leader's workgroup still saw all records and committed the pivot.
+__device__ __forceinline__ int committed_pivots(const BlockCtl *__restrict__ blk, int k, unsigned stamp, int la_nw)
+{
+    for (int w = 0; w < la_nw; ++w) {
+        const int64_t d = blk->done[w];
+        const int dw = (unsigned)((unsigned long long)d >> 8) == stamp ? (int)(d & 0xff) : 0;
+        k = dw < k ? dw : k;
+    }
+    return k;
+}
+
+// After a lost exchange: the sweep applied committed_pivots() of the n_pending pivots the leader
+// recorded; take the bookkeeping of the others (at most one) back, newest first, so that the
+// handle describes the tableau as it is -- the host then continues on the two-launch look-ahead.
+__global__ void k_la_rollback(TabView t, unsigned stamp, int la_nw)
+{
+    BlockCtl *blk = t.blk;
+    Ctl *ctl = t.ctl;
+    const int n = (int)blk->n_pending;
+    if (n == 0 || (unsigned)blk->stamp != stamp) return;
+    const int keep = committed_pivots(blk, n, stamp, la_nw);
+    for (int i = n - 1; i >= keep; --i) {
+        const int64_t cr = blk->cr[i], slot = blk->slot[i];
+        const int64_t ec = t.basis[cr], leaving = t.p2l[slot];
+        t.p2l[slot] = ec;
+        t.l2p[ec] = slot;
+        t.l2p[leaving] = -1;
+        t.basis[cr] = leaving;
+        ctl->n_pivots -= 1;
+        ctl->trace_n -= 1;
+    }
+    blk->n_pending = keep;
 }
 
 // The sweep.  A workgroup owns a strip of <= 256 column pairs x tr rows and walks it four rows
@@ -1937,15 +1993,17 @@ __device__ __forceinline__ void sload_chunk(v8i (&c)[CH], const double *base, co
 
 template <int BLOCK, int KMAX, bool NT>
 __global__ __launch_bounds__(BLOCK) void k_sweep(TabView t, const int tr, const int strip_pairs,
-                                                 const double sgn, const int price, const unsigned stamp)
+                                                 const double sgn, const int price, const unsigned stamp,
+                                                 const int la_nw)
 {
     constexpr int U = 4;                                       // rows per step
     constexpr int CH = KMAX < 4 ? KMAX : 4;                    // pivots per SGPR chunk (32 SGPRs: more would spill)
     t = lp_slice(t);                                           // batch: grid.z = LP
     const BlockCtl *__restrict__ blk = t.blk;
-    const int k = (int)blk->n_pending;
+    int k = (int)blk->n_pending;
     if (k == 0) return;
     if (stamp != 0u && (unsigned)blk->stamp != stamp) return;  // the list is not this block's
+    if (stamp != 0u && (k = committed_pivots(blk, k, stamp, la_nw)) == 0) return;
     double *__restrict__ M = t.M;
     const int64_t ld = t.ld, rows = t.rows, vc = t.cols - 1;
     const int64_t ldv  = ld >> 1;
@@ -2136,14 +2194,16 @@ template <> struct ColChunk<8> {
 
 template <bool NT, int U>
 __global__ __launch_bounds__(256) void k_sweep16(TabView t, const int tr, const int strip_pairs,
-                                                 const double sgn, const int price, const unsigned stamp)
+                                                 const double sgn, const int price, const unsigned stamp,
+                                                 const int la_nw)
 {
     constexpr int K = kSweepK, CP = ColChunk<U>::CP, NCH = K / CP;
     t = lp_slice(t);                                           // batch: grid.z = LP
     const BlockCtl *__restrict__ blk = t.blk;
-    const int k = (int)blk->n_pending;
+    int k = (int)blk->n_pending;
     if (k == 0) return;
     if (stamp != 0u && (unsigned)blk->stamp != stamp) return;  // the list is not this block's
+    if (stamp != 0u && (k = committed_pivots(blk, k, stamp, la_nw)) == 0) return;
     double *__restrict__ M = t.M;
     const int64_t ld = t.ld, rows = t.rows, vc = t.cols - 1;
     const int64_t ldv  = ld >> 1;
@@ -3178,7 +3238,7 @@ bool launch_batch_block_split(const TabView &t, int is_max, double f, hipStream_
     int64_t tr = g_sweep_tr ? g_sweep_tr : 16;
     while (tr > 4 && ((t.rows + tr - 1) / tr) * strips * t.n_lps < 2048) tr /= 2;
     const dim3 grid((unsigned)strips, (unsigned)((t.rows + tr - 1) / tr), (unsigned)t.n_lps);
-    hipLaunchKernelGGL((k_sweep<256, 16, false>), grid, dim3(256), 0, s, t, (int)tr, (int)sp, sgn_of(is_max), 0, 0u);
+    hipLaunchKernelGGL((k_sweep<256, 16, false>), grid, dim3(256), 0, s, t, (int)tr, (int)sp, sgn_of(is_max), 0, 0u, 0);
     return true;
 }
 void launch_verify_basis(const TabView &t, int *flag, hipStream_t s)
@@ -3377,12 +3437,22 @@ static int      g_la_one_xcd = 1, g_la_fault = 0;
 static unsigned g_la_max_spins = 1u << 21;
 void set_la_one_xcd(int on) { g_la_one_xcd = on ? 1 : 0; }
 void set_la_max_spins(unsigned n) { g_la_max_spins = n ? n : (1u << 21); }
-void set_la_fault(int step_plus_1) { g_la_fault = step_plus_1 > 0 ? step_plus_1 : 0; }
+void set_la_fault(int step_plus_1) { g_la_fault = step_plus_1; }
+
+int la_block_workgroups(const TabView &t)
+{
+    const int64_t need = t.rows > (t.ld >> 1) ? t.rows : (t.ld >> 1);
+    return (int)((need + kLaThreads - 1) / kLaThreads);
+}
+
+void launch_la_rollback(const TabView &t, unsigned stamp, int la_nw, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_la_rollback, dim3(1), dim3(1), 0, s, t, stamp, la_nw);
+}
 
 void launch_la_block(const TabView &t, int ksteps, int is_max, double f, unsigned epoch_base, hipStream_t s)
 {
-    const int64_t need = t.rows > (t.ld >> 1) ? t.rows : (t.ld >> 1);
-    const int nw = (int)((need + kLaThreads - 1) / kLaThreads);
+    const int nw = la_block_workgroups(t);
     // one-XCD mode: 8 x nw blocks, every eighth takes part (the kernel verifies where they run)
     const int one_xcd = g_la_one_xcd && nw > 1;
     hipLaunchKernelGGL(k_la_block<kMaxBlock>, dim3(one_xcd ? 8 * nw : nw), dim3(kLaThreads), 0, s, t, ksteps,
@@ -3397,14 +3467,14 @@ void set_sweep_impl(int impl) { g_sweep_impl = impl == 1 ? 1 : 0; if (impl == 4 
 
 template <int KMAX>
 static void launch_sweep_t(const TabView &t, dim3 grid, int tr, int sp, double sgn, bool nt, unsigned stamp,
-                           hipStream_t s)
+                           int la_nw, hipStream_t s)
 {
-    if (nt) hipLaunchKernelGGL((k_sweep<256, KMAX, true>),  grid, dim3(256), 0, s, t, tr, sp, sgn, 1, stamp);
-    else    hipLaunchKernelGGL((k_sweep<256, KMAX, false>), grid, dim3(256), 0, s, t, tr, sp, sgn, 1, stamp);
+    if (nt) hipLaunchKernelGGL((k_sweep<256, KMAX, true>),  grid, dim3(256), 0, s, t, tr, sp, sgn, 1, stamp, la_nw);
+    else    hipLaunchKernelGGL((k_sweep<256, KMAX, false>), grid, dim3(256), 0, s, t, tr, sp, sgn, 1, stamp, la_nw);
 }
 
 // applies up to kmax pending pivots; returns the number of pricing partials it leaves
-int launch_sweep(const TabView &t, int kmax, double sgn, hipStream_t s, unsigned stamp)
+int launch_sweep(const TabView &t, int kmax, double sgn, hipStream_t s, unsigned stamp, int la_nw)
 {
     constexpr int block = 256;
     const int64_t ldv = t.ld >> 1;
@@ -3429,18 +3499,18 @@ int launch_sweep(const TabView &t, int kmax, double sgn, hipStream_t s, unsigned
         // padded to a multiple of 16 rows, so the uint4 mask loads of the last tile stay inside)
         const bool u8 = g_sweep_u == 8 && tr % 8 == 0;
         if (u8) {
-            if (nt) hipLaunchKernelGGL((k_sweep16<true, 8>),  grid, dim3(256), 0, s, t, (int)tr, (int)sp, sgn, 1, stamp);
-            else    hipLaunchKernelGGL((k_sweep16<false, 8>), grid, dim3(256), 0, s, t, (int)tr, (int)sp, sgn, 1, stamp);
+            if (nt) hipLaunchKernelGGL((k_sweep16<true, 8>),  grid, dim3(256), 0, s, t, (int)tr, (int)sp, sgn, 1, stamp, la_nw);
+            else    hipLaunchKernelGGL((k_sweep16<false, 8>), grid, dim3(256), 0, s, t, (int)tr, (int)sp, sgn, 1, stamp, la_nw);
         } else {
-            if (nt) hipLaunchKernelGGL((k_sweep16<true, 4>),  grid, dim3(256), 0, s, t, (int)tr, (int)sp, sgn, 1, stamp);
-            else    hipLaunchKernelGGL((k_sweep16<false, 4>), grid, dim3(256), 0, s, t, (int)tr, (int)sp, sgn, 1, stamp);
+            if (nt) hipLaunchKernelGGL((k_sweep16<true, 4>),  grid, dim3(256), 0, s, t, (int)tr, (int)sp, sgn, 1, stamp, la_nw);
+            else    hipLaunchKernelGGL((k_sweep16<false, 4>), grid, dim3(256), 0, s, t, (int)tr, (int)sp, sgn, 1, stamp, la_nw);
         }
         return strips * (block / 64);
     }
-    if (kmax <= 2)      launch_sweep_t<2>(t, grid, (int)tr, (int)sp, sgn, nt, stamp, s);
-    else if (kmax <= 4) launch_sweep_t<4>(t, grid, (int)tr, (int)sp, sgn, nt, stamp, s);
-    else if (kmax <= 8) launch_sweep_t<8>(t, grid, (int)tr, (int)sp, sgn, nt, stamp, s);
-    else                launch_sweep_t<16>(t, grid, (int)tr, (int)sp, sgn, nt, stamp, s);
+    if (kmax <= 2)      launch_sweep_t<2>(t, grid, (int)tr, (int)sp, sgn, nt, stamp, la_nw, s);
+    else if (kmax <= 4) launch_sweep_t<4>(t, grid, (int)tr, (int)sp, sgn, nt, stamp, la_nw, s);
+    else if (kmax <= 8) launch_sweep_t<8>(t, grid, (int)tr, (int)sp, sgn, nt, stamp, la_nw, s);
+    else                launch_sweep_t<16>(t, grid, (int)tr, (int)sp, sgn, nt, stamp, la_nw, s);
     return strips * (block / 64);
 }
 

@@ -232,12 +232,17 @@ def test_persistent_lookahead_handoff_under_load(n, m, one_xcd):
         torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("fault_step", [1, 4, 16])
+@pytest.mark.parametrize("fault_step", [1, 4, 16, -1, -4, -9, -16])
 def test_lost_exchange_falls_back_to_two_launch_lookahead(fault_step):
     """A workgroup of the persistent look-ahead that stops publishing (what a workgroup that is
     not resident looks like to the others): the others give up after the poll bound, the pivots
     selected before are applied, the host switches the handle to the two-launch look-ahead and the
-    solve ends with the oracle's pivots and bits -- no error, no hang."""
+    solve ends with the oracle's pivots and bits -- no error, no hang.
+    fault_step < 0: ONE workgroup gives up alone, right after publishing its ratio record of step
+    -fault_step - 1 -- every workgroup times out on its own, so the leader still sees all records
+    and commits a pivot whose col / prow entries that workgroup never stored (round-2 advisor
+    finding).  The sweep must apply only what every workgroup completed (BlockCtl::done) and the
+    recovery must take the leader's bookkeeping of that one pivot back (k_la_rollback)."""
     L = lp.capi.lib()
     n, m = 1500, 700
     seed = lp.synth.seed_for(2, 77)
@@ -265,6 +270,44 @@ def test_lost_exchange_falls_back_to_two_launch_lookahead(fault_step):
     M2, b2 = M0.copy(), b0.copy()
     so2, no2, _ = oracle.solve(M2, b2)
     assert rc == so2 and np.array_equal(t.matrix.view(np.int64), M2.view(np.int64))
+
+
+@pytest.mark.parametrize("fault_step", [3, -3, -16])
+def test_lost_exchange_through_solve_async_and_sync(fault_step):
+    """The same through the asynchronous entry points: mi355x_tab_sync reports MI_RUNNING with
+    FEWER pivots than requested (documented), the count is what the tableau really holds, and
+    enqueueing the difference reaches the oracle's state bit for bit -- also with the persistent
+    look-ahead forced (mode 2), which must not be re-launched for ever on such a handle."""
+    L = lp.capi.lib()
+    n, m = 1500, 700
+    seed = lp.synth.seed_for(2, 78)
+    M0, b0 = lp.synth.tableau(n, m, seed)
+    want = 48
+    M, b = M0.copy(), b0.copy()
+    st_o, npiv, trace = oracle.solve(M, b, max_pivots=want, trace_cap=want)
+    assert npiv == want
+    try:
+        L.mi355x_tune_set_la_max_spins(20000)
+        L.mi355x_tune_set_la_fault(fault_step)
+        L.mi355x_tune_set_lookahead_mode(2)
+        t = lp.Tableau(None, lp.Problem(type="max"), M0, b0, n + m, m, {})
+        k = ctypes.c_int64(0)
+        lp.capi.check(L.mi355x_tab_solve_async(t._h, 1, 1024.0, want, 1), "solve_async")
+        rc = L.mi355x_tab_sync(t._h, ctypes.byref(k))
+        assert rc == lp.capi.MI_RUNNING and 0 <= k.value < want and L.mi355x_tab_la_lost(t._h) == 1
+        applied = abs(fault_step) - 1                # pivots every workgroup had completed
+        assert k.value == applied
+        lp.capi.check(L.mi355x_tab_solve_async(t._h, 1, 1024.0, want - k.value, 0), "solve_async (rest)")
+        rc = L.mi355x_tab_sync(t._h, ctypes.byref(k))
+        t._touch()
+    finally:
+        L.mi355x_tune_set_la_max_spins(0)
+        L.mi355x_tune_set_la_fault(0)
+        L.mi355x_tune_set_lookahead_mode(0)
+    assert (rc, k.value) == (lp.capi.MI_RUNNING, want)
+    assert np.array_equal(t.pivot_trace()[:want], trace)
+    assert np.array_equal(t.matrix.view(np.int64), M.view(np.int64))
+    assert np.array_equal(t.basis_columns, b)
 
 
 # =========================================================================== multi-device C ABI
@@ -323,10 +366,16 @@ def test_colpart_c_abi_cap_resume_synthetic_and_dense_fallback():
     tab.close()
 
 
-def test_colpart_c_abi_over_rccl_single_rank(monkeypatch):
-    """The RCCL code path itself (ncclCommInitAll, ncclAllGather / ncclAllReduce on the shard's
-    stream, communicator teardown) on the one GPU this box has: a single shard forced through its
-    one-rank communicator.  (Two ranks need two devices: RCCL refuses two ranks on one GPU.)"""
+@pytest.mark.parametrize("exchange", [0, 1], ids=["allreduce", "rooted-broadcast"])
+@pytest.mark.parametrize("entry", ["comm-init-all", "comm-init-rank"])
+def test_colpart_c_abi_over_rccl_single_rank(monkeypatch, entry, exchange):
+    """The RCCL code path itself on the one GPU this box has: a single shard forced through its
+    one-rank communicator -- ncclAllGather + ncclAllReduce (or, exchange 1, ncclBroadcast from the
+    owner with the root read back from the all-gather) on the shard's stream, communicator
+    teardown.  Both ways in: ncclCommInitAll (one process, what the Lisp host's `:devices` reaches)
+    and EXACTLY what `bench.py --gpus N` does on every rank -- mi355x_rccl_unique_id ->
+    mi355x_colpart_create_synthetic_rank(world, rank, device, id) -> ncclCommInitRank -- at
+    world = 1.  (Two ranks need two devices: RCCL refuses two ranks on one GPU.)"""
     import importlib
     cp = importlib.import_module("linear-programming_amd.colpart")
     monkeypatch.setenv("MI355X_COLPART_FORCE_RCCL", "1")
@@ -334,7 +383,17 @@ def test_colpart_c_abi_over_rccl_single_rank(monkeypatch):
     seed = lp.synth.seed_for(5, 11)
     M, b = lp.synth.tableau(n, m, seed)
     so, no, trace = oracle.solve(M, b, trace_cap=1 << 14)
-    tab = cp.NativeColumnPartition.synthetic(n, m, seed, 1)
+    L = lp.capi.lib()
+    try:
+        L.mi355x_tune_set_colpart_exchange(exchange)
+        if entry == "comm-init-rank":
+            uid = cp.NativeColumnPartition.rccl_unique_id()
+            assert len(uid) == 128 and any(uid)
+            tab = cp.NativeColumnPartition.synthetic_rank(n, m, seed, 1, 0, 0, uid)
+        else:
+            tab = cp.NativeColumnPartition.synthetic(n, m, seed, 1)
+    finally:
+        L.mi355x_tune_set_colpart_exchange(0)
     assert tab.info() == {"n_shards": 1, "n_devices_used": 1, "uses_rccl": True}
     tab.exchange_timing(4, 64)
     st, k = tab.solve()
@@ -344,6 +403,28 @@ def test_colpart_c_abi_over_rccl_single_rank(monkeypatch):
     G, bg, _, _ = tab.download()
     assert np.array_equal(G.view(np.int64), M.view(np.int64)) and np.array_equal(bg, b)
     tab.close()
+
+
+def test_bench_colpart_one_rank_through_the_multi_gpu_entry():
+    """`bench.py --workload colpart --gpus 1` forced through the branch N > 1 takes (unique id ->
+    create_synthetic_rank -> ncclCommInitRank -> collectives on a one-rank communicator), incl. the
+    second leg with the rooted-broadcast exchange and the steady-state figure."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, MI355X_COLPART_FORCE_RCCL="1", BENCH_COLPART_RANK_ENTRY="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "colpart", "--gpus", "1",
+                          "--steps", "20", "--warmup", "5", "--colpart-vars", "4096"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["rccl_ranks"] == 1 and "ncclCommInitRank" in rec["config"]["driver"]
+    assert rec["value"] > 0 and rec["steady_state_pivots_per_s"] > 0
+    assert rec["exchange"]["samples"] > 0
+    modes = rec["exchange_modes"]
+    assert modes["int64_sum_allreduce"]["value"] > 0 and modes["rooted_broadcast"]["value"] > 0
 
 
 def test_plain_c_client_on_the_gpu(tmp_path):
@@ -415,6 +496,7 @@ def test_bench_two_ranks_headline_is_the_column_partition():
     rec = _bench_two_ranks({})
     assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["steps"] == 20
     assert rec["value"] > 0 and "column-partitioned" in rec["config"]["workload"]
+    assert "one_gpu_same_workload" in rec and "speedup_vs_one_gpu" in rec and "steady_state_pivots_per_s" in rec
     weak = rec["independent_lps_weak_scaling"]
     assert weak["scaling"] == "weak" and weak["value"] > 0 and weak["roofline"]["frac"] > 0
 

@@ -192,3 +192,42 @@ def test_batches_with_overflowing_members_every_mode():
                 assert np.array_equal(bg, b), where
     finally:
         L.mi355x_tune_set_batch_mode(0)
+
+
+@pytest.mark.parametrize("split", [1, 2], ids=["one-workgroup-step", "split-step"])
+def test_dense_column_shards_nan_in_a_later_shards_first_column(split):
+    """Round-2 advisor finding: the NaN-in-column-0 rule is about GLOBAL column 0.  A dense column
+    shard numbers its columns from 0, and the look-ahead step of a shard priced its slice without
+    the shard's column offset -- a NaN objective entry in LOCAL column 0 of shard r > 0 became the
+    unbeatable candidate and every shard stopped as optimal.  The reference simply never enters
+    that column (find-entering-column, src/simplex.lisp:362-379)."""
+    import importlib
+    cp = importlib.import_module("linear-programming_amd.colpart")
+    L = lp.capi.lib()
+    rng = np.random.default_rng(5)
+    m, n = 25, 40
+    A = rng.uniform(0.1, 1.5, (m, n))
+    M0, b0 = _tableau(A, rng.uniform(1.0, 4.0, m), -rng.uniform(0.5, 2.0, n))
+    M0[:m, n:n + m] *= 2.0                               # basis columns != e_i: dense shards, all 65 columns distributed
+    for shards in (2, 3):
+        first = [(n + m) // shards * r + min(r, (n + m) % shards) for r in range(shards)]
+        for r in range(1, shards):
+            M1 = M0.copy()
+            M1[m, first[r]] = NAN                        # local column 0 of shard r
+            M, b = M1.copy(), b0.copy()
+            with np.errstate(all="ignore"):
+                so, no, trace = oracle.solve(M, b, trace_cap=4096)
+            assert no > 3                                # the oracle pivots on: the NaN column just never enters
+            try:
+                L.mi355x_tune_set_shard_la_split(split)
+                tab = cp.NativeColumnPartition.from_arrays(M1, b0, shards)
+                st, k = tab.solve()
+            finally:
+                L.mi355x_tune_set_shard_la_split(0)
+            assert (st, k) == (so, no), (shards, r, st, k, so, no)
+            assert np.array_equal(tab.trace(no), trace)
+            G, bg, _, _ = tab.download()
+            nan_o, nan_g = np.isnan(M), np.isnan(G)
+            assert np.array_equal(nan_o, nan_g)
+            assert np.array_equal(G[~nan_g].view(np.int64), M[~nan_o].view(np.int64)) and np.array_equal(bg, b)
+            tab.close()

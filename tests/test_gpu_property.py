@@ -1,5 +1,7 @@
-"""Property-based parity: random shapes, senses, degeneracy patterns and internal code paths --
-the HIP path must always take the oracle's pivots and end with the oracle's bits."""
+"""Property-based parity: random shapes, senses, degeneracy patterns, tolerance factors and
+internal code paths -- the HIP path must always take the oracle's pivots and end with the oracle's
+bits.  The reference's one solver knob, `:fp-tolerance` (src/simplex.lisp:506-511; thresholds
+factor/8, factor/2 and factor times epsilon, src/utils.lisp:84-124), is drawn in every test."""
 import ctypes
 
 import numpy as np
@@ -11,6 +13,7 @@ from tests.helpers import lp_amd
 
 pytestmark = pytest.mark.gpu
 lp = lp_amd()
+FACTORS = [16, 128, 1024, 8192, 2 ** 20]
 
 
 def _random_tableau(rng, n, m, kind, density, degenerate):
@@ -38,15 +41,17 @@ def _random_tableau(rng, n, m, kind, density, degenerate):
        kind=st.sampled_from(["max", "min"]), density=st.sampled_from([1.0, 0.5, 0.1]),
        degenerate=st.booleans(), select_mode=st.sampled_from([0, 1, 2]),
        compact=st.sampled_from([0, 1]), variant=st.integers(0, 17),
-       block=st.sampled_from([1, 2, 5, 8, 16]), lookahead=st.sampled_from([0, 1, 2]))
+       block=st.sampled_from([1, 2, 5, 8, 16]), lookahead=st.sampled_from([0, 1, 2]),
+       factor=st.sampled_from(FACTORS))
 def test_random_lps_bitwise(n, m, seed, kind, density, degenerate, select_mode, compact, variant,
-                            block, lookahead):
+                            block, lookahead, factor):
     L = lp.capi.lib()
     rng = np.random.default_rng(seed)
     M0, b0 = _random_tableau(rng, n, m, kind, density, degenerate)
     M, b = M0.copy(), b0.copy()
     cap = 400                                        # degenerate LPs may cycle: no anti-cycling rule
-    st_o, npiv, trace = oracle.solve(M, b, is_max=(kind == "max"), max_pivots=cap, trace_cap=cap)
+    st_o, npiv, trace = oracle.solve(M, b, is_max=(kind == "max"), factor=float(factor), max_pivots=cap,
+                                     trace_cap=cap)
     try:
         L.mi355x_tune_set_select_mode(select_mode)
         L.mi355x_tune_set_compact(compact)
@@ -55,7 +60,7 @@ def test_random_lps_bitwise(n, m, seed, kind, density, degenerate, select_mode, 
         L.mi355x_tune_set_lookahead_mode(lookahead)  # auto / two launches per step / one persistent launch
         t = lp.Tableau(None, lp.Problem(type=kind), M0, b0, n + m, m, {})
         k = ctypes.c_int64(0)
-        rc = L.mi355x_tab_solve(t._h, int(kind == "max"), 1024.0, cap, ctypes.byref(k))
+        rc = L.mi355x_tab_solve(t._h, int(kind == "max"), float(factor), cap, ctypes.byref(k))
         t._touch()
     finally:
         L.mi355x_tune_set_select_mode(0)
@@ -77,8 +82,9 @@ def test_random_lps_bitwise(n, m, seed, kind, density, degenerate, select_mode, 
 @settings(max_examples=60, deadline=None, derandomize=True, database=None,
           suppress_health_check=list(HealthCheck))
 @given(n=st.integers(2, 60), mle=st.integers(0, 20), mge=st.integers(0, 15), meq=st.integers(0, 10),
-       seed=st.integers(0, 2 ** 31 - 1), kind=st.sampled_from(["max", "min"]))
-def test_random_two_phase_bitwise(n, mle, mge, meq, seed, kind):
+       seed=st.integers(0, 2 ** 31 - 1), kind=st.sampled_from(["max", "min"]),
+       factor=st.sampled_from(FACTORS))
+def test_random_two_phase_bitwise(n, mle, mge, meq, seed, kind, factor):
     from tests.helpers import random_mixed_problem
     if mge + meq == 0:
         mge = 1
@@ -87,9 +93,9 @@ def test_random_two_phase_bitwise(n, mle, mge, meq, seed, kind):
     art, main = tabs
     A, ab = art.matrix.copy(), art.basis_columns.copy()
     Mm, mb = main.matrix.copy(), main.basis_columns.copy()
-    st_o, npv = oracle.solve_two_phase(A, ab, Mm, mb, main_is_max=main.is_max)
+    st_o, npv = oracle.solve_two_phase(A, ab, Mm, mb, main_is_max=main.is_max, factor=float(factor))
     npiv = (ctypes.c_int64 * 2)()
-    rc = lp.capi.lib().mi355x_solve_two_phase(art._h, main._h, int(main.is_max), 1024.0, npiv)
+    rc = lp.capi.lib().mi355x_solve_two_phase(art._h, main._h, int(main.is_max), float(factor), npiv)
     art._touch(); main._touch()
     assert rc == st_o
     assert np.array_equal(art.matrix.view(np.int64), A.view(np.int64))
@@ -188,22 +194,24 @@ def test_random_entry_point_sequences(n, m, seed, ops):
           suppress_health_check=list(HealthCheck))
 @given(n=st.integers(2, 120), m=st.integers(1, 70), nl=st.integers(1, 12),
        seed=st.integers(0, 2 ** 31 - 1), mode=st.sampled_from([1, 2]), compact=st.sampled_from([0, 1]),
-       cap=st.sampled_from([0, 5, 17]))
-def test_random_batches_bitwise(n, m, nl, seed, mode, compact, cap):
+       cap=st.sampled_from([0, 5, 17]), factor=st.sampled_from(FACTORS), is_max=st.booleans())
+def test_random_batches_bitwise(n, m, nl, seed, mode, compact, cap, factor, is_max):
     L = lp.capi.lib()
     tabs = [lp.synth.tableau(n, m, seed + 7 * k) for k in range(nl)]
     Ms = np.stack([x[0] for x in tabs]); Bs = np.stack([x[1] for x in tabs])
+    if not is_max:
+        Ms[:, -1, :] *= -1.0                         # the same LPs stated as min problems (arg-max pricing)
     try:
         L.mi355x_tune_set_batch_mode(mode)
         L.mi355x_tune_set_compact(compact)
         batch = lp.TableauBatch.from_arrays(Ms, Bs)
-        st_g, npv = batch.solve(max_pivots=cap)
+        st_g, npv = batch.solve(is_max=is_max, fp_tolerance=factor, max_pivots=cap)
     finally:
         L.mi355x_tune_set_batch_mode(0)
         L.mi355x_tune_set_compact(1)
     for k in range(nl):
         M, b = Ms[k].copy(), Bs[k].copy()
-        so, no, _ = oracle.solve(M, b, max_pivots=cap)
+        so, no, _ = oracle.solve(M, b, is_max=is_max, factor=float(factor), max_pivots=cap)
         Mg, bg = batch.download(k)
         assert (st_g[k], npv[k]) == (so, no)
         assert np.array_equal(Mg.view(np.int64), M.view(np.int64)) and np.array_equal(bg, b)
@@ -212,18 +220,19 @@ def test_random_batches_bitwise(n, m, nl, seed, mode, compact, cap):
 @settings(max_examples=25, deadline=None, derandomize=True, database=None,
           suppress_health_check=list(HealthCheck))
 @given(n=st.integers(6, 150), m=st.integers(1, 80), shards=st.integers(1, 5),
-       seed=st.integers(0, 2 ** 31 - 1), compact=st.booleans(), cap=st.sampled_from([0, 9]))
-def test_random_column_partitions_bitwise(n, m, shards, seed, compact, cap):
+       seed=st.integers(0, 2 ** 31 - 1), compact=st.booleans(), cap=st.sampled_from([0, 9]),
+       factor=st.sampled_from(FACTORS))
+def test_random_column_partitions_bitwise(n, m, shards, seed, compact, cap, factor):
     import importlib
     import torch
     cp = importlib.import_module("linear-programming_amd.colpart")
     shards = min(shards, n)
     sh = cp.synthetic_shards(torch, n, m, seed, list(range(shards)), shards, 0, compact=compact)
     try:
-        tab = cp.ColumnPartitionedTableau(sh, cp.LocalComm(torch), cp.HipBackend())
+        tab = cp.ColumnPartitionedTableau(sh, cp.LocalComm(torch), cp.HipBackend(fp_factor=factor))
         st_g, npiv = tab.solve(max_pivots=cap, check_every=8)
         M, b = lp.synth.tableau(n, m, seed)
-        so, no, _ = oracle.solve(M, b, max_pivots=cap)
+        so, no, _ = oracle.solve(M, b, factor=float(factor), max_pivots=cap)
         assert (st_g, npiv) == (so, no)
         if compact:
             got, bs = cp.assemble_compact(sh, n + m)
@@ -235,3 +244,78 @@ def test_random_column_partitions_bitwise(n, m, shards, seed, compact, cap):
             assert all(np.array_equal(p[0][:, -1], M[:, -1]) and np.array_equal(p[1], b) for p in parts)
     finally:
         cp.destroy_shards(sh)
+
+
+@settings(max_examples=25, deadline=None, derandomize=True, database=None,
+          suppress_health_check=list(HealthCheck))
+@given(n=st.integers(6, 150), m=st.integers(1, 80), shards=st.integers(1, 5),
+       seed=st.integers(0, 2 ** 31 - 1), kind=st.sampled_from(["max", "min"]), degenerate=st.booleans(),
+       factor=st.sampled_from(FACTORS))
+def test_random_native_column_partitions_bitwise(n, m, shards, seed, kind, degenerate, factor):
+    """mi355x_colpart_* (the C++ driver) on random tableaux -- both senses, integer-degenerate data
+    (ties across shards go to the lowest global column), every tolerance factor."""
+    import importlib
+    cp = importlib.import_module("linear-programming_amd.colpart")
+    rng = np.random.default_rng(seed)
+    M0, b0 = _random_tableau(rng, n, m, kind, 1.0, degenerate)
+    M, b = M0.copy(), b0.copy()
+    cap = 300
+    so, no, trace = oracle.solve(M, b, is_max=(kind == "max"), factor=float(factor), max_pivots=cap, trace_cap=cap)
+    tab = cp.NativeColumnPartition.from_arrays(M0, b0, shards)
+    try:
+        st_g, k = tab.solve(is_max=(kind == "max"), fp_tolerance=factor, max_pivots=cap)
+        assert (st_g, k) == (so, no) and np.array_equal(tab.trace(no), trace)
+        G, bg, _, _ = tab.download()
+        assert np.array_equal(G.view(np.int64), M.view(np.int64)) and np.array_equal(bg, b)
+    finally:
+        tab.close()
+
+
+def _tolerance_sensitive_tableau():
+    """A small LP on which `:fp-tolerance` decides the pivot sequence (src/simplex.lisp:370-372,
+    386-387): column 1's reduced cost -1e-13 clears the pricing threshold (factor/8) eps only for
+    small factors, and row 0's entry 1e-12 in column 0 clears the ratio-test threshold (factor/2) eps
+    only for small factors -- with 1024 the first pivot is (column 0, row 0), with 2^20 row 0 is no
+    longer eligible and column 1 never enters."""
+    #            x0      x1     x2   s0   s1   s2   rhs
+    M = np.array([[1e-12, 1.0,  2.0, 1.0, 0.0, 0.0, 1e-12],
+                  [1.0,   2.0,  1.0, 0.0, 1.0, 0.0, 4.0],
+                  [2.0,   1.0,  3.0, 0.0, 0.0, 1.0, 6.0],
+                  [-3.0, -1e-13, -2.0, 0.0, 0.0, 0.0, 0.0]])
+    return M, np.array([3, 4, 5], dtype=np.int64)
+
+
+def _pricing_sensitive_tableau():
+    """Every reduced cost is -1e-13: below -(factor/8) eps for factors up to 1024 (the solve pivots),
+    not for 2^20 (find-entering-column returns NIL at once, src/simplex.lisp:370-372)."""
+    M = np.array([[1.0, 2.0, 1.0, 0.0, 4.0],
+                  [3.0, 1.0, 0.0, 1.0, 6.0],
+                  [-1e-13, -1e-13, 0.0, 0.0, 0.0]])
+    return M, np.array([2, 3], dtype=np.int64)
+
+
+@pytest.mark.parametrize("make,nv,nc", [(_tolerance_sensitive_tableau, 6, 3), (_pricing_sensitive_tableau, 4, 2)],
+                         ids=["ratio-threshold", "pricing-threshold"])
+def test_tolerance_factor_changes_the_pivot_sequence_and_the_gpu_follows(make, nv, nc):
+    L = lp.capi.lib()
+    traces = {}
+    for factor in (16.0, 1024.0, float(2 ** 20)):
+        M0, b0 = make()
+        M, b = M0.copy(), b0.copy()
+        so, no, trace = oracle.solve(M, b, factor=factor, trace_cap=64)
+        traces[factor] = trace.tolist()
+        for block, compact in ((16, 1), (1, 1), (1, 0)):
+            try:
+                L.mi355x_tune_set_block(block)
+                L.mi355x_tune_set_compact(compact)
+                t = lp.Tableau(None, lp.Problem(type="max"), M0, b0, nv, nc, {})
+                k = ctypes.c_int64(0)
+                rc = L.mi355x_tab_solve(t._h, 1, factor, 0, ctypes.byref(k))
+                t._touch()
+            finally:
+                L.mi355x_tune_set_block(16)
+                L.mi355x_tune_set_compact(1)
+            assert (rc, k.value) == (so, no), (factor, block, compact)
+            assert t.pivot_trace().tolist() == trace.tolist(), (factor, block, compact)
+            assert np.array_equal(t.matrix.view(np.int64), M.view(np.int64))
+    assert traces[1024.0] != traces[float(2 ** 20)], traces      # the knob really decides here
