@@ -281,6 +281,9 @@ void mi355x_batch_destroy(mi355x_batch *b);
  * (DESIGN.md 4.5), so ownership of logical columns moves between slots but a shard's size never
  * changes and basic columns are stored nowhere.  basis[] holds global column indices.
  * mi355x_shard_columns reads the current slot -> global column map back. */
+/* global_cols[j] == -1: slot j is DEAD -- stored and updated like any other column, never priced
+ * and owned by no logical column (what the two-phase hand-over leaves in a shard that held
+ * artificial columns only). */
 int  mi355x_shard_set_compact(mi355x_tab *t, int64_t global_var_count, const int64_t *global_cols);
 int  mi355x_shard_columns(mi355x_tab *t, int64_t *global_cols);
 int  mi355x_shard_price(mi355x_tab *t, int is_max, int64_t col_offset, double *dev_out2);
@@ -346,6 +349,26 @@ int  mi355x_colpart_info(const mi355x_colpart *p, int *n_shards, int *n_devices_
  * MI_NONFINITE (compact shards, see above) or an error */
 int  mi355x_colpart_solve(mi355x_colpart *p, int is_max, double fp_factor, int64_t max_pivots,
                           int64_t *n_pivots);
+/* n-solve-tableau, two-phase branch (src/simplex.lisp:402-452) with the artificial tableau
+ * column-partitioned (`art`: made by mi355x_colpart_create[_on] from the artificial tableau of
+ * build-tableau; its basis columns are unit columns, so its shards are compact).  Phase 1 = the
+ * partitioned loop on `art` (a min problem); the feasibility test (fp= 0 objective), the drive-out
+ * pivots of artificials still basic (the owner contributes the chosen column, one exchange, every
+ * shard pivots on the given row) and the hand-over run as in mi355x_solve_two_phase.  The main
+ * tableau is never uploaded: its constraint rows ARE the artificial tableau's (:437-441), so every
+ * shard keeps the main problem's columns among its slots (gathered on its own device, nothing moves
+ * between devices; a shard left with artificial columns only keeps one as a dead slot that is
+ * never priced), and its objective row -- main_objective_row: the last row of the main tableau,
+ * main_cols doubles -- is re-eliminated over the basic rows on the devices (:444-451).
+ * *main_out (also set on MI_UNBOUNDED) is the main tableau, solved by phase 2: read it with
+ * mi355x_colpart_download (rows x main_cols), destroy it like any other handle.  `art` keeps the
+ * artificial tableau as phase 1 and the drive-out pivots left it (download / destroy only: its
+ * communicators now belong to *main_out).  One-process forms only (logical shards, or one shard
+ * per visible device).  n_pivots[0] = phase 1 incl. drive-out pivots, n_pivots[1] = phase 2.
+ * Returns what mi355x_solve_two_phase returns. */
+int  mi355x_colpart_solve_two_phase(mi355x_colpart *art, int64_t main_cols,
+                                    const double *main_objective_row, int main_is_max,
+                                    double fp_factor, int64_t *n_pivots, mi355x_colpart **main_out);
 /* benchmarks: enqueue exactly n_pivots iterations (reset != 0: restart the pivot count), then
  * mi355x_colpart_sync waits, applies pending pivots and reports like mi355x_tab_sync */
 int  mi355x_colpart_solve_async(mi355x_colpart *p, int is_max, double fp_factor, int64_t n_pivots,

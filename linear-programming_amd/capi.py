@@ -89,6 +89,7 @@ SIGNATURES = {
     "mi355x_colpart_create_synthetic_rank": (_int, [_pp, _i64, _i64, ctypes.c_uint64, _int, _int, _int, _p]),
     "mi355x_colpart_info": (_int, [_p, _p, _p, _p]),
     "mi355x_colpart_solve": (_int, [_p, _int, _dbl, _i64, _p]),
+    "mi355x_colpart_solve_two_phase": (_int, [_p, _i64, _p, _int, _dbl, _p, _pp]),
     "mi355x_colpart_solve_async": (_int, [_p, _int, _dbl, _i64, _int]),
     "mi355x_colpart_sync": (_int, [_p, _p]),
     "mi355x_colpart_download": (_int, [_p, _p, _p, _p, _p]),

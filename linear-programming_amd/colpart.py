@@ -361,6 +361,23 @@ class NativeColumnPartition:
                                                         int(max_pivots), ctypes.byref(n)), "mi355x_colpart_solve")
         return rc, int(n.value)
 
+    def solve_two_phase(self, main_objective_row, main_is_max=True, fp_tolerance=1024):
+        """n-solve-tableau's two-phase branch with THIS handle as the artificial tableau
+        (mi355x_colpart_solve_two_phase).  Returns (status, (phase-1 pivots, phase-2 pivots), main)
+        with `main` the solved main tableau as a new NativeColumnPartition (None when phase 1 did
+        not end in a feasible basis)."""
+        obj = np.ascontiguousarray(main_objective_row, dtype=np.float64)
+        npv = (ctypes.c_int64 * 2)()
+        h = ctypes.c_void_p()
+        rc = capi.check(capi.lib().mi355x_colpart_solve_two_phase(
+            self._h, int(obj.shape[0]), obj.ctypes.data_as(ctypes.c_void_p), int(bool(main_is_max)),
+            float(fp_tolerance), npv, ctypes.byref(h)), "mi355x_colpart_solve_two_phase")
+        main = None
+        if h:
+            main = NativeColumnPartition(h)
+            main.rows, main.cols = self.rows, int(obj.shape[0])
+        return rc, (int(npv[0]), int(npv[1])), main
+
     def solve_async(self, n_pivots, is_max=True, fp_tolerance=1024, reset=False):
         capi.check(capi.lib().mi355x_colpart_solve_async(self._h, int(bool(is_max)), float(fp_tolerance),
                                                          int(n_pivots), int(bool(reset))), "mi355x_colpart_solve_async")

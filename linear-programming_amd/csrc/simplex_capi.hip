@@ -109,8 +109,7 @@ struct mi355x_tab {
     int64_t     update_launches = 0;
     int64_t     sweeps = 0;               // update launches so far: odd ones sweep bottom-up
     unsigned    la_epoch = 1;             // next epoch base of the persistent look-ahead kernel
-    unsigned    la_last_stamp = 0;        // epoch base / workgroups of the persistent launch enqueued
-    int         la_last_nw = 0;           // last (what a recovery rolls back against)
+    int         la_last_nw = 0;           // workgroups of the persistent launches (what a recovery rolls back against)
     bool        la_lost = false;          // an exchange of the persistent look-ahead was lost once
                                           // (its workgroups were not co-resident): this handle
                                           // stays on the two-launch look-ahead
@@ -508,7 +507,6 @@ int enqueue_block(mi355x_tab *t, int is_max, double f, int k)
         stamp = t->la_epoch;
         la_nw = la_block_workgroups(v);
         launch_la_block(v, k, is_max, f, t->la_epoch, t->stream);
-        t->la_last_stamp = stamp;
         t->la_last_nw = la_nw;
         t->la_epoch += 2 * kMaxBlock + 2;
     } else {
@@ -540,7 +538,7 @@ int recover_lost_exchange(mi355x_tab *t)
 {
     t->la_lost = true;
     t->n_part = 0;
-    if (t->la_last_stamp) launch_la_rollback(t->c, t->la_last_stamp, t->la_last_nw, t->stream);
+    if (t->la_last_nw) launch_la_rollback(t->c, t->la_last_nw, t->stream);
     launch_ctl_resume(t->v, t->stream, kSyncLost);
     HIP_TRY(hipGetLastError());
     return MI_OK;
@@ -1412,6 +1410,7 @@ int mi355x_shard_set_compact(mi355x_tab *t, int64_t global_var_count, const int6
     std::vector<int64_t> l2p((size_t)global_var_count, -1);
     for (int64_t j = 0; j < n_local; ++j) {
         const int64_t g = global_cols[j];
+        if (g == -1) continue;                      // a dead slot: stored and updated, never priced (see the header)
         if (g < 0 || g >= global_var_count || l2p[(size_t)g] != -1)
             return fail(MI_BAD_ARG, "global column %lld out of range or repeated", (long long)g);
         l2p[(size_t)g] = j;
@@ -1599,8 +1598,9 @@ void cp_partition(int64_t count, int n, int r, int64_t *b, int64_t *e)
     *e = *b + base + (r < extra ? 1 : 0);
 }
 
-// exchange buffers (+ communicators) once the shards' handles exist
-int cp_finish_setup(mi355x_colpart *p, const void *id128, int rank)
+// exchange buffers (+ communicators, unless they are handed over from another handle) once the
+// shards' handles exist
+int cp_finish_setup(mi355x_colpart *p, const void *id128, int rank, bool make_comms = true)
 {
     const int nl = (int)p->sh.size();
     if (!p->rccl) {
@@ -1630,6 +1630,7 @@ int cp_finish_setup(mi355x_colpart *p, const void *id128, int rank)
         HIP_TRY(hipHostMalloc((void **)&s.h_gathered, 2 * p->world * sizeof(double)));
         s.bits_in = s.bits;                                  // all-reduce / broadcast in place
     }
+    if (!make_comms) return MI_OK;
     if (p->multi_process) {
         ncclUniqueId id;
         memcpy(&id, id128, sizeof id);
@@ -2069,6 +2070,223 @@ int mi355x_colpart_solve(mi355x_colpart *p, int is_max, double f, int64_t max_pi
     }
 }
 
+}  // extern "C"
+
+namespace {
+
+// fn(shard) on every local shard: one after the other, except over RCCL with several shards in
+// this process, where every shard's collectives must be issued from its own thread
+template <class F> int cp_each_shard(mi355x_colpart *p, F fn)
+{
+    if (!p->rccl || p->sh.size() == 1) {
+        for (CpShard &s : p->sh) {
+            const int rc = fn(s);
+            if (rc != MI_OK) return rc;
+        }
+        return MI_OK;
+    }
+    std::vector<int> rcs(p->sh.size(), MI_OK);
+    std::vector<std::string> errs(p->sh.size());
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < p->sh.size(); ++i)
+        th.emplace_back([&, i]() { rcs[i] = fn(p->sh[i]); if (rcs[i] != MI_OK) errs[i] = g_err; });
+    for (auto &x : th) x.join();
+    for (size_t i = 0; i < p->sh.size(); ++i)
+        if (rcs[i] != MI_OK) { cp_abort(p); g_err = errs[i]; return rcs[i]; }
+    return MI_OK;
+}
+
+// n-pivot-row with a column AND row the caller chose (src/simplex.lisp:434), on every shard: the
+// owner contributes the column, exchange B delivers it, every shard normalises its slice of the
+// row and updates its slice (per-pivot kernels; no pending block may be open)
+int cp_forced_pivot(mi355x_colpart *p, int64_t ec, int64_t cr)
+{
+    if (p->dead) return fail(MI_RCCL_ERROR, "this handle's communicators were aborted after an earlier failure");
+    auto contribute = [&](CpShard &s) -> int {
+        mi355x_tab *t = s.t;
+        HIP_TRY(hipSetDevice(s.device));
+        t->v.col_bias = t->v.p2l ? 0 : s.col_begin;
+        launch_shard_forced_contribute(t->v, ec, s.col_begin, (int64_t *)s.bits, s.ec, t->stream);
+        HIP_TRY(hipGetLastError());
+        return MI_OK;
+    };
+    auto pivot = [&](CpShard &s) -> int {
+        mi355x_tab *t = s.t;
+        HIP_TRY(hipSetDevice(s.device));
+        launch_shard_prepare(t->v, reinterpret_cast<const double *>(s.bits_in), s.ec, 1024.0, t->stream, cr);
+        (void)launch_update(t->v, 1.0, 0, t->stream);
+        t->n_part = 0;
+        HIP_TRY(hipGetLastError());
+        return MI_OK;
+    };
+    if (!p->rccl) {
+        int rc;
+        for (CpShard &s : p->sh) if ((rc = contribute(s)) != MI_OK) return rc;
+        int blocks = (int)((p->rows + 255) / 256);
+        if (blocks > 256) blocks = 256;
+        hipLaunchKernelGGL(k_local_sum, dim3(blocks), dim3(256), 0, p->sh[0].t->stream, p->l_bits_all, p->l_bits_sum,
+                           p->rows, p->world);
+        for (CpShard &s : p->sh) if ((rc = pivot(s)) != MI_OK) return rc;
+        return MI_OK;
+    }
+    return cp_each_shard(p, [&](CpShard &s) -> int {
+        int rc = contribute(s);
+        if (rc != MI_OK) return rc;
+        RCCL_TRY(rccl().AllReduce(s.bits, s.bits, (size_t)p->rows, ncclInt64, ncclSum, s.comm, s.t->stream));
+        return pivot(s);
+    });
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355x_colpart_solve_two_phase(mi355x_colpart *art, int64_t main_cols, const double *main_obj,
+                                   int main_is_max, double f, int64_t *n_pivots, mi355x_colpart **main_out)
+{
+    if (main_out) *main_out = nullptr;
+    if (n_pivots) { n_pivots[0] = 0; n_pivots[1] = 0; }
+    if (!art || !main_obj || !main_out) return fail(MI_BAD_ARG, "NULL argument");
+    const int64_t rows = art->rows, m = rows - 1, num_art_vars = art->var_count, num_vars = main_cols - 1;
+    if (num_vars < 1 || num_vars > num_art_vars)
+        return fail(MI_BAD_ARG, "main tableau has %lld columns, the artificial one %lld", (long long)main_cols,
+                    (long long)(num_art_vars + 1));
+    if (art->multi_process || (int)art->sh.size() != art->world)
+        return fail(MI_UNSUPPORTED, "the two-phase hand-over needs every shard in this process");
+    if (!art->compact)
+        return fail(MI_UNSUPPORTED, "the artificial tableau's basis is not a set of unit columns (dense shards): "
+                                    "the column-parallel hand-over does not apply");
+    int64_t n1 = 0, n2 = 0;
+    int rc = mi355x_colpart_solve(art, /*is_max=*/0, f, 0, &n1);                  // simplex.lisp:403
+    if (n_pivots) n_pivots[0] = n1;
+    if (rc != MI_OPTIMAL) return rc;
+    std::vector<int64_t> basis((size_t)std::max<int64_t>(m, 1));
+    std::vector<double> last_col((size_t)rows);
+    rc = mi355x_colpart_download(art, nullptr, basis.data(), nullptr, last_col.data());
+    if (rc != MI_OK) return rc;
+    // (fp= 0 objective factor)                                                    simplex.lisp:405-407
+    const double diff = 0.0 - last_col[(size_t)m];
+    if (!((diff < 0.0 ? -diff : diff) <= f * kClEpsilon)) return MI_INFEASIBLE;
+    // degenerate artificials still basic: pivot them out                        simplex.lisp:419-434
+    bool reset_done = false;
+    std::vector<double> rowbuf;
+    std::vector<int64_t> gcols;
+    for (int64_t i = 0; i < m; ++i) {
+        if (basis[(size_t)i] < num_vars) continue;
+        // the RHS entry of row i (every shard holds the RHS column)
+        {
+            CpShard &s0 = art->sh[0];
+            HIP_TRY(hipSetDevice(s0.device));
+            double rhs_i = 0.0;
+            HIP_TRY(hipMemcpyAsync(&rhs_i, s0.t->v.M + i * s0.t->v.ld + (s0.t->v.cols - 1), sizeof(double),
+                                   hipMemcpyDeviceToHost, s0.t->stream));
+            HIP_TRY(hipStreamSynchronize(s0.t->stream));
+            if (rhs_i != 0.0) return MI_ART_NONZERO;
+        }
+        // first non-basic column of the main problem with a non-zero entry in row i: only stored
+        // columns can qualify (a basic column other than basis[i] holds +0 there)
+        int64_t new_col = -1;
+        for (CpShard &s : art->sh) {
+            const int64_t nloc = s.t->v.cols - 1;
+            gcols.resize((size_t)nloc);
+            rowbuf.resize((size_t)nloc);
+            if ((rc = mi355x_shard_columns(s.t, gcols.data())) != MI_OK) return rc;
+            HIP_TRY(hipMemcpyAsync(rowbuf.data(), s.t->v.M + i * s.t->v.ld, nloc * sizeof(double),
+                                   hipMemcpyDeviceToHost, s.t->stream));
+            HIP_TRY(hipStreamSynchronize(s.t->stream));
+            for (int64_t k = 0; k < nloc; ++k) {
+                const int64_t g = gcols[(size_t)k];
+                if (g >= 0 && g < num_vars && rowbuf[(size_t)k] != 0.0 && (new_col < 0 || g < new_col)) new_col = g;
+            }
+        }
+        if (new_col < 0) return MI_ART_STUCK;
+        if (!reset_done) {                                    // phase 1 left every shard's status at OPTIMAL
+            for (CpShard &s : art->sh)
+                if ((rc = mi355x_tab_reset(s.t, 0)) != MI_OK) return rc;
+            reset_done = true;
+        }
+        rc = cp_forced_pivot(art, new_col, i);
+        if (rc != MI_OK) return rc;
+        basis[(size_t)i] = new_col;
+        ++n1;
+    }
+    if (n_pivots) n_pivots[0] = n1;
+    if (reset_done) {                                         // a non-finite column in a drive-out pivot
+        int64_t np = 0;
+        const int st = cp_status(art, &np);
+        if (st != MI_RUNNING) return st < 0 ? st : (st == MI_NONFINITE ? MI_NONFINITE : fail(MI_HIP_ERROR, "drive-out pivot failed (status %d)", st));
+    }
+    // ---- hand-over (simplex.lisp:437-451): the main tableau's shards are the artificial shards'
+    // main-problem columns, gathered slot by slot on each device; the objective row is the main
+    // tableau's own, re-eliminated over the basic rows
+    mi355x_colpart *mp = new (std::nothrow) mi355x_colpart;
+    if (!mp) return fail(MI_NO_MEMORY, "host allocation failed");
+    mp->world = art->world;
+    mp->rccl = art->rccl;
+    mp->compact = true;
+    mp->rows = rows;
+    mp->var_count = num_vars;
+    mp->exchange = art->exchange;
+    std::vector<double> scales((size_t)std::max<int64_t>(m, 1));
+    for (int64_t i = 0; i < m; ++i) scales[(size_t)i] = main_obj[basis[(size_t)i]];
+    std::vector<int64_t> keep, newcols;
+    std::vector<double> obj0;
+    for (CpShard &as : art->sh) {
+        const int64_t nloc = as.t->v.cols - 1;
+        gcols.resize((size_t)nloc);
+        rc = mi355x_shard_columns(as.t, gcols.data());
+        if (rc != MI_OK) { cp_free(mp); return rc; }
+        keep.clear(); newcols.clear(); obj0.clear();
+        for (int64_t k = 0; k < nloc; ++k)
+            if (gcols[(size_t)k] >= 0 && gcols[(size_t)k] < num_vars) {
+                keep.push_back(k); newcols.push_back(gcols[(size_t)k]); obj0.push_back(main_obj[gcols[(size_t)k]]);
+            }
+        if (keep.empty()) {                                   // nothing but artificial columns here: keep ONE slot as a
+            keep.push_back(0); newcols.push_back(-1); obj0.push_back(0.0);   // dead slot (a shard stores a column)
+        }
+        obj0.push_back(main_obj[num_vars]);
+        const int64_t nk = (int64_t)keep.size();
+        CpShard ns;
+        ns.index = as.index;
+        ns.device = as.device;
+        ns.col_begin = 0; ns.col_end = nk;
+        rc = alloc_tab(&ns.t, rows, nk + 1, ns.device);
+        mp->sh.push_back(ns);
+        if (rc != MI_OK) { cp_free(mp); return rc; }
+        mi355x_tab *nt = mp->sh.back().t;
+        int64_t *d_keep = nullptr;
+        double *d_obj0 = nullptr, *d_scales = nullptr;
+        hipError_t e = hipMalloc((void **)&d_keep, nk * sizeof(int64_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&d_obj0, (nk + 1) * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&d_scales, std::max<int64_t>(m, 1) * sizeof(double));
+        hipStream_t st = as.t->stream;                        // behind everything phase 1 enqueued on this shard
+        if (e == hipSuccess) e = hipMemcpyAsync(d_keep, keep.data(), nk * sizeof(int64_t), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_obj0, obj0.data(), (nk + 1) * sizeof(double), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && m > 0) e = hipMemcpyAsync(d_scales, scales.data(), m * sizeof(double), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(nt->stream);          // alloc_tab's memsets
+        if (e == hipSuccess) e = hipMemsetAsync(nt->v.M, 0, (size_t)rows * nt->v.ld * sizeof(double), st);   // padding columns
+        if (e == hipSuccess) {
+            launch_shard_handover(as.t->v, nt->v, d_keep, d_obj0, d_scales, st);
+            launch_ctl_reset(nt->v, 0, 1, st);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(d_keep); (void)hipFree(d_obj0); (void)hipFree(d_scales);
+        if (e != hipSuccess) { cp_free(mp); return fail(MI_HIP_ERROR, "hand-over failed: %s", hipGetErrorString(e)); }
+        rc = mi355x_shard_set_compact(nt, num_vars, newcols.data());
+        if (rc != MI_OK) { cp_free(mp); return rc; }
+    }
+    rc = cp_finish_setup(mp, nullptr, -1, /*make_comms=*/false);
+    if (rc != MI_OK) { cp_free(mp); return rc; }
+    // the communicators move to the main tableau: the artificial one can still be read, not solved
+    for (size_t i = 0; i < art->sh.size(); ++i) { mp->sh[i].comm = art->sh[i].comm; art->sh[i].comm = nullptr; }
+    art->dead = art->rccl;
+    *main_out = mp;
+    rc = mi355x_colpart_solve(mp, main_is_max, f, 0, &n2);                       // simplex.lisp:452
+    if (n_pivots) n_pivots[1] = n2;
+    return rc;
+}
+
 int mi355x_colpart_trace(mi355x_colpart *p, int64_t *ecs, int64_t *crs, int64_t cap, int64_t *n)
 {
     if (!p) return fail(MI_BAD_ARG, "handle is NULL");
@@ -2105,16 +2323,19 @@ int mi355x_colpart_download(mi355x_colpart *p, double *hm, int64_t *hb, double *
             rc = mi355x_tab_download(s.t, loc.data(), first ? basis.data() : nullptr, nullptr, nullptr);
             if (rc != MI_OK) return rc;
             for (int64_t r = 0; r < rows; ++r) {
-                for (int64_t k = 0; k < nloc; ++k) hm[r * cols + gcols[(size_t)k]] = loc[(size_t)(r * (nloc + 1) + k)];
+                for (int64_t k = 0; k < nloc; ++k)
+                    if (gcols[(size_t)k] >= 0) hm[r * cols + gcols[(size_t)k]] = loc[(size_t)(r * (nloc + 1) + k)];   // (< 0: a dead slot)
                 if (first) hm[r * cols + vc] = loc[(size_t)(r * (nloc + 1) + nloc)];
             }
-            if (last_row) for (int64_t k = 0; k < nloc; ++k) last_row[gcols[(size_t)k]] = loc[(size_t)(m * (nloc + 1) + k)];
+            if (last_row) for (int64_t k = 0; k < nloc; ++k)
+                if (gcols[(size_t)k] >= 0) last_row[gcols[(size_t)k]] = loc[(size_t)(m * (nloc + 1) + k)];
             if (last_row && first) last_row[vc] = loc[(size_t)(m * (nloc + 1) + nloc)];
         } else if (last_row) {
             loc.resize((size_t)(nloc + 1));
             rc = mi355x_tab_download(s.t, nullptr, first ? basis.data() : nullptr, loc.data(), nullptr);
             if (rc != MI_OK) return rc;
-            for (int64_t k = 0; k < nloc; ++k) last_row[gcols[(size_t)k]] = loc[(size_t)k];
+            for (int64_t k = 0; k < nloc; ++k)
+                if (gcols[(size_t)k] >= 0) last_row[gcols[(size_t)k]] = loc[(size_t)k];
             if (first) last_row[vc] = loc[(size_t)nloc];
         } else if (first && (hb || last_col)) {
             rc = mi355x_tab_download(s.t, nullptr, basis.data(), nullptr, nullptr);

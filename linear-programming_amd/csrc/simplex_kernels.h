@@ -130,7 +130,7 @@ int  launch_lookahead(const TabView &t, int j, int is_max, double fp_factor, int
 int  launch_sweep(const TabView &t, int kmax, double sgn, hipStream_t s, unsigned stamp = 0, int la_nw = 0);
 // after a lost exchange (kSyncLost): undo the bookkeeping (column maps, basis, pivot count, trace)
 // of the pivots the leader committed but the sweep did not apply
-void launch_la_rollback(const TabView &t, unsigned stamp, int la_nw, hipStream_t s);
+void launch_la_rollback(const TabView &t, int la_nw, hipStream_t s);
 int  la_block_workgroups(const TabView &t);
 // the whole look-ahead of a block (steps 0 .. ksteps-1) as ONE launch of a few persistent
 // workgroups that exchange their reduction candidates through la_px / la_rx; epoch_base (> 0)
@@ -153,8 +153,16 @@ void launch_shard_price(const TabView &t, int is_max, int64_t col_offset, double
 void launch_shard_contribute(const TabView &t, const double *gathered, int n_shards,
                              int64_t col_offset, double fp_factor, int64_t *bits_out,
                              int64_t *ec_out, hipStream_t s);
+// forced_cr >= 0: no ratio test, the pivot row is the caller's
 void launch_shard_prepare(const TabView &t, const double *col, const int64_t *ec_dev,
-                          double fp_factor, hipStream_t s);
+                          double fp_factor, hipStream_t s, int64_t forced_cr = -1);
+// the owner of logical column ec contributes it (a pivot the caller chose)
+void launch_shard_forced_contribute(const TabView &t, int64_t ec, int64_t col_offset, int64_t *bits_out,
+                                    int64_t *ec_out, hipStream_t s);
+// two-phase hand-over of one compact column shard: slots keep[] of `art` + its RHS copy -> `mt`,
+// objective row obj0 re-eliminated with the given scales (src/simplex.lisp:437-451)
+void launch_shard_handover(const TabView &art, const TabView &mt, const int64_t *keep, const double *obj0,
+                           const double *scales, hipStream_t s);
 // ... and their blocked forms: step j of a block (no update), the sweep is launch_sweep
 void launch_shard_la_contribute(const TabView &t, int j, const double *gathered, int n_shards,
                                 int64_t col_offset, double fp_factor, int64_t *bits_out,

@@ -642,13 +642,30 @@ __global__ __launch_bounds__(kSelThreads) void k_shard_contribute(TabView t, con
     if (blockIdx.x == 0 && threadIdx.x == 0) *ec_out = ec;
 }
 
+// The same contribution for a column the CALLER chose (drive-out pivots of the two-phase
+// hand-over): the owner writes the column's bit patterns, everyone else zeros.
+__global__ __launch_bounds__(kSelThreads) void k_shard_forced_contribute(TabView t, int64_t ec, int64_t col_offset,
+                                                                        long long *bits_out, int64_t *ec_out)
+{
+    const int64_t lc = t.l2p ? t.l2p[ec] : ec - col_offset;
+    const bool mine = lc >= 0 && lc < t.cols - 1;
+    for (int64_t r = blockIdx.x * (int64_t)kSelThreads + threadIdx.x; r < t.rows;
+         r += (int64_t)gridDim.x * kSelThreads) {
+        bits_out[r] = mine ? __double_as_longlong(t.M[r * t.ld + lc]) : 0ll;
+        t.rhs[r] = t.M[r * t.ld + (t.cols - 1)];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *ec_out = ec;
+}
+
 // Column-partitioned tableau, local step after the exchange: ratio test on the (now global)
 // entering column against the shard's own RHS copy (identical on every shard => identical
 // pivot row everywhere, no further exchange), row scale = col[cr] (== M[cr][ec] bit for bit),
 // normalise the local slice of row cr.  *ec_dev < 0: the tableau is optimal.
+// forced_cr >= 0 (the drive-out pivots of the two-phase hand-over, src/simplex.lisp:419-434: the caller
+// chose column AND row): no ratio test, the exchanged column is only snapshotted.
 __global__ __launch_bounds__(kSelThreads) void k_shard_prepare(TabView t, const double *col_src,
                                                               const int64_t *ec_dev,
-                                                              double ratio_thr)
+                                                              double ratio_thr, int64_t forced_cr)
 {
     __shared__ double    s_v[kSelWaves];
     __shared__ long long s_i[kSelWaves];
@@ -665,7 +682,16 @@ __global__ __launch_bounds__(kSelThreads) void k_shard_prepare(TabView t, const 
         return;
     }
     int bad = 0;
-    const ValIdx q = block_gather_ratio(t, 0, col_src, ratio_thr, s_v, s_i, t.rhs, &bad);
+    ValIdx q; q.v = 0.0; q.i = forced_cr; q.s = 0;
+    if (forced_cr < 0) {
+        q = block_gather_ratio(t, 0, col_src, ratio_thr, s_v, s_i, t.rhs, &bad);
+    } else {
+        for (int64_t r = threadIdx.x; r < t.rows; r += kSelThreads) {
+            const double a = col_src[r];
+            t.col[r] = a;
+            bad |= !(fabs(a) <= 1.7976931348623157e308);
+        }
+    }
     if (t.p2l && __syncthreads_or(bad)) {           // compact shard: cannot follow the reference
         if (threadIdx.x == 0) ctl->status = 6;      // MI_NONFINITE
         return;
@@ -1937,12 +1963,15 @@ __device__ __forceinline__ int committed_pivots(const BlockCtl *__restrict__ blk
 // After a lost exchange: the sweep applied committed_pivots() of the n_pending pivots the leader
 // recorded; take the bookkeeping of the others (at most one) back, newest first, so that the
 // handle describes the tableau as it is -- the host then continues on the two-launch look-ahead.
-__global__ void k_la_rollback(TabView t, unsigned stamp, int la_nw)
+// (The list and its stamp are those of the launch that lost the exchange: the launches enqueued
+// behind it find the status kSyncLost and leave both alone.)
+__global__ void k_la_rollback(TabView t, int la_nw)
 {
     BlockCtl *blk = t.blk;
     Ctl *ctl = t.ctl;
     const int n = (int)blk->n_pending;
-    if (n == 0 || (unsigned)blk->stamp != stamp) return;
+    const unsigned stamp = (unsigned)blk->stamp;
+    if (n == 0 || stamp == 0u) return;
     const int keep = committed_pivots(blk, n, stamp, la_nw);
     for (int i = n - 1; i >= keep; --i) {
         const int64_t cr = blk->cr[i], slot = blk->slot[i];
@@ -3012,6 +3041,39 @@ __global__ __launch_bounds__(256) void k_handover_objective_columns(TabView mt)
     obj[c] = v;
 }
 
+// The hand-over on a compact column shard (mi355x_colpart_solve_two_phase).  The artificial
+// shard `art` holds non-basic columns of the artificial tableau in its slots -- columns of the main
+// problem and artificial columns mixed, wherever the pivots of phase 1 left them.  The main shard
+// `mt` takes over the slots keep[0 .. nk) (the main problem's columns; the host chose them from
+// the slot map) and the RHS copy: rows < m are copied (src/simplex.lisp:437-441), and the objective
+// row is the main tableau's own (obj0, gathered by the host: obj0[k] = objective coefficient of the
+// logical column in keep[k], obj0[nk] = its constant) re-eliminated over the basic rows
+// (:444-451) in the column-parallel form of k_handover_objective_columns -- the basic columns of a
+// compact shard are exact unit vectors by construction, so scale_i = objective coefficient of
+// basis[i] is known up front (scales[], gathered by the host) and every column's chain
+// ((obj0 - s_0 row_0) - s_1 row_1) - ... runs on its own, same operations, same order.
+__global__ __launch_bounds__(256) void k_shard_handover(TabView art, TabView mt, const int64_t *keep,
+                                                        const double *obj0, const double *scales)
+{
+    const int64_t m = mt.rows - 1, nk = mt.cols - 1;
+    const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (k <= nk) {
+        const int64_t src = k < nk ? keep[k] : art.cols - 1;
+        double v = obj0[k];
+        for (int64_t i = 0; i < m; ++i) {
+            const double x = art.M[i * art.ld + src];
+            mt.M[i * mt.ld + k] = x;
+            const double scale = scales[i];                     // wave-uniform
+            if (scale != 0.0) {
+                const double prod = scale * x;
+                v = v - prod;
+            }
+        }
+        mt.M[m * mt.ld + k] = v;
+    }
+    for (int64_t i = k; i < m; i += (int64_t)gridDim.x * blockDim.x) mt.basis[i] = art.basis[i];
+}
+
 // ------------------------------------------------------------------ synthetic LP generator
 // splitmix64 stream, element k of the stream = mix(seed + (k+1)*gamma); u = (z >> 11) * 2^-53.
 // Stream layout: A row-major (n_cons x n_vars), then b (n_cons), then c (n_vars).
@@ -3114,10 +3176,24 @@ void launch_shard_contribute(const TabView &t, const double *gathered, int n_sha
                        n_shards, col_offset, (f / 8.0) * kClEpsilon, (long long *)bits_out, ec_out);
 }
 void launch_shard_prepare(const TabView &t, const double *col, const int64_t *ec_dev, double f,
-                          hipStream_t s)
+                          hipStream_t s, int64_t forced_cr)
 {
     hipLaunchKernelGGL(k_shard_prepare, dim3(1), dim3(kSelThreads), 0, s, t, col, ec_dev,
-                       0.0 + (f / 2.0) * kClEpsilon);
+                       0.0 + (f / 2.0) * kClEpsilon, forced_cr);
+}
+void launch_shard_forced_contribute(const TabView &t, int64_t ec, int64_t col_offset, int64_t *bits_out,
+                                    int64_t *ec_out, hipStream_t s)
+{
+    int blocks = (int)((t.rows + kSelThreads - 1) / kSelThreads);
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(k_shard_forced_contribute, dim3(blocks), dim3(kSelThreads), 0, s, t, ec, col_offset,
+                       (long long *)bits_out, ec_out);
+}
+void launch_shard_handover(const TabView &art, const TabView &mt, const int64_t *keep, const double *obj0,
+                           const double *scales, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_shard_handover, dim3((unsigned)((mt.cols + 255) / 256)), dim3(256), 0, s, art, mt,
+                       keep, obj0, scales);
 }
 void launch_shard_la_contribute(const TabView &t, int j, const double *gathered, int n_shards,
                                 int64_t col_offset, double f, int64_t *bits_out, int64_t *ec_out,
@@ -3445,9 +3521,9 @@ int la_block_workgroups(const TabView &t)
     return (int)((need + kLaThreads - 1) / kLaThreads);
 }
 
-void launch_la_rollback(const TabView &t, unsigned stamp, int la_nw, hipStream_t s)
+void launch_la_rollback(const TabView &t, int la_nw, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_la_rollback, dim3(1), dim3(1), 0, s, t, stamp, la_nw);
+    hipLaunchKernelGGL(k_la_rollback, dim3(1), dim3(1), 0, s, t, la_nw);
 }
 
 void launch_la_block(const TabView &t, int ksteps, int is_max, double f, unsigned epoch_base, hipStream_t s)

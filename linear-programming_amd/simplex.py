@@ -440,20 +440,66 @@ def _solve_column_partitioned(tableau, devices, max_pivots=0):
     return True
 
 
+def _solve_two_phase_column_partitioned(art, main, devices):
+    """The two-phase branch with the artificial tableau column-partitioned over `devices` GPUs
+    (mi355x_colpart_create -> mi355x_colpart_solve_two_phase -> download of both tableaux).  The
+    main tableau is never uploaded: the library takes its objective row only.  Returns False when
+    the partitioned path does not apply (MI_UNSUPPORTED: the artificial basis is not a set of unit
+    columns; MI_NONFINITE: the tableau overflowed) -- the caller's tableaux are untouched."""
+    L = capi.lib()
+    A, ab = art.matrix, art.basis_columns
+    Mm = main.matrix
+    h = ctypes.c_void_p()
+    capi.check(L.mi355x_colpart_create(ctypes.byref(h), A.shape[0], A.shape[1], _ptr(A), _ptr(ab),
+                                       int(devices)), "mi355x_colpart_create")
+    hm = ctypes.c_void_p()
+    try:
+        obj = np.ascontiguousarray(Mm[-1])
+        npv = (ctypes.c_int64 * 2)()
+        rc = L.mi355x_colpart_solve_two_phase(h, int(Mm.shape[1]), _ptr(obj), int(main.is_max),
+                                              float(main.fp_tolerance_factor), npv, ctypes.byref(hm))
+        if rc in (capi.MI_UNSUPPORTED, capi.MI_NONFINITE):
+            return False
+        capi.check(rc, "mi355x_colpart_solve_two_phase")
+        GA, ga = np.empty_like(A), np.empty_like(ab)
+        capi.check(L.mi355x_colpart_download(h, _ptr(GA), _ptr(ga), None, None), "mi355x_colpart_download")
+        GM, gm = None, None
+        if hm:
+            GM, gm = np.empty_like(Mm), np.empty_like(main.basis_columns)
+            capi.check(L.mi355x_colpart_download(hm, _ptr(GM), _ptr(gm), None, None), "mi355x_colpart_download")
+    finally:
+        if hm:
+            L.mi355x_colpart_destroy(hm)
+        L.mi355x_colpart_destroy(h)
+    for tab, G, g in ((art, GA, ga), (main, GM, gm)):
+        if G is None:
+            continue
+        old, tab._handle = tab._handle, None
+        if old:
+            L.mi355x_tab_destroy(old)
+        tab._matrix, tab._basis, tab._stale, tab._light = G, g, False, None
+    main.n_pivots = (int(npv[0]), int(npv[1]))
+    _raise_for(rc)
+    return True
+
+
 def mi355x_simplex_solver(problem, fp_tolerance=1024, device=0, devices=1, **_ignored):
     """What the Lisp glue installs as `*solver*` (src/solver.lisp:39-56): takes a problem and
     backend keyword arguments, returns a solved tableau answering the four solution-*
     generics.  LP only: integer/binary variables are declined the way a backend must
     (unsupported-constraint-error, src/conditions.lisp:69-77); branch-and-bound
     (src/simplex.lisp:506-542) stays with the reference's own solver.  devices > 1: the tableau
-    of a single-phase problem is column-partitioned over that many GPUs (logical shards of one
-    GPU when fewer are visible); two-phase problems and tableaux that overflow run on `device`."""
+    (single-phase problems) or the artificial tableau (two-phase problems: phase 1, the hand-over
+    and phase 2 all stay partitioned) is column-partitioned over that many GPUs (logical shards of
+    one GPU when fewer are visible); tableaux that overflow run on `device`."""
     if problem.integer_vars:
         raise UnsupportedConstraintError(("integer",) + tuple(problem.integer_vars),
                                          "mi355x-simplex")
     tabs = build_tableau(problem, problem, fp_tolerance_factor=fp_tolerance, device=device)
     if devices > 1 and isinstance(tabs, Tableau) and _solve_column_partitioned(tabs, devices):
         return tabs
+    if devices > 1 and isinstance(tabs, list) and _solve_two_phase_column_partitioned(tabs[0], tabs[1], devices):
+        return tabs[1]
     return n_solve_tableau(tabs)
 
 

@@ -533,6 +533,105 @@ def test_two_phase_bitwise_vs_oracle(n, mle, mge, meq, seed, handover):
     assert np.array_equal(main.matrix, M_or) and np.array_equal(main.basis_columns, b_or)
 
 
+def _colpart_two_phase(tabs, shards):
+    """mi355x_colpart_create on the artificial tableau + mi355x_colpart_solve_two_phase with the main
+    tableau's objective row -> (status, pivots, artificial tableau, its basis, main tableau, its basis)."""
+    import importlib
+    cp = importlib.import_module("linear-programming_amd.colpart")
+    art, main = tabs
+    tab = cp.NativeColumnPartition.from_arrays(art.matrix.copy(), art.basis_columns.copy(), shards)
+    try:
+        rc, npv, mt = tab.solve_two_phase(main.matrix[-1].copy(), main.is_max, main.fp_tolerance_factor)
+        A, ab, _, _ = tab.download()
+        Mm = mb = None
+        if mt is not None:
+            Mm, mb, last_row, last_col = mt.download()
+            assert np.array_equal(last_row.view(np.int64), Mm[-1].view(np.int64))
+            assert np.array_equal(last_col.view(np.int64), Mm[:, -1].view(np.int64))
+            mt.close()
+    finally:
+        tab.close()
+    return rc, npv, A, ab, Mm, mb
+
+
+@pytest.mark.parametrize("shards", [1, 2, 3, 8])
+@pytest.mark.parametrize("name", ["equality", "geq"])
+def test_two_phase_goldens_on_the_column_partition(golden, name, shards):
+    """The reference's two-phase goldens (t/simplex.lisp:196-275) with the artificial tableau
+    column-partitioned over 1 / 2 / 3 / 8 logical shards: phase 1, the hand-over and phase 2 all
+    on the partition -- same bits as the oracle (and therefore as the single-device path)."""
+    case = golden["cases"][name]
+    problem = _problem(case)
+    tabs = lp.build_tableau(problem, problem)
+    st, M_or, b_or, (A_or, ab_or, npv) = _oracle_solve(tabs)
+    rc, got_npv, A, ab, Mm, mb = _colpart_two_phase(tabs, shards)
+    assert rc == st == oracle.OPTIMAL and got_npv == (int(npv[0]), int(npv[1]))
+    assert np.array_equal(A.view(np.int64), A_or.view(np.int64)) and np.array_equal(ab, ab_or)
+    assert np.array_equal(Mm.view(np.int64), M_or.view(np.int64)) and np.array_equal(mb, b_or)
+    # and through the hook: (solve-problem problem :devices n)
+    sol = lp.solve_problem(problem, devices=max(shards, 2))
+    assert np.array_equal(sol.matrix.view(np.int64), M_or.view(np.int64)) and np.array_equal(sol.basis_columns, b_or)
+    if name == "equality":
+        assert lp.solution_objective_value(sol) == 28.5
+
+
+@pytest.mark.parametrize("shards", [1, 2, 3, 8])
+@pytest.mark.parametrize("n,mle,mge,meq,seed", [(6, 3, 2, 1, 1), (30, 10, 8, 4, 2), (80, 30, 20, 10, 3),
+                                                (40, 0, 25, 0, 4), (300, 100, 60, 30, 5), (12, 4, 4, 4, 6),
+                                                (9, 2, 7, 5, 7)])
+def test_two_phase_on_the_column_partition_bitwise_vs_oracle(n, mle, mge, meq, seed, shards):
+    """Random LPs with >= and = rows through mi355x_colpart_solve_two_phase on 1 / 2 / 3 / 8 logical
+    shards (the last shape leaves shards with artificial columns only: dead slots)."""
+    problem = random_mixed_problem(lp, n, mle, mge, meq, seed)
+    tabs = lp.build_tableau(problem, problem)
+    st, M_or, b_or, (A_or, ab_or, npv) = _oracle_solve(tabs)
+    rc, got_npv, A, ab, Mm, mb = _colpart_two_phase(tabs, shards)
+    assert rc == st
+    assert np.array_equal(A.view(np.int64), A_or.view(np.int64)) and np.array_equal(ab, ab_or)
+    if st == oracle.OPTIMAL:
+        assert got_npv == (int(npv[0]), int(npv[1]))
+        assert np.array_equal(Mm.view(np.int64), M_or.view(np.int64)) and np.array_equal(mb, b_or)
+    else:
+        assert st == oracle.INFEASIBLE and Mm is None
+
+
+def test_two_phase_column_partition_drives_degenerate_artificials_out():
+    """Artificial variables still basic at level zero after phase 1 (src/simplex.lisp:419-434): the
+    partition pivots them out with a caller-chosen column AND row (the owner contributes the
+    column, every shard pivots on the given row).  Equality rows through a degenerate vertex (a
+    point with zero components, integer data) make that happen in about half the draws; the rest
+    are ordinary two-phase solves or end as the reference's "cannot be replaced" error."""
+    hit = 0
+    for seed in range(40):
+        rng = np.random.default_rng(seed)
+        n = 6
+        names = ["x%d" % i for i in range(n)]
+        x0 = rng.integers(0, 3, n).astype(float) * (rng.uniform(size=n) < 0.5)
+        rows = [rng.integers(0, 3, n).astype(float) for _ in range(4)]
+        cons = [("=", list(zip(names, a.tolist())), float(a @ x0)) for a in rows if a.any()]
+        cons.append(("<=", list(zip(names, [1.0] * n)), float(x0.sum() + 3)))
+        problem = lp.Problem(type="max", vars=names, objective_var="obj",
+                             objective_func=list(zip(names, rng.integers(1, 4, n).astype(float).tolist())),
+                             constraints=cons)
+        tabs = lp.build_tableau(problem, problem)
+        if not isinstance(tabs, list):
+            continue
+        st, M_or, b_or, (A_or, ab_or, npv) = _oracle_solve(tabs)
+        # drive-out pivots happened iff phase 1 of the oracle counted more pivots than its plain solve
+        A1, b1 = tabs[0].matrix.copy(), tabs[0].basis_columns.copy()
+        _, n_plain, _ = oracle.solve(A1, b1, is_max=False)
+        drove = int(npv[0]) > n_plain
+        for shards in (2, 3):
+            rc, got_npv, A, ab, Mm, mb = _colpart_two_phase(tabs, shards)
+            assert rc == st, (seed, shards, rc, st)
+            if st in (oracle.OPTIMAL, oracle.UNBOUNDED):
+                assert got_npv[0] == int(npv[0])
+                assert np.array_equal(A.view(np.int64), A_or.view(np.int64)) and np.array_equal(ab, ab_or)
+                assert np.array_equal(Mm.view(np.int64), M_or.view(np.int64)) and np.array_equal(mb, b_or)
+        hit += drove and st == oracle.OPTIMAL
+    assert hit >= 10, "the seeds produced too few drive-out pivots (%d)" % hit
+
+
 def test_degenerate_shapes():
     """Edge shapes: no constraint rows at all, a single column, one row x many columns, many
     rows x few columns, a 1 x 1 tableau -- same outcome and bits as the oracle."""
@@ -1044,8 +1143,8 @@ def test_config3_first_pivots_bitwise_and_full_solve_properties():
 def test_solver_hook_devices_keyword(devices):
     """(solve-problem problem :devices n): the call sequence of the Lisp glue's
     solve-column-partitioned (create -> solve -> download -> destroy) through the Python mirror.
-    Single-phase problems go through the column partition (logical shards on this one GPU) and
-    end with the same solution object as on one device; a two-phase problem ignores the keyword."""
+    Single-phase AND two-phase problems go through the column partition (logical shards on this
+    one GPU) and end with the same solution object as on one device."""
     p = lp.Problem(type="max", vars=["x", "y", "z"], objective_var="w",          # README.md:43-47
                    objective_func=[("x", 1), ("y", 4), ("z", 3)],
                    constraints=[("<=", [("x", 2), ("y", 1)], 8), ("<=", [("y", 1), ("z", 1)], 7)])
@@ -1067,10 +1166,13 @@ def test_solver_hook_devices_keyword(devices):
     one, many = lp.solve_problem(q), lp.solve_problem(q, devices=devices)
     assert np.array_equal(many.matrix.view(np.int64), one.matrix.view(np.int64))
     assert lp.solution_objective_value(many) == lp.solution_objective_value(one)
-    # two-phase problem (a >= row): the keyword is ignored, the answer is the single-device one
+    # two-phase problem (>= and = rows): phase 1, hand-over and phase 2 on the partition, same bits
     from tests.helpers import random_mixed_problem
     r = random_mixed_problem(lp, 12, 5, 3, 2, 77)
-    assert lp.solution_objective_value(lp.solve_problem(r, devices=devices)) == lp.solution_objective_value(lp.solve_problem(r))
+    one, many = lp.solve_problem(r), lp.solve_problem(r, devices=devices)
+    assert np.array_equal(many.matrix.view(np.int64), one.matrix.view(np.int64))
+    assert np.array_equal(many.basis_columns, one.basis_columns) and many.n_pivots == one.n_pivots
+    assert lp.solution_objective_value(many) == lp.solution_objective_value(one)
 
 
 def test_solver_hook_devices_falls_back_when_the_tableau_overflows():
