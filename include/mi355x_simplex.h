@@ -257,6 +257,35 @@ int  mi355x_batch_timing_enable(mi355x_batch *b, int enable);
 int  mi355x_batch_timing_read(mi355x_batch *b, int64_t *n_launches, double *sum_ms, double *min_ms);
 void mi355x_batch_destroy(mi355x_batch *b);
 
+/* The same without blocking the caller: the batch loop is driven by the host (blind chunks of
+ * launches, one status read-back per chunk), so the asynchronous form runs it on a worker thread
+ * of the library; mi355x_batch_sync waits for it and delivers what mi355x_batch_solve delivers.
+ * One solve at a time per batch; the batch must not be touched in between.  (How a
+ * single-threaded host -- the Lisp image -- keeps the sub-batches of several GPUs going.) */
+int  mi355x_batch_solve_async(mi355x_batch *b, int is_max, double fp_factor, int64_t max_pivots);
+int  mi355x_batch_sync(mi355x_batch *b, int32_t *status, int64_t *n_pivots);
+
+/* One batch over several devices (config 4 as specified: 1024 LPs over 8 GPUs): LP k lives in
+ * sub-batch k / ceil(n_lps / n_devices) (contiguous blocks, one sub-batch per device), independent
+ * units, no communication.  mi355x_multibatch_solve starts every sub-batch's loop on its own worker
+ * thread and waits; status / n_pivots are indexed by the GLOBAL LP index.  device_ids: one per
+ * sub-batch, or NULL = devices 0 .. n_devices-1 -- with fewer visible devices than that the
+ * sub-batches become logical sub-batches on device 0 (own stream each; how the path is tested on
+ * one GPU).  n_devices is capped at n_lps; mi355x_multibatch_info reports what is in use. */
+typedef struct mi355x_multibatch mi355x_multibatch;
+int  mi355x_multibatch_create(mi355x_multibatch **out, int64_t n_lps, int64_t rows, int64_t cols,
+                              const double *host_matrices, const int64_t *host_bases, int n_devices,
+                              const int *device_ids);
+int  mi355x_multibatch_create_synthetic(mi355x_multibatch **out, int64_t n_lps, int64_t n_vars,
+                                        int64_t n_cons, const uint64_t *seeds, int n_devices,
+                                        const int *device_ids);
+int  mi355x_multibatch_info(const mi355x_multibatch *mb, int *n_sub_batches, int *n_devices_used);
+int  mi355x_multibatch_solve(mi355x_multibatch *mb, int is_max, double fp_factor, int64_t max_pivots,
+                             int32_t *status, int64_t *n_pivots);
+int  mi355x_multibatch_download(mi355x_multibatch *mb, int64_t lp_index, double *host_matrix,
+                                int64_t *host_basis, double *last_row, double *last_col);
+void mi355x_multibatch_destroy(mi355x_multibatch *mb);
+
 /* ---- column-partitioned tableau: per-shard steps (BASELINE config 5) --------------- */
 /* One tableau whose non-RHS columns are split across shards (one shard = one handle = one
  * GPU / rank; every shard keeps its own copy of the RHS column as its last column and updates
@@ -365,7 +394,10 @@ int  mi355x_colpart_solve(mi355x_colpart *p, int is_max, double fp_factor, int64
  * artificial tableau as phase 1 and the drive-out pivots left it (download / destroy only: its
  * communicators now belong to *main_out).  One-process forms only (logical shards, or one shard
  * per visible device).  n_pivots[0] = phase 1 incl. drive-out pivots, n_pivots[1] = phase 2.
- * Returns what mi355x_solve_two_phase returns. */
+ * Returns what mi355x_solve_two_phase returns, or MI_UNSUPPORTED when the partition cannot follow
+ * the reference bit for bit: an artificial tableau whose basis is not a set of unit columns, or a
+ * drive-out pivot on a NEGATIVE element (it leaves -0.0 in basic columns, which compact shards do
+ * not store) -- solve the caller's (untouched) tableaux with mi355x_solve_two_phase then. */
 int  mi355x_colpart_solve_two_phase(mi355x_colpart *art, int64_t main_cols,
                                     const double *main_objective_row, int main_is_max,
                                     double fp_factor, int64_t *n_pivots, mi355x_colpart **main_out);

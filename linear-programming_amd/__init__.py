@@ -15,7 +15,7 @@ GPU, and fails loudly otherwise.
 """
 from . import batch, capi, native, simplex, solver, synth       # noqa: F401
 from .native import NativeProblem, NativeSolution               # noqa: F401
-from .batch import TableauBatch                                 # noqa: F401
+from .batch import TableauBatch, MultiDeviceBatch               # noqa: F401
 from .conditions import (SolverError, UnboundedProblemError, InfeasibleProblemError,   # noqa: F401
                          UnsupportedConstraintError, ParsingError)
 from .problem import Problem                                    # noqa: F401

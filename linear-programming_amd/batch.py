@@ -48,6 +48,18 @@ class TableauBatch:
                    "mi355x_batch_solve")
         return st, npv
 
+    def solve_async(self, is_max=True, fp_tolerance=1024, max_pivots=0):
+        """Start the solve on a worker thread of the library (mi355x_batch_solve_async)."""
+        capi.check(capi.lib().mi355x_batch_solve_async(self._h, int(bool(is_max)), float(fp_tolerance),
+                                                       int(max_pivots)), "mi355x_batch_solve_async")
+
+    def sync(self):
+        """Wait for solve_async; returns what solve() returns."""
+        st = np.zeros(self.n_lps, dtype=np.int32)
+        npv = np.zeros(self.n_lps, dtype=np.int64)
+        capi.check(capi.lib().mi355x_batch_sync(self._h, _ptr(st), _ptr(npv)), "mi355x_batch_sync")
+        return st, npv
+
     def download(self, k):
         """(matrix, basis) of LP k."""
         M = np.empty((self.rows, self.cols), dtype=np.float64)
@@ -70,5 +82,69 @@ class TableauBatch:
         if h:
             try:
                 capi.lib().mi355x_batch_destroy(h)
+            except Exception:
+                pass
+
+
+class MultiDeviceBatch:
+    """One batch spread over several GPUs behind ONE handle (mi355x_multibatch_*): LP k lives in
+    sub-batch k // ceil(n_lps / n_devices); solve() runs every sub-batch's loop on a worker thread
+    of the library, so one host thread drives all devices (BASELINE config 4: 1024 LPs, 8 GPUs)."""
+
+    def __init__(self, handle, n_lps, rows, cols):
+        self._h, self.n_lps, self.rows, self.cols = handle, int(n_lps), int(rows), int(cols)
+
+    @staticmethod
+    def _devs(device_ids):
+        if device_ids is None:
+            return None, None
+        arr = (ctypes.c_int * len(device_ids))(*[int(d) for d in device_ids])
+        return arr, arr
+
+    @classmethod
+    def from_arrays(cls, matrices, bases, n_devices, device_ids=None):
+        M = np.ascontiguousarray(matrices, dtype=np.float64)
+        B = np.ascontiguousarray(bases, dtype=np.int64)
+        n, R, C = M.shape
+        keep, devs = cls._devs(device_ids)
+        h = ctypes.c_void_p()
+        capi.check(capi.lib().mi355x_multibatch_create(ctypes.byref(h), n, R, C, _ptr(M), _ptr(B), int(n_devices),
+                                                       devs), "mi355x_multibatch_create")
+        return cls(h, n, R, C)
+
+    @classmethod
+    def synthetic(cls, n_lps, n_vars, n_cons, seeds, n_devices, device_ids=None):
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        keep, devs = cls._devs(device_ids)
+        h = ctypes.c_void_p()
+        capi.check(capi.lib().mi355x_multibatch_create_synthetic(ctypes.byref(h), n_lps, n_vars, n_cons, _ptr(seeds),
+                                                                 int(n_devices), devs),
+                   "mi355x_multibatch_create_synthetic")
+        return cls(h, n_lps, n_cons + 1, n_vars + n_cons + 1)
+
+    def info(self):
+        a, b = ctypes.c_int(0), ctypes.c_int(0)
+        capi.check(capi.lib().mi355x_multibatch_info(self._h, ctypes.byref(a), ctypes.byref(b)), "mi355x_multibatch_info")
+        return {"n_sub_batches": a.value, "n_devices_used": b.value}
+
+    def solve(self, is_max=True, fp_tolerance=1024, max_pivots=0):
+        st = np.zeros(self.n_lps, dtype=np.int32)
+        npv = np.zeros(self.n_lps, dtype=np.int64)
+        capi.check(capi.lib().mi355x_multibatch_solve(self._h, int(bool(is_max)), float(fp_tolerance), int(max_pivots),
+                                                      _ptr(st), _ptr(npv)), "mi355x_multibatch_solve")
+        return st, npv
+
+    def download(self, k):
+        M = np.empty((self.rows, self.cols), dtype=np.float64)
+        b = np.empty(self.rows - 1, dtype=np.int64)
+        capi.check(capi.lib().mi355x_multibatch_download(self._h, int(k), _ptr(M), _ptr(b), None, None),
+                   "mi355x_multibatch_download")
+        return M, b
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                capi.lib().mi355x_multibatch_destroy(h)
             except Exception:
                 pass

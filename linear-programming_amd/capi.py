@@ -74,6 +74,14 @@ SIGNATURES = {
     "mi355x_batch_timing_enable": (_int, [_p, _int]),
     "mi355x_batch_timing_read": (_int, [_p, _p, _p, _p]),
     "mi355x_batch_destroy": (None, [_p]),
+    "mi355x_batch_solve_async": (_int, [_p, _int, _dbl, _i64]),
+    "mi355x_batch_sync": (_int, [_p, _p, _p]),
+    "mi355x_multibatch_create": (_int, [_pp, _i64, _i64, _i64, _p, _p, _int, _p]),
+    "mi355x_multibatch_create_synthetic": (_int, [_pp, _i64, _i64, _i64, _p, _int, _p]),
+    "mi355x_multibatch_info": (_int, [_p, _p, _p]),
+    "mi355x_multibatch_solve": (_int, [_p, _int, _dbl, _i64, _p, _p]),
+    "mi355x_multibatch_download": (_int, [_p, _i64, _p, _p, _p, _p]),
+    "mi355x_multibatch_destroy": (None, [_p]),
     "mi355x_shard_set_compact": (_int, [_p, _i64, _p]),
     "mi355x_shard_columns": (_int, [_p, _p]),
     "mi355x_shard_price": (_int, [_p, _int, _i64, _p]),

@@ -121,6 +121,20 @@ struct mi355x_tab {
 
 struct mi355x_batch {
     mi355x_tab *t = nullptr;              // same machinery, TabView::n_lps > 1
+    // mi355x_batch_solve_async: the (host-driven) solve loop runs on a worker thread of the library
+    std::thread worker;
+    bool        running = false;
+    int         worker_rc = MI_OK;
+    std::string worker_err;
+    std::vector<int32_t> w_status;
+    std::vector<int64_t> w_pivots;
+};
+
+// Several sub-batches, one per device (or logical sub-batches on one device), behind one handle
+struct mi355x_multibatch {
+    int64_t n_lps = 0, rows = 0, cols = 0;
+    std::vector<mi355x_batch *> sub;
+    std::vector<int64_t> first;           // global index of each sub-batch's first LP (+ n_lps at the end)
 };
 
 namespace {
@@ -1285,9 +1299,189 @@ int mi355x_batch_timing_read(mi355x_batch *b, int64_t *n_launches, double *sum_m
 void mi355x_batch_destroy(mi355x_batch *b)
 {
     if (!b) return;
+    if (b->worker.joinable()) b->worker.join();
     free_tab(b->t);
     delete b;
 }
+
+// ---- asynchronous batch solve: the loop of mi355x_batch_solve on a worker thread ---------------
+// The batch solve is host-driven (blind chunks of launches, one status read-back per chunk), so
+// "asynchronous" means: the library drives it from a thread of its own while the caller's thread
+// goes on -- e.g. starts the sub-batches of the other GPUs.  One solve at a time per batch.
+int mi355x_batch_solve_async(mi355x_batch *b, int is_max, double f, int64_t max_pivots)
+{
+    if (!b || !b->t) return fail(MI_BAD_ARG, "batch is NULL");
+    if (max_pivots < 0) return fail(MI_BAD_ARG, "max_pivots < 0");
+    if (b->running) return fail(MI_BAD_ARG, "a solve of this batch is already running (mi355x_batch_sync first)");
+    if (b->worker.joinable()) b->worker.join();
+    const int64_t n = b->t->v.n_lps;
+    b->w_status.assign((size_t)n, 0);
+    b->w_pivots.assign((size_t)n, 0);
+    b->worker_rc = MI_OK;
+    b->worker_err.clear();
+    b->running = true;
+    try {
+        b->worker = std::thread([b, is_max, f, max_pivots]() {
+            b->worker_rc = mi355x_batch_solve(b, is_max, f, max_pivots, b->w_status.data(), b->w_pivots.data());
+            if (b->worker_rc != MI_OK) b->worker_err = g_err;        // g_err is thread-local
+        });
+    } catch (...) {
+        b->running = false;
+        return fail(MI_NO_MEMORY, "could not start the worker thread");
+    }
+    return MI_OK;
+}
+
+int mi355x_batch_sync(mi355x_batch *b, int32_t *status, int64_t *n_pivots)
+{
+    if (!b || !b->t) return fail(MI_BAD_ARG, "batch is NULL");
+    if (!b->running) return fail(MI_BAD_ARG, "no asynchronous solve of this batch is in flight");
+    if (b->worker.joinable()) b->worker.join();
+    b->running = false;
+    if (b->worker_rc != MI_OK) { g_err = b->worker_err; return b->worker_rc; }
+    const int64_t n = b->t->v.n_lps;
+    if (status) std::copy(b->w_status.begin(), b->w_status.begin() + n, status);
+    if (n_pivots) std::copy(b->w_pivots.begin(), b->w_pivots.begin() + n, n_pivots);
+    return MI_OK;
+}
+
+// ---- one batch over several devices (BASELINE config 4: 1024 LPs over 8 GPUs) -------------------
+// LP k lives in sub-batch k / ceil(n_lps / n_devices) (contiguous blocks); independent units, no
+// communication.  One call solves all of them: every sub-batch's loop runs on its own worker
+// thread (mi355x_batch_solve_async), the caller's thread only waits -- so a single-threaded host
+// keeps all GPUs busy.  Fewer visible devices than sub-batches (device_ids == NULL): the
+// sub-batches become logical sub-batches on device 0, each with its own stream.
+static void mb_free(mi355x_multibatch *mb)
+{
+    if (!mb) return;
+    for (mi355x_batch *b : mb->sub) mi355x_batch_destroy(b);
+    delete mb;
+}
+
+static int mb_layout(mi355x_multibatch *mb, int64_t n_lps, int64_t rows, int64_t cols, int *n_devices,
+                     const int *device_ids, std::vector<int> &devs)
+{
+    if (n_lps < 1 || *n_devices < 1) return fail(MI_BAD_ARG, "need n_lps >= 1 and n_devices >= 1");
+    const int ndev = device_count_checked();
+    if (ndev <= 0) return fail(MI_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    if ((int64_t)*n_devices > n_lps) *n_devices = (int)n_lps;
+    devs.resize((size_t)*n_devices);
+    for (int d = 0; d < *n_devices; ++d) {
+        if (device_ids) {
+            if (device_ids[d] < 0 || device_ids[d] >= ndev) return fail(MI_BAD_ARG, "device %d out of range [0,%d)", device_ids[d], ndev);
+            devs[(size_t)d] = device_ids[d];
+        } else {
+            devs[(size_t)d] = ndev >= *n_devices ? d : 0;
+        }
+    }
+    mb->n_lps = n_lps; mb->rows = rows; mb->cols = cols;
+    const int64_t per = (n_lps + *n_devices - 1) / *n_devices;
+    mb->first.clear();
+    for (int d = 0; d < *n_devices; ++d) mb->first.push_back(std::min<int64_t>((int64_t)d * per, n_lps));
+    mb->first.push_back(n_lps);
+    return MI_OK;
+}
+
+int mi355x_multibatch_create(mi355x_multibatch **out, int64_t n_lps, int64_t rows, int64_t cols,
+                             const double *host_matrices, const int64_t *host_bases, int n_devices,
+                             const int *device_ids)
+{
+    if (!out) return fail(MI_BAD_ARG, "out is NULL");
+    *out = nullptr;
+    if (!host_matrices) return fail(MI_BAD_ARG, "host_matrices is NULL");
+    mi355x_multibatch *mb = new (std::nothrow) mi355x_multibatch;
+    if (!mb) return fail(MI_NO_MEMORY, "host allocation failed");
+    std::vector<int> devs;
+    int rc = mb_layout(mb, n_lps, rows, cols, &n_devices, device_ids, devs);
+    for (int d = 0; rc == MI_OK && d < n_devices; ++d) {
+        const int64_t k0 = mb->first[(size_t)d], k1 = mb->first[(size_t)d + 1];
+        if (k1 <= k0) continue;
+        mi355x_batch *b = nullptr;
+        rc = mi355x_batch_create(&b, k1 - k0, rows, cols, host_matrices + k0 * rows * cols,
+                                 host_bases ? host_bases + k0 * std::max<int64_t>(rows - 1, 0) : nullptr, devs[(size_t)d]);
+        if (rc == MI_OK) mb->sub.push_back(b);
+    }
+    if (rc != MI_OK) { mb_free(mb); return rc; }
+    // (sub-batches that would be empty were skipped: first[] keeps only the boundaries in use)
+    std::vector<int64_t> f2;
+    for (size_t d = 0; d + 1 < mb->first.size(); ++d)
+        if (mb->first[d + 1] > mb->first[d]) f2.push_back(mb->first[d]);
+    f2.push_back(n_lps);
+    mb->first = f2;
+    *out = mb;
+    return MI_OK;
+}
+
+int mi355x_multibatch_create_synthetic(mi355x_multibatch **out, int64_t n_lps, int64_t n_vars, int64_t n_cons,
+                                       const uint64_t *seeds, int n_devices, const int *device_ids)
+{
+    if (!out) return fail(MI_BAD_ARG, "out is NULL");
+    *out = nullptr;
+    if (!seeds) return fail(MI_BAD_ARG, "seeds is NULL");
+    mi355x_multibatch *mb = new (std::nothrow) mi355x_multibatch;
+    if (!mb) return fail(MI_NO_MEMORY, "host allocation failed");
+    std::vector<int> devs;
+    int rc = mb_layout(mb, n_lps, n_cons + 1, n_vars + n_cons + 1, &n_devices, device_ids, devs);
+    std::vector<int64_t> f2;
+    for (int d = 0; rc == MI_OK && d < n_devices; ++d) {
+        const int64_t k0 = mb->first[(size_t)d], k1 = mb->first[(size_t)d + 1];
+        if (k1 <= k0) continue;
+        mi355x_batch *b = nullptr;
+        rc = mi355x_batch_create_synthetic(&b, k1 - k0, n_vars, n_cons, seeds + k0, devs[(size_t)d]);
+        if (rc == MI_OK) { mb->sub.push_back(b); f2.push_back(k0); }
+    }
+    if (rc != MI_OK) { mb_free(mb); return rc; }
+    f2.push_back(n_lps);
+    mb->first = f2;
+    *out = mb;
+    return MI_OK;
+}
+
+int mi355x_multibatch_info(const mi355x_multibatch *mb, int *n_sub_batches, int *n_devices_used)
+{
+    if (!mb) return fail(MI_BAD_ARG, "handle is NULL");
+    if (n_sub_batches) *n_sub_batches = (int)mb->sub.size();
+    if (n_devices_used) {
+        std::vector<int> seen;
+        for (mi355x_batch *b : mb->sub)
+            if (std::find(seen.begin(), seen.end(), b->t->device) == seen.end()) seen.push_back(b->t->device);
+        *n_devices_used = (int)seen.size();
+    }
+    return MI_OK;
+}
+
+int mi355x_multibatch_solve(mi355x_multibatch *mb, int is_max, double f, int64_t max_pivots, int32_t *status,
+                            int64_t *n_pivots)
+{
+    if (!mb) return fail(MI_BAD_ARG, "handle is NULL");
+    int rc = MI_OK;
+    size_t started = 0;
+    for (; started < mb->sub.size(); ++started) {
+        rc = mi355x_batch_prepare(mb->sub[started]);                 // representation change: before the worker starts
+        if (rc == MI_OK) rc = mi355x_batch_solve_async(mb->sub[started], is_max, f, max_pivots);
+        if (rc != MI_OK) break;
+    }
+    std::string err = rc != MI_OK ? g_err : std::string();
+    for (size_t d = 0; d < started; ++d) {                           // wait for every worker that did start
+        const int64_t k0 = mb->first[d];
+        const int r2 = mi355x_batch_sync(mb->sub[d], status ? status + k0 : nullptr, n_pivots ? n_pivots + k0 : nullptr);
+        if (r2 != MI_OK && rc == MI_OK) { rc = r2; err = g_err; }
+    }
+    if (rc != MI_OK) g_err = err;
+    return rc;
+}
+
+int mi355x_multibatch_download(mi355x_multibatch *mb, int64_t k, double *hm, int64_t *hb, double *last_row,
+                               double *last_col)
+{
+    if (!mb) return fail(MI_BAD_ARG, "handle is NULL");
+    if (k < 0 || k >= mb->n_lps) return fail(MI_BAD_ARG, "lp_index %lld out of range", (long long)k);
+    size_t d = 0;
+    while (d + 1 < mb->sub.size() && k >= mb->first[d + 1]) ++d;
+    return mi355x_batch_download(mb->sub[d], k - mb->first[d], hm, hb, last_row, last_col);
+}
+
+void mi355x_multibatch_destroy(mi355x_multibatch *mb) { mb_free(mb); }
 
 // ---- column-partitioned shards ------------------------------------------------------
 int mi355x_shard_price(mi355x_tab *t, int is_max, int64_t col_offset, double *dev_out2)
@@ -2186,6 +2380,7 @@ int mi355x_colpart_solve_two_phase(mi355x_colpart *art, int64_t main_cols, const
         // first non-basic column of the main problem with a non-zero entry in row i: only stored
         // columns can qualify (a basic column other than basis[i] holds +0 there)
         int64_t new_col = -1;
+        double new_val = 0.0;
         for (CpShard &s : art->sh) {
             const int64_t nloc = s.t->v.cols - 1;
             gcols.resize((size_t)nloc);
@@ -2196,10 +2391,21 @@ int mi355x_colpart_solve_two_phase(mi355x_colpart *art, int64_t main_cols, const
             HIP_TRY(hipStreamSynchronize(s.t->stream));
             for (int64_t k = 0; k < nloc; ++k) {
                 const int64_t g = gcols[(size_t)k];
-                if (g >= 0 && g < num_vars && rowbuf[(size_t)k] != 0.0 && (new_col < 0 || g < new_col)) new_col = g;
+                if (g >= 0 && g < num_vars && rowbuf[(size_t)k] != 0.0 && (new_col < 0 || g < new_col)) {
+                    new_col = g;
+                    new_val = rowbuf[(size_t)k];
+                }
             }
         }
         if (new_col < 0) return MI_ART_STUCK;
+        // A NEGATIVE pivot element turns the +0 entries the basic columns hold in the pivot row into
+        // -0.0 (+0 / negative), and compact shards store no basic column: the bits of the reference's
+        // tableau cannot be kept.  (The ratio test only ever picks positive pivot elements; a
+        // drive-out pivot takes whatever is there.)  The caller's tableaux are untouched: it solves
+        // them on one device, where the drive-out pivots run on the dense tableau.
+        if (new_val < 0.0)
+            return fail(MI_UNSUPPORTED, "drive-out pivot on a negative element (row %lld, column %lld): not "
+                                        "representable on compact column shards", (long long)i, (long long)new_col);
         if (!reset_done) {                                    // phase 1 left every shard's status at OPTIMAL
             for (CpShard &s : art->sh)
                 if ((rc = mi355x_tab_reset(s.t, 0)) != MI_OK) return rc;

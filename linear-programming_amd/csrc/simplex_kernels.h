@@ -51,6 +51,7 @@ struct BlockCtl {
     // behind it, so the sweep applies min(n_pending, min over w of steps) pivots and the host's
     // recovery takes the bookkeeping of the pivot beyond that back (k_la_rollback).
     int64_t done[32];             // kMaxLaWorkgroups entries
+    int64_t ec[kMaxBlock];        // persistent look-ahead: the logical columns that entered (k_la_rollback)
 };
 
 // Record one workgroup of the persistent look-ahead kernel publishes per exchange: eight

@@ -1719,7 +1719,7 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
     auto leave = [&](int steps) {
         if (tid == 0) st_wt(&blk->done[w], (int64_t)(((unsigned long long)epoch_base << 8) | (unsigned)steps));
     };
-    if (c0.status != kRunning) { leave(0); return; }
+    if (c0.status != kRunning) return;       // (nothing pending; behind a lost exchange `done` belongs to that launch)
 
     double  b = (has_row && r < m) ? t.M[r * ld + vc] : 0.0;     // RHS entry of my row
     double2 z = has_pair ? M2[m * ldv + p] : make_double2(0.0, 0.0);   // objective row, my pair
@@ -1928,6 +1928,7 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
             ctl->n_pivots = c0.n_pivots + J + 1;
             blk->cr[J] = cr;
             blk->slot[J] = slot;
+            blk->ec[J] = ec;
             blk->n_pending = J + 1;
         }
         if (lane == J) { v_cr = cr; v_sl = slot; }
@@ -1974,12 +1975,16 @@ __global__ void k_la_rollback(TabView t, int la_nw)
     if (n == 0 || stamp == 0u) return;
     const int keep = committed_pivots(blk, n, stamp, la_nw);
     for (int i = n - 1; i >= keep; --i) {
-        const int64_t cr = blk->cr[i], slot = blk->slot[i];
-        const int64_t ec = t.basis[cr], leaving = t.p2l[slot];
-        t.p2l[slot] = ec;
-        t.l2p[ec] = slot;
-        t.l2p[leaving] = -1;
-        t.basis[cr] = leaving;
+        const int64_t cr = blk->cr[i], slot = blk->slot[i], ec = blk->ec[i];
+        // the maps are swapped by the thread that owns the slot's column pair -- which sits in the
+        // workgroup that gave up when that workgroup holds the slot: then there is nothing to undo
+        if (t.basis[cr] == ec) {
+            const int64_t leaving = t.p2l[slot];
+            t.p2l[slot] = ec;
+            t.l2p[ec] = slot;
+            t.l2p[leaving] = -1;
+            t.basis[cr] = leaving;
+        }
         ctl->n_pivots -= 1;
         ctl->trace_n -= 1;
     }

@@ -61,6 +61,9 @@
 (cffi:defcfun ("mi355x_tab_create" %tab-create) :int
   (out :pointer) (rows :int64) (cols :int64) (host-matrix :pointer) (host-basis :pointer)
   (device :int))
+(cffi:defcfun ("mi355x_tab_create_compact" %tab-create-compact) :int
+  (out :pointer) (rows :int64) (var-count :int64) (n-stored :int64) (host-stored :pointer)
+  (stored-cols :pointer) (host-basis :pointer) (device :int))
 (cffi:defcfun ("mi355x_tab_destroy" %tab-destroy) :void (tab :pointer))
 (cffi:defcfun ("mi355x_tab_solve" %tab-solve) :int
   (tab :pointer) (is-max :int) (fp-factor :double) (max-pivots :int64) (n-pivots :pointer))
@@ -70,9 +73,12 @@
   (tab :pointer) (host-matrix :pointer) (host-basis :pointer) (last-row :pointer)
   (last-col :pointer))
 ;; one tableau column-partitioned over several GPUs (include/mi355x_simplex.h, mi355x_colpart_*)
-(cffi:defcfun ("mi355x_colpart_create" %colpart-create) :int
+(cffi:defcfun ("mi355x_colpart_create_on" %colpart-create-on) :int
   (out :pointer) (rows :int64) (cols :int64) (host-matrix :pointer) (host-basis :pointer)
-  (n-devices :int))
+  (n-devices :int) (device-ids :pointer))
+(cffi:defcfun ("mi355x_colpart_solve_two_phase" %colpart-solve-two-phase) :int
+  (art :pointer) (main-cols :int64) (main-objective-row :pointer) (main-is-max :int)
+  (fp-factor :double) (n-pivots :pointer) (main-out :pointer))
 (cffi:defcfun ("mi355x_colpart_solve" %colpart-solve) :int
   (handle :pointer) (is-max :int) (fp-factor :double) (max-pivots :int64) (n-pivots :pointer))
 (cffi:defcfun ("mi355x_colpart_download" %colpart-download) :int
@@ -144,6 +150,70 @@ the arrays are not), so tableau-variable & co. (src/simplex.lisp:74-120) read GP
                    (%tab-create out rows cols pm pb device)))))
       (values (cffi:mem-ref out :pointer) flat basis))))
 
+(defun exact-unit-entry-p (x one)
+  "X is exactly 1 (ONE true) / exactly +0 (ONE false): the integers build-tableau stores
+(src/simplex.lisp:217-219, 255-259) or their float forms, never -0.0."
+  (if one
+      (= x 1)
+      (and (zerop x) (not (and (floatp x) (minusp (float-sign x)))))))
+
+(defun unit-basis-p (tableau)
+  "True when every basis column is exactly the unit vector of its row (objective row included):
+what build-tableau produces for the slack columns of a single-phase problem."
+  (let* ((matrix (tableau-matrix tableau))
+         (rows (array-dimension matrix 0))
+         (var-count (1- (array-dimension matrix 1)))
+         (basis (tableau-basis-columns tableau))
+         (seen (make-array var-count :element-type 'bit :initial-element 0)))
+    (dotimes (i (length basis) t)
+      (let ((b (aref basis i)))
+        (unless (and (integerp b) (<= 0 b) (< b var-count) (zerop (aref seen b)))
+          (return nil))
+        (setf (aref seen b) 1)
+        (dotimes (r rows)
+          (unless (exact-unit-entry-p (aref matrix r b) (= r i))
+            (return-from unit-basis-p nil)))))))
+
+(defun upload-tableau-compact (tableau device)
+  "Single-phase problems: only [non-basic columns | RHS] is coerced and crosses PCIe
+(mi355x_tab_create_compact); the slack identity block -- a third of the boxed matrix at n = 2m --
+is neither converted nor uploaded, and no dense device buffer exists for a plain solve with the
+light read-back.  Returns (values handle basis), or NIL when the basis columns are not exact unit
+vectors (the caller then uploads the dense tableau)."
+  (when (and (plusp (length (tableau-basis-columns tableau))) (unit-basis-p tableau))
+    (let* ((matrix (tableau-matrix tableau))
+           (rows (array-dimension matrix 0))
+           (var-count (1- (array-dimension matrix 1)))
+           (basis-src (tableau-basis-columns tableau))
+           (m (length basis-src))
+           (n-stored (- var-count m))
+           (basic (make-array var-count :element-type 'bit :initial-element 0)))
+      (when (plusp n-stored)
+        (dotimes (i m) (setf (aref basic (aref basis-src i)) 1))
+        (let ((stored-cols (make-array n-stored :element-type '(signed-byte 64)))
+              (stored (make-array (* rows (1+ n-stored)) :element-type 'double-float))
+              (basis (make-array m :element-type '(signed-byte 64)))
+              (j 0))
+          (dotimes (c var-count)
+            (when (zerop (aref basic c))
+              (setf (aref stored-cols j) c)
+              (incf j)))
+          (dotimes (r rows)
+            (let ((base (* r (1+ n-stored))))
+              (dotimes (k n-stored)
+                (setf (aref stored (+ base k))
+                      (coerce (aref matrix r (aref stored-cols k)) 'double-float)))
+              (setf (aref stored (+ base n-stored))
+                    (coerce (aref matrix r var-count) 'double-float))))
+          (dotimes (i m) (setf (aref basis i) (aref basis-src i)))
+          (cffi:with-foreign-object (out :pointer)
+            (cffi:with-pointer-to-vector-data (ps stored)
+              (cffi:with-pointer-to-vector-data (pc stored-cols)
+                (cffi:with-pointer-to-vector-data (pb basis)
+                  (check (with-foreign-fp-mode
+                           (%tab-create-compact out rows var-count n-stored ps pc pb device))))))
+            (values (cffi:mem-ref out :pointer) basis)))))))
+
 (defun download-tableau (handle tableau flat basis)
   "Full write-back: every entry of the solved tableau (400 MB and 5e7 boxed doubles at
 8192 x 4096 -- only worth it when the caller wants to look inside the tableau)."
@@ -176,18 +246,91 @@ the interior of the matrix keeps its pre-solve contents."
     tableau))
 
 ;;; ------------------------------------------------------------------ several GPUs
+(defun device-count-of (devices)
+  "DEVICES is a count (devices 0 .. n-1) or a list of device ids."
+  (if (listp devices) (length devices) devices))
+
+(defun colpart-create (flat basis rows cols devices)
+  "mi355x_colpart_create_on: one shard per device of DEVICES (a count, or a list of distinct ids)."
+  (let ((n (device-count-of devices)))
+    (cffi:with-foreign-object (out :pointer)
+      (cffi:with-foreign-object (ids :int (max n 1))
+        (when (listp devices)
+          (loop for d in devices for i from 0 do (setf (cffi:mem-aref ids :int i) d)))
+        (cffi:with-pointer-to-vector-data (pm flat)
+          (cffi:with-pointer-to-vector-data (pb basis)
+            (check (with-foreign-fp-mode
+                     (%colpart-create-on out rows cols pm pb n
+                                         (if (listp devices) ids (cffi:null-pointer))))))))
+      (cffi:mem-ref out :pointer))))
+
+(defun colpart-read-back (handle tableau flat basis rows cols full-tableau)
+  "Full or light write-back from a column-partitioned handle into TABLEAU's arrays."
+  (let* ((matrix (tableau-matrix tableau))
+         (last-row (make-array cols :element-type 'double-float))
+         (last-col (make-array rows :element-type 'double-float))
+         (basis-dst (tableau-basis-columns tableau)))
+    (cffi:with-pointer-to-vector-data (pr last-row)
+      (cffi:with-pointer-to-vector-data (pc last-col)
+        (cffi:with-pointer-to-vector-data (pb basis)
+          (if full-tableau
+              (cffi:with-pointer-to-vector-data (pm flat)
+                (check (%colpart-download handle pm pb pr pc)))
+              (check (%colpart-download handle (cffi:null-pointer) pb pr pc))))))
+    (if full-tableau
+        (vectors->tableau tableau flat basis)
+        (progn
+          (dotimes (r rows) (setf (aref matrix r (1- cols)) (aref last-col r)))
+          (dotimes (c cols) (setf (aref matrix (1- rows) c) (aref last-row c)))
+          (dotimes (i (length basis-dst)) (setf (aref basis-dst i) (aref basis i)))
+          tableau))))
+
+(defun solve-two-phase-column-partitioned (art-tab main-tab devices factor full-tableau n-pivots)
+  "Two-phase n-solve-tableau (src/simplex.lisp:402-452) with the ARTIFICIAL tableau
+column-partitioned over DEVICES: phase 1, the drive-out pivots, the hand-over and phase 2 all stay
+on the partition (mi355x_colpart_solve_two_phase).  The main tableau is not uploaded -- the library
+takes its objective row only; its constraint rows are the artificial tableau's.  Returns
+:unsupported / :overflowed when the partitioned path does not apply (the caller's tableaux are
+untouched and it solves them on one device)."
+  (multiple-value-bind (art-flat art-basis rows art-cols) (tableau->vectors art-tab)
+    (let* ((main-matrix (tableau-matrix main-tab))
+           (main-cols (array-dimension main-matrix 1))
+           (objective (make-array main-cols :element-type 'double-float))
+           (art-handle (colpart-create art-flat art-basis rows art-cols devices))
+           (main-handle (cffi:null-pointer)))
+      (dotimes (c main-cols)
+        (setf (aref objective c) (coerce (aref main-matrix (1- rows) c) 'double-float)))
+      (unwind-protect
+           (let ((status
+                   (cffi:with-foreign-object (out :pointer)
+                     (setf (cffi:mem-ref out :pointer) (cffi:null-pointer))
+                     (prog1
+                         (cffi:with-pointer-to-vector-data (po objective)
+                           (with-foreign-fp-mode
+                             (%colpart-solve-two-phase art-handle main-cols po
+                                                       (max-problem-p main-tab) factor n-pivots
+                                                       out)))
+                       (setf main-handle (cffi:mem-ref out :pointer))))))
+             (cond
+               ((= status -6) :unsupported)                 ; MI_UNSUPPORTED: artificial basis not unit columns
+               ((= status +mi-nonfinite+) :overflowed)
+               (t
+                (check status)
+                (signal-outcome status)
+                (let ((main-flat (make-array (* rows main-cols) :element-type 'double-float))
+                      (main-basis (make-array (max 1 (1- rows)) :element-type '(signed-byte 64)
+                                                                :initial-element 0)))
+                  (colpart-read-back main-handle main-tab main-flat main-basis rows main-cols
+                                     full-tableau)))))
+        (unless (cffi:null-pointer-p main-handle) (%colpart-destroy main-handle))
+        (%colpart-destroy art-handle)))))
+
 (defun solve-column-partitioned (tableau devices factor max-pivots full-tableau n-pivots)
   "Single-phase n-solve-tableau (src/simplex.lisp:453-461) with the tableau's non-basic columns
 distributed over DEVICES GPUs of this node (RCCL over xGMI inside the library; logical shards on
 one GPU when fewer are visible).  Same pivots, same bits as on one device."
   (multiple-value-bind (flat basis rows cols) (tableau->vectors tableau)
-    (let ((handle
-            (cffi:with-foreign-object (out :pointer)
-              (cffi:with-pointer-to-vector-data (pm flat)
-                (cffi:with-pointer-to-vector-data (pb basis)
-                  (check (with-foreign-fp-mode
-                           (%colpart-create out rows cols pm pb devices)))))
-              (cffi:mem-ref out :pointer))))
+    (let ((handle (colpart-create flat basis rows cols devices)))
       (unwind-protect
            (let ((status (check (with-foreign-fp-mode
                                   (%colpart-solve handle (max-problem-p tableau) factor
@@ -199,24 +342,7 @@ one GPU when fewer are visible).  Same pivots, same bits as on one device."
              (when (= status +mi-nonfinite+)
                (return-from solve-column-partitioned :overflowed))
              (signal-outcome status)
-             (let* ((matrix (tableau-matrix tableau))
-                    (last-row (make-array cols :element-type 'double-float))
-                    (last-col (make-array rows :element-type 'double-float))
-                    (basis-dst (tableau-basis-columns tableau)))
-               (cffi:with-pointer-to-vector-data (pr last-row)
-                 (cffi:with-pointer-to-vector-data (pc last-col)
-                   (cffi:with-pointer-to-vector-data (pb basis)
-                     (if full-tableau
-                         (cffi:with-pointer-to-vector-data (pm flat)
-                           (check (%colpart-download handle pm pb pr pc)))
-                         (check (%colpart-download handle (cffi:null-pointer) pb pr pc))))))
-               (if full-tableau
-                   (vectors->tableau tableau flat basis)
-                   (progn
-                     (dotimes (r rows) (setf (aref matrix r (1- cols)) (aref last-col r)))
-                     (dotimes (c cols) (setf (aref matrix (1- rows) c) (aref last-row c)))
-                     (dotimes (i (length basis-dst)) (setf (aref basis-dst i) (aref basis i)))
-                     tableau))))
+             (colpart-read-back handle tableau flat basis rows cols full-tableau))
         (%colpart-destroy handle)))))
 
 (defun signal-outcome (status)
@@ -242,11 +368,12 @@ one GPU when fewer are visible).  Same pivots, same bits as on one device."
   "Solver interface function for the MI355X backend (the value of
 linear-programming:*solver*, src/solver.lisp:39-49).  Takes a problem and backend keyword
 arguments -- :fp-tolerance (as the built-in solver, src/simplex.lisp:506-511), :device,
-:devices (> 1: the tableau of a single-phase problem is column-partitioned over that many GPUs
-of the node; two-phase problems run on :device), :max-pivots, :full-tableau (write every entry
+:devices (a count > 1 or a list of device ids: the tableau -- for a two-phase problem the
+artificial tableau, with phase 1, the hand-over and phase 2 all on the partition -- is
+column-partitioned over those GPUs of the node), :max-pivots, :full-tableau (write every entry
 of the solved tableau back instead of only what the solution-* generics read) -- and returns a
 solved `tableau`.  solve-problem forwards these keywords (src/solver.lisp:53-56):
-  (solve-problem problem :devices 8)"
+  (solve-problem problem :devices 8)        (solve-problem problem :devices '(4 5 6 7))"
   (declare (ignore args))
   (when (problem-integer-vars problem)
     (error 'unsupported-constraint-error
@@ -258,6 +385,11 @@ solved `tableau`.  solve-problem forwards these keywords (src/solver.lisp:53-56)
       (if (listp tableaus)
           ;; two-phase: (art-tableau main-tableau), src/simplex.lisp:326-328, 402-452
           (destructuring-bind (art-tab main-tab) tableaus
+           (if (and (> (device-count-of devices) 1)
+                    (not (member (solve-two-phase-column-partitioned art-tab main-tab devices factor
+                                                                     full-tableau n-pivots)
+                                 '(:unsupported :overflowed))))
+               main-tab
             (multiple-value-bind (art-handle art-flat art-basis) (upload-tableau art-tab device)
               (declare (ignorable art-flat art-basis))
               (unwind-protect
@@ -273,20 +405,33 @@ solved `tableau`.  solve-problem forwards these keywords (src/solver.lisp:53-56)
                                 (download-tableau main-handle main-tab main-flat main-basis)
                                 (download-solution main-handle main-tab main-basis)))
                        (%tab-destroy main-handle)))
-                (%tab-destroy art-handle))))
+                (%tab-destroy art-handle)))))
           ;; single phase, src/simplex.lisp:453-461
-          (if (and (> devices 1)
+          (if (and (> (device-count-of devices) 1)
                    (not (eq :overflowed
                             (solve-column-partitioned tableaus devices factor max-pivots
                                                       full-tableau n-pivots))))
               tableaus
-          (multiple-value-bind (handle flat basis) (upload-tableau tableaus device)
-            (unwind-protect
-                 (let ((status (check (with-foreign-fp-mode
-                                        (%tab-solve handle (max-problem-p tableaus) factor
-                                                    max-pivots n-pivots)))))
-                   (signal-outcome status)
-                   (if full-tableau
-                       (download-tableau handle tableaus flat basis)
-                       (download-solution handle tableaus basis)))
-              (%tab-destroy handle))))))))
+              ;; one device.  With the light read-back (the default) only [non-basic columns | RHS]
+              ;; is coerced and uploaded (mi355x_tab_create_compact); :full-tableau, or a basis that
+              ;; is not a set of exact unit columns, takes the dense upload.
+              (multiple-value-bind (compact-handle compact-basis)
+                  (if full-tableau (values nil nil) (upload-tableau-compact tableaus device))
+                (if compact-handle
+                    (unwind-protect
+                         (let ((status (check (with-foreign-fp-mode
+                                                (%tab-solve compact-handle (max-problem-p tableaus)
+                                                            factor max-pivots n-pivots)))))
+                           (signal-outcome status)
+                           (download-solution compact-handle tableaus compact-basis))
+                      (%tab-destroy compact-handle))
+                    (multiple-value-bind (handle flat basis) (upload-tableau tableaus device)
+                      (unwind-protect
+                           (let ((status (check (with-foreign-fp-mode
+                                                  (%tab-solve handle (max-problem-p tableaus) factor
+                                                              max-pivots n-pivots)))))
+                             (signal-outcome status)
+                             (if full-tableau
+                                 (download-tableau handle tableaus flat basis)
+                                 (download-solution handle tableaus basis)))
+                        (%tab-destroy handle))))))))))

@@ -621,15 +621,27 @@ def test_two_phase_column_partition_drives_degenerate_artificials_out():
         A1, b1 = tabs[0].matrix.copy(), tabs[0].basis_columns.copy()
         _, n_plain, _ = oracle.solve(A1, b1, is_max=False)
         drove = int(npv[0]) > n_plain
+        followed = False
         for shards in (2, 3):
-            rc, got_npv, A, ab, Mm, mb = _colpart_two_phase(tabs, shards)
+            try:
+                rc, got_npv, A, ab, Mm, mb = _colpart_two_phase(tabs, shards)
+            except lp.capi.Mi355xError as e:
+                # a drive-out pivot on a NEGATIVE element leaves -0.0 in basic columns, which compact
+                # shards do not store: declined (MI_UNSUPPORTED), the hook then solves on one device
+                assert e.code == lp.capi.MI_UNSUPPORTED and drove, (seed, shards, str(e))
+                continue
+            followed = True
             assert rc == st, (seed, shards, rc, st)
             if st in (oracle.OPTIMAL, oracle.UNBOUNDED):
                 assert got_npv[0] == int(npv[0])
                 assert np.array_equal(A.view(np.int64), A_or.view(np.int64)) and np.array_equal(ab, ab_or)
                 assert np.array_equal(Mm.view(np.int64), M_or.view(np.int64)) and np.array_equal(mb, b_or)
-        hit += drove and st == oracle.OPTIMAL
-    assert hit >= 10, "the seeds produced too few drive-out pivots (%d)" % hit
+        # whatever the partition did, the hook ends with the oracle's bits (falling back when declined)
+        if st == oracle.OPTIMAL:
+            sol = lp.solve_problem(problem, devices=3)
+            assert np.array_equal(sol.matrix.view(np.int64), M_or.view(np.int64)) and np.array_equal(sol.basis_columns, b_or)
+        hit += drove and followed and st == oracle.OPTIMAL
+    assert hit >= 5, "the seeds produced too few drive-out pivots the partition could follow (%d)" % hit
 
 
 def test_degenerate_shapes():
@@ -836,6 +848,62 @@ def test_batch_blocked_kernel_bitwise_vs_oracle(block, n, m, nl):
                 assert np.array_equal(Mg, M) and np.array_equal(bg, b), (k, cap)
     finally:
         L.mi355x_tune_set_batch_block(0)
+
+
+@pytest.mark.parametrize("n_sub", [1, 3, 8])
+def test_multi_device_batch_logical_sub_batches_bitwise(n_sub):
+    """mi355x_multibatch_*: one batch handle over n sub-batches (one per device; this box has one
+    GPU, so they are logical sub-batches on it, each driven by its own worker thread of the
+    library and its own stream, all in flight at once).  Status, pivot count and final tableau of
+    every LP against the oracle, by GLOBAL LP index; ragged split (37 LPs over 8)."""
+    n, m, nl = 60, 35, 37
+    tabs = [lp.synth.tableau(n, m, lp.synth.seed_for(4, 100 + k)) for k in range(nl)]
+    Ms = np.stack([x[0] for x in tabs]); Bs = np.stack([x[1] for x in tabs])
+    mb = lp.MultiDeviceBatch.from_arrays(Ms, Bs, n_sub)
+    assert mb.info() == {"n_sub_batches": n_sub, "n_devices_used": 1}
+    st, npv = mb.solve()
+    for k in range(nl):
+        M, b = Ms[k].copy(), Bs[k].copy()
+        so, no, _ = oracle.solve(M, b)
+        G, bg = mb.download(k)
+        assert (int(st[k]), int(npv[k])) == (so, no), k
+        assert np.array_equal(G.view(np.int64), M.view(np.int64)) and np.array_equal(bg, b), k
+    # synthetic form (generated in HBM), more sub-batches than LPs asked for: capped
+    seeds = np.array([lp.synth.seed_for(4, 300 + k) for k in range(5)], dtype=np.uint64)
+    mb2 = lp.MultiDeviceBatch.synthetic(5, 40, 20, seeds, 8)
+    assert mb2.info()["n_sub_batches"] == 5
+    st, npv = mb2.solve(max_pivots=7)
+    for k in range(5):
+        M, b = lp.synth.tableau(40, 20, int(seeds[k]))
+        so, no, _ = oracle.solve(M, b, max_pivots=7)
+        G, bg = mb2.download(k)
+        assert (int(st[k]), int(npv[k])) == (so, no)
+        assert np.array_equal(G.view(np.int64), M.view(np.int64)) and np.array_equal(bg, b)
+
+
+def test_batch_solve_async_overlaps_two_batches():
+    """mi355x_batch_solve_async / _sync: two batches started back to back from ONE host thread and
+    collected afterwards -- both equal the blocking solve's results; a second async call on a
+    batch in flight and a sync without a solve are refused."""
+    L = lp.capi.lib()
+    n, m = 80, 45
+    sets = []
+    for base in (0, 50):
+        tabs = [lp.synth.tableau(n, m, lp.synth.seed_for(4, 500 + base + k)) for k in range(9)]
+        sets.append((np.stack([x[0] for x in tabs]), np.stack([x[1] for x in tabs])))
+    batches = [lp.TableauBatch.from_arrays(Ms, Bs) for Ms, Bs in sets]
+    assert L.mi355x_batch_sync(batches[0]._h, None, None) == lp.capi.MI_BAD_ARG
+    for b in batches:
+        b.solve_async()
+    assert L.mi355x_batch_solve_async(batches[0]._h, 1, 1024.0, 0) == lp.capi.MI_BAD_ARG
+    for b, (Ms, Bs) in zip(batches, sets):
+        st, npv = b.sync()
+        for k in range(Ms.shape[0]):
+            M, bb = Ms[k].copy(), Bs[k].copy()
+            so, no, _ = oracle.solve(M, bb)
+            G, bg = b.download(k)
+            assert (int(st[k]), int(npv[k])) == (so, no)
+            assert np.array_equal(G.view(np.int64), M.view(np.int64)) and np.array_equal(bg, bb)
 
 
 @pytest.mark.parametrize("n,m,nl", [(60, 30, 37), (7, 3, 5), (300, 40, 9), (33, 200, 6)])
