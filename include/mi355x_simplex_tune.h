@@ -51,6 +51,15 @@ int         mi355x_tune_set_handover_mode(int mode);         /* 0 auto, 1 sequen
 int         mi355x_tune_set_batch_mode(int mode);            /* 0 auto, 1 lockstep, 2 all in one workgroup
                                                                 per LP, 3 look-ahead per LP + sweeps over all LPs */
 int         mi355x_tune_set_batch_block(int k);              /* blocked per-LP kernel, 1 = off   */
+int         mi355x_tune_set_resident(int mode);              /* resident solve (the stored tableau in
+                                                                registers, one exchange per pivot):
+                                                                0 auto = whenever the shape fits AND
+                                                                every knob above is at its default,
+                                                                1 never, 2 whenever the shape fits  */
+int         mi355x_tune_set_resident_fault(int on);          /* TEST: the last workgroup of every LP
+                                                                never publishes (co-residency lost) */
+/* 1 when the solve entry points would run this handle (in its current representation) resident */
+int         mi355x_tab_resident(mi355x_tab *t);
 
 /* ---- persistent look-ahead (k_la_block) ------------------------------------------------ */
 int         mi355x_tune_set_la_one_xcd(int on);              /* 1 (default): all its workgroups on

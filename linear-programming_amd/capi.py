@@ -109,6 +109,9 @@ _EXTRA = {
     "mi355x_tune_set_sweep_impl": (_int, [_int]),
     "mi355x_tune_set_shard_la_split": (_int, [_int]),
     "mi355x_tune_set_tail_policy": (_int, [_int]),
+    "mi355x_tune_set_resident": (_int, [_int]),
+    "mi355x_tune_set_resident_fault": (_int, [_int]),
+    "mi355x_tab_resident": (_int, [_p]),
     "mi355x_tune_set_colpart_exchange": (_int, [_int]),
     "mi355x_colpart_exchange_timing_enable": (_int, [_p, _int, _int]),
     "mi355x_colpart_exchange_timing_read": (_int, [_p, _p, _p, _p]),

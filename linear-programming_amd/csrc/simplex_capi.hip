@@ -38,6 +38,9 @@ int g_batch_mode = 0;                     // 0 auto, 1 lockstep launch pairs, 2 
 int g_tail_policy = 1;                    // a request that is not a whole number of blocks: 0 spread evenly, 1 full blocks + remainder
 int g_la_mode = 0;                        // look-ahead: 0 auto, 1 two launches per step, 2 one persistent launch per block
 int g_block_k = 16;                       // pivots selected ahead and applied per sweep (1 = off)
+int g_resident_mode = 0;                  // resident solve (tableau in registers): 0 auto -- whenever the shape fits and
+                                          // every other implementation knob is at its default --, 1 never, 2 whenever it fits
+int g_batch_block_k = 0;                  // mirror of the blocked per-LP kernel's knob (0 = default)
 int g_cp_exchange = 0;                    // column partition over RCCL, exchange B (the entering column):
                                           // 0 int64 SUM all-reduce of (owner's bits + zeros), 1 rooted
                                           // ncclBroadcast (root = the rank whose pricing winner won, read
@@ -110,6 +113,12 @@ struct mi355x_tab {
     int64_t     sweeps = 0;               // update launches so far: odd ones sweep bottom-up
     unsigned    la_epoch = 1;             // next epoch base of the persistent look-ahead kernel
     int         la_last_nw = 0;           // workgroups of the persistent launches (what a recovery rolls back against)
+    // resident solve: exchange buffer, next epoch base, and whether its workgroups
+    // once failed to become co-resident (the handle then stays on the established paths)
+    unsigned long long *res_x = nullptr;
+    unsigned    res_epoch = 1;
+    bool        res_lost = false;
+    bool        last_was_resident = false;  // kind of the launch enqueued last (what a kSyncLost status refers to)
     bool        la_lost = false;          // an exchange of the persistent look-ahead was lost once
                                           // (its workgroups were not co-resident): this handle
                                           // stays on the two-launch look-ahead
@@ -179,6 +188,7 @@ void free_tab(mi355x_tab *t)
     (void)hipFree(t->v.l2p);
     (void)hipFree(t->brow);
     (void)hipFree(t->flag);
+    (void)hipFree(t->res_x);
     if (t->h_ctl) (void)hipHostFree(t->h_ctl);
     if (t->own_stream) (void)hipStreamDestroy(t->own_stream);
     delete t;
@@ -512,6 +522,7 @@ int enqueue_block(mi355x_tab *t, int is_max, double f, int k)
     }
     unsigned stamp = 0;
     int la_nw = 0;
+    t->last_was_resident = false;
     if (persistent) {
         if (t->la_epoch > 0x7fff0000u) {              // 32-bit tags: start over on clean records
             HIP_TRY(hipMemsetAsync(v.la_px, 0, kMaxLaRecords * sizeof(ExchRec), t->stream));
@@ -550,15 +561,55 @@ int enqueue_block(mi355x_tab *t, int is_max, double f, int k)
 // two-launch look-ahead, which needs no co-residency, for the rest of this handle's life.
 int recover_lost_exchange(mi355x_tab *t)
 {
-    t->la_lost = true;
     t->n_part = 0;
-    if (t->la_last_nw) launch_la_rollback(t->c, t->la_last_nw, t->stream);
+    if (t->last_was_resident) {
+        // the resident solve's workgroups were not co-resident at their first exchange: nothing was
+        // modified (it writes the tableau back only at the end of a launch that got through)
+        t->res_lost = true;
+    } else {
+        t->la_lost = true;
+        if (t->la_last_nw) launch_la_rollback(t->c, t->la_last_nw, t->stream);
+    }
     launch_ctl_resume(t->v, t->stream, kSyncLost);
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }
 
 int status_to_rc(int32_t st) { return st == kRunning ? MI_RUNNING : (int)st; }
+
+// ---- the resident solve (tableaux that fit the register files; simplex_kernels.hip, k_resident)
+bool knobs_at_default()
+{
+    return g_select_mode == 0 && g_la_mode == 0 && g_block_k == kMaxBlock && g_batch_mode == 0 && g_batch_block_k == 0;
+}
+
+bool resident_mode(const mi355x_tab *t)
+{
+    if (!t->compact || t->res_lost || g_resident_mode == 1) return false;
+    if (g_resident_mode == 0 && !knobs_at_default()) return false;   // an explicit knob asks for another path
+    return resident_plan(t->c, nullptr);
+}
+
+// one launch of up to `cap` pivots per LP (cap <= 65536)
+int enqueue_resident(mi355x_tab *t, int is_max, double f, int cap)
+{
+    if (!t->res_x) {
+        const size_t bytes = resident_xbuf_bytes(t->c);
+        HIP_TRY(hipMalloc((void **)&t->res_x, bytes));
+        HIP_TRY(hipMemsetAsync(t->res_x, 0, bytes, t->stream));
+        t->res_epoch = 1;
+    }
+    if (t->res_epoch > 0x7ffe0000u) {                 // 32-bit tags: start over on clean buffers
+        HIP_TRY(hipMemsetAsync(t->res_x, 0, resident_xbuf_bytes(t->c), t->stream));
+        t->res_epoch = 1;
+    }
+    if (!launch_resident(t->c, t->res_x, is_max, f, cap, t->res_epoch, t->stream))
+        return fail(MI_BAD_ARG, "resident launch refused");
+    t->res_epoch += (unsigned)cap + 2u;
+    t->last_was_resident = true;
+    t->n_part = 0;                                    // no pricing partials are left behind
+    return MI_OK;
+}
 
 }  // namespace
 
@@ -773,6 +824,15 @@ int mi355x_tab_solve_async(mi355x_tab *t, int is_max, double f, int64_t n_pivots
     rc = ensure_compact(t);
     if (rc != MI_OK) return rc;
     if (reset) launch_ctl_reset(t->v, 0, 0, t->stream);
+    if (resident_mode(t)) {
+        // the tableau stays on chip for the whole request (one launch per 65536 pivots)
+        for (int64_t left = n_pivots; left > 0; left -= 65536) {
+            rc = enqueue_resident(t, is_max, f, (int)std::min<int64_t>(left, 65536));
+            if (rc != MI_OK) return rc;
+        }
+        HIP_TRY(hipGetLastError());
+        return MI_OK;
+    }
     if (block_mode(t)) {
         // whole blocks, then the remainder as one shorter block (k_sweep16 for the full ones, a
         // k_sweep with as few links as the remainder needs: 20 pivots 371 us, 40 pivots 627 us), or
@@ -827,6 +887,9 @@ int mi355x_tab_sync(mi355x_tab *t, int64_t *n_pivots)
         if (rc != MI_OK) return rc;
         return MI_RUNNING;
     }
+    if (t->h_ctl->status == kResidentStuck)
+        return fail(MI_HIP_ERROR, "the resident solve lost an exchange after its first one (hung GPU?): the tableau in HBM "
+                                  "is as it was before that launch, but the request was not carried out");
     return status_to_rc(t->h_ctl->status);
 }
 
@@ -839,6 +902,32 @@ int mi355x_tab_solve(mi355x_tab *t, int is_max, double f, int64_t max_pivots, in
     rc = ensure_compact(t);
     if (rc != MI_OK) return rc;
     launch_ctl_reset(t->v, max_pivots, 0, t->stream);
+    if (resident_mode(t)) {
+        // the whole solve with the tableau on chip: one launch per 65536 pivots, one read-back each
+        for (;;) {
+            rc = enqueue_resident(t, is_max, f, 65536);
+            if (rc != MI_OK) return rc;
+            HIP_TRY(hipGetLastError());
+            rc = read_ctl(t);
+            if (rc != MI_OK) return rc;
+            const int32_t st = t->h_ctl->status;
+            if (st == kRunning) continue;
+            if (st == kSyncLost) {                    // its workgroups were not co-resident: nothing happened
+                rc = recover_lost_exchange(t);
+                if (rc != MI_OK) return rc;
+                break;                                // the established paths below
+            }
+            if (st == kResidentStuck)
+                return fail(MI_HIP_ERROR, "the resident solve lost an exchange after its first one (hung GPU?)");
+            if (st == kNeedDense) {
+                rc = fall_back_to_dense(t);           // redo that pivot, and the rest, densely (below)
+                if (rc != MI_OK) return rc;
+                break;
+            }
+            if (n_pivots) *n_pivots = t->h_ctl->n_pivots;
+            return (int)st;
+        }
+    }
     if (block_mode(t)) {
         // blocks of g_block_k pivots, blind enqueue in growing chunks of blocks; a block whose
         // look-ahead terminates the solve still sweeps (applies what was selected before)
@@ -1160,6 +1249,37 @@ int mi355x_batch_solve(mi355x_batch *b, int is_max, double f, int64_t max_pivots
     rc = ensure_compact(t);
     if (rc != MI_OK) return rc;
     launch_ctl_reset(t->v, max_pivots, 0, t->stream);
+    if (resident_mode(t)) {
+        // every LP on chip, a few workgroups each, all LPs in one launch (they progress and finish
+        // independently); whatever that launch could not finish continues on the paths below
+        for (;;) {
+            rc = enqueue_resident(t, is_max, f, 65536);
+            if (rc != MI_OK) return rc;
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(t->h_ctl, t->v.ctl, n * sizeof(Ctl), hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            bool running = false, other = false, lost = false;
+            for (int64_t i = 0; i < n; ++i) {
+                const int32_t st = t->h_ctl[i].status;
+                if (st == kResidentStuck) return fail(MI_HIP_ERROR, "the resident solve lost an exchange after its first one (hung GPU?)");
+                running |= st == kRunning;
+                lost |= st == kSyncLost;
+                other |= st == kNeedDense;
+            }
+            if (lost) {                               // some LP's workgroups were not co-resident
+                rc = recover_lost_exchange(t);
+                if (rc != MI_OK) return rc;
+                break;
+            }
+            if (other) break;                         // an LP met an inf / NaN: the established path takes it
+            if (running) continue;
+            for (int64_t i = 0; i < n; ++i) {
+                if (status) status[i] = t->h_ctl[i].status;
+                if (n_pivots) n_pivots[i] = t->h_ctl[i].n_pivots;
+            }
+            return MI_OK;
+        }
+    }
     // preferred: one launch, one workgroup per LP (k_batch_solve); lockstep launch pairs when
     // an LP is too large for the LDS budget (or when forced by the tuning hook)
     // measured (257x769 LPs, compact representation): one workgroup per LP 1.76 M pivots/s at
@@ -2578,7 +2698,10 @@ int         mi355x_debug_rhs(mi355x_tab *t, double *out, int64_t n, int clear)
     if (clear) (void)hipMemset(buf, 0, n * sizeof(double));
     return 0;
 }
-int         mi355x_tune_set_batch_block(int k) { set_batch_block(k); return k; }
+int         mi355x_tune_set_batch_block(int k) { set_batch_block(k); g_batch_block_k = k; return k; }
+int         mi355x_tune_set_resident(int mode) { g_resident_mode = (mode == 1 || mode == 2) ? mode : 0; return g_resident_mode; }
+int         mi355x_tune_set_resident_fault(int on) { set_resident_fault(on); return on; }
+int         mi355x_tab_resident(mi355x_tab *t) { return (t && resident_mode(t)) ? 1 : 0; }
 int         mi355x_tune_set_lookahead_mode(int mode) { g_la_mode = mode; return g_la_mode; }
 int         mi355x_tune_set_block(int k) { g_block_k = k < 1 ? 1 : (k > kMaxBlock ? kMaxBlock : k); return g_block_k; }
 int         mi355x_tune_set_sweep_shape(int tr, int nt) { set_sweep_shape(tr, nt); return tr; }

@@ -20,6 +20,10 @@ constexpr int32_t kNeedDense = 101;
 // persistent look-ahead kernel only: a workgroup gave up waiting for the others' records (cannot
 // happen while all its workgroups are resident; bounded so that a bug reports instead of hanging)
 constexpr int32_t kSyncLost = 102;
+// resident solve only: an exchange was lost AFTER the first one (the first is the co-residency
+// check and ends as kSyncLost): cannot happen short of a hung GPU; nothing was written back, but
+// the launch may have been partly observed -- reported as an error, never as a result
+constexpr int32_t kResidentStuck = 103;
 
 // Control block living in device memory: the whole price -> ratio -> pivot loop
 // runs without host round trips, kernels communicate through this struct.
@@ -193,6 +197,25 @@ void launch_ctl_resume(const TabView &t, hipStream_t s, int32_t from);
 // synthetic LP straight into HBM
 void launch_synth_fill(const TabView &t, int64_t n_vars, int64_t n_cons, uint64_t seed,
                        const uint64_t *dev_seeds, int64_t col_begin, int64_t col_end, hipStream_t s);
+
+// The resident solve (tableaux whose stored part fits the register files: DESIGN.md): the strip
+// layout of a compact view, the exchange buffer it needs (per handle; zero it once), and ONE launch
+// that runs up to `cap` pivots of n-solve-tableau per LP with the tableau on chip.  epoch_base must
+// grow by at least cap + 2 from launch to launch on the same buffer.
+struct ResidentPlan { int TR, CW, G; int64_t slot_granules, lp_granules; };
+struct ResidentArgs {
+    double sgn, price_tol, ratio_thr;
+    unsigned long long *xbuf;
+    int64_t xs_lp, xs_slot;
+    int G, cap;
+    unsigned epoch_base, spins_first, spins;
+    int fault;
+};
+bool   resident_plan(const TabView &compact, ResidentPlan *p);
+size_t resident_xbuf_bytes(const TabView &compact);
+bool   launch_resident(const TabView &compact, unsigned long long *xbuf, int is_max, double fp_factor,
+                       int cap, unsigned epoch_base, hipStream_t s);
+void   set_resident_fault(int on);      // test hook: the last workgroup of every LP never publishes
 
 int         update_variant_count();
 const char *update_variant_name(int v);

@@ -384,9 +384,8 @@ __device__ __forceinline__ void record_pivot(const TabView &t, const Ctl &c0, in
 
 // A batch of same-shape LPs is one TabView plus per-LP element strides; grid.z = LP index
 // (all strides are zero for a single tableau, where grid.z == 1).
-__device__ __forceinline__ TabView lp_slice(TabView t)
+__device__ __forceinline__ TabView lp_slice_at(TabView t, const int64_t z)
 {
-    const int64_t z = blockIdx.z;
     t.M      += z * t.zs_M;
     t.basis  += z * t.zs_basis;
     t.col    += z * t.zs_col;
@@ -403,6 +402,7 @@ __device__ __forceinline__ TabView lp_slice(TabView t)
     }
     return t;
 }
+__device__ __forceinline__ TabView lp_slice(TabView t) { return lp_slice_at(t, blockIdx.z); }
 
 // ------------------------------------------------------------------ select kernels
 template <int THREADS>
@@ -2872,6 +2872,467 @@ __global__ __launch_bounds__(kBbThreads) void k_batch_block(TabView t, double sg
     }
 }
 
+
+// ------------------------------------------------------------------ the resident solve
+// Tableaux that fit the chip's REGISTER FILES (BASELINE config 2: 513 x 1025 stored doubles = 4.2 MB
+// against 256 CUs x 512 KB of vector registers; every LP of config 4) never need to move through
+// HBM inside the solve loop at all.  The stored tableau [non-basic columns | RHS] is split into
+// column strips of CW columns; workgroup w of the LP keeps strip w -- ALL constraint rows of its
+// CW columns -- in registers (thread t owns rows t, t + 256, ...: TR x CW doubles), plus its own
+// copy of the RHS column, its part of the objective row and the basis.  One pivot of
+// n-solve-tableau (src/simplex.lisp:453-461) is then
+//     local pricing of the strip's objective entries -> this workgroup's best column
+//     ONE exchange: every workgroup publishes (key, logical column) AND that column itself
+//         (speculatively: 16 bytes per row); everybody reduces the G records to the same winner
+//         -- lexicographic (key, logical column) minimum = find-entering-column's lowest-index
+//         strict minimum -- and reads the winner's column, which is already there
+//     ratio test on (column, own RHS copy): identical in every workgroup, no exchange
+//     pivot row: the strip's own entries of row cr, normalised locally; rank-1 update of the
+//         strip, the RHS copy and the objective entries in registers
+// so a pivot costs one all-to-all exchange through L2 (about a microsecond) plus a few hundred
+// cycles of arithmetic, and no HBM traffic.  The operations on every element are n-pivot-row's
+// (rounded product, rounded difference, true division), so pivots and bits are those of every
+// other path.  The tableau is read from HBM when the launch starts and written back when it ends
+// (optimal / unbounded / cap / a pivot the compact representation cannot follow).
+//
+// Exchange: slot (workgroup, epoch parity) = 8 record granules (4 in use) + 2 granules per row, every granule
+// {tag = epoch, 32 bits of payload} written by one write-through store and polled with
+// L1-bypassing loads until the tag matches (as k_la_block's records).  Two parities suffice: a
+// workgroup can only publish epoch e + 2 after everybody has published e + 1, i.e. has finished
+// reading e.  All workgroups of an LP must be co-resident: block b of the launch serves LP
+// (b / 8 / G) * 8 + b % 8, so the G workgroups of an LP are dispatched together (and to one XCD);
+// a workgroup that waits in vain at the FIRST exchange gives up (kSyncLost, nothing has been
+// modified: the host continues on the established paths), a later one cannot happen short of a
+// hung GPU and is reported as an error (kResidentStuck) instead of a wrong tableau.
+constexpr int kResThreads = 256;
+
+typedef double v16d __attribute__((ext_vector_type(16)));
+
+template <int TR, int CW>
+__global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(TabView t, const ResidentArgs a)
+{
+    static_assert(CW % 16 == 0 && CW <= 64 && TR * CW <= 64, "strip of TR x CW doubles per thread, pricing in one wave");
+    constexpr int CH = CW / 16;                                  // 16-column register chunks (indexable by a uniform value)
+    constexpr int NW = kResThreads / 64;
+    __shared__ double    s_wv[2][NW];                            // ratio reduction: wave winners (double-buffered by pivot parity)
+    __shared__ int       s_wi[2][NW];
+    __shared__ unsigned  s_wf[2][NW];
+    __shared__ __attribute__((aligned(16))) double s_row[CW];    // raw pivot-row entries of the strip (owner wave only)
+    __shared__ __attribute__((aligned(16))) double s_prow[CW + 2];   // normalised; [CW] = rhs[cr] / piv
+    __shared__ long long s_win[8];                               // the exchange's winner, from wave 0 to the others
+    __shared__ long long s_leave;                                // logical column that leaves the basis
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, xq = b >> 3;
+    const int64_t lpi = (int64_t)(xq / a.G) * 8 + (b & 7);
+    const int wg = xq % a.G;
+    if (lpi >= t.n_lps) return;
+    t = lp_slice_at(t, lpi);
+    Ctl *ctl = t.ctl;
+    const Ctl c0 = *ctl;
+    if (c0.status != kRunning) return;
+    const int64_t m = t.rows - 1, nnb = t.cols - 1, ld = t.ld;
+    const int64_t col0 = (int64_t)wg * CW;
+    const int ncl = (int)((nnb - col0) < CW ? (nnb - col0) : CW);   // valid local columns (>= 1)
+    unsigned long long *xb = a.xbuf + lpi * a.xs_lp;
+    unsigned long long *lostflag = xb + (int64_t)a.G * 2 * a.xs_slot;   // one word behind the slots
+    const bool leader = wg == 0 && tid == 0;
+
+    // ---- load the strip: thread t owns rows t, t + 256, ... of all CW columns
+    v16d    x[TR][CH];
+    double  rhs[TR];
+    int64_t bas[TR];
+    bool    valid[TR];
+#pragma unroll
+    for (int k = 0; k < TR; ++k) {
+        const int64_t r = tid + (int64_t)kResThreads * k;
+        valid[k] = r < m;
+        const double *row = t.M + r * ld + col0;
+#pragma unroll
+        for (int c = 0; c < CW; c += 2) {
+            double2 v = make_double2(0.0, 0.0);
+            if (valid[k] && c < ncl) v = *reinterpret_cast<const double2 *>(row + c);
+            x[k][c >> 4][c & 15] = v.x;
+            x[k][c >> 4][(c & 15) + 1] = (c + 1 < ncl) ? v.y : 0.0;
+        }
+        rhs[k] = valid[k] ? t.M[r * ld + nnb] : 0.0;
+        bas[k] = valid[k] ? t.basis[r] : -1;
+    }
+    // objective entry / logical column of local column `lane`: replicated in every wave (all four
+    // price and update them identically, so no wave waits for another to know the local best column)
+    double  obj = 0.0;
+    int64_t lidx = -1;
+    if (lane < ncl) { obj = t.M[m * ld + col0 + lane]; lidx = t.p2l[col0 + lane]; }
+    double  objv = t.M[m * ld + nnb];
+    int64_t n_piv = c0.n_pivots, tn = c0.trace_n, last_ec = c0.ec, last_cr = c0.cr;
+    int32_t status = kRunning;
+    bool lost = false;
+    // all workgroups of the LP on one XCD (verified by the first exchange, whose records carry the
+    // XCC ids): later stores may stay in the shared L2, where the polls find them sooner
+    bool local = false;
+    int it = 0;
+#ifdef MI355X_RES_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RES_T(i) T##i = wall_clock64()
+#else
+#define RES_T(i)
+#endif
+
+    // The loop is software-pipelined around the exchange: as soon as pivot k's normalised row is known,
+    // the objective entries are brought up to date, priced, and the workgroup's best column for pivot
+    // k + 1 is computed AS THE UPDATE WILL LEAVE IT and published -- the rest of the strip is updated
+    // while those records travel.
+    int lcb = 0;                                                 // this workgroup's best local column (uniform)
+    Cand cc; cc.v = 0.0; cc.i = -1;                              // ... its (key, logical column)
+    bool pnan0 = false;
+    auto price_local = [&]() {
+        ValIdx pc; pc.v = 0.0; pc.i = -1; pc.s = 0;
+        if (lane < ncl) pc = price_cand(obj * a.sgn, lidx, lane);
+        cc.v = pc.v; cc.i = (int)pc.i;
+        int psrc;
+        cc = wave_argmin(cc, psrc);
+        const int64_t pcs = lane_pick(pc.s, psrc);
+        pnan0 = cc.i >= 0 && pcs == kNanColumn0;
+        lcb = __builtin_amdgcn_readfirstlane((cc.i < 0 || pnan0) ? 0 : (int)pcs);
+    };
+    // record + column of epoch `ep`: v[] = my rows' entries of local column lcb, vobj = its objective entry
+    auto publish = [&](unsigned ep, const double (&v)[TR], double vobj, bool mute) {
+        unsigned long long *slot = xb + ((int64_t)wg * 2 + (ep & 1u)) * a.xs_slot;
+        if (wave == 0 && !mute) {
+            const unsigned long long vb = dbits(cc.v);
+            const unsigned iw = (cc.i < 0 ? kEmptyIdx : (unsigned)cc.i) | (pnan0 ? 0x80000000u : 0u);
+            const unsigned word[4] = { (unsigned)vb, (unsigned)(vb >> 32), iw, (unsigned)lcb | (xcc_id() << 8) };
+            unsigned val = word[0];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) val = lane == k ? word[k] : val;
+            if (lane < 4) st_x(&slot[lane], ((unsigned long long)ep << 32) | val, local);
+        }
+        unsigned long long *cg = slot + 8;
+        const unsigned long long tg = (unsigned long long)ep << 32;
+#pragma unroll
+        for (int k = 0; k < TR; ++k)
+            if (valid[k]) {
+                const int r = tid + kResThreads * k;
+                const unsigned long long vb = dbits(v[k]);
+                st_x(&cg[2 * r], tg | (vb & 0xffffffffull), local);
+                st_x(&cg[2 * r + 1], tg | (vb >> 32), local);
+            }
+        if (tid == lcb) {
+            const unsigned long long vb = dbits(vobj);
+            st_x(&cg[2 * m], tg | (vb & 0xffffffffull), local);
+            st_x(&cg[2 * m + 1], tg | (vb >> 32), local);
+        }
+    };
+    // my rows' entries of local column c (uniform): a macro, not a lambda -- a closure that indexes x
+    // dynamically makes the compiler keep the whole strip in scratch memory
+#define RES_COLUMN_OF(c, v)                                                                     \
+    do {                                                                                        \
+        const int lh_ = (c) >> 4, lj_ = (c) & 15;                                               \
+        _Pragma("unroll") for (int k = 0; k < TR; ++k) {                                        \
+            (v)[k] = x[k][0][lj_];                                                              \
+            _Pragma("unroll") for (int h = 1; h < CH; ++h)                                      \
+                if (h == lh_) (v)[k] = x[k][h][lj_];              /* (uniform) */               \
+        }                                                                                       \
+    } while (0)
+    double vnext[TR];                                             // my rows' entries of column lcb, as published
+    price_local();
+    RES_COLUMN_OF(lcb, vnext);
+    if (a.G > 1) publish(a.epoch_base + 1u, vnext, obj, a.fault > 0 && wg == a.G - 1);
+
+#pragma unroll 1
+    for (; it < a.cap; ++it) {
+#ifdef MI355X_RES_TIMING
+        unsigned long long T0 = 0, T1 = 0, T2 = 0, T3 = 0, T4 = 0, T5 = 0, T6 = 0;
+#endif
+        RES_T(0);
+        const unsigned epoch = a.epoch_base + (unsigned)it + 1u;
+        const int par = it & 1;
+        ValIdx e;
+        int owner = wg, lc = lcb;
+        if (a.G > 1) {
+            // ---- everybody's records -> the same winner everywhere (wave 0 polls, LDS to the others)
+            if (wave == 0) {
+                const bool have = lane < a.G;
+                const unsigned long long *rp = xb + ((int64_t)(have ? lane : 0) * 2 + (epoch & 1u)) * a.xs_slot;
+                unsigned long long g[4];
+                unsigned spins = 0;
+                const unsigned limit = it == 0 ? a.spins_first : a.spins;
+                bool fine = true;
+                for (;;) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) g[k] = ld_l2(&rp[k]);
+                    bool ok = true;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ok &= (unsigned)(g[k] >> 32) == epoch;
+                    if (__all(ok | !have)) break;
+                    if (++spins > limit) { fine = false; break; }
+                }
+                Cand rc; rc.v = 0.0; rc.i = -1;
+                const unsigned iw = (unsigned)g[2];
+                if (have && fine && (iw & kEmptyIdx) != kEmptyIdx) { rc.v = join_bits(g[0], g[1]); rc.i = (int)(iw & kEmptyIdx); }
+                int src;
+                const Cand w = wave_argmin(rc, src);
+                const int own = src < 0 ? 0 : src;
+                const unsigned wiw = (unsigned)lane_pick((int)iw, own);
+                const int wlc = lane_pick((int)((unsigned)g[3] & 0xffu), own);
+                const unsigned x0 = (unsigned)lane_pick((int)((unsigned)g[3] >> 8), 0);
+                const bool same = __all(!have || ((unsigned)g[3] >> 8) == x0);
+                if (lane == 0) {
+                    s_win[0] = (long long)dbits(w.v); s_win[1] = w.i; s_win[2] = own; s_win[3] = wlc;
+                    s_win[4] = (w.i >= 0 && (wiw >> 31)) ? 1 : 0; s_win[5] = fine ? 0 : 1;
+                    s_win[6] = (fine && same) ? 1 : 0;
+                }
+            }
+            __syncthreads();                                      // barrier A
+            e.v = __longlong_as_double(s_win[0]);
+            e.i = s_win[1];
+            owner = __builtin_amdgcn_readfirstlane((int)s_win[2]);
+            lc = __builtin_amdgcn_readfirstlane((int)s_win[3]);
+            e.s = s_win[4] ? kNanColumn0 : lc;
+            if (s_win[5]) { lost = true; break; }
+            if (it == 0) local = s_win[6] != 0;                   // same records, same decision everywhere
+        } else {
+            e.v = cc.v; e.i = cc.i; e.s = pnan0 ? kNanColumn0 : lcb;
+        }
+        RES_T(1);
+        if (price_says_optimal(e, a.price_tol)) { status = 0; break; }                    // MI_OPTIMAL
+        if (c0.max_pivots > 0 && n_piv >= c0.max_pivots) { status = 3; break; }          // MI_MAX_PIVOTS
+        const int64_t ec = e.i;
+        // ---- the entering column: my rows' entries and the objective row's
+        double col[TR], colm;
+        unsigned flags = 0u;                                      // 1: inf / NaN (kNeedDense), 2: the column never arrived
+        if (a.G > 1) {
+            const unsigned long long *wsl = xb + ((int64_t)owner * 2 + (epoch & 1u)) * a.xs_slot + 8;
+            unsigned long long gl[TR], gh[TR], ml, mh;
+            unsigned spins = 0;
+            const unsigned limit = it == 0 ? a.spins_first : a.spins;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < TR; ++k) {
+                    const int64_t r = valid[k] ? tid + (int64_t)kResThreads * k : m;
+                    gl[k] = ld_l2(&wsl[2 * r]);
+                    gh[k] = ld_l2(&wsl[2 * r + 1]);
+                }
+                ml = ld_l2(&wsl[2 * m]);
+                mh = ld_l2(&wsl[2 * m + 1]);
+#pragma unroll
+                for (int k = 0; k < TR; ++k) ok &= (unsigned)(gl[k] >> 32) == epoch && (unsigned)(gh[k] >> 32) == epoch;
+                ok &= (unsigned)(ml >> 32) == epoch && (unsigned)(mh >> 32) == epoch;
+                if (ok) break;
+                if (++spins > limit) { flags |= 2u; break; }
+            }
+#pragma unroll
+            for (int k = 0; k < TR; ++k) col[k] = valid[k] ? join_bits(gl[k], gh[k]) : 0.0;
+            colm = join_bits(ml, mh);
+        } else {
+#pragma unroll
+            for (int k = 0; k < TR; ++k) col[k] = valid[k] ? vnext[k] : 0.0;
+            colm = lane_value_dyn(obj, lc);                       // (every wave holds the objective entries)
+        }
+        RES_T(2);
+        // ---- find-pivoting-row on (column, my RHS copy): the same in every workgroup
+        Cand rbest; rbest.v = 0.0; rbest.i = -1;
+        if (!(fabs(colm) <= 1.7976931348623157e308)) flags |= 1u;
+#pragma unroll
+        for (int k = 0; k < TR; ++k)
+            if (valid[k]) {
+                const double av = col[k];
+                if (!(fabs(av) <= 1.7976931348623157e308)) flags |= 1u;
+                if (a.ratio_thr < av) {
+                    const double qv = rhs[k] / av;
+                    if (qv != qv) flags |= 1u;                    // a NaN quotient: decided on the dense path (kNeedDense)
+                    else {
+                        Cand c; c.v = qv; c.i = tid + kResThreads * k;
+                        rbest = cand_min(rbest, c);
+                    }
+                }
+            }
+        {
+            int src;
+            const Cand w = wave_argmin(rbest, src);
+            const unsigned wf = (__any((flags & 1u) != 0u) ? 1u : 0u) | (__any((flags & 2u) != 0u) ? 2u : 0u);
+            if (lane == 0) { s_wv[par][wave] = w.v; s_wi[par][wave] = w.i; s_wf[par][wave] = wf; }
+        }
+        __syncthreads();                                          // barrier B
+        Cand q; q.v = s_wv[par][0]; q.i = s_wi[par][0];
+        unsigned allf = s_wf[par][0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+            Cand y; y.v = s_wv[par][w]; y.i = s_wi[par][w];
+            q = cand_min(q, y);
+            allf |= s_wf[par][w];
+        }
+        if (allf & 2u) { lost = true; break; }
+        if (allf & 1u) { status = kNeedDense; break; }
+        if (q.i < 0) { status = 1; break; }                      // MI_UNBOUNDED
+        const int cr = __builtin_amdgcn_readfirstlane(q.i);
+        const int otid = cr & (kResThreads - 1), okk = cr >> 8;
+        const bool mine = owner == wg;
+        RES_T(3);
+        // ---- the pivot row's entries of this strip, normalised -- inside the wave that owns row cr
+        if (wave == (otid >> 6)) {
+            double pivl = 0.0, rhsl = 0.0;
+            if (tid == otid) {
+#pragma unroll
+                for (int k = 0; k < TR; ++k)
+                    if (k == okk) {
+#pragma unroll
+                        for (int c = 0; c < CW; c += 2)
+                            *reinterpret_cast<double2 *>(&s_row[c]) = make_double2(x[k][c >> 4][c & 15], x[k][c >> 4][(c & 15) + 1]);
+                        pivl = col[k];
+                        rhsl = rhs[k];
+                        s_leave = bas[k];
+                        bas[k] = ec;                              // src/simplex.lisp:358
+                    }
+            }
+            const double piv = lane_value_dyn(pivl, otid & 63);   // == M[cr][ec] bit for bit
+            const double rhsc = lane_value_dyn(rhsl, otid & 63);
+            __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): the owner lane's LDS stores (same wave: in order)
+            __builtin_amdgcn_wave_barrier();
+            if (lane < CW) {
+                double rv = s_row[lane];
+                if (mine && lane == lc) rv = 1.0;                 // the slot takes over the leaving column e_cr
+                s_prow[lane] = (lane < ncl) ? rv / piv : 0.0;
+            }
+            if (lane == 0) s_prow[CW] = rhsc / piv;
+        }
+        __syncthreads();                                          // barrier C
+        const int64_t leaving = s_leave;
+        const double prhs = s_prow[CW];
+        RES_T(4);
+        // ---- objective entries through the pivot (every wave: its own copy), priced at once; the
+        // workgroup's best column for the NEXT pivot as the update below will leave it -> published
+        if (lane < CW) {
+            const double pr = s_prow[lane];
+            if (mine && lane == lc) { obj = 0.0; lidx = leaving; }
+            const double prod = colm * pr;
+            obj = obj - prod;
+        }
+        bool is_cr[TR];
+#pragma unroll
+        for (int k = 0; k < TR; ++k) is_cr[k] = valid[k] && tid + kResThreads * k == cr;
+        price_local();
+        {
+            RES_COLUMN_OF(lcb, vnext);
+            const double pl = s_prow[lcb];
+            const bool slot_col = mine && lcb == lc;
+#pragma unroll
+            for (int k = 0; k < TR; ++k) {
+                const double base = slot_col ? (is_cr[k] ? 1.0 : 0.0) : vnext[k];
+                const double prod = col[k] * pl;
+                const double d = base - prod;
+                vnext[k] = is_cr[k] ? pl : d;
+            }
+        }
+        if (a.G > 1 && it + 1 < a.cap) publish(epoch + 1u, vnext, obj, false);
+        RES_T(5);
+        // ---- rank-1 update of the strip, the RHS copy and the objective value (n-pivot-row), while
+        // the records travel
+        if (mine) {
+            const int lh = lc >> 4, lj = lc & 15;
+#pragma unroll
+            for (int k = 0; k < TR; ++k) {
+                const double unit = is_cr[k] ? 1.0 : 0.0;
+#pragma unroll
+                for (int h = 0; h < CH; ++h)
+                    if (h == lh) x[k][h][lj] = unit;              // (uniform)
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < CH; ++h) {
+#pragma unroll
+            for (int j0 = 0; j0 < 16; j0 += 8) {
+                double p8[8];
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const double2 pp = *reinterpret_cast<const double2 *>(&s_prow[h * 16 + j0 + j]);
+                    p8[j] = pp.x; p8[j + 1] = pp.y;
+                }
+#pragma unroll
+                for (int k = 0; k < TR; ++k) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const double prod = col[k] * p8[j];       // rounded product
+                        x[k][h][j0 + j] = x[k][h][j0 + j] - prod; // rounded difference
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < TR; ++k)
+            if (is_cr[k]) {                                       // ONE thread of the workgroup: the pivot row itself
+#pragma unroll
+                for (int c = 0; c < CW; c += 2) {
+                    const double2 pp = *reinterpret_cast<const double2 *>(&s_prow[c]);
+                    x[k][c >> 4][c & 15] = pp.x;
+                    x[k][c >> 4][(c & 15) + 1] = pp.y;
+                    if ((c & 7) == 6) __builtin_amdgcn_sched_barrier(0);   // (a few loads in flight, not CW / 2: registers)
+                }
+            }
+#pragma unroll
+        for (int k = 0; k < TR; ++k) {
+            const double prod = col[k] * prhs;
+            const double d = rhs[k] - prod;
+            rhs[k] = is_cr[k] ? prhs : d;
+        }
+        {
+            const double prod = colm * prhs;
+            objv = objv - prod;
+        }
+        // ---- bookkeeping
+        if (mine && tid == lc) {
+            t.l2p[ec] = -1;
+            t.l2p[leaving] = col0 + lc;
+        }
+        if (leader && t.trace_ec && tn < t.trace_cap) { t.trace_ec[tn] = ec; t.trace_cr[tn] = cr; }
+        last_ec = ec; last_cr = cr;
+        n_piv += 1; tn += 1;
+#ifdef MI355X_RES_TIMING
+        if (a.G > 1) {
+            RES_T(6);
+            tacc[0] += 1; tacc[1] += T1 - T0; tacc[2] += T2 - T1; tacc[3] += T3 - T2; tacc[4] += T4 - T3;
+            tacc[5] += T5 - T4; tacc[6] += T6 - T5;
+        }
+#endif
+    }
+#ifdef MI355X_RES_TIMING
+    if (leader && t.rhs) for (int k = 0; k < 8; ++k) t.rhs[k] += (double)tacc[k];
+#endif
+
+    if (lost) {
+        // nothing is written back: the tableau is what it was when the launch started
+        if (tid == 0) {
+            bool first = it == 0;
+            if (first) st_wt(lostflag, (unsigned long long)a.epoch_base);
+            else first = ld_l2(lostflag) == (unsigned long long)a.epoch_base;    // somebody never got past the first exchange
+            st_wt(&ctl->status, first ? kSyncLost : kResidentStuck);
+        }
+        return;
+    }
+    // ---- write back
+#pragma unroll
+    for (int k = 0; k < TR; ++k)
+        if (valid[k]) {
+            const int64_t r = tid + (int64_t)kResThreads * k;
+            double *row = t.M + r * ld + col0;
+#pragma unroll
+            for (int c = 0; c < CW; c += 2) {
+                const double a0 = x[k][c >> 4][c & 15], a1 = x[k][c >> 4][(c & 15) + 1];
+                if (c + 1 < ncl)  *reinterpret_cast<double2 *>(row + c) = make_double2(a0, a1);
+                else if (c < ncl) row[c] = a0;
+            }
+            if (wg == 0) { t.M[r * ld + nnb] = rhs[k]; t.basis[r] = bas[k]; }
+        }
+    if (tid < ncl) { t.M[m * ld + col0 + tid] = obj; t.p2l[col0 + tid] = lidx; }
+    if (leader) {
+        t.M[m * ld + nnb] = objv;
+        ctl->ec = last_ec; ctl->cr = last_cr;
+        ctl->n_pivots = n_piv;
+        ctl->trace_n = tn;
+        if (status != kRunning) ctl->status = status;
+    }
+}
+
 // ------------------------------------------------------------------ compact representation
 // Basic columns of a consistent tableau are unit vectors and stay bit-for-bit unchanged under
 // every pivot (x - s*(+0) == x, and a column that becomes basic is produced as x - x = +0 /
@@ -3539,6 +4000,61 @@ void launch_la_block(const TabView &t, int ksteps, int is_max, double f, unsigne
     hipLaunchKernelGGL(k_la_block<kMaxBlock>, dim3(one_xcd ? 8 * nw : nw), dim3(kLaThreads), 0, s, t, ksteps,
                        sgn_of(is_max), (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon, epoch_base,
                        g_la_max_spins, one_xcd, g_la_fault);
+}
+
+
+// ---- the resident solve
+static int g_res_fault = 0;
+void set_resident_fault(int on) { g_res_fault = on; }
+
+bool resident_plan(const TabView &c, ResidentPlan *p)
+{
+    if (!c.p2l || !c.l2p || c.rows < 2 || c.cols < 2) return false;
+    const int64_t m = c.rows - 1, nnb = c.cols - 1;
+    if (m > 1024) return false;
+    const int TR = m <= 256 ? 1 : (m <= 512 ? 2 : 4);
+    const int CW = 64 / TR;
+    const int64_t G = (nnb + CW - 1) / CW;
+    if (G > 32) return false;
+    if (p) {
+        p->TR = TR; p->CW = CW; p->G = (int)G;
+        p->slot_granules = 8 + 2 * ((m + 1 + 7) / 8 * 8);
+        p->lp_granules = G * 2 * p->slot_granules + 8;            // + the lost flag (padded)
+    }
+    return true;
+}
+
+size_t resident_xbuf_bytes(const TabView &c)
+{
+    ResidentPlan p;
+    if (!resident_plan(c, &p)) return 0;
+    return (size_t)c.n_lps * (size_t)p.lp_granules * sizeof(unsigned long long);
+}
+
+bool launch_resident(const TabView &c, unsigned long long *xbuf, int is_max, double f, int cap,
+                     unsigned epoch_base, hipStream_t s)
+{
+    ResidentPlan p;
+    if (!xbuf || cap < 1 || !resident_plan(c, &p)) return false;
+    ResidentArgs a;
+    a.sgn = sgn_of(is_max);
+    a.price_tol = (f / 8.0) * kClEpsilon;
+    a.ratio_thr = 0.0 + (f / 2.0) * kClEpsilon;
+    a.xbuf = xbuf;
+    a.xs_lp = p.lp_granules;
+    a.xs_slot = p.slot_granules;
+    a.G = p.G;
+    a.cap = cap;
+    a.epoch_base = epoch_base;
+    a.spins_first = g_la_max_spins;
+    a.spins = 1u << 27;
+    a.fault = g_res_fault;
+    const unsigned groups = (unsigned)((c.n_lps + 7) / 8);
+    const dim3 grid(groups * 8u * (unsigned)p.G);
+    if (p.TR == 1)      hipLaunchKernelGGL((k_resident<1, 64>), grid, dim3(kResThreads), 0, s, c, a);
+    else if (p.TR == 2) hipLaunchKernelGGL((k_resident<2, 32>), grid, dim3(kResThreads), 0, s, c, a);
+    else                hipLaunchKernelGGL((k_resident<4, 16>), grid, dim3(kResThreads), 0, s, c, a);
+    return true;
 }
 
 static int g_sweep_u = 4;                                       // rows per step of k_sweep16: 4, or 8 (measured

@@ -640,8 +640,34 @@ def test_two_phase_column_partition_drives_degenerate_artificials_out():
         if st == oracle.OPTIMAL:
             sol = lp.solve_problem(problem, devices=3)
             assert np.array_equal(sol.matrix.view(np.int64), M_or.view(np.int64)) and np.array_equal(sol.basis_columns, b_or)
-        hit += drove and followed and st == oracle.OPTIMAL
-    assert hit >= 5, "the seeds produced too few drive-out pivots the partition could follow (%d)" % hit
+        hit += drove and st == oracle.OPTIMAL
+    assert hit >= 10, "the seeds produced too few drive-out pivots (%d)" % hit
+    # Drive-out pivots on POSITIVE elements (equality rows with right-hand side 0 whose artificial
+    # columns cancel in the phase-1 objective: phase 1 is optimal at once with the artificials still
+    # basic; seeds searched on the oracle): the partition follows, bit for bit.
+    followed = 0
+    for seed in (282, 957, 959, 1396, 1481, 1610, 1832, 2136, 2288, 2340, 2737):
+        rng = np.random.default_rng(seed)
+        n = 5
+        names = ["x%d" % i for i in range(n)]
+        rows = [rng.integers(-2, 3, n).astype(float) for _ in range(3)]
+        cons = [("=", list(zip(names, a.tolist())), 0.0) for a in rows if a.any()]
+        cons.append(("<=", list(zip(names, [1.0] * n)), 5.0))
+        problem = lp.Problem(type="max", vars=names, objective_var="obj",
+                             objective_func=list(zip(names, rng.integers(1, 4, n).astype(float).tolist())),
+                             constraints=cons)
+        tabs = lp.build_tableau(problem, problem)
+        st, M_or, b_or, (A_or, ab_or, npv) = _oracle_solve(tabs)
+        A1, b1 = tabs[0].matrix.copy(), tabs[0].basis_columns.copy()
+        _, n_plain, _ = oracle.solve(A1, b1, is_max=False)
+        assert st == oracle.OPTIMAL and int(npv[0]) > n_plain            # drive-out pivots happened
+        for shards in (1, 2, 3):
+            rc, got_npv, A, ab, Mm, mb = _colpart_two_phase(tabs, shards)
+            assert rc == st and got_npv == (int(npv[0]), int(npv[1])), (seed, shards)
+            assert np.array_equal(A.view(np.int64), A_or.view(np.int64)) and np.array_equal(ab, ab_or), (seed, shards)
+            assert np.array_equal(Mm.view(np.int64), M_or.view(np.int64)) and np.array_equal(mb, b_or), (seed, shards)
+            followed += 1
+    assert followed == 33
 
 
 def test_degenerate_shapes():
