@@ -216,7 +216,8 @@ def other_configs(lp, L, device, block):
     lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h), n, m, seed, 0, -1, device), "cfg2")
     lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, 0, 1), "cfg2 prepare")   # representation change outside the timing
     L.mi355x_tab_sync(h, ctypes.byref(k))
-    L.mi355x_tab_timing_enable(h, 4)          # every fourth block: the event records are host work inside the timing
+    resident = bool(L.mi355x_tab_resident(h))
+    L.mi355x_tab_timing_enable(h, 1 if resident else 4)   # (blocked path: every fourth block -- the event records are host work inside the timing)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     rc = L.mi355x_tab_solve(h, 1, 1024.0, 0, ctypes.byref(k))
@@ -233,7 +234,10 @@ def other_configs(lp, L, device, block):
     out["cfg2_full_solve"] = {
         "workload": "BASELINE config 2: dense random LP 1024 vars x 512 <=-constraints (513x1537 f64), solved to optimality",
         "value": k.value / dt, "unit": "pivots/s", "pivots": int(k.value), "ms": dt * 1e3, "us_per_pivot": dt / max(k.value, 1) * 1e6,
-        "kernels": {"lookahead_per_block_of_%d" % block: _events(L, h, 1), "sweep_per_block": _events(L, h, 0)},
+        "path": "resident: the stored 513x1025 tableau in registers (32 workgroups x 256 threads x 64 doubles), one "
+                "exchange per pivot, no HBM traffic inside the loop" if resident else "blocked: look-ahead + sweep",
+        "kernels": ({"k_resident_whole_solve": _events(L, h, 0)} if resident else
+                    {"lookahead_per_block_of_%d" % block: _events(L, h, 1), "sweep_per_block": _events(L, h, 0)}),
         "parity": {"identical": bool(ident), "checked_against": "oracle, whole solve: status, pivot count, pivot "
                    "sequence, RHS column, objective row, basis (bit for bit)"}}
     L.mi355x_tab_destroy(h)
@@ -266,9 +270,11 @@ def other_configs(lp, L, device, block):
         "value": float(npv.sum()) / dt, "unit": "pivots/s (aggregate)", "pivots_total": int(npv.sum()), "ms": dt * 1e3,
         "pivots_per_lp_min_mean_max": [int(npv.min()), float(npv.mean()), int(npv.max())],
         "all_optimal": bool((st == 0).all()),
-        "kernels": {"sweep_over_all_lps": {"launches_timed": int(nlch.value),
-                                           "avg_us": sm.value / nlch.value * 1e3 if nlch.value else None,
-                                           "min_us": mn.value * 1e3 if nlch.value else None}},
+        "path": "resident: every LP in registers (8 workgroups per LP, 64 LPs in flight), one exchange per pivot"
+                if L.mi355x_tab_resident is not None and nlch.value <= 2 else "blocked: look-ahead per LP + sweeps over all LPs",
+        "kernels": {"update_or_resident_launches": {"launches_timed": int(nlch.value),
+                                                    "avg_us": sm.value / nlch.value * 1e3 if nlch.value else None,
+                                                    "min_us": mn.value * 1e3 if nlch.value else None}},
         "parity": {"identical": bool(same), "checked_against": "oracle, LPs 0..%d of the batch: status, pivot count, "
                    "every entry of the final tableau, basis (bit for bit)" % (checked - 1)}}
     del batch

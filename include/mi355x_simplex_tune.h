@@ -56,6 +56,9 @@ int         mi355x_tune_set_resident(int mode);              /* resident solve (
                                                                 0 auto = whenever the shape fits AND
                                                                 every knob above is at its default,
                                                                 1 never, 2 whenever the shape fits  */
+int         mi355x_tune_set_resident_poll(int mode);         /* who polls the exchange records:
+                                                                0 by size (every wave when an LP has
+                                                                <= 8 workgroups), 1 wave 0, 2 every */
 int         mi355x_tune_set_resident_fault(int on);          /* TEST: the last workgroup of every LP
                                                                 never publishes (co-residency lost) */
 /* 1 when the solve entry points would run this handle (in its current representation) resident */

@@ -111,6 +111,7 @@ _EXTRA = {
     "mi355x_tune_set_tail_policy": (_int, [_int]),
     "mi355x_tune_set_resident": (_int, [_int]),
     "mi355x_tune_set_resident_fault": (_int, [_int]),
+    "mi355x_tune_set_resident_poll": (_int, [_int]),
     "mi355x_tab_resident": (_int, [_p]),
     "mi355x_tune_set_colpart_exchange": (_int, [_int]),
     "mi355x_colpart_exchange_timing_enable": (_int, [_p, _int, _int]),

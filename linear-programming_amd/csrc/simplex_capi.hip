@@ -603,8 +603,25 @@ int enqueue_resident(mi355x_tab *t, int is_max, double f, int cap)
         HIP_TRY(hipMemsetAsync(t->res_x, 0, resident_xbuf_bytes(t->c), t->stream));
         t->res_epoch = 1;
     }
+    // (mi355x_tab_timing_*: a resident launch is bracketed like an update launch)
+    const bool timed = t->timing_stride > 0 && t->n_timed < kTimingCap &&
+                       (t->update_launches++ % t->timing_stride) == 0;
+    if (timed) {
+        if ((int)t->ev0.size() <= t->n_timed) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            t->ev0.push_back(a);
+            t->ev1.push_back(b);
+        }
+        HIP_TRY(hipEventRecord(t->ev0[t->n_timed], t->stream));
+    }
     if (!launch_resident(t->c, t->res_x, is_max, f, cap, t->res_epoch, t->stream))
         return fail(MI_BAD_ARG, "resident launch refused");
+    if (timed) {
+        HIP_TRY(hipEventRecord(t->ev1[t->n_timed], t->stream));
+        t->n_timed++;
+    }
     t->res_epoch += (unsigned)cap + 2u;
     t->last_was_resident = true;
     t->n_part = 0;                                    // no pricing partials are left behind
@@ -2701,6 +2718,7 @@ int         mi355x_debug_rhs(mi355x_tab *t, double *out, int64_t n, int clear)
 int         mi355x_tune_set_batch_block(int k) { set_batch_block(k); g_batch_block_k = k; return k; }
 int         mi355x_tune_set_resident(int mode) { g_resident_mode = (mode == 1 || mode == 2) ? mode : 0; return g_resident_mode; }
 int         mi355x_tune_set_resident_fault(int on) { set_resident_fault(on); return on; }
+int         mi355x_tune_set_resident_poll(int mode) { set_resident_poll(mode); return mode; }
 int         mi355x_tab_resident(mi355x_tab *t) { return (t && resident_mode(t)) ? 1 : 0; }
 int         mi355x_tune_set_lookahead_mode(int mode) { g_la_mode = mode; return g_la_mode; }
 int         mi355x_tune_set_block(int k) { g_block_k = k < 1 ? 1 : (k > kMaxBlock ? kMaxBlock : k); return g_block_k; }

@@ -2908,7 +2908,7 @@ constexpr int kResThreads = 256;
 
 typedef double v16d __attribute__((ext_vector_type(16)));
 
-template <int TR, int CW>
+template <int TR, int CW, bool EVERY>
 __global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(TabView t, const ResidentArgs a)
 {
     static_assert(CW % 16 == 0 && CW <= 64 && TR * CW <= 64, "strip of TR x CW doubles per thread, pricing in one wave");
@@ -2960,8 +2960,8 @@ __global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(Tab
     // objective entry / logical column of local column `lane`: replicated in every wave (all four
     // price and update them identically, so no wave waits for another to know the local best column)
     double  obj = 0.0;
-    int64_t lidx = -1;
-    if (lane < ncl) { obj = t.M[m * ld + col0 + lane]; lidx = t.p2l[col0 + lane]; }
+    int     lidx = -1;
+    if (lane < ncl) { obj = t.M[m * ld + col0 + lane]; lidx = (int)t.p2l[col0 + lane]; }
     double  objv = t.M[m * ld + nnb];
     int64_t n_piv = c0.n_pivots, tn = c0.trace_n, last_ec = c0.ec, last_cr = c0.cr;
     int32_t status = kRunning;
@@ -2985,14 +2985,21 @@ __global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(Tab
     Cand cc; cc.v = 0.0; cc.i = -1;                              // ... its (key, logical column)
     bool pnan0 = false;
     auto price_local = [&]() {
-        ValIdx pc; pc.v = 0.0; pc.i = -1; pc.s = 0;
-        if (lane < ncl) pc = price_cand(obj * a.sgn, lidx, lane);
-        cc.v = pc.v; cc.i = (int)pc.i;
+        // price_cand's rules with lane == local column: a NaN entry is no candidate, except in
+        // logical column 0, where it is the unbeatable one (find-entering-column never replaces it)
+        cc.v = obj * a.sgn;
+        cc.i = lidx;                                              // (-1 in lanes without a column)
+        int n0 = 0;
+        if (__any(cc.i >= 0 && cc.v != cc.v)) {                   // (rare)
+            if (cc.v != cc.v) {
+                if (cc.i == 0) { cc.v = -__builtin_inf(); n0 = 1; }
+                else cc.i = -1;
+            }
+        }
         int psrc;
-        cc = wave_argmin(cc, psrc);
-        const int64_t pcs = lane_pick(pc.s, psrc);
-        pnan0 = cc.i >= 0 && pcs == kNanColumn0;
-        lcb = __builtin_amdgcn_readfirstlane((cc.i < 0 || pnan0) ? 0 : (int)pcs);
+        cc = wave_argmin(cc, psrc);                               // psrc: the lane that holds the winner = its local column
+        pnan0 = cc.i >= 0 && lane_pick(n0, psrc) != 0;
+        lcb = __builtin_amdgcn_readfirstlane((cc.i < 0 || pnan0) ? 0 : psrc);
     };
     // record + column of epoch `ep`: v[] = my rows' entries of local column lcb, vobj = its objective entry
     auto publish = [&](unsigned ep, const double (&v)[TR], double vobj, bool mute) {
@@ -3049,8 +3056,14 @@ __global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(Tab
         ValIdx e;
         int owner = wg, lc = lcb;
         if (a.G > 1) {
-            // ---- everybody's records -> the same winner everywhere (wave 0 polls, LDS to the others)
-            if (wave == 0) {
+            // ---- everybody's records -> the same winner everywhere.  Few workgroups per LP: EVERY
+            // wave polls the (small) records itself -- no LDS hop, no workgroup barrier between the
+            // exchange and the column read (batch of 512 x 256 LPs, 8 workgroups each: 9.2 -> 9.7 M
+            // pivots/s); many: wave 0 polls and hands the winner over through LDS (config 2, 32
+            // workgroups: 240 k pivots/s against 232 k with four times the poll traffic)
+            constexpr bool every_wave = EVERY;                    // (the launcher: G <= 8)
+            long long win[7];
+            if (every_wave || wave == 0) {
                 const bool have = lane < a.G;
                 const unsigned long long *rp = xb + ((int64_t)(have ? lane : 0) * 2 + (epoch & 1u)) * a.xs_slot;
                 unsigned long long g[4];
@@ -3076,20 +3089,26 @@ __global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(Tab
                 const int wlc = lane_pick((int)((unsigned)g[3] & 0xffu), own);
                 const unsigned x0 = (unsigned)lane_pick((int)((unsigned)g[3] >> 8), 0);
                 const bool same = __all(!have || ((unsigned)g[3] >> 8) == x0);
-                if (lane == 0) {
-                    s_win[0] = (long long)dbits(w.v); s_win[1] = w.i; s_win[2] = own; s_win[3] = wlc;
-                    s_win[4] = (w.i >= 0 && (wiw >> 31)) ? 1 : 0; s_win[5] = fine ? 0 : 1;
-                    s_win[6] = (fine && same) ? 1 : 0;
+                win[0] = (long long)dbits(w.v); win[1] = w.i; win[2] = own; win[3] = wlc;
+                win[4] = (w.i >= 0 && (wiw >> 31)) ? 1 : 0; win[5] = fine ? 0 : 1;
+                win[6] = (fine && same) ? 1 : 0;
+                if (!every_wave && lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) s_win[k] = win[k];
                 }
             }
-            __syncthreads();                                      // barrier A
-            e.v = __longlong_as_double(s_win[0]);
-            e.i = s_win[1];
-            owner = __builtin_amdgcn_readfirstlane((int)s_win[2]);
-            lc = __builtin_amdgcn_readfirstlane((int)s_win[3]);
-            e.s = s_win[4] ? kNanColumn0 : lc;
-            if (s_win[5]) { lost = true; break; }
-            if (it == 0) local = s_win[6] != 0;                   // same records, same decision everywhere
+            if (!every_wave) {
+                __syncthreads();                                  // barrier A
+#pragma unroll
+                for (int k = 0; k < 7; ++k) win[k] = s_win[k];
+            }
+            e.v = __longlong_as_double(win[0]);
+            e.i = win[1];
+            owner = __builtin_amdgcn_readfirstlane((int)win[2]);
+            lc = __builtin_amdgcn_readfirstlane((int)win[3]);
+            e.s = win[4] ? kNanColumn0 : lc;
+            if (win[5]) { lost = true; break; }
+            if (it == 0) local = win[6] != 0;                     // same records, same decision everywhere
         } else {
             e.v = cc.v; e.i = cc.i; e.s = pnan0 ? kNanColumn0 : lcb;
         }
@@ -3150,7 +3169,8 @@ __global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(Tab
         {
             int src;
             const Cand w = wave_argmin(rbest, src);
-            const unsigned wf = (__any((flags & 1u) != 0u) ? 1u : 0u) | (__any((flags & 2u) != 0u) ? 2u : 0u);
+            unsigned wf = 0u;
+            if (__any(flags != 0u)) wf = (__any((flags & 1u) != 0u) ? 1u : 0u) | (__any((flags & 2u) != 0u) ? 2u : 0u);   // (rare)
             if (lane == 0) { s_wv[par][wave] = w.v; s_wi[par][wave] = w.i; s_wf[par][wave] = wf; }
         }
         __syncthreads();                                          // barrier B
@@ -3204,7 +3224,7 @@ __global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(Tab
         // workgroup's best column for the NEXT pivot as the update below will leave it -> published
         if (lane < CW) {
             const double pr = s_prow[lane];
-            if (mine && lane == lc) { obj = 0.0; lidx = leaving; }
+            if (mine && lane == lc) { obj = 0.0; lidx = (int)leaving; }
             const double prod = colm * pr;
             obj = obj - prod;
         }
@@ -3323,7 +3343,7 @@ __global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(Tab
             }
             if (wg == 0) { t.M[r * ld + nnb] = rhs[k]; t.basis[r] = bas[k]; }
         }
-    if (tid < ncl) { t.M[m * ld + col0 + tid] = obj; t.p2l[col0 + tid] = lidx; }
+    if (tid < ncl) { t.M[m * ld + col0 + tid] = obj; t.p2l[col0 + tid] = (int64_t)lidx; }
     if (leader) {
         t.M[m * ld + nnb] = objv;
         ctl->ec = last_ec; ctl->cr = last_cr;
@@ -4004,8 +4024,9 @@ void launch_la_block(const TabView &t, int ksteps, int is_max, double f, unsigne
 
 
 // ---- the resident solve
-static int g_res_fault = 0;
+static int g_res_fault = 0, g_res_poll = 0;
 void set_resident_fault(int on) { g_res_fault = on; }
+void set_resident_poll(int mode) { g_res_poll = mode; }     // tuning: 0 by size, 1 wave 0 polls, 2 every wave polls
 
 bool resident_plan(const TabView &c, ResidentPlan *p)
 {
@@ -4051,9 +4072,16 @@ bool launch_resident(const TabView &c, unsigned long long *xbuf, int is_max, dou
     a.fault = g_res_fault;
     const unsigned groups = (unsigned)((c.n_lps + 7) / 8);
     const dim3 grid(groups * 8u * (unsigned)p.G);
-    if (p.TR == 1)      hipLaunchKernelGGL((k_resident<1, 64>), grid, dim3(kResThreads), 0, s, c, a);
-    else if (p.TR == 2) hipLaunchKernelGGL((k_resident<2, 32>), grid, dim3(kResThreads), 0, s, c, a);
-    else                hipLaunchKernelGGL((k_resident<4, 16>), grid, dim3(kResThreads), 0, s, c, a);
+    const bool every = g_res_poll == 0 ? p.G <= 8 : g_res_poll == 2;
+#define MI_RES(TR_, CW_)                                                                                       \
+    do {                                                                                                       \
+        if (every) hipLaunchKernelGGL((k_resident<TR_, CW_, true>),  grid, dim3(kResThreads), 0, s, c, a);    \
+        else       hipLaunchKernelGGL((k_resident<TR_, CW_, false>), grid, dim3(kResThreads), 0, s, c, a);    \
+    } while (0)
+    if (p.TR == 1)      MI_RES(1, 64);
+    else if (p.TR == 2) MI_RES(2, 32);
+    else                MI_RES(4, 16);
+#undef MI_RES
     return true;
 }
 
