@@ -44,7 +44,12 @@ int         mi355x_tune_set_colpart_exchange(int mode);      /* column partition
                                                                 all-reduce of owner's bits + zeros
                                                                 (no host sync), 1 ncclBroadcast from
                                                                 the owner (root read back from the
-                                                                all-gather: one host sync per pivot) */
+                                                                all-gather: one host sync per pivot),
+                                                                2 no collective at all: the shards
+                                                                write pricing pairs and the entering
+                                                                column straight into each other's
+                                                                fine-grained buffers (P2P / IPC over
+                                                                xGMI), self-validating granules    */
 int         mi355x_tune_set_tail_policy(int p);              /* n pivots, n not a multiple of the block:
                                                                 0 spread evenly, 1 full blocks + remainder */
 int         mi355x_tune_set_handover_mode(int mode);         /* 0 auto, 1 sequential re-elimination */

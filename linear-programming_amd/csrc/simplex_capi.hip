@@ -1860,6 +1860,105 @@ __global__ __launch_bounds__(256) void k_local_sum(const long long *all, long lo
     }
 }
 
+// ---- exchange mode 2: the shards write straight into each other's memory (P2P over xGMI) -----------
+// No collective and no host in the loop: every shard owns ONE fine-grained exchange buffer that its
+// peers can write (peer access within a process, IPC handles between processes), laid out as
+//     pairs  [2 parities][world][4 granules]     the local pricing winners (exchange A)
+//     column [2 parities][2 x rows granules]     the entering column (exchange B)
+// with every granule {tag = epoch of the pivot, 32 bits of payload} written by one 8-byte
+// system-scope store and polled with system-scope loads until the tag matches -- self-validating,
+// so nothing depends on the order in which stores from another GPU become visible, and there is no
+// flag, fence or counter.  Producers never wait for anybody (a shard's pricing precedes its own
+// waits in its stream), so the scheme cannot deadlock; a shard can run at most one pivot ahead of
+// the slowest one (it needs that one's pair to go on), hence two parities.
+constexpr int32_t kExchangeLost = 104;      // device status: a peer's data never arrived (-> MI_RCCL_ERROR)
+struct P2pLayout {
+    int world; int64_t rows_p;
+    __host__ __device__ int64_t pair_off(unsigned par, int r) const { return ((int64_t)par * world + r) * 4; }
+    __host__ __device__ int64_t col_off(unsigned par) const { return (int64_t)2 * world * 4 + (int64_t)par * 2 * rows_p; }
+    __host__ __device__ int64_t granules() const { return (int64_t)2 * world * 4 + (int64_t)4 * rows_p; }
+};
+__device__ __forceinline__ void st_sys(unsigned long long *p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// exchange A, producer: my (key, global column) pair into slot `rank` of EVERY shard's buffer
+__global__ __launch_bounds__(64) void k_p2p_push_pair(const double *send2, unsigned long long *const *peers,
+                                                      P2pLayout lay, int rank, unsigned epoch)
+{
+    const int r = threadIdx.x;
+    if (r >= lay.world) return;
+    const unsigned long long kb = (unsigned long long)__double_as_longlong(send2[0]);
+    const unsigned long long cb = (unsigned long long)__double_as_longlong(send2[1]);
+    unsigned long long *dst = peers[r] + lay.pair_off(epoch & 1u, rank);
+    const unsigned long long tg = (unsigned long long)epoch << 32;
+    st_sys(dst + 0, tg | (kb & 0xffffffffull));
+    st_sys(dst + 1, tg | (kb >> 32));
+    st_sys(dst + 2, tg | (cb & 0xffffffffull));
+    st_sys(dst + 3, tg | (cb >> 32));
+}
+// exchange A, consumer: wait for every shard's pair of this pivot -> the plain `gathered` array
+__global__ __launch_bounds__(64) void k_p2p_wait_pairs(Ctl *ctl, const unsigned long long *mine, P2pLayout lay,
+                                                       unsigned epoch, double *gathered, unsigned max_spins)
+{
+    const int r = threadIdx.x;
+    if (ctl->status != kRunning || r >= lay.world) return;      // (iterations enqueued past termination: no-ops)
+    const unsigned long long *src = mine + lay.pair_off(epoch & 1u, r);
+    unsigned long long g[4];
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { g[k] = ld_sys(src + k); ok &= (unsigned)(g[k] >> 32) == epoch; }
+        if (ok) break;
+        if (spins > max_spins) { ctl->status = kExchangeLost; return; }
+    }
+    gathered[2 * r]     = __longlong_as_double((long long)(((g[1] & 0xffffffffull) << 32) | (g[0] & 0xffffffffull)));
+    gathered[2 * r + 1] = __longlong_as_double((long long)(((g[3] & 0xffffffffull) << 32) | (g[2] & 0xffffffffull)));
+}
+// exchange B, producer: the shard that owns the entering column (the contribution kernel left its
+// bit patterns in `bits`; everybody else holds zeros there and stays silent) writes it to every shard
+__global__ __launch_bounds__(256) void k_p2p_push_column(TabView t, const long long *bits, const int64_t *ec_dev,
+                                                         int64_t col_offset, unsigned long long *const *peers,
+                                                         P2pLayout lay, unsigned epoch)
+{
+    const int64_t ec = *ec_dev;
+    if (ec < 0) return;
+    const int64_t lc = t.l2p ? t.l2p[ec] : ec - col_offset;
+    if (!(lc >= 0 && lc < t.cols - 1)) return;                  // not mine
+    const unsigned long long tg = (unsigned long long)epoch << 32;
+    const int64_t off = lay.col_off(epoch & 1u);
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < t.rows; r += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long vb = (unsigned long long)bits[r];
+        for (int q = 0; q < lay.world; ++q) {
+            unsigned long long *dst = peers[q] + off + 2 * r;
+            st_sys(dst, tg | (vb & 0xffffffffull));
+            st_sys(dst + 1, tg | (vb >> 32));
+        }
+    }
+}
+// exchange B, consumer: wait for the column of this pivot -> the plain `bits_in` array
+__global__ __launch_bounds__(256) void k_p2p_wait_column(Ctl *ctl, const int64_t *ec_dev, const unsigned long long *mine,
+                                                         P2pLayout lay, unsigned epoch, int64_t rows, long long *bits_in,
+                                                         unsigned max_spins)
+{
+    if (ctl->status != kRunning || *ec_dev < 0) return;         // nothing enters (every shard decides the same)
+    const unsigned long long *src = mine + lay.col_off(epoch & 1u);
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        unsigned long long lo, hi;
+        for (unsigned spins = 0;; ++spins) {
+            lo = ld_sys(src + 2 * r);
+            hi = ld_sys(src + 2 * r + 1);
+            if ((unsigned)(lo >> 32) == epoch && (unsigned)(hi >> 32) == epoch) break;
+            if (spins > max_spins) { ctl->status = kExchangeLost; return; }
+        }
+        bits_in[r] = (long long)(((hi & 0xffffffffull) << 32) | (lo & 0xffffffffull));
+    }
+}
+
 struct CpShard {
     mi355x_tab *t = nullptr;
     int         device = 0, index = 0;        // physical device, global shard index
@@ -1869,6 +1968,11 @@ struct CpShard {
     int64_t    *ec = nullptr;
     ncclComm_t  comm = nullptr;
     double     *h_gathered = nullptr;         // pinned: the all-gathered winners (exchange B as a rooted broadcast)
+    // exchange mode 2 (P2P): my fine-grained exchange buffer, the device array of every shard's
+    // buffer address as THIS process maps it, and what had to be opened through IPC
+    unsigned long long  *xch = nullptr;
+    unsigned long long **d_peers = nullptr;
+    std::vector<void *>  ipc_opened;
     bool        aborted = false;              // its communicator was aborted after a failure: no stream syncs
     // exchange timing (mi355x_colpart_exchange_timing): event quads around the two collectives of
     // sampled pivots -- [before all-gather, after, before all-reduce, after]
@@ -1886,6 +1990,9 @@ struct mi355x_colpart {
     int     is_max = 1;
     int     timing_stride = 0;               // 0 = no exchange timing, k = every k-th pivot
     int     exchange = 0;                    // g_cp_exchange when the handle was created
+    unsigned xepoch = 0;                     // P2P exchange: pivots exchanged so far (the granules' tags)
+    unsigned p2p_spins = 1u << 24;           // polls before a shard gives a peer up (kExchangeLost)
+    P2pLayout lay{};
     std::vector<CpShard> sh;                 // the shards of THIS process
     // logical shards: one allocation each, shared by all of them
     double    *l_gathered = nullptr;
@@ -1906,6 +2013,9 @@ void cp_free(mi355x_colpart *p)
         if (s.comm && rccl().ok) (void)rccl().CommDestroy(s.comm);
         for (hipEvent_t e : s.ev) (void)hipEventDestroy(e);
         if (s.h_gathered) (void)hipHostFree(s.h_gathered);
+        for (void *q : s.ipc_opened) (void)hipIpcCloseMemHandle(q);
+        if (s.xch) { (void)hipSetDevice(s.device); (void)hipFree(s.xch); }
+        if (s.d_peers) { (void)hipSetDevice(s.device); (void)hipFree(s.d_peers); }
         if (s.aborted && s.t) s.t->own_stream = nullptr;   // free_tab must not synchronise / destroy it either
     }
     for (CpShard &s : p->sh) {
@@ -1929,6 +2039,100 @@ void cp_partition(int64_t count, int n, int r, int64_t *b, int64_t *e)
     *e = *b + base + (r < extra ? 1 : 0);
 }
 
+// Exchange mode 2: one fine-grained buffer per shard, every shard's address of every buffer.
+// One process: the shards' devices get peer access to each other.  One process per GPU: the IPC
+// handle of this rank's buffer is all-gathered over the (already initialised) communicator and the
+// other ranks' buffers are opened -- set-up only, the pivots themselves use no collective.
+int cp_setup_p2p(mi355x_colpart *p)
+{
+    p->lay.world = p->world;
+    p->lay.rows_p = (p->rows + 7) / 8 * 8;
+    const size_t bytes = (size_t)p->lay.granules() * sizeof(unsigned long long);
+    for (CpShard &s : p->sh) {
+        HIP_TRY(hipSetDevice(s.device));
+        HIP_TRY(hipExtMallocWithFlags((void **)&s.xch, bytes, hipDeviceMallocFinegrained));
+        HIP_TRY(hipMemset(s.xch, 0, bytes));
+        HIP_TRY(hipMalloc((void **)&s.d_peers, p->world * sizeof(unsigned long long *)));
+    }
+    std::vector<unsigned long long *> ptrs((size_t)p->world, nullptr);
+    if (!p->multi_process) {
+        for (CpShard &s : p->sh) ptrs[(size_t)s.index] = s.xch;
+        if (p->rccl)                                          // distinct devices: let them write to each other
+            for (CpShard &a : p->sh) {
+                HIP_TRY(hipSetDevice(a.device));
+                for (CpShard &b : p->sh) {
+                    if (a.device == b.device) continue;
+                    const hipError_t e = hipDeviceEnablePeerAccess(b.device, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                        return fail(MI_HIP_ERROR, "no peer access from device %d to device %d: %s", a.device, b.device,
+                                    hipGetErrorString(e));
+                    (void)hipGetLastError();
+                }
+            }
+        for (CpShard &s : p->sh) {
+            HIP_TRY(hipSetDevice(s.device));
+            HIP_TRY(hipMemcpy(s.d_peers, ptrs.data(), p->world * sizeof(unsigned long long *), hipMemcpyHostToDevice));
+        }
+        return MI_OK;
+    }
+    CpShard &s = p->sh[0];
+    HIP_TRY(hipSetDevice(s.device));
+    ptrs[(size_t)s.index] = s.xch;
+    if (p->world > 1) {
+        RCCL_NEED();
+        static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+        hipIpcMemHandle_t mine;
+        HIP_TRY(hipIpcGetMemHandle(&mine, s.xch));
+        char *d_one = nullptr, *d_all = nullptr;
+        HIP_TRY(hipMalloc((void **)&d_one, 64));
+        HIP_TRY(hipMalloc((void **)&d_all, (size_t)64 * p->world));
+        HIP_TRY(hipMemcpy(d_one, &mine, 64, hipMemcpyHostToDevice));
+        RCCL_TRY(rccl().AllGather(d_one, d_all, 64, ncclChar, s.comm, s.t->stream));
+        HIP_TRY(hipStreamSynchronize(s.t->stream));
+        std::vector<hipIpcMemHandle_t> all((size_t)p->world);
+        HIP_TRY(hipMemcpy(all.data(), d_all, (size_t)64 * p->world, hipMemcpyDeviceToHost));
+        (void)hipFree(d_one); (void)hipFree(d_all);
+        for (int r = 0; r < p->world; ++r) {
+            if (r == s.index) continue;
+            void *q = nullptr;
+            HIP_TRY(hipIpcOpenMemHandle(&q, all[(size_t)r], hipIpcMemLazyEnablePeerAccess));
+            s.ipc_opened.push_back(q);
+            ptrs[(size_t)r] = (unsigned long long *)q;
+        }
+    }
+    HIP_TRY(hipMemcpy(s.d_peers, ptrs.data(), p->world * sizeof(unsigned long long *), hipMemcpyHostToDevice));
+    return MI_OK;
+}
+
+// the two exchanges of one pivot in mode 2, on shard s's stream (epoch = the pivot's tag)
+int cp_p2p_push_pair(mi355x_colpart *p, CpShard &s, unsigned epoch)
+{
+    hipLaunchKernelGGL(k_p2p_push_pair, dim3(1), dim3(64), 0, s.t->stream, s.send, s.d_peers, p->lay, s.index, epoch);
+    hipLaunchKernelGGL(k_p2p_wait_pairs, dim3(1), dim3(64), 0, s.t->stream, s.t->v.ctl, s.xch, p->lay, epoch, s.gathered,
+                       p->p2p_spins);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+int cp_p2p_push_wait_pairs_split(mi355x_colpart *p, CpShard &s, unsigned epoch, bool push)
+{
+    if (push) hipLaunchKernelGGL(k_p2p_push_pair, dim3(1), dim3(64), 0, s.t->stream, s.send, s.d_peers, p->lay, s.index, epoch);
+    else      hipLaunchKernelGGL(k_p2p_wait_pairs, dim3(1), dim3(64), 0, s.t->stream, s.t->v.ctl, s.xch, p->lay, epoch,
+                                 s.gathered, p->p2p_spins);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+int cp_p2p_column(mi355x_colpart *p, CpShard &s, unsigned epoch, bool push, bool wait)
+{
+    int blocks = (int)((p->rows + 255) / 256);
+    if (blocks > 256) blocks = 256;
+    if (push) hipLaunchKernelGGL(k_p2p_push_column, dim3(blocks), dim3(256), 0, s.t->stream, s.t->v, s.bits, s.ec,
+                                 s.col_begin, s.d_peers, p->lay, epoch);
+    if (wait) hipLaunchKernelGGL(k_p2p_wait_column, dim3(blocks), dim3(256), 0, s.t->stream, s.t->v.ctl, s.ec, s.xch,
+                                 p->lay, epoch, p->rows, s.bits_in, p->p2p_spins);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
 // exchange buffers (+ communicators, unless they are handed over from another handle) once the
 // shards' handles exist
 int cp_finish_setup(mi355x_colpart *p, const void *id128, int rank, bool make_comms = true)
@@ -1949,7 +2153,7 @@ int cp_finish_setup(mi355x_colpart *p, const void *id128, int rank, bool make_co
         }
         // the logical shards run one after the other on ONE stream (that of the first)
         for (CpShard &s : p->sh) s.t->stream = p->sh[0].t->own_stream;
-        return MI_OK;
+        return p->exchange == 2 ? cp_setup_p2p(p) : MI_OK;
     }
     RCCL_NEED();
     for (CpShard &s : p->sh) {
@@ -1961,7 +2165,7 @@ int cp_finish_setup(mi355x_colpart *p, const void *id128, int rank, bool make_co
         HIP_TRY(hipHostMalloc((void **)&s.h_gathered, 2 * p->world * sizeof(double)));
         s.bits_in = s.bits;                                  // all-reduce / broadcast in place
     }
-    if (!make_comms) return MI_OK;
+    if (!make_comms) return p->exchange == 2 ? cp_setup_p2p(p) : MI_OK;
     if (p->multi_process) {
         ncclUniqueId id;
         memcpy(&id, id128, sizeof id);
@@ -1974,7 +2178,7 @@ int cp_finish_setup(mi355x_colpart *p, const void *id128, int rank, bool make_co
         RCCL_TRY(rccl().CommInitAll(comms.data(), nl, devs.data()));
         for (int i = 0; i < nl; ++i) p->sh[(size_t)i].comm = comms[(size_t)i];
     }
-    return MI_OK;
+    return p->exchange == 2 ? cp_setup_p2p(p) : MI_OK;
 }
 
 // ---- one pivot, as the three local steps of shard s with the exchanges between them
@@ -2021,8 +2225,10 @@ int cp_run_rccl(mi355x_colpart *p, CpShard &s, double f, int64_t n, int j0)
         hipEvent_t *e = timed ? &s.ev[(size_t)s.ev_used] : nullptr;
         int rc = mi355x_shard_price(s.t, p->is_max, s.col_begin, s.send);
         if (rc != MI_OK) return rc;
+        const unsigned epoch = p->xepoch + (unsigned)i + 1u;     // (mode 2: the tag of this pivot's granules)
         if (timed) HIP_TRY(hipEventRecord(e[0], s.t->stream));
-        RCCL_TRY(rccl().AllGather(s.send, s.gathered, 2, ncclDouble, s.comm, s.t->stream));
+        if (p->exchange == 2) { if ((rc = cp_p2p_push_pair(p, s, epoch)) != MI_OK) return rc; }
+        else RCCL_TRY(rccl().AllGather(s.send, s.gathered, 2, ncclDouble, s.comm, s.t->stream));
         if (timed) HIP_TRY(hipEventRecord(e[1], s.t->stream));
         if (p->block > 1) rc = mi355x_shard_la_contribute(s.t, j, s.gathered, p->world, s.col_begin, f, (int64_t *)s.bits, s.ec);
         else              rc = mi355x_shard_contribute(s.t, s.gathered, p->world, s.col_begin, f, (int64_t *)s.bits, s.ec);
@@ -2039,7 +2245,8 @@ int cp_run_rccl(mi355x_colpart *p, CpShard &s, double f, int64_t n, int j0)
             root = cp_winner_rank(s.h_gathered, p->world);
         }
         if (timed) HIP_TRY(hipEventRecord(e[2], s.t->stream));
-        if (root >= 0)
+        if (p->exchange == 2) { if ((rc = cp_p2p_column(p, s, epoch, true, true)) != MI_OK) return rc; }
+        else if (root >= 0)
             RCCL_TRY(rccl().Broadcast(s.bits, s.bits, (size_t)p->rows, ncclInt64, root, s.comm, s.t->stream));
         else
             RCCL_TRY(rccl().AllReduce(s.bits, s.bits, (size_t)p->rows, ncclInt64, ncclSum, s.comm, s.t->stream));
@@ -2102,6 +2309,7 @@ int cp_run(mi355x_colpart *p, double f, int64_t n)
                 }
         }
         if (p->block > 1) p->j = (int)((j0 + n) % p->block);
+        p->xepoch += (unsigned)n;
         return MI_OK;
     }
     // logical shards on one device, one stream: step by step over all of them
@@ -2109,11 +2317,23 @@ int cp_run(mi355x_colpart *p, double f, int64_t n)
     hipStream_t st = p->sh[0].t->stream;
     for (int64_t i = 0; i < n; ++i) {
         int rc;
+        const unsigned epoch = ++p->xepoch;
         for (CpShard &s : p->sh) if ((rc = cp_price(p, s)) != MI_OK) return rc;
+        if (p->exchange == 2) {
+            // the P2P protocol on one device and ONE stream: all producers of an exchange are
+            // enqueued before its consumers, so no consumer ever waits (same kernels, same buffers)
+            for (CpShard &s : p->sh) if ((rc = cp_p2p_push_wait_pairs_split(p, s, epoch, true)) != MI_OK) return rc;
+            for (CpShard &s : p->sh) if ((rc = cp_p2p_push_wait_pairs_split(p, s, epoch, false)) != MI_OK) return rc;
+        }
         for (CpShard &s : p->sh) if ((rc = cp_contribute(p, s, f)) != MI_OK) return rc;
-        int blocks = (int)((p->rows + 255) / 256);
-        if (blocks > 256) blocks = 256;
-        hipLaunchKernelGGL(k_local_sum, dim3(blocks), dim3(256), 0, st, p->l_bits_all, p->l_bits_sum, p->rows, p->world);
+        if (p->exchange == 2) {
+            for (CpShard &s : p->sh) if ((rc = cp_p2p_column(p, s, epoch, true, false)) != MI_OK) return rc;
+            for (CpShard &s : p->sh) if ((rc = cp_p2p_column(p, s, epoch, false, true)) != MI_OK) return rc;
+        } else {
+            int blocks = (int)((p->rows + 255) / 256);
+            if (blocks > 256) blocks = 256;
+            hipLaunchKernelGGL(k_local_sum, dim3(blocks), dim3(256), 0, st, p->l_bits_all, p->l_bits_sum, p->rows, p->world);
+        }
         for (CpShard &s : p->sh) if ((rc = cp_pivot(p, s, f)) != MI_OK) return rc;
         if (p->block > 1 && ++p->j == p->block) {
             for (CpShard &s : p->sh) if ((rc = mi355x_shard_sweep(s.t)) != MI_OK) return rc;
@@ -2147,6 +2367,9 @@ int cp_status(mi355x_colpart *p, int64_t *n_pivots)
         int64_t n = 0;
         const int st = mi355x_tab_sync(p->sh[i].t, &n);
         if (st < 0) return st;
+        if (st == kExchangeLost)
+            return fail(MI_RCCL_ERROR, "P2P exchange: a peer's data never arrived at shard %d (after %lld pivots)",
+                        p->sh[i].index, (long long)n);
         if (i == 0) { st0 = st; n0 = n; }
         else if (st != st0 || n != n0)
             return fail(MI_HIP_ERROR, "shards disagree: (%d, %lld) vs (%d, %lld)", st0, (long long)n0, st, (long long)n);
@@ -2450,20 +2673,27 @@ int cp_forced_pivot(mi355x_colpart *p, int64_t ec, int64_t cr)
         HIP_TRY(hipGetLastError());
         return MI_OK;
     };
+    const unsigned epoch = ++p->xepoch;
     if (!p->rccl) {
         int rc;
         for (CpShard &s : p->sh) if ((rc = contribute(s)) != MI_OK) return rc;
-        int blocks = (int)((p->rows + 255) / 256);
-        if (blocks > 256) blocks = 256;
-        hipLaunchKernelGGL(k_local_sum, dim3(blocks), dim3(256), 0, p->sh[0].t->stream, p->l_bits_all, p->l_bits_sum,
-                           p->rows, p->world);
+        if (p->exchange == 2) {
+            for (CpShard &s : p->sh) if ((rc = cp_p2p_column(p, s, epoch, true, false)) != MI_OK) return rc;
+            for (CpShard &s : p->sh) if ((rc = cp_p2p_column(p, s, epoch, false, true)) != MI_OK) return rc;
+        } else {
+            int blocks = (int)((p->rows + 255) / 256);
+            if (blocks > 256) blocks = 256;
+            hipLaunchKernelGGL(k_local_sum, dim3(blocks), dim3(256), 0, p->sh[0].t->stream, p->l_bits_all, p->l_bits_sum,
+                               p->rows, p->world);
+        }
         for (CpShard &s : p->sh) if ((rc = pivot(s)) != MI_OK) return rc;
         return MI_OK;
     }
     return cp_each_shard(p, [&](CpShard &s) -> int {
         int rc = contribute(s);
         if (rc != MI_OK) return rc;
-        RCCL_TRY(rccl().AllReduce(s.bits, s.bits, (size_t)p->rows, ncclInt64, ncclSum, s.comm, s.t->stream));
+        if (p->exchange == 2) { if ((rc = cp_p2p_column(p, s, epoch, true, true)) != MI_OK) return rc; }
+        else RCCL_TRY(rccl().AllReduce(s.bits, s.bits, (size_t)p->rows, ncclInt64, ncclSum, s.comm, s.t->stream));
         return pivot(s);
     });
 }
@@ -2570,6 +2800,7 @@ int mi355x_colpart_solve_two_phase(mi355x_colpart *art, int64_t main_cols, const
     mp->rows = rows;
     mp->var_count = num_vars;
     mp->exchange = art->exchange;
+    mp->xepoch = 0;                                           // (its own buffers, zeroed: tags start over)
     std::vector<double> scales((size_t)std::max<int64_t>(m, 1));
     for (int64_t i = 0; i < m; ++i) scales[(size_t)i] = main_obj[basis[(size_t)i]];
     std::vector<int64_t> keep, newcols;
@@ -2727,7 +2958,7 @@ int         mi355x_tune_set_compact(int on) { g_compact_enabled = on ? 1 : 0; re
 int         mi355x_tune_set_sweep_impl(int impl) { set_sweep_impl(impl); return impl; }
 int         mi355x_tune_set_shard_la_split(int mode) { set_shard_la_split(mode); return mode; }
 int         mi355x_tune_set_tail_policy(int p) { g_tail_policy = p == 1 ? 1 : 0; return g_tail_policy; }
-int         mi355x_tune_set_colpart_exchange(int mode) { g_cp_exchange = mode == 1 ? 1 : 0; return g_cp_exchange; }
+int         mi355x_tune_set_colpart_exchange(int mode) { g_cp_exchange = (mode == 1 || mode == 2) ? mode : 0; return g_cp_exchange; }
 /* measurement aid: the sweep of the CURRENT pending list launched n more times (the list is not
  * consumed by a sweep); average launch duration by HIP events.  Leaves the tableau meaningless. */
 int         mi355x_debug_repeat_sweep(mi355x_tab *t, int n, double *avg_us)

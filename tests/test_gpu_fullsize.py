@@ -366,13 +366,14 @@ def test_colpart_c_abi_cap_resume_synthetic_and_dense_fallback():
     tab.close()
 
 
-@pytest.mark.parametrize("exchange", [0, 1], ids=["allreduce", "rooted-broadcast"])
+@pytest.mark.parametrize("exchange", [0, 1, 2], ids=["allreduce", "rooted-broadcast", "p2p-push"])
 @pytest.mark.parametrize("entry", ["comm-init-all", "comm-init-rank"])
 def test_colpart_c_abi_over_rccl_single_rank(monkeypatch, entry, exchange):
     """The RCCL code path itself on the one GPU this box has: a single shard forced through its
     one-rank communicator -- ncclAllGather + ncclAllReduce (or, exchange 1, ncclBroadcast from the
-    owner with the root read back from the all-gather) on the shard's stream, communicator
-    teardown.  Both ways in: ncclCommInitAll (one process, what the Lisp host's `:devices` reaches)
+    owner with the root read back from the all-gather; or, exchange 2, no collective at all: the
+    P2P push / poll kernels on the shard's own fine-grained buffer) on the shard's stream,
+    communicator teardown.  Both ways in: ncclCommInitAll (one process, what the Lisp host's `:devices` reaches)
     and EXACTLY what `bench.py --gpus N` does on every rank -- mi355x_rccl_unique_id ->
     mi355x_colpart_create_synthetic_rank(world, rank, device, id) -> ncclCommInitRank -- at
     world = 1.  (Two ranks need two devices: RCCL refuses two ranks on one GPU.)"""
@@ -405,6 +406,60 @@ def test_colpart_c_abi_over_rccl_single_rank(monkeypatch, entry, exchange):
     tab.close()
 
 
+@pytest.mark.parametrize("n_devices", [1, 2, 3, 8])
+@pytest.mark.parametrize("n,m,seed", [(96, 64, 1), (700, 333, 2)])
+def test_colpart_p2p_exchange_logical_shards_bitwise(n, m, seed, n_devices):
+    """Exchange mode 2 -- every shard writes its pricing pair and (the owner) the entering column
+    straight into the other shards' fine-grained buffers as self-validating granules, the consumers
+    poll their own buffer: no collective, no host in the loop.  On this one GPU the shards are
+    logical (all producers of an exchange are enqueued before its consumers on the one stream), so
+    the data path, the buffer layout, the parities and the tags are what is exercised here; the
+    cross-device visibility of the stores needs a multi-GPU node.  Pivots and bits as the oracle's,
+    incl. a capped solve that resumes (the tags go on counting) and the two-phase hand-over."""
+    import importlib
+    cp = importlib.import_module("linear-programming_amd.colpart")
+    L = lp.capi.lib()
+    M0, b0 = lp.synth.tableau(n, m, lp.synth.seed_for(5, seed))
+    M, b = M0.copy(), b0.copy()
+    st_o, npiv, trace = oracle.solve(M, b, trace_cap=1 << 14)
+    try:
+        L.mi355x_tune_set_colpart_exchange(2)
+        tab = cp.NativeColumnPartition.from_arrays(M0, b0, n_devices)
+    finally:
+        L.mi355x_tune_set_colpart_exchange(0)
+    st, k = tab.solve(max_pivots=23)
+    assert (st, k) == (lp.capi.MI_MAX_PIVOTS, 23)
+    st, k = tab.solve()
+    assert (st, k) == (st_o, npiv - 23)
+    assert np.array_equal(tab.trace(npiv), trace)
+    G, bg, last_row, last_col = tab.download()
+    assert np.array_equal(G.view(np.int64), M.view(np.int64)) and np.array_equal(bg, b)
+    tab.close()
+    # two-phase on the partition, exchanges in mode 2 (drive-out pivots push their column the same way)
+    from tests.helpers import random_mixed_problem
+    problem = random_mixed_problem(lp, 30, 10, 8, 4, seed)
+    tabs = lp.build_tableau(problem, problem)
+    art, main = tabs
+    A, ab = art.matrix.copy(), art.basis_columns.copy()
+    Mm, mb = main.matrix.copy(), main.basis_columns.copy()
+    so, npv = oracle.solve_two_phase(A, ab, Mm, mb, main_is_max=main.is_max)
+    try:
+        L.mi355x_tune_set_colpart_exchange(2)
+        tab = cp.NativeColumnPartition.from_arrays(art.matrix.copy(), art.basis_columns.copy(), n_devices)
+        rc, got, mt = tab.solve_two_phase(main.matrix[-1].copy(), main.is_max, 1024)
+    finally:
+        L.mi355x_tune_set_colpart_exchange(0)
+    assert rc == so
+    GA, ga, _, _ = tab.download()
+    assert np.array_equal(GA.view(np.int64), A.view(np.int64)) and np.array_equal(ga, ab)
+    if mt is not None:
+        GM, gm, _, _ = mt.download()
+        assert got == (int(npv[0]), int(npv[1]))
+        assert np.array_equal(GM.view(np.int64), Mm.view(np.int64)) and np.array_equal(gm, mb)
+        mt.close()
+    tab.close()
+
+
 def test_bench_colpart_one_rank_through_the_multi_gpu_entry():
     """`bench.py --workload colpart --gpus 1` forced through the branch N > 1 takes (unique id ->
     create_synthetic_rank -> ncclCommInitRank -> collectives on a one-rank communicator), incl. the
@@ -425,6 +480,7 @@ def test_bench_colpart_one_rank_through_the_multi_gpu_entry():
     assert rec["exchange"]["samples"] > 0
     modes = rec["exchange_modes"]
     assert modes["int64_sum_allreduce"]["value"] > 0 and modes["rooted_broadcast"]["value"] > 0
+    assert modes["p2p_push"]["value"] > 0
 
 
 def test_plain_c_client_on_the_gpu(tmp_path):
@@ -508,8 +564,9 @@ def test_bench_two_ranks_watchdog_still_prints_a_line():
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and "did not finish" in rec["colpart_error"]
 
 
+@pytest.mark.parametrize("exchange", [0, 1, 2], ids=["allreduce", "rooted-broadcast", "p2p-push"])
 @pytest.mark.parametrize("n_devices", [2, 4, 8])
-def test_colpart_over_rccl_on_real_devices(n_devices):
+def test_colpart_over_rccl_on_real_devices(n_devices, exchange):
     """The column partition with one shard per PHYSICAL GPU (ncclCommInitAll, one host thread and one
     RCCL rank per device, all-gather + all-reduce over xGMI per pivot).  Needs that many GPUs in
     this process: skipped on the one-GPU test box, where the same code runs over a one-rank
@@ -522,7 +579,11 @@ def test_colpart_over_rccl_on_real_devices(n_devices):
     seed = lp.synth.seed_for(5, 21)
     M, b = lp.synth.tableau(n, m, seed)
     so, no, trace = oracle.solve(M, b, trace_cap=1 << 14)
-    tab = cp.NativeColumnPartition.synthetic(n, m, seed, n_devices)
+    try:
+        lp.capi.lib().mi355x_tune_set_colpart_exchange(exchange)
+        tab = cp.NativeColumnPartition.synthetic(n, m, seed, n_devices)
+    finally:
+        lp.capi.lib().mi355x_tune_set_colpart_exchange(0)
     assert tab.info() == {"n_shards": n_devices, "n_devices_used": n_devices, "uses_rccl": True}
     tab.exchange_timing(8, 64)
     st, k = tab.solve()
