@@ -5,11 +5,15 @@
  * neil-lindquist/linear-programming.  bench.py, tools/ and tests/ use these to pick between
  * implementations of the same bit-identical path and to read back measurement data.
  *
- * State model: every mi355x_tune_set_* hook sets PROCESS-GLOBAL state that is read when a solve
- * entry point enqueues work.  The per-handle thread-safety promise of mi355x_simplex.h holds for
- * a fixed setting of these knobs only: change them while no other thread is inside the library
- * (bench.py and the tests do so before they create the handles they measure).  Every hook
- * returns the value now in effect.
+ * State model.  The knobs that choose WHICH implementation of the solve loop runs (select mode,
+ * compact, block, look-ahead mode, tail policy, hand-over mode, batch mode, batch block, resident,
+ * column-partition exchange) are SNAPSHOTTED INTO A HANDLE WHEN IT IS CREATED: set them, then create
+ * the handle that should run that way; a handle never changes path because another thread turned
+ * a knob, so the per-handle thread-safety promise of mi355x_simplex.h holds whatever other threads
+ * do with these hooks.  The remaining hooks (update-kernel tiling, sweep shape / implementation,
+ * shard look-ahead split, one-XCD placement, poll bounds, resident poll mode, the test faults) are
+ * process-wide and read at every launch: measurement and test use only, change them while no other
+ * thread is inside the library.  Every hook returns the value now in effect.
  */
 #ifndef MI355X_SIMPLEX_TUNE_H
 #define MI355X_SIMPLEX_TUNE_H

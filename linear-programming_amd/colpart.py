@@ -472,7 +472,7 @@ def one_shard_baseline(n, m, seed, device, steps, warmup, steady_pivots=0):
     return rec
 
 
-def bench(args, rank, local_rank, world):
+def bench(args, rank, local_rank, world, progress=None):
     """ONE dense LP (BASELINE config 5: 65536 vars x 32768 constraints, 32769 x 98305 f64 =
     25.8 GB) column-partitioned over `world` ranks, strong scaling: K pivots timed with both
     per-pivot exchanges in the timed region.  The per-pivot loop runs in the library
@@ -576,36 +576,6 @@ def bench(args, rank, local_rank, world):
         dt2, st, done2 = _timed_pivots(tab, steady_pivots, torch, dist, world)
         if st == capi.MI_RUNNING:
             steady = steady_pivots / dt2
-    if native and info["uses_rccl"] and not getattr(args, "no_colpart_ab", False):
-        # A/B of the exchanges on fresh handles of the same tableau, same K pivots each: rooted
-        # broadcast (one host synchronisation per pivot for the root) and the collective-free P2P
-        # push against the sync-free int64 all-reduce above
-        exchange_modes = {
-            "int64_sum_allreduce": {"value": value, "unit": "pivots/s", "headline": True,
-                                    "steady_state_pivots_per_s": steady,
-                                    "what": "owner's bit patterns + zeros, ncclAllReduce(int64, SUM): no host synchronisation"}}
-        for mode, name, what in ((1, "rooted_broadcast", "ncclBroadcast from the owner; the root is read back from the "
-                                                         "all-gathered pricing winners: one stream synchronisation per pivot"),
-                                 (2, "p2p_push", "no collective: every shard writes its pricing pair, the owner the entering "
-                                                 "column, straight into the peers' fine-grained buffers (peer access / IPC "
-                                                 "over xGMI) as self-validating granules; consumers poll their own memory")):
-            tab.close()
-            entry = {"value": None, "unit": "pivots/s", "what": what}
-            try:
-                tab = make_native(mode)
-                tab.solve_async(args.warmup, reset=True)
-                tab.sync()
-                dtb, stb, doneb = _timed_pivots(tab, args.steps, torch, dist, world)
-                if stb == capi.MI_RUNNING:
-                    entry["value"] = args.steps / dtb
-                    if steady_pivots:
-                        dt3, st3, _ = _timed_pivots(tab, steady_pivots, torch, dist, world)
-                        if st3 == capi.MI_RUNNING:
-                            entry["steady_state_pivots_per_s"] = steady_pivots / dt3
-            except capi.Mi355xError as e:                     # e.g. no peer access / IPC on this box
-                entry["error"] = str(e)
-                tab = make_native(0)
-            exchange_modes[name] = entry
     stored_bytes = 2.0 * R * ((n + m if dense else n) + world) * 8 / block   # per pivot, all shards
     rec = {
         "metric": "simplex pivots/sec, one column-partitioned dense tableau",
@@ -643,6 +613,38 @@ def bench(args, rank, local_rank, world):
                      "frac": stored_bytes * value / 1e9 / world / 8000.0, "traffic": None,
                      "note": "whole-iteration rate per GPU (exchanges included), not kernel-only"},
     }
+    if progress is not None:
+        progress["rec"] = rec                     # (a watchdog that fires during the legs below prints this)
+    if native and info["uses_rccl"] and not getattr(args, "no_colpart_ab", False):
+        # A/B of the exchanges on fresh handles of the same tableau, same K pivots each: rooted
+        # broadcast (one host synchronisation per pivot for the root) and the collective-free P2P
+        # push against the sync-free int64 all-reduce above
+        exchange_modes = rec["exchange_modes"] = {
+            "int64_sum_allreduce": {"value": value, "unit": "pivots/s", "headline": True,
+                                    "steady_state_pivots_per_s": steady,
+                                    "what": "owner's bit patterns + zeros, ncclAllReduce(int64, SUM): no host synchronisation"}}
+        for mode, name, what in ((1, "rooted_broadcast", "ncclBroadcast from the owner; the root is read back from the "
+                                                         "all-gathered pricing winners: one stream synchronisation per pivot"),
+                                 (2, "p2p_push", "no collective: every shard writes its pricing pair, the owner the entering "
+                                                 "column, straight into the peers' fine-grained buffers (peer access / IPC "
+                                                 "over xGMI) as self-validating granules; consumers poll their own memory")):
+            tab.close()
+            entry = {"value": None, "unit": "pivots/s", "what": what}
+            try:
+                tab = make_native(mode)
+                tab.solve_async(args.warmup, reset=True)
+                tab.sync()
+                dtb, stb, doneb = _timed_pivots(tab, args.steps, torch, dist, world)
+                if stb == capi.MI_RUNNING:
+                    entry["value"] = args.steps / dtb
+                    if steady_pivots:
+                        dt3, st3, _ = _timed_pivots(tab, steady_pivots, torch, dist, world)
+                        if st3 == capi.MI_RUNNING:
+                            entry["steady_state_pivots_per_s"] = steady_pivots / dt3
+            except capi.Mi355xError as e:                     # e.g. no peer access / IPC on this box
+                entry["error"] = str(e)
+                tab = make_native(0)
+            exchange_modes[name] = entry
     if native:
         tab.close()
     else:

@@ -46,6 +46,25 @@ int g_cp_exchange = 0;                    // column partition over RCCL, exchang
                                           // ncclBroadcast (root = the rank whose pricing winner won, read
                                           // back from the all-gather: one host synchronisation per pivot)
 
+// The knobs above as a handle sees them: a handle takes a SNAPSHOT of them when it is created
+// and never looks at the process-wide values again, so a host thread that turns a knob cannot
+// change the path of a solve another thread has in flight on its own handle (handles are
+// independent across threads: include/mi355x_simplex.h).  The tiling / placement knobs of
+// simplex_kernels.hip (update variants, sweep shape, one-XCD placement, poll bounds, test faults)
+// stay process-wide measurement and test hooks.
+struct TuneSnapshot {
+    int select_mode, compact_enabled, handover_mode, batch_mode, tail_policy, la_mode, block_k, resident_mode,
+        batch_block_k;
+};
+TuneSnapshot tune_now()
+{
+    TuneSnapshot t;
+    t.select_mode = g_select_mode; t.compact_enabled = g_compact_enabled; t.handover_mode = g_handover_mode;
+    t.batch_mode = g_batch_mode; t.tail_policy = g_tail_policy; t.la_mode = g_la_mode; t.block_k = g_block_k;
+    t.resident_mode = g_resident_mode; t.batch_block_k = g_batch_block_k;
+    return t;
+}
+
 int fail(int code, const char *fmt, ...)
 {
     char buf[512];
@@ -92,6 +111,7 @@ int device_count_checked()
 }  // namespace
 
 struct mi355x_tab {
+    TuneSnapshot tn = tune_now();         // the implementation knobs as they were when the handle was created
     int         device = 0;
     TabView     v{};
     hipStream_t own_stream = nullptr;
@@ -370,7 +390,7 @@ int ensure_compact(mi355x_tab *t)
 {
     TabView &v = t->v;
     const int64_t m = v.rows - 1, vc = v.cols - 1, n_nb = vc - m, nl = v.n_lps;
-    if (t->compact || !g_compact_enabled || t->compact_failed || m < 1 || n_nb < 1) return MI_OK;
+    if (t->compact || !t->tn.compact_enabled || t->compact_failed || m < 1 || n_nb < 1) return MI_OK;
     if (v.p2l) return MI_OK;                          // a compact column shard stays as it is
     t->compact_failed = true;                         // until proven otherwise
     std::vector<int64_t> basis((size_t)(nl * m));
@@ -444,8 +464,8 @@ void enqueue_select(mi355x_tab *t, int is_max, double f)
     // ones (the strided column gather needs many workgroups' memory pipelines)
     const TabView &v = cur(t);
     bool split = (v.rows > 1024 || v.ld > 4096);
-    if (g_select_mode == 1) split = false;
-    if (g_select_mode == 2) split = true;
+    if (t->tn.select_mode == 1) split = false;
+    if (t->tn.select_mode == 2) split = true;
     if (split && select_split_supported(v)) launch_select_split(v, is_max, f, np, t->stream);
     else                                    launch_select(v, is_max, f, np, t->stream);
 }
@@ -483,12 +503,12 @@ int enqueue_iteration(mi355x_tab *t, int is_max, double f)
 // ---- blocked pivoting: k look-ahead selects, then one sweep applies them all
 bool block_mode(const mi355x_tab *t)
 {
-    if (g_block_k <= 1 || !t->compact || !block_supported(t->c)) return false;
-    if (g_select_mode == 1) return false;                 // forced: single-workgroup select, per pivot
-    if (g_select_mode == 2) return true;
+    if (t->tn.block_k <= 1 || !t->compact || !block_supported(t->c)) return false;
+    if (t->tn.select_mode == 1) return false;             // forced: single-workgroup select, per pivot
+    if (t->tn.select_mode == 2) return true;
     // the persistent look-ahead pays at every size (a step costs less than the select + update
     // launches of one pivot); the two-launches-per-step form only where the split select is used
-    if (g_la_mode != 1 && la_block_supported(t->c)) return true;
+    if (t->tn.la_mode != 1 && la_block_supported(t->c)) return true;
     return t->c.rows > 1024 || t->c.ld > 4096;
 }
 
@@ -499,10 +519,10 @@ int enqueue_block(mi355x_tab *t, int is_max, double f, int k)
     // (a handle that lost an exchange once stays on the two-launch form, forced mode 2 or not:
     // re-launching the persistent kernel for ever on a GPU that cannot co-schedule its workgroups
     // would never return)
-    const bool persistent = g_la_mode != 1 && !t->la_lost && la_block_supported(v);
+    const bool persistent = t->tn.la_mode != 1 && !t->la_lost && la_block_supported(v);
     // event pairs around FULL blocks only: the statistics are per (look-ahead of g_block_k
     // pivots, sweep of g_block_k pivots), the partial last block of a run is left out
-    const bool timed = t->timing_stride > 0 && t->n_timed < kTimingCap && k == g_block_k &&
+    const bool timed = t->timing_stride > 0 && t->n_timed < kTimingCap && k == t->tn.block_k &&
                        (t->update_launches++ % t->timing_stride) == 0;
     auto ensure_events = [](std::vector<hipEvent_t> &a, std::vector<hipEvent_t> &b, int n) -> hipError_t {
         while ((int)a.size() <= n) {
@@ -578,15 +598,15 @@ int recover_lost_exchange(mi355x_tab *t)
 int status_to_rc(int32_t st) { return st == kRunning ? MI_RUNNING : (int)st; }
 
 // ---- the resident solve (tableaux that fit the register files; simplex_kernels.hip, k_resident)
-bool knobs_at_default()
+bool knobs_at_default(const TuneSnapshot &k)
 {
-    return g_select_mode == 0 && g_la_mode == 0 && g_block_k == kMaxBlock && g_batch_mode == 0 && g_batch_block_k == 0;
+    return k.select_mode == 0 && k.la_mode == 0 && k.block_k == kMaxBlock && k.batch_mode == 0 && k.batch_block_k == 0;
 }
 
 bool resident_mode(const mi355x_tab *t)
 {
-    if (!t->compact || t->res_lost || g_resident_mode == 1) return false;
-    if (g_resident_mode == 0 && !knobs_at_default()) return false;   // an explicit knob asks for another path
+    if (!t->compact || t->res_lost || t->tn.resident_mode == 1) return false;
+    if (t->tn.resident_mode == 0 && !knobs_at_default(t->tn)) return false;   // an explicit knob asks for another path
     return resident_plan(t->c, nullptr);
 }
 
@@ -854,10 +874,11 @@ int mi355x_tab_solve_async(mi355x_tab *t, int is_max, double f, int64_t n_pivots
         // whole blocks, then the remainder as one shorter block (k_sweep16 for the full ones, a
         // k_sweep with as few links as the remainder needs: 20 pivots 371 us, 40 pivots 627 us), or
         // (g_tail_policy 0) the remainder spread evenly over the blocks (378 / 656 us)
-        const int64_t nblk = (n_pivots + g_block_k - 1) / g_block_k;
+        const int bk = t->tn.block_k;
+        const int64_t nblk = (n_pivots + bk - 1) / bk;
         for (int64_t b = 0; b < nblk; ++b) {
             int64_t k = n_pivots / nblk + (b < n_pivots % nblk ? 1 : 0);
-            if (g_tail_policy == 1) k = (b + 1 < nblk || n_pivots % g_block_k == 0) ? g_block_k : n_pivots % g_block_k;
+            if (t->tn.tail_policy == 1) k = (b + 1 < nblk || n_pivots % bk == 0) ? bk : n_pivots % bk;
             rc = enqueue_block(t, is_max, f, (int)k);
             if (rc != MI_OK) return rc;
         }
@@ -951,7 +972,7 @@ int mi355x_tab_solve(mi355x_tab *t, int is_max, double f, int64_t max_pivots, in
         int64_t blocks = 2;
         for (;;) {
             for (int64_t i = 0; i < blocks; ++i) {
-                rc = enqueue_block(t, is_max, f, g_block_k);
+                rc = enqueue_block(t, is_max, f, t->tn.block_k);
                 if (rc != MI_OK) return rc;
             }
             HIP_TRY(hipGetLastError());
@@ -1054,7 +1075,7 @@ int mi355x_solve_two_phase(mi355x_tab *art, mi355x_tab *mt, int main_is_max, dou
     if (n_pivots) n_pivots[0] = n1;
     // copy rows + basis, re-eliminate the objective row                simplex.lisp:437-451
     HIP_TRY(hipStreamSynchronize(mt->stream));
-    launch_handover(art->v, mt->v, art->unit_basis && g_handover_mode != 1, art->stream);
+    launch_handover(art->v, mt->v, art->unit_basis && art->tn.handover_mode != 1, art->stream);
     mt->n_part = 0;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(art->stream));
@@ -1305,7 +1326,7 @@ int mi355x_batch_solve(mi355x_batch *b, int is_max, double f, int64_t max_pivots
     // part that moves the tableaux; the look-ahead of a block is one workgroup per LP): 128 LPs of
     // 512 x 256 3.5 -> 7.2 M pivots/s, 1024 LPs 8.2 -> 11.4 M against the all-in-one-workgroup
     // kernel.  Needs the compact representation and an LP whose block state fits the LDS.
-    if ((g_batch_mode == 0 || g_batch_mode == 3) && t->compact) {
+    if ((t->tn.batch_mode == 0 || t->tn.batch_mode == 3) && t->compact) {
         bool split_ok = true;
         int64_t blocks = 2;
         for (;;) {
@@ -1340,7 +1361,7 @@ int mi355x_batch_solve(mi355x_batch *b, int is_max, double f, int64_t max_pivots
             }
         }
     }
-    const bool want_persistent = g_batch_mode != 1;
+    const bool want_persistent = t->tn.batch_mode != 1;
     bool persistent = want_persistent && launch_batch_solve(cur(t), is_max, f, t->stream);
     if (persistent) t->n_part = 0;
     if (!persistent) enqueue_select(t, is_max, f);
@@ -2938,7 +2959,7 @@ int         mi355x_tune_set_handover_mode(int mode) { g_handover_mode = mode; re
 int         mi355x_tune_set_batch_mode(int mode) { g_batch_mode = mode; return g_batch_mode; }
 int         mi355x_tune_set_alternate_sweep(int on) { set_alternate_sweep(on); return on; }
 // pivots one tableau-update launch of this handle applies in its current representation
-int         mi355x_tab_block_size(mi355x_tab *t) { return (t && block_mode(t)) ? g_block_k : 1; }
+int         mi355x_tab_block_size(mi355x_tab *t) { return (t && block_mode(t)) ? t->tn.block_k : 1; }
 int         mi355x_debug_rhs(mi355x_tab *t, double *out, int64_t n, int clear)
 {
     double *buf = t->v.rhs ? t->v.rhs : t->v.col;          // batches have no rhs buffer: their col buffer
