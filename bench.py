@@ -395,6 +395,18 @@ def bench_batch(args, lp, rank, local_rank, N, barrier, torch, dist):
                    "pivots_per_lp_min_mean_max": [int(npv.min()), float(npv.mean()), int(npv.max())]},
         "aggregate_GBps": 2.0 * R * C * 8 * total_pivots / elapsed / 1e9,
         "update_launches": int(nlch.value), "update_ms_total": sm.value,
+        # default path: the resident solve -- every LP in registers, the whole batch ONE launch that
+        # reads every stored tableau once and writes it once; per pivot one exchange through L2
+        "roofline": {"bound": "latency", "kernel": "k_resident" if nlch.value <= 2 else "k_sweep (batch)",
+                     "achieved": 2.0 * R * (n + 1) * 8 * nl / (sm.value * 1e-3) / 1e9 if sm.value else None,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": 2.0 * R * (n + 1) * 8 * nl / (sm.value * 1e-3) / 1e9 / HBM_PEAK_GBPS if sm.value else None,
+                     "traffic": pmc_traffic("resident", "k_resident cfg4")[0] if nl == 128 else None,
+                     "traffic_source": pmc_traffic("resident", "k_resident cfg4")[1] if nl == 128 else None,
+                     "what": "physical bytes of the launch(es) that move the stored tableaux (load + write-back) / their "
+                             "duration; the loop itself makes no HBM traffic -- informational, the path is latency-bound",
+                     "launches_timed": int(nlch.value),
+                     "us_per_pivot_per_lp": (sm.value * 1e3 / max(float(npv.mean()), 1.0)) if sm.value else None},
     }
 
 
@@ -527,6 +539,9 @@ def main():
     # blocked pivoting: one launch of the update kernel applies `block` pivots to every element
     # while it is in registers; the bytes above are then moved once per BLOCK
     block = L.mi355x_tab_block_size(h)
+    resident = bool(L.mi355x_tab_resident(h))      # the stored tableau in registers: one launch per request
+    if resident:
+        block = 1
 
     def read_events(kind):
         tot_n, tot_ms, mn_ms = 0, 0.0, None
@@ -573,7 +588,23 @@ def main():
         value = N * args.steps / elapsed
         roofline = None
         Cs = stored_cols.value
-        if upd_avg_ms:
+        if upd_avg_ms and resident:
+            # the resident solve: the tableau is read once when a launch starts and written once when
+            # it ends; inside the loop a pivot is one exchange through L2 and register arithmetic --
+            # latency-bound by construction, HBM is idle
+            per_launch = max(1, args.steps)
+            ach = kernel_bytes / (upd_avg_ms * 1e-3) / 1e9
+            roofline = {"bound": "latency", "kernel": "k_resident", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBPS, "traffic": pmc_traffic("resident", "k_resident " + args.workload)[0],
+                        "traffic_source": pmc_traffic("resident", "k_resident " + args.workload)[1],
+                        "what": "resident solve: the stored tableau lives in registers for the whole launch (load + "
+                                "write-back = bytes_moved_per_launch); per pivot one all-to-all exchange through L2 "
+                                "and register arithmetic, no HBM traffic -- the HBM figure is informational",
+                        "kernel_avg_us": upd_avg_ms * 1e3, "launches_timed": int(upd_n),
+                        "pivots_timed": per_launch, "us_per_pivot_in_kernel": upd_avg_ms * upd_n * 1e3 / per_launch,
+                        "bytes_moved_per_launch": kernel_bytes,
+                        "representation": "compact [non-basic columns | RHS], %d of %d columns stored" % (Cs, C)}
+        elif upd_avg_ms:
             # ---- the model the path is held to ----------------------------
             # Blocked pivoting: per block of `block` pivots ONE sweep moves every stored element
             # through HBM once each way (bound: HBM, 2*R*Cs*8 bytes) and applies `block` rank-1

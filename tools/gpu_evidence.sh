@@ -16,13 +16,18 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_flags.log 2>&1;
 python bench.py --workload cfg4 > $O/bench_cfg4.log 2>&1; echo "bench cfg4 rc=$?"; tail -1 $O/bench_cfg4.log | cut -c1-300
 python bench.py --workload cfg4 --batch-lps 1024 > $O/bench_cfg4_1024.log 2>&1; echo "bench cfg4 x1024 rc=$?"
 python bench.py --workload cfg2 --steps 128 --no-cpu-baseline > $O/bench_cfg2.log 2>&1; echo "bench cfg2 rc=$?"
+python tools/native_end_to_end.py > $O/native_end_to_end.log 2>&1; echo "native end to end rc=$?"; tail -3 $O/native_end_to_end.log
 python bench.py --workload colpart --steps 64 --warmup 16 > $O/bench_colpart_1gpu.log 2>&1; echo "bench colpart rc=$?"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats -- python $R/bench.py --no-cpu-baseline --no-per-pivot > $O/kernel_stats.log 2>&1; echo "rocprof stats rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats_cfg4 -- python $R/bench.py --workload cfg4 > $O/kernel_stats_cfg4.log 2>&1; echo "rocprof stats cfg4 rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats_cfg2 -- python $R/bench.py --workload cfg2 --steps 128 --no-cpu-baseline > $O/kernel_stats_cfg2.log 2>&1; echo "rocprof stats cfg2 rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats_perpivot -- python $R/bench.py --block 1 --steps 320 --no-cpu-baseline --no-per-pivot > $O/kernel_stats_perpivot.log 2>&1; echo "rocprof stats per-pivot rc=$?"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python $R/tools/pmc_probe.py 64 > $O/pmc_$c.log 2>&1; echo "pmc $c rc=$?"
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_perpivot_$c -- python $R/tools/pmc_probe.py 24 1 > $O/pmc_perpivot_$c.log 2>&1; echo "pmc per-pivot $c rc=$?"
+done
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_resident_$c -- python $R/tools/pmc_probe_resident.py > $O/pmc_resident_$c.log 2>&1; echo "pmc resident $c rc=$?"
 done
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --kernel-trace --output-format csv -d $O/pmc_SQ -- python $R/tools/pmc_probe.py 64 > $O/pmc_SQ.log 2>&1; echo "pmc SQ rc=$?"

@@ -94,6 +94,46 @@ def main(tag):
             out["kernels"][k] = rec
     json.dump(out, open(os.path.join(PR, tag + "_cfg3_pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
+    # the resident solve (tools/pmc_probe_resident.py): config 2 as ONE k_resident launch, then a
+    # 128-LP config-4 batch as one launch
+    fp = one("pmc_resident_FETCH_SIZE/*/*counter_collection.csv", required=False)
+    wp = one("pmc_resident_WRITE_SIZE/*/*counter_collection.csv", required=False)
+    lg = one("pmc_resident_FETCH_SIZE.log", required=False)
+    if fp and wp and lg:
+        shutil.copy(fp, os.path.join(PR, tag + "_resident_pmc_FETCH_SIZE.csv"))
+        shutil.copy(wp, os.path.join(PR, tag + "_resident_pmc_WRITE_SIZE.csv"))
+        layout, piv = {}, {}
+        for l in open(lg):
+            if l.startswith("layout"):
+                layout = dict(kv.split("=") for kv in l.split()[1:])
+            if l.startswith("cfg2 rc"):
+                piv["cfg2"] = int(l.split()[-1])
+            if l.startswith("cfg4 batch"):
+                piv["cfg4"] = int(l.split()[3])
+        rows, cols, dld = int(layout["rows"]), int(layout["stored_cols"]), int(layout["dense_ld"])
+        cf, cw = max(counter(fp, "copyBuffer")), max(counter(wp, "copyBuffer"))
+        copy_kib = rows * dld * 8 / 1024.0
+        res = {"calibration": {"KiB_each_way": copy_kib, "FETCH_SIZE_reported_KiB": cf, "WRITE_SIZE_reported_KiB": cw,
+                               "fetch_factor_measured": copy_kib / cf, "write_factor_measured": copy_kib / cw,
+                               "correction_applied": "FETCH x2 (gfx950), WRITE x1"}, "kernels": {}}
+        f, w = counter(fp, "k_resident"), counter(wp, "k_resident")
+        names = ["cfg2 (513 x 1025 stored, 32 workgroups, whole solve = 1 launch)",
+                 "cfg4 (128 LPs of 257 x 513 stored, 8 workgroups each, whole batch = 1 launch)"]
+        big = sorted(range(len(f)), key=lambda i: -(2 * f[i] + w[i]))[:2]
+        for name, i, key, stored in zip(names, sorted(big), ("cfg2", "cfg4"), (rows * cols * 8, 128 * 257 * 513 * 8)):
+            hb = (2 * f[i] + w[i]) * 1024
+            res["kernels"]["k_resident " + name] = {
+                "FETCH_SIZE_KiB": f[i], "WRITE_SIZE_KiB": w[i], "hbm_bytes_per_launch": hb, "pivots_in_the_launch": piv.get(key),
+                "stored_tableau_bytes": stored, "traffic_over_load_plus_writeback": hb / (2.0 * stored),
+                "hbm_bytes_per_pivot": hb / piv[key] if piv.get(key) else None}
+        json.dump(res, open(os.path.join(PR, tag + "_resident_pmc_traffic.json"), "w"), indent=1)
+        print(json.dumps(res, indent=1))
+    f = one("kernel_stats_cfg2/*/*kernel_stats.csv", required=False)
+    if f:
+        shutil.copy(f, os.path.join(PR, tag + "_cfg2_kernel_stats.csv"))
+    f = one("native_end_to_end.log", required=False)
+    if f:
+        shutil.copy(f, os.path.join(PR, tag + "_native_end_to_end.log"))
     for f in sorted(glob.glob(os.path.join(PR, tag + "*kernel_stats.csv"))):
         print(f)
         print(open(f).read()[:900])
