@@ -39,6 +39,12 @@ int main(void)
             mi355x_colpart *cp = NULL;
             if (mi355x_colpart_create(&cp, rows, cols, M, basis, 8) != MI_NO_DEVICE || cp != NULL) return 14;
             if (mi355x_colpart_solve(NULL, 1, 1024.0, 0, NULL) != MI_BAD_ARG) return 15;
+            if (mi355x_colpart_create_on(&cp, rows, cols, M, basis, 2, NULL) != MI_NO_DEVICE || cp != NULL) return 20;
+        }
+        {   /* ... and the batch handles */
+            mi355x_multibatch *mb = NULL;
+            if (mi355x_multibatch_create(&mb, 1, rows, cols, M, basis, 8, NULL) != MI_NO_DEVICE || mb != NULL) return 21;
+            if (mi355x_batch_sync(NULL, NULL, NULL) != MI_BAD_ARG) return 22;
         }
         printf("no device: %s\n", mi355x_last_error());
     } else {
@@ -59,6 +65,47 @@ int main(void)
             if (mi355x_colpart_download(cp, NULL, b2, NULL, last_col) != MI_OK) return 18;
             if (last_col[2] != 28.5 || b2[0] != 0 || b2[1] != 1) return 19;
             mi355x_colpart_destroy(cp);
+        }
+        {   /* two copies of the LP as one batch over 2 (logical) sub-batches, one call */
+            mi355x_multibatch *mb = NULL;
+            double MM[2 * 18], lc[3];
+            int64_t bb[4], npv[2] = {0, 0};
+            int32_t st[2] = {-1, -1};
+            int nsub = 0, ndev = 0;
+            memcpy(MM, M, sizeof M); memcpy(MM + 18, M, sizeof M);
+            bb[0] = bb[2] = basis[0]; bb[1] = bb[3] = basis[1];
+            if (mi355x_multibatch_create(&mb, 2, rows, cols, MM, bb, 2, NULL) != MI_OK) return 23;
+            if (mi355x_multibatch_info(mb, &nsub, &ndev) != MI_OK || nsub != 2 || ndev != 1) return 24;
+            if (mi355x_multibatch_solve(mb, 1, 1024.0, 0, st, npv) != MI_OK) return 25;
+            if (st[0] != MI_OPTIMAL || st[1] != MI_OPTIMAL || npv[0] != 2 || npv[1] != 2) return 26;
+            if (mi355x_multibatch_download(mb, 1, NULL, NULL, NULL, lc) != MI_OK || lc[2] != 28.5) return 27;
+            mi355x_multibatch_destroy(mb);
+        }
+        {   /* a two-phase problem (x + y >= 2 next to the two <= rows) with its ARTIFICIAL tableau
+             * column-partitioned: phase 1, hand-over and phase 2 on the partition; the main tableau
+             * contributes its objective row only */
+            mi355x_problem *q = NULL;
+            int64_t v3[] = {0, 1};  double c3[] = {1, 1};
+            int64_t ar = 0, ac = 0, mr = 0, mc = 0, npv[2] = {0, 0};
+            double A[4 * 9], Mm[4 * 8], lc[4];
+            int64_t ab[3], mb2[3];
+            mi355x_colpart *art = NULL, *mn = NULL;
+            int tp = 0;
+            if (mi355x_problem_create(&q, 1, 3) != MI_OK) return 28;
+            mi355x_problem_set_objective(q, ov, oc, 3);
+            mi355x_problem_add_constraint(q, 0, v1, c1, 2, 8.0);
+            mi355x_problem_add_constraint(q, 0, v2, c2, 2, 7.0);
+            mi355x_problem_add_constraint(q, 1, v3, c3, 2, 2.0);
+            if (mi355x_build_tableau(q, 1, &ar, &ac, NULL, NULL, &tp) != MI_OK || !tp || ar != 4 || ac > 9) return 29;
+            if (mi355x_build_tableau(q, 1, NULL, NULL, A, ab, NULL) != MI_OK) return 30;
+            if (mi355x_build_tableau(q, 0, &mr, &mc, NULL, NULL, NULL) != MI_OK || mr != 4 || mc > 8) return 31;
+            if (mi355x_build_tableau(q, 0, NULL, NULL, Mm, mb2, NULL) != MI_OK) return 32;
+            if (mi355x_colpart_create(&art, ar, ac, A, ab, 2) != MI_OK) return 33;
+            if (mi355x_colpart_solve_two_phase(art, mc, Mm + (mr - 1) * mc, 1, 1024.0, npv, &mn) != MI_OPTIMAL || !mn) return 34;
+            if (mi355x_colpart_download(mn, NULL, NULL, NULL, lc) != MI_OK || lc[3] != 28.5) return 35;
+            mi355x_colpart_destroy(mn);
+            mi355x_colpart_destroy(art);
+            mi355x_problem_destroy(q);
         }
         printf("solved on the GPU: w = %g, x = %g\n", w, x);
     }

@@ -15,8 +15,10 @@ lp = lp_amd(); L = lp.capi.lib()
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 kind_arg = sys.argv[3] if len(sys.argv) > 3 else "extreme"
-MODES = [("default", 0, 16, 1, 0), ("two-launch", 1, 16, 1, 0), ("per-pivot", 0, 1, 1, 0),
-         ("dense-1wg", 0, 16, 0, 1), ("dense-split", 0, 16, 0, 2)]
+# (name, look-ahead mode, block, compact, select mode, resident mode); the default path is the
+# resident solve at these sizes, "persistent" is the blocked path with the resident solve off
+MODES = [("resident", 0, 16, 1, 0, 0), ("persistent", 0, 16, 1, 0, 1), ("two-launch", 1, 16, 1, 0, 0),
+         ("per-pivot", 0, 1, 1, 0, 0), ("dense-1wg", 0, 16, 0, 1, 0), ("dense-split", 0, 16, 0, 2, 0)]
 
 
 def ptr(a):
@@ -57,8 +59,9 @@ for case in range(cases):
     M, b = M0.copy(), b0.copy()
     with np.errstate(all="ignore"):
         st_o, npiv, trace = oracle.solve(M, b, is_max=bool(is_max), max_pivots=cap, trace_cap=cap)
-    name, la, blk, cmp_, sel = MODES[case % len(MODES)]
+    name, la, blk, cmp_, sel, res = MODES[case % len(MODES)]
     L.mi355x_tune_set_lookahead_mode(la); L.mi355x_tune_set_block(blk); L.mi355x_tune_set_compact(cmp_); L.mi355x_tune_set_select_mode(sel)
+    L.mi355x_tune_set_resident(res)
     h = ctypes.c_void_p()
     lp.capi.check(L.mi355x_tab_create(ctypes.byref(h), m + 1, n + m + 1, ptr(M0), ptr(b0), 0), "create")
     k = ctypes.c_int64(0)
@@ -79,5 +82,6 @@ for case in range(cases):
         if bad >= 10:
             break
 L.mi355x_tune_set_lookahead_mode(0); L.mi355x_tune_set_block(16); L.mi355x_tune_set_compact(1); L.mi355x_tune_set_select_mode(0)
+L.mi355x_tune_set_resident(0)
 print("%d cases, %d mismatches, %.0f s" % (case + 1, bad, time.time() - t0), flush=True)
 sys.exit(1 if bad else 0)
