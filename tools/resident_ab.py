@@ -1,5 +1,7 @@
+"""A/B of the resident solve's record polling (wave 0 polls + LDS hand-over vs every wave polls) in ONE run on one
+box: config 2 (32 workgroups) and config-4 batches (8 workgroups per LP).  python tools/resident_ab.py"""
 import ctypes, sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, importlib
 lp = importlib.import_module("linear-programming_amd")
 L = lp.capi.lib()
