@@ -54,6 +54,14 @@ int         mi355x_tune_set_colpart_exchange(int mode);      /* column partition
                                                                 column straight into each other's
                                                                 fine-grained buffers (P2P / IPC over
                                                                 xGMI), self-validating granules    */
+/* one process per GPU in exchange mode 2: the ranks' exchange buffers are mapped into each other's
+ * address space through IPC handles.  With a communicator (an id from mi355x_rccl_unique_id) the
+ * library all-gathers the handles itself when the handle is created; with id128 == NULL no
+ * communicator exists at all (RCCL is not touched) and the host connects the ranks: every rank
+ * takes its 64-byte handle, the host gathers them in rank order (world x 64 bytes) and hands the
+ * table to every rank before the first solve. */
+int         mi355x_colpart_p2p_handle(mi355x_colpart *p, void *handle64);
+int         mi355x_colpart_p2p_connect(mi355x_colpart *p, const void *handles);
 int         mi355x_tune_set_tail_policy(int p);              /* n pivots, n not a multiple of the block:
                                                                 0 spread evenly, 1 full blocks + remainder */
 int         mi355x_tune_set_handover_mode(int mode);         /* 0 auto, 1 sequential re-elimination */

@@ -334,15 +334,27 @@ class NativeColumnPartition:
 
     @classmethod
     def synthetic_rank(cls, n_vars, n_cons, seed, world, rank, device, unique_id):
-        """One process per GPU: `unique_id` = the 128 bytes rank 0 got from rccl_unique_id()."""
+        """One process per GPU: `unique_id` = the 128 bytes rank 0 got from rccl_unique_id(), or
+        None in exchange mode 2 (no communicator: connect the ranks with p2p_handle / p2p_connect)."""
         h = ctypes.c_void_p()
-        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
         capi.check(capi.lib().mi355x_colpart_create_synthetic_rank(ctypes.byref(h), n_vars, n_cons, seed,
                                                                    int(world), int(rank), int(device), buf),
                    "mi355x_colpart_create_synthetic_rank")
         obj = cls(h)
         obj.rows, obj.cols = n_cons + 1, n_vars + n_cons + 1
         return obj
+
+    def p2p_handle(self):
+        """Exchange mode 2, one process per GPU: the 64-byte IPC handle of this rank's exchange buffer."""
+        buf = ctypes.create_string_buffer(64)
+        capi.check(capi.lib().mi355x_colpart_p2p_handle(self._h, buf), "mi355x_colpart_p2p_handle")
+        return buf.raw
+
+    def p2p_connect(self, handles):
+        """`handles`: every rank's 64-byte handle, concatenated in rank order."""
+        buf = ctypes.create_string_buffer(bytes(handles), len(handles))
+        capi.check(capi.lib().mi355x_colpart_p2p_connect(self._h, buf), "mi355x_colpart_p2p_connect")
 
     @staticmethod
     def rccl_unique_id():
@@ -398,14 +410,17 @@ class NativeColumnPartition:
         rc = capi.check(capi.lib().mi355x_colpart_sync(self._h, ctypes.byref(n)), "mi355x_colpart_sync")
         return rc, int(n.value)
 
-    def download(self, matrix=True):
+    def download(self, matrix=True, last_row=True):
+        """(matrix, basis, objective row, RHS column); a rank of the one-process-per-GPU form holds
+        one shard only: matrix=False, last_row=False there (basis and RHS column are replicated)."""
         M = np.empty((self.rows, self.cols)) if matrix else None
         b = np.empty(self.rows - 1, dtype=np.int64)
-        last_row, last_col = np.empty(self.cols), np.empty(self.rows)
+        lr, last_col = (np.empty(self.cols) if last_row else None), np.empty(self.rows)
         capi.check(capi.lib().mi355x_colpart_download(
             self._h, M.ctypes.data_as(ctypes.c_void_p) if matrix else None, b.ctypes.data_as(ctypes.c_void_p),
-            last_row.ctypes.data_as(ctypes.c_void_p), last_col.ctypes.data_as(ctypes.c_void_p)), "mi355x_colpart_download")
-        return M, b, last_row, last_col
+            lr.ctypes.data_as(ctypes.c_void_p) if last_row else None, last_col.ctypes.data_as(ctypes.c_void_p)),
+            "mi355x_colpart_download")
+        return M, b, lr, last_col
 
     def trace(self, cap):
         ec = np.empty(max(cap, 1), dtype=np.int64); cr = np.empty(max(cap, 1), dtype=np.int64)
@@ -428,7 +443,7 @@ class NativeColumnPartition:
 
 
 # ------------------------------------------------------------------ bench.py --workload colpart
-def _timed_pivots(tab, k, torch, dist, world, sync_ranks=True):
+def _timed_pivots(tab, k, torch, dist, world, sync_ranks=True, red_dev="cuda"):
     """k pivots through the library's loop, bracketed as bench.py's contract asks: barrier +
     device synchronisation on both sides, MAX over ranks."""
     if world > 1 and sync_ranks:
@@ -442,7 +457,7 @@ def _timed_pivots(tab, k, torch, dist, world, sync_ranks=True):
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1 and sync_ranks:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     return dt, st, done
@@ -496,10 +511,14 @@ def bench(args, rank, local_rank, world, progress=None):
     if getattr(args, "colpart_vars", None):
         n, m = args.colpart_vars, args.colpart_vars // 2
     seed = synth.seed_for(5)
-    staged = world > 1 and dist.get_backend() != "nccl"          # test hook: ranks share one GPU
+    staged = world > 1 and dist.get_backend() != "nccl"          # test hook: ranks share one GPU (no RCCL between them)
+    red_dev = "cpu" if staged else "cuda"
     dense = getattr(args, "colpart_dense", False)
     block = getattr(args, "colpart_block", 0) or ColumnPartitionedTableau.MAX_BLOCK
-    native = not staged and not dense and block == ColumnPartitionedTableau.MAX_BLOCK
+    # the library's own loop whenever the shards are the default ones; ranks that share a GPU run it
+    # in exchange mode 2 without a communicator (IPC handles gathered here), everything else the
+    # Python protocol driver with the exchanges staged through the host
+    native = not dense and block == ColumnPartitionedTableau.MAX_BLOCK
     # BENCH_COLPART_RANK_ENTRY=1 (test hook): also a single rank goes through the entry N > 1 uses --
     # mi355x_rccl_unique_id -> mi355x_colpart_create_synthetic_rank -> ncclCommInitRank (with
     # MI355X_COLPART_FORCE_RCCL=1 over a one-rank communicator)
@@ -510,6 +529,17 @@ def bench(args, rank, local_rank, world, progress=None):
     exchange_modes = None
 
     def make_native(exchange):
+        if staged:                                    # exchange mode 2, host-connected, RCCL never touched
+            L.mi355x_tune_set_colpart_exchange(2)
+            try:
+                t = NativeColumnPartition.synthetic_rank(n, m, seed, world, rank, local_rank, None)
+            finally:
+                L.mi355x_tune_set_colpart_exchange(0)
+            handles = [None] * world
+            dist.all_gather_object(handles, t.p2p_handle())
+            t.p2p_connect(b"".join(handles))
+            dist.barrier()
+            return t
         L.mi355x_tune_set_colpart_exchange(exchange)
         try:
             if rank_entry:
@@ -530,7 +560,7 @@ def bench(args, rank, local_rank, world, progress=None):
         info = tab.info()
         tab.solve_async(args.warmup, reset=True)
         st, done = tab.sync()
-        if info["uses_rccl"]:
+        if info["uses_rccl"] and not staged:
             tab.exchange_timing(max(1, args.steps // 64), 128)
     else:
         shards = synthetic_shards(torch, n, m, seed, [rank], world, local_rank, compact=not dense)
@@ -542,7 +572,7 @@ def bench(args, rank, local_rank, world, progress=None):
         st, done = tab.status()
     steady = None
     if native:
-        elapsed, st, done = _timed_pivots(tab, args.steps, torch, dist, world)
+        elapsed, st, done = _timed_pivots(tab, args.steps, torch, dist, world, red_dev=red_dev)
     else:
         if world > 1:
             dist.barrier()
@@ -563,7 +593,7 @@ def bench(args, rank, local_rank, world, progress=None):
     R, C = m + 1, n + m + 1
     value = args.steps / elapsed
     exchange = None
-    if native and info["uses_rccl"]:
+    if native and info["uses_rccl"] and not staged:
         ns, ag_us, ar_us = tab.exchange_timing_read()
         tab.exchange_timing(0, 0)
         if ns:
@@ -573,7 +603,7 @@ def bench(args, rank, local_rank, world, progress=None):
                                 "ncclAllReduce (int64 x %d rows) of sampled pivots; includes waiting "
                                 "for the slowest rank" % R}
     if native and steady_pivots:
-        dt2, st, done2 = _timed_pivots(tab, steady_pivots, torch, dist, world)
+        dt2, st, done2 = _timed_pivots(tab, steady_pivots, torch, dist, world, red_dev=red_dev)
         if st == capi.MI_RUNNING:
             steady = steady_pivots / dt2
     stored_bytes = 2.0 * R * ((n + m if dense else n) + world) * 8 / block   # per pivot, all shards
@@ -589,11 +619,13 @@ def bench(args, rank, local_rank, world, progress=None):
                    "parallelism": "column partition, per-pivot all-gather(16 B/rank) + int64 "
                                   "all-reduce(%d B) over RCCL; shards swept once per %d pivots"
                                   % (R * 8, block),
-                   "driver": ("mi355x_colpart_* (C++ loop, RCCL from the library; entry: %s)"
-                              % ("mi355x_colpart_create_synthetic_rank / ncclCommInitRank" if rank_entry
+                   "driver": ("mi355x_colpart_* (C++ loop in the library; entry: %s)"
+                              % ("mi355x_colpart_create_synthetic_rank, exchange mode 2 (P2P push), no communicator: IPC "
+                                 "handles gathered by the host" if staged else
+                                 "mi355x_colpart_create_synthetic_rank / ncclCommInitRank" if rank_entry
                                  else "mi355x_colpart_create_synthetic")) if native
                              else "Python protocol driver (torch.distributed)"},
-        "rccl_ranks": world if info["uses_rccl"] else 0,
+        "rccl_ranks": world if (info["uses_rccl"] and not staged) else 0,
         "exchange_bytes_per_pivot_per_rank": 16 * world + 8 * R,
         "exchange": exchange,
         "exchange_modes": exchange_modes,
@@ -615,7 +647,7 @@ def bench(args, rank, local_rank, world, progress=None):
     }
     if progress is not None:
         progress["rec"] = rec                     # (a watchdog that fires during the legs below prints this)
-    if native and info["uses_rccl"] and not getattr(args, "no_colpart_ab", False):
+    if native and info["uses_rccl"] and not staged and not getattr(args, "no_colpart_ab", False):
         # A/B of the exchanges on fresh handles of the same tableau, same K pivots each: rooted
         # broadcast (one host synchronisation per pivot for the root) and the collective-free P2P
         # push against the sync-free int64 all-reduce above

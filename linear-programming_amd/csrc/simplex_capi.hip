@@ -2013,6 +2013,7 @@ struct mi355x_colpart {
     int     exchange = 0;                    // g_cp_exchange when the handle was created
     unsigned xepoch = 0;                     // P2P exchange: pivots exchanged so far (the granules' tags)
     unsigned p2p_spins = 1u << 24;           // polls before a shard gives a peer up (kExchangeLost)
+    bool     p2p_connected = false;          // mode 2: every peer's buffer is mapped
     P2pLayout lay{};
     std::vector<CpShard> sh;                 // the shards of THIS process
     // logical shards: one allocation each, shared by all of them
@@ -2060,6 +2061,28 @@ void cp_partition(int64_t count, int n, int r, int64_t *b, int64_t *e)
     *e = *b + base + (r < extra ? 1 : 0);
 }
 
+// One process per GPU, exchange mode 2: map the other ranks' exchange buffers (`handles`: world x
+// 64 bytes, the hipIpcMemHandle_t of every rank's buffer in rank order, this rank's own included)
+int cp_p2p_connect(mi355x_colpart *p, const char *handles)
+{
+    CpShard &s = p->sh[0];
+    HIP_TRY(hipSetDevice(s.device));
+    std::vector<unsigned long long *> ptrs((size_t)p->world, nullptr);
+    ptrs[(size_t)s.index] = s.xch;
+    for (int r = 0; r < p->world; ++r) {
+        if (r == s.index) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, handles + (size_t)64 * r, 64);
+        void *q = nullptr;
+        HIP_TRY(hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess));
+        s.ipc_opened.push_back(q);
+        ptrs[(size_t)r] = (unsigned long long *)q;
+    }
+    HIP_TRY(hipMemcpy(s.d_peers, ptrs.data(), p->world * sizeof(unsigned long long *), hipMemcpyHostToDevice));
+    p->p2p_connected = true;
+    return MI_OK;
+}
+
 // Exchange mode 2: one fine-grained buffer per shard, every shard's address of every buffer.
 // One process: the shards' devices get peer access to each other.  One process per GPU: the IPC
 // handle of this rank's buffer is all-gathered over the (already initialised) communicator and the
@@ -2094,35 +2117,32 @@ int cp_setup_p2p(mi355x_colpart *p)
             HIP_TRY(hipSetDevice(s.device));
             HIP_TRY(hipMemcpy(s.d_peers, ptrs.data(), p->world * sizeof(unsigned long long *), hipMemcpyHostToDevice));
         }
+        p->p2p_connected = true;
         return MI_OK;
     }
     CpShard &s = p->sh[0];
     HIP_TRY(hipSetDevice(s.device));
-    ptrs[(size_t)s.index] = s.xch;
-    if (p->world > 1) {
-        RCCL_NEED();
-        static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
-        hipIpcMemHandle_t mine;
-        HIP_TRY(hipIpcGetMemHandle(&mine, s.xch));
-        char *d_one = nullptr, *d_all = nullptr;
-        HIP_TRY(hipMalloc((void **)&d_one, 64));
-        HIP_TRY(hipMalloc((void **)&d_all, (size_t)64 * p->world));
-        HIP_TRY(hipMemcpy(d_one, &mine, 64, hipMemcpyHostToDevice));
-        RCCL_TRY(rccl().AllGather(d_one, d_all, 64, ncclChar, s.comm, s.t->stream));
-        HIP_TRY(hipStreamSynchronize(s.t->stream));
-        std::vector<hipIpcMemHandle_t> all((size_t)p->world);
-        HIP_TRY(hipMemcpy(all.data(), d_all, (size_t)64 * p->world, hipMemcpyDeviceToHost));
-        (void)hipFree(d_one); (void)hipFree(d_all);
-        for (int r = 0; r < p->world; ++r) {
-            if (r == s.index) continue;
-            void *q = nullptr;
-            HIP_TRY(hipIpcOpenMemHandle(&q, all[(size_t)r], hipIpcMemLazyEnablePeerAccess));
-            s.ipc_opened.push_back(q);
-            ptrs[(size_t)r] = (unsigned long long *)q;
-        }
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    if (p->world == 1) {
+        ptrs[0] = s.xch;
+        HIP_TRY(hipMemcpy(s.d_peers, ptrs.data(), sizeof(unsigned long long *), hipMemcpyHostToDevice));
+        p->p2p_connected = true;
+        return MI_OK;
     }
-    HIP_TRY(hipMemcpy(s.d_peers, ptrs.data(), p->world * sizeof(unsigned long long *), hipMemcpyHostToDevice));
-    return MI_OK;
+    if (!s.comm) return MI_OK;             // no communicator: the host passes the handles (mi355x_colpart_p2p_connect)
+    RCCL_NEED();
+    hipIpcMemHandle_t mine;
+    HIP_TRY(hipIpcGetMemHandle(&mine, s.xch));
+    char *d_one = nullptr, *d_all = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_one, 64));
+    HIP_TRY(hipMalloc((void **)&d_all, (size_t)64 * p->world));
+    HIP_TRY(hipMemcpy(d_one, &mine, 64, hipMemcpyHostToDevice));
+    RCCL_TRY(rccl().AllGather(d_one, d_all, 64, ncclChar, s.comm, s.t->stream));
+    HIP_TRY(hipStreamSynchronize(s.t->stream));
+    std::vector<char> all((size_t)64 * p->world);
+    HIP_TRY(hipMemcpy(all.data(), d_all, (size_t)64 * p->world, hipMemcpyDeviceToHost));
+    (void)hipFree(d_one); (void)hipFree(d_all);
+    return cp_p2p_connect(p, all.data());
 }
 
 // the two exchanges of one pivot in mode 2, on shard s's stream (epoch = the pivot's tag)
@@ -2176,7 +2196,7 @@ int cp_finish_setup(mi355x_colpart *p, const void *id128, int rank, bool make_co
         for (CpShard &s : p->sh) s.t->stream = p->sh[0].t->own_stream;
         return p->exchange == 2 ? cp_setup_p2p(p) : MI_OK;
     }
-    RCCL_NEED();
+    if (!(p->multi_process && !id128 && p->exchange == 2)) RCCL_NEED();
     for (CpShard &s : p->sh) {
         HIP_TRY(hipSetDevice(s.device));
         HIP_TRY(hipMalloc((void **)&s.send, 2 * sizeof(double)));
@@ -2188,10 +2208,12 @@ int cp_finish_setup(mi355x_colpart *p, const void *id128, int rank, bool make_co
     }
     if (!make_comms) return p->exchange == 2 ? cp_setup_p2p(p) : MI_OK;
     if (p->multi_process) {
-        ncclUniqueId id;
-        memcpy(&id, id128, sizeof id);
-        HIP_TRY(hipSetDevice(p->sh[0].device));
-        RCCL_TRY(rccl().CommInitRank(&p->sh[0].comm, p->world, id, rank));
+        if (id128) {                                         // (NULL: exchange mode 2 without a communicator)
+            ncclUniqueId id;
+            memcpy(&id, id128, sizeof id);
+            HIP_TRY(hipSetDevice(p->sh[0].device));
+            RCCL_TRY(rccl().CommInitRank(&p->sh[0].comm, p->world, id, rank));
+        }
     } else {
         std::vector<ncclComm_t> comms((size_t)nl);
         std::vector<int> devs((size_t)nl);
@@ -2303,6 +2325,8 @@ void cp_abort(mi355x_colpart *p)
 int cp_run(mi355x_colpart *p, double f, int64_t n)
 {
     if (p->dead) return fail(MI_RCCL_ERROR, "this handle's communicators were aborted after an earlier failure");
+    if (p->exchange == 2 && !p->p2p_connected)
+        return fail(MI_BAD_ARG, "exchange mode 2: the ranks' buffers are not connected yet (mi355x_colpart_p2p_connect)");
     if (n <= 0) return MI_OK;
     if (p->rccl) {
         const int j0 = p->j;
@@ -2430,7 +2454,9 @@ static int cp_create_synthetic(mi355x_colpart **out, int64_t n_vars, int64_t n_c
     *out = nullptr;
     if (world < 1 || n_vars < world || n_cons < 1) return fail(MI_BAD_ARG, "need 1 <= shards <= n_vars and n_cons >= 1");
     const bool mp = rank >= 0;
-    if (mp && (rank >= world || !id128)) return fail(MI_BAD_ARG, "bad rank / id");
+    if (mp && (rank >= world || (!id128 && g_cp_exchange != 2)))
+        return fail(MI_BAD_ARG, "bad rank / id (a NULL id is accepted in exchange mode 2 only: no communicator, "
+                                "the host connects the ranks with mi355x_colpart_p2p_handle / _p2p_connect)");
     if (device_count_checked() <= 0) return fail(MI_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
     mi355x_colpart *p = new (std::nothrow) mi355x_colpart;
     if (!p) return fail(MI_NO_MEMORY, "host allocation failed");
@@ -2552,6 +2578,27 @@ int mi355x_colpart_create_on(mi355x_colpart **out, int64_t rows, int64_t cols, c
     if (rc != MI_OK) { cp_free(p); return rc; }
     *out = p;
     return MI_OK;
+}
+
+int mi355x_colpart_p2p_handle(mi355x_colpart *p, void *handle64)
+{
+    if (!p || !handle64) return fail(MI_BAD_ARG, "NULL argument");
+    if (p->exchange != 2 || !p->multi_process || p->sh.empty() || !p->sh[0].xch)
+        return fail(MI_BAD_ARG, "not a one-process-per-GPU handle in exchange mode 2");
+    HIP_TRY(hipSetDevice(p->sh[0].device));
+    hipIpcMemHandle_t h;
+    HIP_TRY(hipIpcGetMemHandle(&h, p->sh[0].xch));
+    memcpy(handle64, &h, 64);
+    return MI_OK;
+}
+
+int mi355x_colpart_p2p_connect(mi355x_colpart *p, const void *handles)
+{
+    if (!p || !handles) return fail(MI_BAD_ARG, "NULL argument");
+    if (p->exchange != 2 || !p->multi_process || p->sh.empty() || !p->sh[0].xch)
+        return fail(MI_BAD_ARG, "not a one-process-per-GPU handle in exchange mode 2");
+    if (p->p2p_connected) return MI_OK;
+    return cp_p2p_connect(p, static_cast<const char *>(handles));
 }
 
 int mi355x_colpart_info(const mi355x_colpart *p, int *n_shards, int *n_devices_used, int *uses_rccl)
