@@ -1802,15 +1802,20 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
                         pa[k] = lane_value(v_pa, i0 + k);
                         prod[k] = ci * pa[k];                          // rounded product
                     }
+                    if (((gen >> i0) & 0xfu) == 0u) {                  // (uniform) the bare chain: ONE branch per four links
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if ((gen >> (i0 + k)) & 1u) {                  // (uniform; rare)
-                            const bool is_cr = (my_rm >> (i0 + k)) & 1u;
-                            if ((slmask >> (i0 + k)) & 1u) a = is_cr ? 1.0 : 0.0;
-                            const double d = a - prod[k];
-                            a = is_cr ? pa[k] : d;
-                        } else {
-                            a = a - prod[k];                           // rounded difference
+                        for (int k = 0; k < 4; ++k) a = a - prod[k];   // rounded differences
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if ((gen >> (i0 + k)) & 1u) {              // (uniform; rare)
+                                const bool is_cr = (my_rm >> (i0 + k)) & 1u;
+                                if ((slmask >> (i0 + k)) & 1u) a = is_cr ? 1.0 : 0.0;
+                                const double d = a - prod[k];
+                                a = is_cr ? pa[k] : d;
+                            } else {
+                                a = a - prod[k];                       // rounded difference
+                            }
                         }
                     }
                 }
@@ -1877,18 +1882,26 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
                         prod[k].x = ccr * pii[k].x;                    // rounded products
                         prod[k].y = ccr * pii[k].y;
                     }
+                    if (((gen >> i0) & 0xfu) == 0u) {                  // (uniform) the bare chain: ONE branch per four links
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if ((gen >> (i0 + k)) & 1u) {                  // (uniform; rare)
-                            const bool is_cr = (crmask >> (i0 + k)) & 1u;
-                            if ((my_sm >> (i0 + k)) & 1u)      y.x = is_cr ? 1.0 : 0.0;
-                            if ((my_sm >> (16 + i0 + k)) & 1u) y.y = is_cr ? 1.0 : 0.0;
-                            const double dx = y.x - prod[k].x, dy = y.y - prod[k].y;
-                            y.x = is_cr ? pii[k].x : dx;
-                            y.y = is_cr ? pii[k].y : dy;
-                        } else {
+                        for (int k = 0; k < 4; ++k) {
                             y.x = y.x - prod[k].x;
                             y.y = y.y - prod[k].y;
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if ((gen >> (i0 + k)) & 1u) {              // (uniform; rare)
+                                const bool is_cr = (crmask >> (i0 + k)) & 1u;
+                                if ((my_sm >> (i0 + k)) & 1u)      y.x = is_cr ? 1.0 : 0.0;
+                                if ((my_sm >> (16 + i0 + k)) & 1u) y.y = is_cr ? 1.0 : 0.0;
+                                const double dx = y.x - prod[k].x, dy = y.y - prod[k].y;
+                                y.x = is_cr ? pii[k].x : dx;
+                                y.y = is_cr ? pii[k].y : dy;
+                            } else {
+                                y.x = y.x - prod[k].x;
+                                y.y = y.y - prod[k].y;
+                            }
                         }
                     }
                 }
