@@ -1642,7 +1642,12 @@ int mi355x_multibatch_download(mi355x_multibatch *mb, int64_t k, double *hm, int
 void mi355x_multibatch_destroy(mi355x_multibatch *mb) { mb_free(mb); }
 
 // ---- column-partitioned shards ------------------------------------------------------
+static int shard_price_x(mi355x_tab *t, int is_max, int64_t col_offset, double *dev_out2, const P2pArgs &x);
 int mi355x_shard_price(mi355x_tab *t, int is_max, int64_t col_offset, double *dev_out2)
+{
+    return shard_price_x(t, is_max, col_offset, dev_out2, P2pArgs());
+}
+static int shard_price_x(mi355x_tab *t, int is_max, int64_t col_offset, double *dev_out2, const P2pArgs &x)
 {
     if (!t || !dev_out2) return fail(MI_BAD_ARG, "NULL argument");
     int rc = use_device(t);
@@ -1652,7 +1657,7 @@ int mi355x_shard_price(mi355x_tab *t, int is_max, int64_t col_offset, double *de
     t->shard_is_max = is_max ? 1 : 0;
     t->v.col_bias = t->v.p2l ? 0 : col_offset;        // a dense shard's column 0 is global column col_offset
     const int np = (t->n_part > 0 && t->part_is_max == (is_max ? 1 : 0)) ? t->n_part : 0;
-    launch_shard_price(t->v, is_max, col_offset, dev_out2, np, t->stream);
+    launch_shard_price(t->v, is_max, col_offset, dev_out2, np, t->stream, x);
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }
@@ -1687,8 +1692,15 @@ int mi355x_shard_pivot(mi355x_tab *t, const int64_t *dev_col_bits, const int64_t
 }
 
 // ---- blocked column shards: step j of a block, then the sweep --------------
+static int shard_la_contribute_x(mi355x_tab *t, int j, const double *dev_gathered, int n_shards, int64_t col_offset,
+                                 double f, int64_t *dev_col_bits, int64_t *dev_ec, const P2pArgs &x);
 int mi355x_shard_la_contribute(mi355x_tab *t, int j, const double *dev_gathered, int n_shards,
                                int64_t col_offset, double f, int64_t *dev_col_bits, int64_t *dev_ec)
+{
+    return shard_la_contribute_x(t, j, dev_gathered, n_shards, col_offset, f, dev_col_bits, dev_ec, P2pArgs());
+}
+static int shard_la_contribute_x(mi355x_tab *t, int j, const double *dev_gathered, int n_shards, int64_t col_offset,
+                                 double f, int64_t *dev_col_bits, int64_t *dev_ec, const P2pArgs &x)
 {
     if (!t || !dev_gathered || !dev_col_bits || !dev_ec) return fail(MI_BAD_ARG, "NULL argument");
     if (n_shards < 1 || j < 0 || j >= kMaxBlock) return fail(MI_BAD_ARG, "n_shards < 1 or step outside [0,%d)", kMaxBlock);
@@ -1697,12 +1709,19 @@ int mi355x_shard_la_contribute(mi355x_tab *t, int j, const double *dev_gathered,
     if (rc != MI_OK) return rc;
     rc = ensure_dense(t);
     if (rc != MI_OK) return rc;
-    launch_shard_la_contribute(t->v, j, dev_gathered, n_shards, col_offset, f, dev_col_bits, dev_ec, t->stream);
+    launch_shard_la_contribute(t->v, j, dev_gathered, n_shards, col_offset, f, dev_col_bits, dev_ec, t->stream, x);
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }
 
+static int shard_la_pivot_x(mi355x_tab *t, int j, const int64_t *dev_col_bits, const int64_t *dev_ec, double f,
+                            const P2pArgs &x);
 int mi355x_shard_la_pivot(mi355x_tab *t, int j, const int64_t *dev_col_bits, const int64_t *dev_ec, double f)
+{
+    return shard_la_pivot_x(t, j, dev_col_bits, dev_ec, f, P2pArgs());
+}
+static int shard_la_pivot_x(mi355x_tab *t, int j, const int64_t *dev_col_bits, const int64_t *dev_ec, double f,
+                            const P2pArgs &x)
 {
     if (!t || !dev_col_bits || !dev_ec) return fail(MI_BAD_ARG, "NULL argument");
     if (j < 0 || j >= kMaxBlock) return fail(MI_BAD_ARG, "step outside [0,%d)", kMaxBlock);
@@ -1713,7 +1732,7 @@ int mi355x_shard_la_pivot(mi355x_tab *t, int j, const int64_t *dev_col_bits, con
     if (rc != MI_OK) return rc;
     // the step prices the local objective-row slice as it will be, for the next mi355x_shard_price
     t->n_part = launch_shard_la_prepare(t->v, j, reinterpret_cast<const double *>(dev_col_bits), dev_ec, f,
-                                        t->shard_is_max, t->stream);
+                                        t->shard_is_max, t->stream, x);
     t->part_is_max = t->shard_is_max;
     HIP_TRY(hipGetLastError());
     return MI_OK;
@@ -1892,13 +1911,11 @@ __global__ __launch_bounds__(256) void k_local_sum(const long long *all, long lo
 // flag, fence or counter.  Producers never wait for anybody (a shard's pricing precedes its own
 // waits in its stream), so the scheme cannot deadlock; a shard can run at most one pivot ahead of
 // the slowest one (it needs that one's pair to go on), hence two parities.
-constexpr int32_t kExchangeLost = 104;      // device status: a peer's data never arrived (-> MI_RCCL_ERROR)
-struct P2pLayout {
-    int world; int64_t rows_p;
-    __host__ __device__ int64_t pair_off(unsigned par, int r) const { return ((int64_t)par * world + r) * 4; }
-    __host__ __device__ int64_t col_off(unsigned par) const { return (int64_t)2 * world * 4 + (int64_t)par * 2 * rows_p; }
-    __host__ __device__ int64_t granules() const { return (int64_t)2 * world * 4 + (int64_t)4 * rows_p; }
-};
+// (layout and tag conventions: P2pLayout / P2pArgs in simplex_kernels.h.  The blocked shard steps run
+// FUSED -- the pricing kernel pushes the pair, the contribution kernel waits for the pairs and pushes
+// the column, the split look-ahead step waits for the column: four launches per pivot and shard; the
+// kernels below are the unfused forms, used by the per-pivot path, the one-workgroup look-ahead step
+// of small shards and the drive-out pivots of the two-phase hand-over)
 __device__ __forceinline__ void st_sys(unsigned long long *p, unsigned long long v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2256,6 +2273,24 @@ int cp_winner_rank(const double *g, int world)
     return best < 0 ? 0 : best;
 }
 
+// Exchange mode 2, blocked shards: one pivot of shard s as its three fused phases --
+//   0  pricing kernel, which also pushes this shard's pair into every shard's buffer
+//   1  contribution kernel: waits for all pairs, chains, and (the owner) pushes the column
+//   2  the look-ahead step: its split form waits for the column itself; the one-workgroup form of
+//      small shards takes it from the (unfused) wait kernel
+// On ONE stream (logical shards) phase k of every shard is enqueued before phase k + 1 of any.
+int cp_fused_p2p_step(mi355x_colpart *p, CpShard &s, double f, int j, unsigned epoch, int phase)
+{
+    P2pArgs x;
+    x.peers = s.d_peers; x.mine = s.xch; x.lay = p->lay; x.rank = s.index; x.epoch = epoch; x.max_spins = p->p2p_spins;
+    if (phase == 0) return shard_price_x(s.t, p->is_max, s.col_begin, s.send, x);
+    if (phase == 1) return shard_la_contribute_x(s.t, j, s.gathered, p->world, s.col_begin, f, (int64_t *)s.bits, s.ec, x);
+    if (shard_la_split(s.t->v)) return shard_la_pivot_x(s.t, j, (const int64_t *)s.bits_in, s.ec, f, x);
+    int rc = cp_p2p_column(p, s, epoch, false, true);
+    if (rc != MI_OK) return rc;
+    return mi355x_shard_la_pivot(s.t, j, (const int64_t *)s.bits_in, s.ec, f);
+}
+
 // n iterations of shard s over RCCL (its own thread in the one-process form).  j0 = step of the
 // block the first iteration is; every shard runs the same sequence, so they meet in the collectives.
 int cp_run_rccl(mi355x_colpart *p, CpShard &s, double f, int64_t n, int j0)
@@ -2266,9 +2301,22 @@ int cp_run_rccl(mi355x_colpart *p, CpShard &s, double f, int64_t n, int j0)
         const bool timed = p->timing_stride > 0 && i % p->timing_stride == 0 &&
                            (size_t)s.ev_used + 4 <= s.ev.size();
         hipEvent_t *e = timed ? &s.ev[(size_t)s.ev_used] : nullptr;
+        const unsigned epoch = p->xepoch + (unsigned)i + 1u;     // (mode 2: the tag of this pivot's granules)
+        if (p->exchange == 2 && p->block > 1) {
+            // mode 2, blocked: the exchanges are INSIDE the step kernels -- four launches per pivot
+            int rc = cp_fused_p2p_step(p, s, f, j, epoch, 0);
+            if (rc == MI_OK) rc = cp_fused_p2p_step(p, s, f, j, epoch, 1);
+            if (rc == MI_OK) rc = cp_fused_p2p_step(p, s, f, j, epoch, 2);
+            if (rc != MI_OK) return rc;
+            if (++j == p->block) {
+                rc = mi355x_shard_sweep(s.t);
+                if (rc != MI_OK) return rc;
+                j = 0;
+            }
+            continue;
+        }
         int rc = mi355x_shard_price(s.t, p->is_max, s.col_begin, s.send);
         if (rc != MI_OK) return rc;
-        const unsigned epoch = p->xepoch + (unsigned)i + 1u;     // (mode 2: the tag of this pivot's granules)
         if (timed) HIP_TRY(hipEventRecord(e[0], s.t->stream));
         if (p->exchange == 2) { if ((rc = cp_p2p_push_pair(p, s, epoch)) != MI_OK) return rc; }
         else RCCL_TRY(rccl().AllGather(s.send, s.gathered, 2, ncclDouble, s.comm, s.t->stream));
@@ -2363,6 +2411,15 @@ int cp_run(mi355x_colpart *p, double f, int64_t n)
     for (int64_t i = 0; i < n; ++i) {
         int rc;
         const unsigned epoch = ++p->xepoch;
+        if (p->exchange == 2 && p->block > 1) {
+            for (int phase = 0; phase < 3; ++phase)
+                for (CpShard &s : p->sh) if ((rc = cp_fused_p2p_step(p, s, f, p->j, epoch, phase)) != MI_OK) return rc;
+            if (++p->j == p->block) {
+                for (CpShard &s : p->sh) if ((rc = mi355x_shard_sweep(s.t)) != MI_OK) return rc;
+                p->j = 0;
+            }
+            continue;
+        }
         for (CpShard &s : p->sh) if ((rc = cp_price(p, s)) != MI_OK) return rc;
         if (p->exchange == 2) {
             // the P2P protocol on one device and ONE stream: all producers of an exchange are

@@ -69,6 +69,27 @@ constexpr int kMaxLaWorkgroups = 32;
 static_assert(sizeof(BlockCtl::done) / sizeof(int64_t) == kMaxLaWorkgroups, "BlockCtl::done");
 constexpr int kMaxLaRecords = 4 * kMaxLaWorkgroups;     // one record per wave of a 256-thread workgroup
 
+// Column partition, exchange mode 2 (the shards write into each other's fine-grained buffers):
+// layout of one shard's exchange buffer in 8-byte granules {tag = pivot number, 32 bits of payload}
+//     pairs  [2 parities][world][4]      the local pricing winners (key, global column)
+//     column [2 parities][2 x rows_p]    the entering column
+// and what a kernel needs to take part: every shard's buffer as THIS process maps it, the own one,
+// the own rank, the tag of this pivot and the poll bound.  peers == nullptr: not in this mode.
+constexpr int32_t kExchangeLost = 104;      // device status: a peer's data never arrived (-> MI_RCCL_ERROR)
+struct P2pLayout {
+    int world; int64_t rows_p;
+    __host__ __device__ int64_t pair_off(unsigned par, int r) const { return ((int64_t)par * world + r) * 4; }
+    __host__ __device__ int64_t col_off(unsigned par) const { return (int64_t)2 * world * 4 + (int64_t)par * 2 * rows_p; }
+    __host__ __device__ int64_t granules() const { return (int64_t)2 * world * 4 + (int64_t)4 * rows_p; }
+};
+struct P2pArgs {
+    unsigned long long *const *peers = nullptr;
+    unsigned long long *mine = nullptr;
+    P2pLayout lay{};
+    int rank = 0;
+    unsigned epoch = 0, max_spins = 0;
+};
+
 // One tableau in HBM.  Row-major, leading dimension ld (a multiple of 16 doubles so
 // that every row starts on a 128-byte boundary and 16-byte vector accesses never
 // straddle rows); columns [cols, ld) are padding and hold zeros.
@@ -153,8 +174,12 @@ void set_sweep_shape(int tr, int nt);      // tuning hook
 void set_sweep_impl(int impl);             // tuning / test hook: 0 k_sweep16 for full blocks (default), 1 k_sweep always
 UpdateShape update_shape(const TabView &t);
 // column-partitioned shards (one shard = one handle)
+// x.peers != nullptr (exchange mode 2, FUSED form): the kernel also is the producer / consumer of
+// the exchange next to it -- the pricing kernel pushes the pair to every shard, the contribution
+// kernel waits for all pairs and (the owner) pushes the column, the split look-ahead step waits for
+// the column -- so that a pivot is four launches and no collective
 void launch_shard_price(const TabView &t, int is_max, int64_t col_offset, double *out2, int n_part,
-                        hipStream_t s);
+                        hipStream_t s, const P2pArgs &x = P2pArgs());
 void launch_shard_contribute(const TabView &t, const double *gathered, int n_shards,
                              int64_t col_offset, double fp_factor, int64_t *bits_out,
                              int64_t *ec_out, hipStream_t s);
@@ -171,9 +196,10 @@ void launch_shard_handover(const TabView &art, const TabView &mt, const int64_t 
 // ... and their blocked forms: step j of a block (no update), the sweep is launch_sweep
 void launch_shard_la_contribute(const TabView &t, int j, const double *gathered, int n_shards,
                                 int64_t col_offset, double fp_factor, int64_t *bits_out,
-                                int64_t *ec_out, hipStream_t s);
+                                int64_t *ec_out, hipStream_t s, const P2pArgs &x = P2pArgs());
 int  launch_shard_la_prepare(const TabView &t, int j, const double *col, const int64_t *ec_dev,
-                             double fp_factor, int is_max, hipStream_t s);
+                             double fp_factor, int is_max, hipStream_t s, const P2pArgs &x = P2pArgs());
+bool shard_la_split(const TabView &t);     // the look-ahead step of this shard is the multi-workgroup pair
 void set_shard_la_split(int mode);         // tuning / test hook: 0 by size, 1 one workgroup, 2 split over many
 // two-phase hand-over (src/simplex.lisp:437-451)
 // unit_basis: the basic columns of `art` are known to be exact unit vectors (column-parallel

@@ -562,23 +562,41 @@ __global__ __launch_bounds__(kScaleThreads) void k_select_scale(TabView t, int n
 // find-entering-column only: ctl->ec = column or -1.  With out2 (shard pricing) the local
 // best key (v*sgn) and its GLOBAL column (col_offset + local, as a double; -1 = none) go to a
 // device buffer instead, without the threshold (applied once on the global best later).
+// system-scope one-granule store / load (exchange mode 2: another GPU, or another process, is at the other end)
+__device__ __forceinline__ void st_sys(unsigned long long *p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ __launch_bounds__(kSelThreads) void k_price_only(TabView t, double sgn, double price_tol,
                                                            int64_t col_offset, double *out2,
-                                                           int n_part)
+                                                           int n_part, P2pArgs x)
 {
     __shared__ double    s_v[kSelWaves];
     __shared__ long long s_i[kSelWaves];
     const int64_t m = t.rows - 1, vc = t.cols - 1;
     const ValIdx e = n_part > 0 ? block_price_partials(t.part_v, t.part_i, t.part_s, n_part, s_v, s_i)
                                 : block_price(t.M + m * t.ld, vc, sgn, s_v, s_i, t.p2l, t.col_bias);
+    // compact shards price GLOBAL columns already
+    // (-2: the objective entry of GLOBAL column 0 is a NaN -- see price_cand: everybody stops)
+    const double pk = e.i < 0 ? 0.0 : e.v;
+    const double pc = e.i < 0 ? -1.0 : (e.s == kNanColumn0 ? -2.0 : (double)(e.i + (t.p2l ? 0 : col_offset)));
     if (threadIdx.x == 0) {
-        if (out2) {                                 // compact shards price GLOBAL columns already
-            out2[0] = e.i < 0 ? 0.0 : e.v;
-            // (-2: the objective entry of GLOBAL column 0 is a NaN -- see price_cand: everybody stops)
-            out2[1] = e.i < 0 ? -1.0 : (e.s == kNanColumn0 ? -2.0 : (double)(e.i + (t.p2l ? 0 : col_offset)));
-        } else {
-            t.ctl->ec = price_says_optimal(e, price_tol) ? -1 : e.i;
-        }
+        if (out2) { out2[0] = pk; out2[1] = pc; }
+        else      t.ctl->ec = price_says_optimal(e, price_tol) ? -1 : e.i;
+    }
+    if (x.peers && (int)threadIdx.x < x.lay.world) {         // exchange A, producer: my pair into slot `rank` of EVERY shard
+        const unsigned long long kb = (unsigned long long)__double_as_longlong(pk), cb = (unsigned long long)__double_as_longlong(pc);
+        unsigned long long *dst = x.peers[threadIdx.x] + x.lay.pair_off(x.epoch & 1u, x.rank);
+        const unsigned long long tg = (unsigned long long)x.epoch << 32;
+        st_sys(dst + 0, tg | (kb & 0xffffffffull));
+        st_sys(dst + 1, tg | (kb >> 32));
+        st_sys(dst + 2, tg | (cb & 0xffffffffull));
+        st_sys(dst + 3, tg | (cb >> 32));
     }
 }
 
@@ -1060,15 +1078,39 @@ __global__ __launch_bounds__(kScaleThreads) void k_la_scale(TabView t, int n_rp,
 // after the last step k_sweep.  The chain of the pending pivots needs col_i (every shard has the
 // whole exchanged column), prow_i on the shard's own columns and on its RHS copy (local), and the
 // pivot rows (identical everywhere), so it needs no exchange of its own.
-__global__ __launch_bounds__(kSelThreads) void k_shard_la_contribute(TabView t, int j, const double *gathered,
-                                                                    int n_shards, int64_t col_offset,
-                                                                    double price_tol, long long *bits_out,
-                                                                    int64_t *ec_out)
+__global__ __launch_bounds__(256) void k_shard_la_contribute(TabView t, int j, const double *gathered,
+                                                            int n_shards, int64_t col_offset,
+                                                            double price_tol, long long *bits_out,
+                                                            int64_t *ec_out, P2pArgs x)
 {
+    __shared__ double s_g[2 * 64];
     const bool running = t.ctl->status == kRunning;
     BlockCtl *blk = t.blk;
     const int64_t ldv = t.ld >> 1, vcl = t.cols - 1;
-    const int64_t gid = blockIdx.x * (int64_t)kSelThreads + threadIdx.x, gsz = (int64_t)gridDim.x * kSelThreads;
+    const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+    if (x.peers) {
+        // exchange A, consumer (every workgroup for itself): wait for every shard's pair of this pivot
+        int lost = 0;
+        if (running && (int)threadIdx.x < n_shards) {
+            const unsigned long long *src = x.mine + x.lay.pair_off(x.epoch & 1u, (int)threadIdx.x);
+            unsigned long long g[4];
+            for (unsigned spins = 0;; ++spins) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { g[k] = ld_sys(src + k); ok &= (unsigned)(g[k] >> 32) == x.epoch; }
+                if (ok) break;
+                if (spins > x.max_spins) { lost = 1; break; }
+            }
+            s_g[2 * threadIdx.x]     = __longlong_as_double((long long)(((g[1] & 0xffffffffull) << 32) | (g[0] & 0xffffffffull)));
+            s_g[2 * threadIdx.x + 1] = __longlong_as_double((long long)(((g[3] & 0xffffffffull) << 32) | (g[2] & 0xffffffffull)));
+        }
+        if (__syncthreads_or(lost)) {
+            if (threadIdx.x == 0) t.ctl->status = kExchangeLost;
+            if (gid == 0) *ec_out = -1;
+            return;
+        }
+        gathered = s_g;
+    }
     if (j == 0) {                                   // a new block starts (whatever the status)
         if (gid == 0) blk->n_pending = 0;
         const int64_t n = t.bk_stride > ldv ? t.bk_stride : ldv;
@@ -1087,19 +1129,42 @@ __global__ __launch_bounds__(kSelThreads) void k_shard_la_contribute(TabView t, 
     const int64_t ec = (running && !nan0 && !price_says_optimal(best, price_tol)) ? best.i : -1;
     const int64_t lc = ec < 0 ? -1 : (t.l2p ? t.l2p[ec] : ec - col_offset);
     const bool mine = ec >= 0 && lc >= 0 && lc < vcl;
+    // The RHS copy is carried from step to step: t.rhs holds it through the pending pivots 0 .. j-2
+    // (step j - 1 left it there), so this step adds ONE link -- the same operations in the same
+    // order as chaining all j links from the tableau, a j-th of the loads (every shard does this
+    // on all its rows at every step; only the owner chains a column).
+    const int64_t crp = j > 0 ? blk->cr[j - 1] : -1;
+    const double  prp = j > 0 ? t.bk_prow[(int64_t)(j - 1) * t.ld + vcl] : 0.0;
     for (int64_t r = gid; r < t.rows; r += gsz) {
         double a = mine ? t.M[r * t.ld + lc] : 0.0;
-        double b = ec >= 0 ? t.M[r * t.ld + vcl] : 0.0;
         if (ec >= 0) {
-            for (int i = 0; i < j; ++i) {
-                const bool   is_cr = r == blk->cr[i];
-                const double ci = t.bk_col[(int64_t)i * t.bk_stride + r];
-                if (mine) a = pend(a, lc == blk->slot[i], is_cr, ci, t.bk_prow[(int64_t)i * t.ld + lc]);
-                b = pend(b, false, is_cr, ci, t.bk_prow[(int64_t)i * t.ld + vcl]);
-            }
+            double b = j == 0 ? t.M[r * t.ld + vcl] : t.rhs[r];
+            if (j > 0) b = pend(b, false, r == crp, t.bk_col[(int64_t)(j - 1) * t.bk_stride + r], prp);
+            if (mine)                                   // four links' operands requested together: the chain is
+                for (int i0 = 0; i0 < j; i0 += 4) {     // j dependent subtractions, not j dependent round trips
+                    double ci[4], pi[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int i = i0 + k < j ? i0 + k : j - 1;
+                        ci[k] = t.bk_col[(int64_t)i * t.bk_stride + r];
+                        pi[k] = t.bk_prow[(int64_t)i * t.ld + lc];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (i0 + k < j) a = pend(a, lc == blk->slot[i0 + k], r == blk->cr[i0 + k], ci[k], pi[k]);
+                }
             t.rhs[r] = b;
         }
-        bits_out[r] = mine ? __double_as_longlong(a) : 0ll;
+        if (!x.peers) bits_out[r] = mine ? __double_as_longlong(a) : 0ll;
+        else if (mine) {
+            // exchange B, producer: the owner writes the column's granules straight into EVERY shard's buffer
+            const unsigned long long vb = (unsigned long long)__double_as_longlong(a), tg = (unsigned long long)x.epoch << 32;
+            const int64_t off = x.lay.col_off(x.epoch & 1u) + 2 * r;
+            for (int q = 0; q < x.lay.world; ++q) {
+                st_sys(x.peers[q] + off, tg | (vb & 0xffffffffull));
+                st_sys(x.peers[q] + off + 1, tg | (vb >> 32));
+            }
+        }
     }
     if (gid == 0) *ec_out = ec;
 }
@@ -1203,7 +1268,7 @@ __global__ __launch_bounds__(kSelThreads) void k_shard_la_prepare(TabView t, int
 //                        (J a template parameter: all operands requested up front), prow_J, the
 //                        objective row through pivot J priced on the way out (per-wave partials).
 __global__ __launch_bounds__(kGatherThreads) void k_shard_la_ratio(TabView t, int j, const double *col_src,
-                                                                   const int64_t *ec_dev, double ratio_thr)
+                                                                   const int64_t *ec_dev, double ratio_thr, P2pArgs x)
 {
     __shared__ double    s_v[kGatherThreads / 64];
     __shared__ long long s_i[kGatherThreads / 64];
@@ -1218,7 +1283,21 @@ __global__ __launch_bounds__(kGatherThreads) void k_shard_la_ratio(TabView t, in
                       !(c0.max_pivots > 0 && c0.n_pivots >= c0.max_pivots);
     ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
     if (live && r < t.rows) {
-        const double a = col_src[r];
+        double a;
+        if (x.peers) {
+            // exchange B, consumer: my row's two granules of this pivot's column, in my own buffer
+            const unsigned long long *src = x.mine + x.lay.col_off(x.epoch & 1u) + 2 * r;
+            unsigned long long lo, hi;
+            for (unsigned spins = 0;; ++spins) {
+                lo = ld_sys(src);
+                hi = ld_sys(src + 1);
+                if ((unsigned)(lo >> 32) == x.epoch && (unsigned)(hi >> 32) == x.epoch) break;
+                if (spins > x.max_spins) { ctl->status = kExchangeLost; lo = hi = 0ull; break; }
+            }
+            a = __longlong_as_double((long long)(((hi & 0xffffffffull) << 32) | (lo & 0xffffffffull)));
+        } else {
+            a = col_src[r];
+        }
         const double b = r < m ? t.rhs[r] : 0.0;
         t.bk_col[(int64_t)j * t.bk_stride + r] = a;
         if (t.p2l && !(fabs(a) <= 1.7976931348623157e308)) atomicOr(&ctl->poison, 1);   // compact shard: MI_NONFINITE
@@ -3648,7 +3727,7 @@ bool select_split_supported(const TabView &t)
 void launch_price_only(const TabView &t, int is_max, double f, hipStream_t s)
 {
     hipLaunchKernelGGL(k_price_only, dim3(1), dim3(kSelThreads), 0, s, t, sgn_of(is_max),
-                       (f / 8.0) * kClEpsilon, (int64_t)0, (double *)nullptr, 0);
+                       (f / 8.0) * kClEpsilon, (int64_t)0, (double *)nullptr, 0, P2pArgs());
 }
 void launch_ratio_only(const TabView &t, int64_t ec, double f, hipStream_t s)
 {
@@ -3660,10 +3739,10 @@ void launch_prepare_pivot(const TabView &t, int64_t ec, int64_t cr, hipStream_t 
     hipLaunchKernelGGL(k_prepare_pivot, dim3(1), dim3(kSelThreads), 0, s, t, ec, cr);
 }
 void launch_shard_price(const TabView &t, int is_max, int64_t col_offset, double *out2, int n_part,
-                        hipStream_t s)
+                        hipStream_t s, const P2pArgs &x)
 {
     hipLaunchKernelGGL(k_price_only, dim3(1), dim3(kSelThreads), 0, s, t, sgn_of(is_max), 0.0,
-                       col_offset, out2, n_part);
+                       col_offset, out2, n_part, x);
 }
 void launch_shard_contribute(const TabView &t, const double *gathered, int n_shards,
                              int64_t col_offset, double f, int64_t *bits_out, int64_t *ec_out,
@@ -3696,12 +3775,14 @@ void launch_shard_handover(const TabView &art, const TabView &mt, const int64_t 
 }
 void launch_shard_la_contribute(const TabView &t, int j, const double *gathered, int n_shards,
                                 int64_t col_offset, double f, int64_t *bits_out, int64_t *ec_out,
-                                hipStream_t s)
+                                hipStream_t s, const P2pArgs &x)
 {
-    int blocks = (int)((t.rows + kSelThreads - 1) / kSelThreads);
-    if (blocks > 256) blocks = 256;
-    hipLaunchKernelGGL(k_shard_la_contribute, dim3(blocks), dim3(kSelThreads), 0, s, t, j, gathered,
-                       n_shards, col_offset, (f / 8.0) * kClEpsilon, (long long *)bits_out, ec_out);
+    // 256-thread workgroups, one row per thread: the strided gather of the entering column (a 64-byte
+    // sector per row) needs many workgroups' memory pipelines (33 x 1024 threads: 12.5 us at 32769 rows)
+    int blocks = (int)((t.rows + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_shard_la_contribute, dim3(blocks), dim3(256), 0, s, t, j, gathered,
+                       n_shards, col_offset, (f / 8.0) * kClEpsilon, (long long *)bits_out, ec_out, x);
 }
 static int g_shard_la_split = 0;                     // 0 by size, 1 always one workgroup, 2 always split
 void set_shard_la_split(int mode) { g_shard_la_split = mode; }
@@ -3712,22 +3793,30 @@ static void launch_shard_la_scale_t(const TabView &t, int g2, int g1, const int6
     hipLaunchKernelGGL(k_shard_la_scale<J>, dim3(g2), dim3(kScaleThreads), 0, s, t, g1, ec_dev, sgn_of(is_max));
 }
 
+bool shard_la_split(const TabView &t)
+{
+    const int g1 = (int)((t.rows + kGatherThreads - 1) / kGatherThreads);
+    const int g2 = (int)(((t.ld >> 1) + kScaleThreads - 1) / kScaleThreads);
+    const bool fits = g1 <= t.part_cap / 2 && g2 * (kScaleThreads / 64) <= t.part_cap / 2;
+    return fits && (g_shard_la_split == 2 || (g_shard_la_split == 0 && (t.rows > 4096 || t.ld > 8192)));
+}
+
+// (x.peers != nullptr is honoured by the split form only: the caller checks shard_la_split())
 int launch_shard_la_prepare(const TabView &t, int j, const double *col, const int64_t *ec_dev, double f,
-                            int is_max, hipStream_t s)
+                            int is_max, hipStream_t s, const P2pArgs &x)
 {
     // one workgroup for small shards (one launch, ~10 us), the split pair for large ones (rows or
     // column pairs in the tens of thousands: config 5 as one shard on one GPU 1 536 -> 2 287 pivots/s)
     const int g1 = (int)((t.rows + kGatherThreads - 1) / kGatherThreads);
     const int g2 = (int)(((t.ld >> 1) + kScaleThreads - 1) / kScaleThreads);
-    const bool fits = g1 <= t.part_cap / 2 && g2 * (kScaleThreads / 64) <= t.part_cap / 2;
-    const bool split = fits && (g_shard_la_split == 2 || (g_shard_la_split == 0 && (t.rows > 4096 || t.ld > 8192)));
+    const bool split = shard_la_split(t);
     if (!split) {
         hipLaunchKernelGGL(k_shard_la_prepare, dim3(1), dim3(kSelThreads), 0, s, t, j, col, ec_dev,
                            0.0 + (f / 2.0) * kClEpsilon, sgn_of(is_max));
         return kSelWaves;                            // pricing partials left for the next step
     }
     hipLaunchKernelGGL(k_shard_la_ratio, dim3(g1), dim3(kGatherThreads), 0, s, t, j, col, ec_dev,
-                       0.0 + (f / 2.0) * kClEpsilon);
+                       0.0 + (f / 2.0) * kClEpsilon, x);
     switch (j) {
 #define MI_SLA(J) case J: launch_shard_la_scale_t<J>(t, g2, g1, ec_dev, is_max, s); break;
         MI_SLA(0) MI_SLA(1) MI_SLA(2) MI_SLA(3) MI_SLA(4) MI_SLA(5) MI_SLA(6) MI_SLA(7)

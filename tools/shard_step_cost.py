@@ -1,0 +1,28 @@
+"""What ONE shard of the 8-GPU column partition of config 5 costs per pivot on its own GPU: a
+tableau with config 5's 32768 constraints and an eighth of its 65536 structural columns is exactly
+the local work of one of eight shards (same rows, same slice width), run here as a single shard
+through mi355x_colpart_* -- with device-local exchanges, over a one-rank RCCL communicator
+(all-gather + all-reduce of the real sizes, no wire), and in the P2P mode (push / poll kernels on
+the shard's own buffer).  The 8-GPU rate is bounded by this plus the wire time of the exchanges.
+    python tools/shard_step_cost.py [pivots]"""
+import ctypes, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import importlib
+lp = importlib.import_module("linear-programming_amd")
+cp = importlib.import_module("linear-programming_amd.colpart")
+L = lp.capi.lib()
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+n, m = 65536 // 8, 32768
+seed = lp.synth.seed_for(5)
+for name, force, mode in (("device-local exchanges", "0", 0), ("one-rank RCCL: all-gather + int64 all-reduce", "1", 0),
+                          ("one-rank RCCL: all-gather + rooted broadcast", "1", 1), ("P2P push / poll kernels", "1", 2)):
+    os.environ["MI355X_COLPART_FORCE_RCCL"] = force
+    L.mi355x_tune_set_colpart_exchange(mode)
+    tab = cp.NativeColumnPartition.synthetic(n, m, seed, 1)
+    L.mi355x_tune_set_colpart_exchange(0)
+    tab.solve_async(32, reset=True); tab.sync()
+    t0 = time.perf_counter()
+    tab.solve_async(K); st, done = tab.sync()
+    dt = time.perf_counter() - t0
+    print("%-48s %7.1f us per pivot (%d pivots, status %d)" % (name, dt / K * 1e6, K, st), flush=True)
+    tab.close()
