@@ -463,6 +463,14 @@ def _timed_pivots(tab, k, torch, dist, world, sync_ranks=True, red_dev="cuda"):
     return dt, st, done
 
 
+def _state_digest(tab):
+    """Digest of what every rank holds of the solved state (basis + RHS column, both replicated):
+    equal digests <=> the same pivots were made on the same numbers."""
+    import hashlib
+    _, basis, _, last_col = tab.download(matrix=False, last_row=False)
+    return hashlib.sha256(basis.tobytes() + last_col.tobytes()).hexdigest()[:16]
+
+
 def one_shard_baseline(n, m, seed, device, steps, warmup, steady_pivots=0):
     """The SAME tableau as ONE shard on ONE GPU through the same driver (mi355x_colpart_*, device-
     local exchanges): the denominator of the north star's '>= 6 x pivots/sec at 8 GPUs vs 1'."""
@@ -590,6 +598,7 @@ def bench(args, rank, local_rank, world, progress=None):
             elapsed = float(tt.item())
     if st != capi.MI_RUNNING or done != args.warmup + args.steps:
         raise SystemExit("colpart: LP terminated early (status %d after %d pivots)" % (st, done))
+    digest = _state_digest(tab) if native else None
     R, C = m + 1, n + m + 1
     value = args.steps / elapsed
     exchange = None
@@ -652,8 +661,8 @@ def bench(args, rank, local_rank, world, progress=None):
         # broadcast (one host synchronisation per pivot for the root) and the collective-free P2P
         # push against the sync-free int64 all-reduce above
         exchange_modes = rec["exchange_modes"] = {
-            "int64_sum_allreduce": {"value": value, "unit": "pivots/s", "headline": True,
-                                    "steady_state_pivots_per_s": steady,
+            "int64_sum_allreduce": {"value": value, "unit": "pivots/s", "steady_state_pivots_per_s": steady,
+                                    "state_digest": digest,
                                     "what": "owner's bit patterns + zeros, ncclAllReduce(int64, SUM): no host synchronisation"}}
         for mode, name, what in ((1, "rooted_broadcast", "ncclBroadcast from the owner; the root is read back from the "
                                                          "all-gathered pricing winners: one stream synchronisation per pivot"),
@@ -669,6 +678,10 @@ def bench(args, rank, local_rank, world, progress=None):
                 dtb, stb, doneb = _timed_pivots(tab, args.steps, torch, dist, world)
                 if stb == capi.MI_RUNNING:
                     entry["value"] = args.steps / dtb
+                    # same start, same pivots, deterministic arithmetic: the state after the K pivots
+                    # must be the default mode's bit for bit, or the mode does not count
+                    entry["state_digest"] = _state_digest(tab)
+                    entry["identical_to_default_mode"] = entry["state_digest"] == digest
                     if steady_pivots:
                         dt3, st3, _ = _timed_pivots(tab, steady_pivots, torch, dist, world)
                         if st3 == capi.MI_RUNNING:
@@ -677,6 +690,30 @@ def bench(args, rank, local_rank, world, progress=None):
                 entry["error"] = str(e)
                 tab = make_native(0)
             exchange_modes[name] = entry
+        # the headline is the fastest mode whose result is bit-identical to the default mode's (every
+        # mode timed exactly K pivots from the same state; all of them are listed above)
+        best = max((nm for nm, en in exchange_modes.items()
+                    if en.get("value") and (nm == "int64_sum_allreduce" or en.get("identical_to_default_mode"))),
+                   key=lambda nm: exchange_modes[nm]["value"])
+        rec["default_mode"] = {"mode": "int64_sum_allreduce", "value": value, "steady_state_pivots_per_s": steady}
+        rec["value_mode"] = best
+        if best != "int64_sum_allreduce":
+            bv, bs = exchange_modes[best]["value"], exchange_modes[best].get("steady_state_pivots_per_s")
+            scale = bv / value
+            rec["value"] = bv
+            rec["ms_per_step"] = 1e3 / bv
+            rec["us_per_pivot"] = 1e6 / bv
+            rec["steady_state_pivots_per_s"] = bs
+            if rec.get("exchange"):                  # (the brackets were around the default mode's collectives)
+                rec["exchange"] = dict(rec["exchange"], measured_in_mode="int64_sum_allreduce")
+            for key in ("per_gpu_physical_GBps", "aggregate_GBps", "dense_equivalent_GBps"):
+                rec[key] *= scale
+            rec["roofline"]["achieved"] *= scale
+            rec["roofline"]["frac"] *= scale
+            if baseline:
+                rec["speedup_vs_one_gpu"] = bv / baseline["value"]
+                rec["steady_state_speedup_vs_one_gpu"] = (bs / baseline["steady_state_pivots_per_s"]) \
+                    if bs and baseline.get("steady_state_pivots_per_s") else None
     if native:
         tab.close()
     else:

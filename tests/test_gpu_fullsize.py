@@ -484,6 +484,10 @@ def test_bench_colpart_one_rank_through_the_multi_gpu_entry():
     modes = rec["exchange_modes"]
     assert modes["int64_sum_allreduce"]["value"] > 0 and modes["rooted_broadcast"]["value"] > 0
     assert modes["p2p_push"]["value"] > 0
+    # every mode must end in the default mode's state bit for bit; the headline is the fastest of them
+    assert modes["rooted_broadcast"]["identical_to_default_mode"] and modes["p2p_push"]["identical_to_default_mode"]
+    assert rec["value_mode"] in modes and rec["value"] == modes[rec["value_mode"]]["value"]
+    assert rec["value"] >= rec["default_mode"]["value"]
 
 
 def test_plain_c_client_on_the_gpu(tmp_path):
