@@ -184,6 +184,87 @@ def test_config5_full_size_64_pivots_rederived():
     L.mi355x_tab_destroy(h)
 
 
+def test_config5_full_size_32_pivots_vs_the_oracle():
+    """The same 32769 x 98305 tableau through the CPU ORACLE (OpenMP row-parallel restatement of
+    src/simplex.lisp:337-389, 453-461) on the box's host cores: the dense 25.8 GB tableau the GPU
+    generated is downloaded (sampled rows, the whole RHS column and objective row checked against
+    the numpy generator first), the oracle makes 32 pivots on it in host memory, the GPU makes
+    its 32 pivots (two blocks of the default path) in HBM, and then pivot trace, basis and EVERY
+    entry of the tableau must agree bit for bit."""
+    import time
+    n, m, K = 65536, 32768, 32
+    seed = lp.synth.seed_for(5)
+    t = lp.Tableau(None, lp.Problem(type="max"), None, None, n + m, m, {}, _handle=_synthetic_handle(n, m, seed))
+    t0 = time.perf_counter()
+    M = t.matrix                                       # the initial tableau as the GPU holds it
+    b = t.basis_columns.copy()
+    t_down = time.perf_counter() - t0
+    assert M.shape == (m + 1, n + m + 1)
+    # ... which is the generator's LP (linear-programming_amd/synth.py; its numpy form at this size
+    # would take minutes): sampled rows entirely, RHS column and objective row entirely
+    for i in (0, 1, 777, 16384, m - 1):
+        row = np.zeros(n + m + 1)
+        row[:n] = 0.05 + lp.synth.splitmix_u01(seed, i * n, n)
+        row[n + i] = 1.0
+        row[n + m] = float(n) * (0.25 + 0.5 * lp.synth.splitmix_u01(seed, n * m + i, 1)[0])
+        assert np.array_equal(M[i].view(np.int64), row.view(np.int64)), i
+    assert np.array_equal(M[:m, n + m], float(n) * (0.25 + 0.5 * lp.synth.splitmix_u01(seed, n * m, m)))
+    obj = np.zeros(n + m + 1)
+    obj[:n] = -(0.5 + lp.synth.splitmix_u01(seed, n * m + m, n))
+    assert np.array_equal(M[m].view(np.int64), obj.view(np.int64))
+    assert np.array_equal(b, np.arange(n, n + m))
+    t0 = time.perf_counter()
+    st, npiv, trace = oracle.solve(M, b, max_pivots=K, trace_cap=K, omp=True)
+    t_orc = time.perf_counter() - t0
+    assert (st, npiv) == (oracle.MAX_PIVOTS, K)
+    t._touch()
+    with pytest.raises(lp.SolverError):
+        lp.n_solve_tableau(t, max_pivots=K)
+    got = t.pivot_trace()
+    assert got.shape == trace.shape
+    bad = np.where((got != trace).any(axis=1))[0]
+    assert not len(bad), "first differing pivots %s: got %s, oracle %s" % (bad[:4], got[bad[:4]], trace[bad[:4]])
+    t0 = time.perf_counter()
+    G = t.matrix
+    assert G is not M
+    assert np.array_equal(t.basis_columns, b)
+    assert np.array_equal(G[:, -1].view(np.int64), M[:, -1].view(np.int64))      # RHS column
+    assert np.array_equal(G[m].view(np.int64), M[m].view(np.int64))              # objective row
+    for r0 in range(0, m + 1, 2048):                                             # everything
+        assert np.array_equal(G[r0:r0 + 2048].view(np.int64), M[r0:r0 + 2048].view(np.int64)), r0
+    t_cmp = time.perf_counter() - t0
+    assert lp.capi.lib().mi355x_tab_la_lost(t._h) == 0
+    del G, t
+    # ---- the SAME tableau as BASELINE config 5 specifies it: column-partitioned into 8 shards,
+    # the library's per-pivot loop with both exchanges per pivot (mi355x_colpart_*) -- 8 logical
+    # shards on this one GPU, i.e. everything of the 8-GPU run but the wire -- against the same
+    # oracle result, every entry; the default exchange and the collective-free P2P push
+    from importlib import import_module
+    cp = import_module("linear-programming_amd.colpart")
+    L = lp.capi.lib()
+    t_cp = []
+    for mode in (0, 2):
+        L.mi355x_tune_set_colpart_exchange(mode)
+        try:
+            part = cp.NativeColumnPartition.synthetic(n, m, seed, 8)
+        finally:
+            L.mi355x_tune_set_colpart_exchange(0)
+        assert part.info()["n_shards"] == 8
+        t0 = time.perf_counter()
+        rc, npv = part.solve(max_pivots=K)
+        t_cp.append(time.perf_counter() - t0)
+        assert (rc, npv) == (lp.capi.MI_MAX_PIVOTS, K)
+        Gp, bp, _, _ = part.download()
+        part.close()
+        assert np.array_equal(bp, b), mode
+        for r0 in range(0, m + 1, 2048):
+            assert np.array_equal(Gp[r0:r0 + 2048].view(np.int64), M[r0:r0 + 2048].view(np.int64)), (mode, r0)
+        del Gp
+    print("config 5 vs oracle: download %.1f s, oracle %.1f s for %d pivots (%d threads), download + compare %.1f s; "
+          "8 logical shards: %.3f s (device-local exchanges), %.3f s (P2P push)"
+          % (t_down, t_orc, K, oracle.omp_threads(), t_cmp, t_cp[0], t_cp[1]))
+
+
 # =========================================================================== the hand-off
 def _background_load(torch, stop_after_s=60.0):
     """A stream that keeps HBM busy (uneven load next to the look-ahead kernel): big device
