@@ -2670,14 +2670,16 @@ __device__ __forceinline__ ValIdx bb_reduce(ValIdx mine, unsigned myflag, BbMsg 
     return r;
 }
 
-template <int KB>
+template <int KB, bool SPLIT>
 __global__ __launch_bounds__(kBbThreads) void k_batch_block(TabView t, double sgn, double price_tol,
-                                                           double ratio_thr, const int split)
+                                                           double ratio_thr)
 {
-    // split == 0: the whole solve of the LP in this launch, look-ahead and sweeps alternating.
-    // split != 0: the look-ahead of ONE block only; col_i / prow_i / masks / pending list go to the
-    // LP's global block state and the sweep is a separate launch over ALL LPs (k_sweep with
-    // grid.z = LP), which uses every CU of the chip instead of one per LP.
+    // SPLIT == false: the whole solve of the LP in this launch, look-ahead and sweeps alternating.
+    // SPLIT == true: the look-ahead of ONE block only; col_i / prow_i / masks / pending list go to
+    // the LP's global block state and the sweep is a separate launch over ALL LPs (k_sweep with
+    // grid.z = LP), which uses every CU of the chip instead of one per LP.  (A template parameter:
+    // the look-ahead-only form carries neither the code nor the registers of the in-kernel sweep.)
+    constexpr bool split = SPLIT;
     static_assert(KB % 4 == 0 && KB <= 16, "chains in groups of four links; 16 + 16 mask bits per pair");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ BbMsg s_wp[kBbThreads / 64], s_wr[kBbThreads / 64];
@@ -2888,7 +2890,7 @@ __global__ __launch_bounds__(kBbThreads) void k_batch_block(TabView t, double sg
         // registers) and every fourth row; the row's col values come out of LDS as broadcasts.
         // The pairs left over beyond the last full strip: flat, operands from LDS.
         if (k > 0) {
-            constexpr int kSU = 4;                                 // rows in flight per thread
+            constexpr int kSU = KB >= 16 ? 2 : 4;                  // rows in flight per thread (16 pending pivots: 64 VGPRs of prow pairs)
             const int pp = tid & 255, rq = tid >> 8;               // pair within the strip, row phase
             const int64_t full = ldv & ~(int64_t)255;
             for (int64_t s0 = 0; s0 < full; s0 += 256) {
@@ -2975,19 +2977,29 @@ __global__ __launch_bounds__(kBbThreads) void k_batch_block(TabView t, double sg
 // n-solve-tableau (src/simplex.lisp:453-461) is then
 //     local pricing of the strip's objective entries -> this workgroup's best column
 //     ONE exchange: every workgroup publishes (key, logical column) AND that column itself
-//         (speculatively: 16 bytes per row); everybody reduces the G records to the same winner
-//         -- lexicographic (key, logical column) minimum = find-entering-column's lowest-index
-//         strict minimum -- and reads the winner's column, which is already there
-//     ratio test on (column, own RHS copy): identical in every workgroup, no exchange
-//     pivot row: the strip's own entries of row cr, normalised locally; rank-1 update of the
-//         strip, the RHS copy and the objective entries in registers
-// so a pivot costs one all-to-all exchange through L2 (about a microsecond) plus a few hundred
-// cycles of arithmetic, and no HBM traffic.  The operations on every element are n-pivot-row's
+//         (speculatively: 16 bytes per row) AND -- a moment later -- the result of
+//         find-pivoting-row on that column (it has the column and, like everybody, an identical
+//         copy of the RHS column); everybody reduces the G records to the same winner --
+//         lexicographic (key, logical column) minimum = find-entering-column's lowest-index strict
+//         minimum -- and reads the winner's column and pivot row, which are already there
+//     pivot row: the strip's own entries of row cr, normalised locally; the objective entries
+//         brought up to date, priced, the next candidate column computed as the update will leave
+//         it and published; the ratio test on it; and only then -- at the top of the next
+//         iteration, between asking for the records and looking at them -- the rank-1 update of
+//         the strip in registers
+// so a pivot costs one all-to-all exchange through L2 plus a few hundred cycles of arithmetic per
+// phase, and no HBM traffic.  What bounds it is the serial chain
+//     price -> publish -> ratio test on the candidate -> (L2) -> winner -> column + row -> pivot row
+// of ONE wave per SIMD (every instruction costs its full latency), which is why the order above
+// puts everything that is not on that chain (the strip update, the store traffic of the publish)
+// under a wait: measured per pivot at config 2, round 3: 4.3 us with the ratio test behind the
+// exchange and the update in front of it, 3.9 us in this order.  The operations on every element
+// are n-pivot-row's
 // (rounded product, rounded difference, true division), so pivots and bits are those of every
 // other path.  The tableau is read from HBM when the launch starts and written back when it ends
 // (optimal / unbounded / cap / a pivot the compact representation cannot follow).
 //
-// Exchange: slot (workgroup, epoch parity) = 8 record granules (4 in use) + 2 granules per row, every granule
+// Exchange: slot (workgroup, epoch parity) = 8 record granules (4 + the pivot row in use) + 2 granules per row, every granule
 // {tag = epoch, 32 bits of payload} written by one write-through store and polled with
 // L1-bypassing loads until the tag matches (as k_la_block's records).  Two parities suffice: a
 // workgroup can only publish epoch e + 2 after everybody has published e + 1, i.e. has finished
@@ -2999,6 +3011,66 @@ __global__ __launch_bounds__(kBbThreads) void k_batch_block(TabView t, double sg
 constexpr int kResThreads = 256;
 
 typedef double v16d __attribute__((ext_vector_type(16)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+// Two adjacent granules (a 16-byte aligned pair) by ONE store / ONE load.  Every granule carries its
+// own tag and is validated on its own, so all that is needed is that an aligned 8-byte half is never
+// torn -- which a naturally aligned 16-byte access does not do.  LOCAL: every reader shares this
+// XCD's L2 (st_x).  Hand-issued: the compiler has no 16-byte access with these cache bits.
+template <bool LOCAL>
+__device__ __forceinline__ void st_pair(unsigned long long *p, unsigned long long g0, unsigned long long g1)
+{
+    const v4u v = { (unsigned)g0, (unsigned)(g0 >> 32), (unsigned)g1, (unsigned)(g1 >> 32) };
+    // (s_nop: a store of more than 8 bytes reads its data registers for a few cycles after it has
+    // issued; the compiler pads its own such stores, it cannot see into this one -- without the
+    // padding the next pair's payload overwrote this one's in flight: records that never validate)
+    if (LOCAL) asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 2" :: "v"(p), "v"(v) : "memory");
+    else       asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ unsigned long long pair_lo(const v4u &v) { return ((unsigned long long)v.y << 32) | v.x; }
+__device__ __forceinline__ unsigned long long pair_hi(const v4u &v) { return ((unsigned long long)v.w << 32) | v.z; }
+// N granule pairs + one more pair + one single granule, all loads in flight together, L1 bypassed
+// (sc1: what ld_l2 compiles to); the wait is part of the statement -- the compiler does not count
+// these loads
+template <int N> struct PairLoads;
+template <> struct PairLoads<1> {
+    static __device__ __forceinline__ void run(v4u (&r)[1], v4u &rm, unsigned long long &g, const unsigned long long *const (&a)[1],
+                                               const unsigned long long *am, const unsigned long long *ag)
+    {
+        asm volatile("global_load_dwordx4 %0, %3, off sc1\n\t"
+                     "global_load_dwordx4 %1, %4, off sc1\n\t"
+                     "global_load_dwordx2 %2, %5, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(r[0]), "=&v"(rm), "=&v"(g) : "v"(a[0]), "v"(am), "v"(ag) : "memory");
+    }
+};
+template <> struct PairLoads<2> {
+    static __device__ __forceinline__ void run(v4u (&r)[2], v4u &rm, unsigned long long &g, const unsigned long long *const (&a)[2],
+                                               const unsigned long long *am, const unsigned long long *ag)
+    {
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                     "global_load_dwordx4 %1, %5, off sc1\n\t"
+                     "global_load_dwordx4 %2, %6, off sc1\n\t"
+                     "global_load_dwordx2 %3, %7, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(r[0]), "=&v"(r[1]), "=&v"(rm), "=&v"(g) : "v"(a[0]), "v"(a[1]), "v"(am), "v"(ag) : "memory");
+    }
+};
+template <> struct PairLoads<4> {
+    static __device__ __forceinline__ void run(v4u (&r)[4], v4u &rm, unsigned long long &g, const unsigned long long *const (&a)[4],
+                                               const unsigned long long *am, const unsigned long long *ag)
+    {
+        asm volatile("global_load_dwordx4 %0, %6, off sc1\n\t"
+                     "global_load_dwordx4 %1, %7, off sc1\n\t"
+                     "global_load_dwordx4 %2, %8, off sc1\n\t"
+                     "global_load_dwordx4 %3, %9, off sc1\n\t"
+                     "global_load_dwordx4 %4, %10, off sc1\n\t"
+                     "global_load_dwordx2 %5, %11, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(rm), "=&v"(g)
+                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(am), "v"(ag) : "memory");
+    }
+};
 
 template <int TR, int CW, bool EVERY>
 __global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(TabView t, const ResidentArgs a)
@@ -3010,9 +3082,9 @@ __global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(Tab
     __shared__ int       s_wi[2][NW];
     __shared__ unsigned  s_wf[2][NW];
     __shared__ __attribute__((aligned(16))) double s_row[CW];    // raw pivot-row entries of the strip (owner wave only)
-    __shared__ __attribute__((aligned(16))) double s_prow[CW + 2];   // normalised; [CW] = rhs[cr] / piv
+    __shared__ __attribute__((aligned(16))) double s_prow[2][CW + 2];   // normalised, by pivot parity; [CW] = rhs[cr] / piv
     __shared__ long long s_win[8];                               // the exchange's winner, from wave 0 to the others
-    __shared__ long long s_leave;                                // logical column that leaves the basis
+    __shared__ long long s_leave[2];                             // logical column that leaves the basis (by pivot parity)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x, xq = b >> 3;
     const int64_t lpi = (int64_t)(xq / a.G) * 8 + (b & 7);
@@ -3063,7 +3135,7 @@ __global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(Tab
     bool local = false;
     int it = 0;
 #ifdef MI355X_RES_TIMING
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define RES_T(i) T##i = wall_clock64()
 #else
 #define RES_T(i)
@@ -3096,30 +3168,34 @@ __global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(Tab
     // record + column of epoch `ep`: v[] = my rows' entries of local column lcb, vobj = its objective entry
     auto publish = [&](unsigned ep, const double (&v)[TR], double vobj, bool mute) {
         unsigned long long *slot = xb + ((int64_t)wg * 2 + (ep & 1u)) * a.xs_slot;
-        if (wave == 0 && !mute) {
+        unsigned long long *cg = slot + 8;
+        const unsigned long long tg = (unsigned long long)ep << 32;
+        unsigned val = 0u;
+        if (wave == 0) {
             const unsigned long long vb = dbits(cc.v);
             const unsigned iw = (cc.i < 0 ? kEmptyIdx : (unsigned)cc.i) | (pnan0 ? 0x80000000u : 0u);
             const unsigned word[4] = { (unsigned)vb, (unsigned)(vb >> 32), iw, (unsigned)lcb | (xcc_id() << 8) };
-            unsigned val = word[0];
+            val = word[0];
 #pragma unroll
             for (int k = 1; k < 4; ++k) val = lane == k ? word[k] : val;
-            if (lane < 4) st_x(&slot[lane], ((unsigned long long)ep << 32) | val, local);
         }
-        unsigned long long *cg = slot + 8;
-        const unsigned long long tg = (unsigned long long)ep << 32;
+        const bool rec = wave == 0 && lane < 4 && !mute;
+        // (ONE branch on `local`, not one per store: as st_x calls this was thirty branches per pivot)
+        auto stores = [&](auto loc) {
+            constexpr bool L = decltype(loc)::value;
+            if (rec) st_x(&slot[lane], tg | val, L);
 #pragma unroll
-        for (int k = 0; k < TR; ++k)
-            if (valid[k]) {
-                const int r = tid + kResThreads * k;
-                const unsigned long long vb = dbits(v[k]);
-                st_x(&cg[2 * r], tg | (vb & 0xffffffffull), local);
-                st_x(&cg[2 * r + 1], tg | (vb >> 32), local);
+            for (int k = 0; k < TR; ++k)
+                if (valid[k]) {
+                    const unsigned long long vb = dbits(v[k]);
+                    st_pair<L>(&cg[2 * (tid + kResThreads * k)], tg | (vb & 0xffffffffull), tg | (vb >> 32));
+                }
+            if (tid == lcb) {
+                const unsigned long long vb = dbits(vobj);
+                st_pair<L>(&cg[2 * m], tg | (vb & 0xffffffffull), tg | (vb >> 32));
             }
-        if (tid == lcb) {
-            const unsigned long long vb = dbits(vobj);
-            st_x(&cg[2 * m], tg | (vb & 0xffffffffull), local);
-            st_x(&cg[2 * m + 1], tg | (vb >> 32), local);
-        }
+        };
+        if (local) stores(std::true_type()); else stores(std::false_type());
     };
     // my rows' entries of local column c (uniform): a macro, not a lambda -- a closure that indexes x
     // dynamically makes the compiler keep the whole strip in scratch memory
@@ -3133,43 +3209,158 @@ __global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(Tab
         }                                                                                       \
     } while (0)
     double vnext[TR];                                             // my rows' entries of column lcb, as published
+    // find-pivoting-row on this workgroup's OWN candidate column, ahead of the exchange: should the
+    // candidate win, its pivot row is what everybody needs next -- so it travels as a second part
+    // of the record (granule 4, published as soon as it is known, while the records travel) instead
+    // of being worked out by every workgroup after the column has arrived.  Same data (the column
+    // as published, the RHS copy that every workgroup holds identically), same result.
+    // 30 low bits: the pivot row; bits 30..31: 0 = a pivot row, 1 = no eligible row (MI_UNBOUNDED),
+    // 2 = inf / NaN in the column or a NaN quotient (kNeedDense)
+    unsigned spec = 0u;
+    // (a macro, as RES_COLUMN_OF: see there)
+#define RES_RATIO_AHEAD(ep_, par_, mute_)                                                                   \
+    do {                                                                                                    \
+        const double vobj_ = lane_value_dyn(obj, lcb);           /* (every wave holds the objective entries) */ \
+        Cand rbest_; rbest_.v = 0.0; rbest_.i = -1;                                                         \
+        unsigned flags_ = 0u;                                                                               \
+        if (!(fabs(vobj_) <= 1.7976931348623157e308)) flags_ = 1u;                                          \
+        _Pragma("unroll") for (int k = 0; k < TR; ++k)                                                      \
+            if (valid[k]) {                                                                                 \
+                const double av_ = vnext[k];                                                                \
+                if (!(fabs(av_) <= 1.7976931348623157e308)) flags_ = 1u;                                    \
+                if (a.ratio_thr < av_) {                                                                    \
+                    const double qv_ = rhs[k] / av_;                                                        \
+                    if (qv_ != qv_) flags_ = 1u;                 /* a NaN quotient: decided on the dense path (kNeedDense) */ \
+                    else {                                                                                  \
+                        Cand c_; c_.v = qv_; c_.i = tid + kResThreads * k;                                  \
+                        rbest_ = cand_min(rbest_, c_);                                                      \
+                    }                                                                                       \
+                }                                                                                           \
+            }                                                                                               \
+        {                                                                                                   \
+            int src_;                                                                                       \
+            const Cand w_ = wave_argmin(rbest_, src_);                                                      \
+            const unsigned wf_ = __any(flags_ != 0u) ? 1u : 0u;                                             \
+            if (lane == 0) { s_wv[par_][wave] = w_.v; s_wi[par_][wave] = w_.i; s_wf[par_][wave] = wf_; }    \
+        }                                                                                                   \
+        __syncthreads();                                         /* barrier B */                            \
+        Cand q_; q_.v = s_wv[par_][0]; q_.i = s_wi[par_][0];                                                \
+        unsigned allf_ = s_wf[par_][0];                                                                     \
+        _Pragma("unroll") for (int w = 1; w < NW; ++w) {                                                    \
+            Cand y_; y_.v = s_wv[par_][w]; y_.i = s_wi[par_][w];                                            \
+            q_ = cand_min(q_, y_);                                                                          \
+            allf_ |= s_wf[par_][w];                                                                         \
+        }                                                                                                   \
+        spec = allf_ ? (2u << 30) : (q_.i < 0 ? (1u << 30) : (unsigned)q_.i);                               \
+        if (a.G > 1 && tid == 0 && !(mute_)) {                                                              \
+            unsigned long long *slot_ = xb + ((int64_t)wg * 2 + ((ep_) & 1u)) * a.xs_slot;                  \
+            st_x(&slot_[4], ((unsigned long long)(ep_) << 32) | spec, local);                               \
+        }                                                                                                   \
+    } while (0)
     price_local();
     RES_COLUMN_OF(lcb, vnext);
     if (a.G > 1) publish(a.epoch_base + 1u, vnext, obj, a.fault > 0 && wg == a.G - 1);
+    RES_RATIO_AHEAD(a.epoch_base + 1u, 0, a.fault > 0 && wg == a.G - 1);
+
+    // The strip update of pivot k is the first thing iteration k + 1 does -- AFTER it has asked for
+    // the records of pivot k + 1 and before it looks at what came back: the update (pure register /
+    // LDS work) runs while the polls travel.  What it needs of pivot k stays in these variables; the
+    // normalised row stays in LDS (two buffers, by pivot parity: the owner wave of the next pivot row
+    // writes the other one).
+    double col[TR];                                               // my rows' entries of the entering column
+    bool   is_cr[TR];
+    bool   mine = false;                                          // the entering column of the pending update is in MY strip
+    int    lc = 0;                                                // ... there
+#pragma unroll
+    for (int k = 0; k < TR; ++k) { col[k] = 0.0; is_cr[k] = false; }
 
 #pragma unroll 1
-    for (; it < a.cap; ++it) {
+    for (;; ++it) {
 #ifdef MI355X_RES_TIMING
-        unsigned long long T0 = 0, T1 = 0, T2 = 0, T3 = 0, T4 = 0, T5 = 0, T6 = 0;
+        unsigned long long T0 = 0, T1 = 0, T2 = 0, T3 = 0, T4 = 0, T5 = 0, T6 = 0, T7 = 0, T8 = 0, T9 = 0, T10 = 0;
 #endif
         RES_T(0);
         const unsigned epoch = a.epoch_base + (unsigned)it + 1u;
-        const int par = it & 1;
+        const bool go = it < a.cap;
+        // ---- ask for everybody's records of this pivot.  Few workgroups per LP: EVERY wave polls the
+        // (small) records itself -- no LDS hop, no workgroup barrier between the exchange and the
+        // column read (batch of 512 x 256 LPs, 8 workgroups each: 9.2 -> 9.7 M pivots/s); many: wave 0
+        // polls and hands the winner over through LDS (config 2, 32 workgroups: 240 k pivots/s against
+        // 232 k with four times the poll traffic)
+        constexpr bool every_wave = EVERY;                        // (the launcher: G <= 8)
+        const bool poller = a.G > 1 && go && (every_wave || wave == 0);
+        const bool have = lane < a.G;
+        const unsigned long long *rp = xb + ((int64_t)(have ? lane : 0) * 2 + (epoch & 1u)) * a.xs_slot;
+        unsigned long long g[4] = {0ull, 0ull, 0ull, 0ull};
+        if (poller) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] = ld_l2(&rp[k]);
+        }
+        // ---- rank-1 update of the strip with the PREVIOUS pivot (n-pivot-row), while those loads travel
+        if (it > 0) {
+            const double *pw = s_prow[(it - 1) & 1];
+            if (mine) {
+                const int lh = lc >> 4, lj = lc & 15;
+#pragma unroll
+                for (int k = 0; k < TR; ++k) {
+                    const double unit = is_cr[k] ? 1.0 : 0.0;
+#pragma unroll
+                    for (int h = 0; h < CH; ++h)
+                        if (h == lh) x[k][h][lj] = unit;          // (uniform)
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < CH; ++h) {
+#pragma unroll
+                for (int j0 = 0; j0 < 16; j0 += 8) {
+                    double p8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const double2 pp = *reinterpret_cast<const double2 *>(&pw[h * 16 + j0 + j]);
+                        p8[j] = pp.x; p8[j + 1] = pp.y;
+                    }
+#pragma unroll
+                    for (int k = 0; k < TR; ++k) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const double prod = col[k] * p8[j];   // rounded product
+                            x[k][h][j0 + j] = x[k][h][j0 + j] - prod;   // rounded difference
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < TR; ++k)
+                if (is_cr[k]) {                                   // ONE thread of the workgroup: the pivot row itself
+#pragma unroll
+                    for (int c = 0; c < CW; c += 2) {
+                        const double2 pp = *reinterpret_cast<const double2 *>(&pw[c]);
+                        x[k][c >> 4][c & 15] = pp.x;
+                        x[k][c >> 4][(c & 15) + 1] = pp.y;
+                        if ((c & 7) == 6) __builtin_amdgcn_sched_barrier(0);   // (a few loads in flight, not CW / 2: registers)
+                    }
+                }
+        }
+        if (!go) break;                                           // (the pivot cap of this launch)
+        RES_T(1);
         ValIdx e;
-        int owner = wg, lc = lcb;
+        int owner = wg;
+        lc = lcb;
         if (a.G > 1) {
-            // ---- everybody's records -> the same winner everywhere.  Few workgroups per LP: EVERY
-            // wave polls the (small) records itself -- no LDS hop, no workgroup barrier between the
-            // exchange and the column read (batch of 512 x 256 LPs, 8 workgroups each: 9.2 -> 9.7 M
-            // pivots/s); many: wave 0 polls and hands the winner over through LDS (config 2, 32
-            // workgroups: 240 k pivots/s against 232 k with four times the poll traffic)
-            constexpr bool every_wave = EVERY;                    // (the launcher: G <= 8)
+            // ---- everybody's records -> the same winner everywhere
             long long win[7];
-            if (every_wave || wave == 0) {
-                const bool have = lane < a.G;
-                const unsigned long long *rp = xb + ((int64_t)(have ? lane : 0) * 2 + (epoch & 1u)) * a.xs_slot;
-                unsigned long long g[4];
+            if (poller) {
                 unsigned spins = 0;
                 const unsigned limit = it == 0 ? a.spins_first : a.spins;
                 bool fine = true;
                 for (;;) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) g[k] = ld_l2(&rp[k]);
                     bool ok = true;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) ok &= (unsigned)(g[k] >> 32) == epoch;
                     if (__all(ok | !have)) break;
                     if (++spins > limit) { fine = false; break; }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) g[k] = ld_l2(&rp[k]);
                 }
                 Cand rc; rc.v = 0.0; rc.i = -1;
                 const unsigned iw = (unsigned)g[2];
@@ -3204,82 +3395,50 @@ __global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(Tab
         } else {
             e.v = cc.v; e.i = cc.i; e.s = pnan0 ? kNanColumn0 : lcb;
         }
-        RES_T(1);
+        RES_T(2);
         if (price_says_optimal(e, a.price_tol)) { status = 0; break; }                    // MI_OPTIMAL
         if (c0.max_pivots > 0 && n_piv >= c0.max_pivots) { status = 3; break; }          // MI_MAX_PIVOTS
         const int64_t ec = e.i;
-        // ---- the entering column: my rows' entries and the objective row's
-        double col[TR], colm;
-        unsigned flags = 0u;                                      // 1: inf / NaN (kNeedDense), 2: the column never arrived
+        // ---- the entering column (my rows' entries and the objective row's) and what its owner found
+        // on it: the pivot row
+        double colm;
+        unsigned p2 = spec;
         if (a.G > 1) {
-            const unsigned long long *wsl = xb + ((int64_t)owner * 2 + (epoch & 1u)) * a.xs_slot + 8;
-            unsigned long long gl[TR], gh[TR], ml, mh;
-            unsigned spins = 0;
-            const unsigned limit = it == 0 ? a.spins_first : a.spins;
+            const unsigned long long *wrec = xb + ((int64_t)owner * 2 + (epoch & 1u)) * a.xs_slot;
+            const unsigned long long *wsl = wrec + 8;
+            v4u gp[TR], gm;
+            unsigned long long g2;
+            const unsigned long long *ap[TR];
+#pragma unroll
+            for (int k = 0; k < TR; ++k) ap[k] = &wsl[2 * (valid[k] ? tid + (int64_t)kResThreads * k : m)];
+            // No bound on this wait.  Every workgroup of the LP has published its record of this epoch
+            // (above), so all of them are running, and between that record and these granules their
+            // owner waits for nobody: they WILL arrive, and a workgroup that the GPU takes off the CU
+            // for a while in between is waited for like at any barrier.  (A bound here -- a second way
+            // out of this loop next to the exit on the owner's result below -- also made the compiler
+            // move the whole strip between registers in every iteration.)
             for (;;) {
-                bool ok = true;
+                PairLoads<TR>::run(gp, gm, g2, ap, &wsl[2 * m], &wrec[4]);
+                bool ok = gm.y == epoch && gm.w == epoch && (unsigned)(g2 >> 32) == epoch;
 #pragma unroll
-                for (int k = 0; k < TR; ++k) {
-                    const int64_t r = valid[k] ? tid + (int64_t)kResThreads * k : m;
-                    gl[k] = ld_l2(&wsl[2 * r]);
-                    gh[k] = ld_l2(&wsl[2 * r + 1]);
-                }
-                ml = ld_l2(&wsl[2 * m]);
-                mh = ld_l2(&wsl[2 * m + 1]);
-#pragma unroll
-                for (int k = 0; k < TR; ++k) ok &= (unsigned)(gl[k] >> 32) == epoch && (unsigned)(gh[k] >> 32) == epoch;
-                ok &= (unsigned)(ml >> 32) == epoch && (unsigned)(mh >> 32) == epoch;
+                for (int k = 0; k < TR; ++k) ok &= gp[k].y == epoch && gp[k].w == epoch;
                 if (ok) break;
-                if (++spins > limit) { flags |= 2u; break; }
             }
 #pragma unroll
-            for (int k = 0; k < TR; ++k) col[k] = valid[k] ? join_bits(gl[k], gh[k]) : 0.0;
-            colm = join_bits(ml, mh);
+            for (int k = 0; k < TR; ++k) col[k] = valid[k] ? join_bits(pair_lo(gp[k]), pair_hi(gp[k])) : 0.0;
+            colm = join_bits(pair_lo(gm), pair_hi(gm));
+            p2 = (unsigned)g2;
         } else {
 #pragma unroll
             for (int k = 0; k < TR; ++k) col[k] = valid[k] ? vnext[k] : 0.0;
             colm = lane_value_dyn(obj, lc);                       // (every wave holds the objective entries)
         }
-        RES_T(2);
-        // ---- find-pivoting-row on (column, my RHS copy): the same in every workgroup
-        Cand rbest; rbest.v = 0.0; rbest.i = -1;
-        if (!(fabs(colm) <= 1.7976931348623157e308)) flags |= 1u;
-#pragma unroll
-        for (int k = 0; k < TR; ++k)
-            if (valid[k]) {
-                const double av = col[k];
-                if (!(fabs(av) <= 1.7976931348623157e308)) flags |= 1u;
-                if (a.ratio_thr < av) {
-                    const double qv = rhs[k] / av;
-                    if (qv != qv) flags |= 1u;                    // a NaN quotient: decided on the dense path (kNeedDense)
-                    else {
-                        Cand c; c.v = qv; c.i = tid + kResThreads * k;
-                        rbest = cand_min(rbest, c);
-                    }
-                }
-            }
-        {
-            int src;
-            const Cand w = wave_argmin(rbest, src);
-            unsigned wf = 0u;
-            if (__any(flags != 0u)) wf = (__any((flags & 1u) != 0u) ? 1u : 0u) | (__any((flags & 2u) != 0u) ? 2u : 0u);   // (rare)
-            if (lane == 0) { s_wv[par][wave] = w.v; s_wi[par][wave] = w.i; s_wf[par][wave] = wf; }
-        }
-        __syncthreads();                                          // barrier B
-        Cand q; q.v = s_wv[par][0]; q.i = s_wi[par][0];
-        unsigned allf = s_wf[par][0];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) {
-            Cand y; y.v = s_wv[par][w]; y.i = s_wi[par][w];
-            q = cand_min(q, y);
-            allf |= s_wf[par][w];
-        }
-        if (allf & 2u) { lost = true; break; }
-        if (allf & 1u) { status = kNeedDense; break; }
-        if (q.i < 0) { status = 1; break; }                      // MI_UNBOUNDED
-        const int cr = __builtin_amdgcn_readfirstlane(q.i);
+        const unsigned code = (unsigned)__builtin_amdgcn_readfirstlane((int)(p2 >> 30));
+        if (code != 0u) { status = code == 2u ? kNeedDense : 1; break; }   // (1: MI_UNBOUNDED)
+        const int cr = __builtin_amdgcn_readfirstlane((int)(p2 & 0x3fffffffu));
         const int otid = cr & (kResThreads - 1), okk = cr >> 8;
-        const bool mine = owner == wg;
+        mine = owner == wg;
+        double *pw = s_prow[it & 1];
         RES_T(3);
         // ---- the pivot row's entries of this strip, normalised -- inside the wave that owns row cr
         if (wave == (otid >> 6)) {
@@ -3293,7 +3452,7 @@ __global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(Tab
                             *reinterpret_cast<double2 *>(&s_row[c]) = make_double2(x[k][c >> 4][c & 15], x[k][c >> 4][(c & 15) + 1]);
                         pivl = col[k];
                         rhsl = rhs[k];
-                        s_leave = bas[k];
+                        s_leave[it & 1] = bas[k];
                         bas[k] = ec;                              // src/simplex.lisp:358
                     }
             }
@@ -3304,29 +3463,30 @@ __global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(Tab
             if (lane < CW) {
                 double rv = s_row[lane];
                 if (mine && lane == lc) rv = 1.0;                 // the slot takes over the leaving column e_cr
-                s_prow[lane] = (lane < ncl) ? rv / piv : 0.0;
+                pw[lane] = (lane < ncl) ? rv / piv : 0.0;
             }
-            if (lane == 0) s_prow[CW] = rhsc / piv;
+            if (lane == 0) pw[CW] = rhsc / piv;
         }
         __syncthreads();                                          // barrier C
-        const int64_t leaving = s_leave;
-        const double prhs = s_prow[CW];
+        const int64_t leaving = s_leave[it & 1];
+        const double prhs = pw[CW];
         RES_T(4);
         // ---- objective entries through the pivot (every wave: its own copy), priced at once; the
-        // workgroup's best column for the NEXT pivot as the update below will leave it -> published
+        // workgroup's best column for the NEXT pivot as the update will leave it -> published
         if (lane < CW) {
-            const double pr = s_prow[lane];
+            const double pr = pw[lane];
             if (mine && lane == lc) { obj = 0.0; lidx = (int)leaving; }
             const double prod = colm * pr;
             obj = obj - prod;
         }
-        bool is_cr[TR];
 #pragma unroll
         for (int k = 0; k < TR; ++k) is_cr[k] = valid[k] && tid + kResThreads * k == cr;
+        RES_T(8);
         price_local();
+        RES_T(9);
         {
             RES_COLUMN_OF(lcb, vnext);
-            const double pl = s_prow[lcb];
+            const double pl = pw[lcb];
             const bool slot_col = mine && lcb == lc;
 #pragma unroll
             for (int k = 0; k < TR; ++k) {
@@ -3336,51 +3496,12 @@ __global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(Tab
                 vnext[k] = is_cr[k] ? pl : d;
             }
         }
-        if (a.G > 1 && it + 1 < a.cap) publish(epoch + 1u, vnext, obj, false);
+        const bool more = it + 1 < a.cap;
+        RES_T(10);
+        if (a.G > 1 && more) publish(epoch + 1u, vnext, obj, false);
         RES_T(5);
-        // ---- rank-1 update of the strip, the RHS copy and the objective value (n-pivot-row), while
-        // the records travel
-        if (mine) {
-            const int lh = lc >> 4, lj = lc & 15;
-#pragma unroll
-            for (int k = 0; k < TR; ++k) {
-                const double unit = is_cr[k] ? 1.0 : 0.0;
-#pragma unroll
-                for (int h = 0; h < CH; ++h)
-                    if (h == lh) x[k][h][lj] = unit;              // (uniform)
-            }
-        }
-#pragma unroll
-        for (int h = 0; h < CH; ++h) {
-#pragma unroll
-            for (int j0 = 0; j0 < 16; j0 += 8) {
-                double p8[8];
-#pragma unroll
-                for (int j = 0; j < 8; j += 2) {
-                    const double2 pp = *reinterpret_cast<const double2 *>(&s_prow[h * 16 + j0 + j]);
-                    p8[j] = pp.x; p8[j + 1] = pp.y;
-                }
-#pragma unroll
-                for (int k = 0; k < TR; ++k) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const double prod = col[k] * p8[j];       // rounded product
-                        x[k][h][j0 + j] = x[k][h][j0 + j] - prod; // rounded difference
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < TR; ++k)
-            if (is_cr[k]) {                                       // ONE thread of the workgroup: the pivot row itself
-#pragma unroll
-                for (int c = 0; c < CW; c += 2) {
-                    const double2 pp = *reinterpret_cast<const double2 *>(&s_prow[c]);
-                    x[k][c >> 4][c & 15] = pp.x;
-                    x[k][c >> 4][(c & 15) + 1] = pp.y;
-                    if ((c & 7) == 6) __builtin_amdgcn_sched_barrier(0);   // (a few loads in flight, not CW / 2: registers)
-                }
-            }
+        // ---- the RHS copy and the objective value through the pivot; then the ratio test on the
+        // candidate just published, and its result behind it
 #pragma unroll
         for (int k = 0; k < TR; ++k) {
             const double prod = col[k] * prhs;
@@ -3391,6 +3512,8 @@ __global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(Tab
             const double prod = colm * prhs;
             objv = objv - prod;
         }
+        if (more) RES_RATIO_AHEAD(epoch + 1u, (it + 1) & 1, false);
+        RES_T(6);
         // ---- bookkeeping
         if (mine && tid == lc) {
             t.l2p[ec] = -1;
@@ -3401,14 +3524,15 @@ __global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(Tab
         n_piv += 1; tn += 1;
 #ifdef MI355X_RES_TIMING
         if (a.G > 1) {
-            RES_T(6);
+            RES_T(7);
             tacc[0] += 1; tacc[1] += T1 - T0; tacc[2] += T2 - T1; tacc[3] += T3 - T2; tacc[4] += T4 - T3;
-            tacc[5] += T5 - T4; tacc[6] += T6 - T5;
+            tacc[5] += T5 - T4; tacc[6] += T6 - T5; tacc[7] += T7 - T6;
+            tacc[8] += T8 - T4; tacc[9] += T9 - T8; tacc[10] += T10 - T9; tacc[11] += T5 - T10;
         }
 #endif
     }
 #ifdef MI355X_RES_TIMING
-    if (leader && t.rhs) for (int k = 0; k < 8; ++k) t.rhs[k] += (double)tacc[k];
+    if (leader && t.rhs) for (int k = 0; k < 12; ++k) t.rhs[k] += (double)tacc[k];
 #endif
 
     if (lost) {
@@ -3853,13 +3977,19 @@ static bool launch_batch_block_t(const TabView &t, int is_max, double f, hipStre
     if (bytes > 150 * 1024) return false;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_block<KB>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_block<KB, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_block<KB, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void)hipGetLastError();
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_batch_block<KB>, dim3(1, 1, (unsigned)t.n_lps), dim3(kBbThreads), bytes, s, t,
-                       sgn_of(is_max), (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon, split);
+    if (split)
+        hipLaunchKernelGGL((k_batch_block<KB, true>), dim3(1, 1, (unsigned)t.n_lps), dim3(kBbThreads), bytes, s, t,
+                           sgn_of(is_max), (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon);
+    else
+        hipLaunchKernelGGL((k_batch_block<KB, false>), dim3(1, 1, (unsigned)t.n_lps), dim3(kBbThreads), bytes, s, t,
+                           sgn_of(is_max), (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon);
     return true;
 }
 
@@ -4128,7 +4258,7 @@ void launch_la_block(const TabView &t, int ksteps, int is_max, double f, unsigne
 // ---- the resident solve
 static int g_res_fault = 0, g_res_poll = 0;
 void set_resident_fault(int on) { g_res_fault = on; }
-void set_resident_poll(int mode) { g_res_poll = mode; }     // tuning: 0 by size, 1 wave 0 polls, 2 every wave polls
+void set_resident_poll(int mode) { g_res_poll = mode; }     // tuning: 0 / 2 every wave polls (default), 1 wave 0 polls
 
 bool resident_plan(const TabView &c, ResidentPlan *p)
 {
@@ -4174,7 +4304,10 @@ bool launch_resident(const TabView &c, unsigned long long *xbuf, int is_max, dou
     a.fault = g_res_fault;
     const unsigned groups = (unsigned)((c.n_lps + 7) / 8);
     const dim3 grid(groups * 8u * (unsigned)p.G);
-    const bool every = g_res_poll == 0 ? p.G <= 8 : g_res_poll == 2;
+    // who polls the records: every wave for itself (no LDS hop, no workgroup barrier behind the
+    // exchange) -- measured round 3, final loop: config 2 (32 workgroups) 257 k pivots/s against 247 k
+    // with wave 0 polling for the workgroup, 128-LP batch 10.3 against 9.8 M
+    const bool every = g_res_poll != 1;
 #define MI_RES(TR_, CW_)                                                                                       \
     do {                                                                                                       \
         if (every) hipLaunchKernelGGL((k_resident<TR_, CW_, true>),  grid, dim3(kResThreads), 0, s, c, a);    \
@@ -4214,7 +4347,9 @@ int launch_sweep(const TabView &t, int kmax, double sgn, hipStream_t s, unsigned
     // 114), fewer when the tableau would otherwise not fill the chip with workgroups
     int64_t tr = g_sweep_tr;
     if (tr == 0) {
-        tr = 32;
+        // (a short block leaves most of the registers free: more, smaller tiles in flight --
+        // config 3, 4 pending pivots: 8 rows 87 us, 16 rows 89, 32 rows 97, 64 rows 95)
+        tr = kmax <= 4 ? 8 : kmax <= 8 ? 16 : 32;
         while (tr > 4 && ((t.rows + tr - 1) / tr) * strips < 2048) tr /= 2;
     }
     while ((t.rows + tr - 1) / tr > 65535) tr *= 2;            // grid.y limit
