@@ -18,6 +18,9 @@ python bench.py --workload cfg4 --batch-lps 1024 > $O/bench_cfg4_1024.log 2>&1; 
 python bench.py --workload cfg2 --steps 128 --no-cpu-baseline > $O/bench_cfg2.log 2>&1; echo "bench cfg2 rc=$?"
 python tools/native_end_to_end.py > $O/native_end_to_end.log 2>&1; echo "native end to end rc=$?"; tail -3 $O/native_end_to_end.log
 python bench.py --workload colpart --steps 64 --warmup 16 > $O/bench_colpart_1gpu.log 2>&1; echo "bench colpart rc=$?"
+python tools/shard_step_cost.py 256 2>&1 | grep "us per pivot" > $O/shard_step_cost.log; echo "shard step cost rc=$?"
+(python tools/resident_timing.py; python tools/resident_timing.py 512 256) 2>&1 | grep -E "us/pivot|inside" > $O/resident_timing.log; echo "resident timing rc=$?"
+python tools/resident_ab.py 2>&1 | grep "poll mode" > $O/resident_ab.log; echo "resident A/B rc=$?"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats -- python $R/bench.py --no-cpu-baseline --no-per-pivot > $O/kernel_stats.log 2>&1; echo "rocprof stats rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats_cfg4 -- python $R/bench.py --workload cfg4 > $O/kernel_stats_cfg4.log 2>&1; echo "rocprof stats cfg4 rc=$?"

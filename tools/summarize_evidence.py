@@ -54,6 +54,11 @@ def main(tag):
                 open(os.path.join(PR, tag + dst), "w").write(last_json(f) + "\n")
             except IndexError:
                 print("no JSON line in", log)
+    for log, dst in (("shard_step_cost.log", "_shard_step_cost.txt"), ("resident_timing.log", "_resident_timing.txt"),
+                     ("resident_ab.log", "_resident_poll_ab.txt"), ("native_end_to_end.log", "_native_end_to_end.log")):
+        f = one(log, required=False)
+        if f and os.path.getsize(f):
+            shutil.copy(f, os.path.join(PR, tag + dst))
     out = {"workload": "cfg3", "kernels": {}}
     dense_ld = (8192 + 4096 + 1 + 15) // 16 * 16
     for variant, kernels in (("", ("k_sweep16", "k_la_block")), ("perpivot_", ("k_update", "k_select_gather", "k_select_scale"))):
