@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """GPU tests run kernels that wait for each other (persistent look-ahead, resident solve, P2P
+    exchanges).  Their waits are bounded or deadlock-free by construction -- but should a change
+    break that, a test must END (pytest-timeout's thread method terminates the process, which tears
+    the GPU context down) instead of holding the GPU box until the lease is killed."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(600, method="thread"))
+
+
 def pytest_sessionstart(session):
     """Make sure the native pieces exist before any test imports them: the HIP extension
     (hipcc cross-compiles without a GPU) and the C oracle.  Both are no-ops when up to date."""
