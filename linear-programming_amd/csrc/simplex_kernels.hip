@@ -1495,6 +1495,48 @@ __device__ __forceinline__ unsigned xcc_id()
 constexpr int kLaThreads = 256;
 constexpr unsigned kEmptyIdx = 0x7fffffffu;
 
+// a 16-byte aligned pair of granules as ONE 16-byte access (every granule is validated on its own,
+// and a naturally aligned 16-byte access never tears an aligned 8-byte half)
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned long long pair_lo(const v4u &v) { return ((unsigned long long)v.y << 32) | v.x; }
+__device__ __forceinline__ unsigned long long pair_hi(const v4u &v) { return ((unsigned long long)v.w << 32) | v.z; }
+// one or two whole records (64 bytes each) per lane: four 16-byte loads per record, all in flight,
+// L1 bypassed (sc1: what ld_l2 compiles to), the wait inside the statement (the compiler does not
+// count these loads).  Half the requests of eight 8-byte loads per record -- and a wave's poll is
+// bound by its requests: the lanes are a record (a 64-byte line) apart.
+__device__ __forceinline__ void load_record(unsigned long long (&g)[8], const ExchRec *r)
+{
+    v4u q0, q1, q2, q3;
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                 "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32 sc1\n\t"
+                 "global_load_dwordx4 %3, %4, off offset:48 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(r) : "memory");
+    g[0] = pair_lo(q0); g[1] = pair_hi(q0); g[2] = pair_lo(q1); g[3] = pair_hi(q1);
+    g[4] = pair_lo(q2); g[5] = pair_hi(q2); g[6] = pair_lo(q3); g[7] = pair_hi(q3);
+}
+__device__ __forceinline__ void load_records2(unsigned long long (&g)[8], unsigned long long (&h)[8],
+                                              const ExchRec *r, const ExchRec *r2)
+{
+    v4u q0, q1, q2, q3, p0, p1, p2, p3;
+    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\t"
+                 "global_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %8, off offset:32 sc1\n\t"
+                 "global_load_dwordx4 %3, %8, off offset:48 sc1\n\t"
+                 "global_load_dwordx4 %4, %9, off sc1\n\t"
+                 "global_load_dwordx4 %5, %9, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %6, %9, off offset:32 sc1\n\t"
+                 "global_load_dwordx4 %7, %9, off offset:48 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3)
+                 : "v"(r), "v"(r2) : "memory");
+    g[0] = pair_lo(q0); g[1] = pair_hi(q0); g[2] = pair_lo(q1); g[3] = pair_hi(q1);
+    g[4] = pair_lo(q2); g[5] = pair_hi(q2); g[6] = pair_lo(q3); g[7] = pair_hi(q3);
+    h[0] = pair_lo(p0); h[1] = pair_hi(p0); h[2] = pair_lo(p1); h[3] = pair_hi(p1);
+    h[4] = pair_lo(p2); h[5] = pair_hi(p2); h[6] = pair_lo(p3); h[7] = pair_hi(p3);
+}
+
 __device__ __forceinline__ unsigned long long dbits(double x) { return (unsigned long long)__double_as_longlong(x); }
 __device__ __forceinline__ double join_bits(unsigned long long lo, unsigned long long hi)
 {
@@ -1688,12 +1730,8 @@ __device__ __forceinline__ bool la_exchange(ValIdx mine, unsigned myflag, ExchRe
         unsigned spins = 0;
         bool fine = true;
         for (;;) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) g0[k] = ld_l2(&r0->g[k]);
-            if (nrec > 64) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) g1[k] = ld_l2(&r1->g[k]);
-            }
+            if (nrec > 64) load_records2(g0, g1, r0, r1);
+            else           load_record(g0, r0);
             bool ok0 = true, ok1 = true;
 #pragma unroll
             for (int k = 0; k < 8; ++k) { ok0 &= (unsigned)(g0[k] >> 32) == tag; ok1 &= (unsigned)(g1[k] >> 32) == tag; }
@@ -3011,7 +3049,6 @@ __global__ __launch_bounds__(kBbThreads) void k_batch_block(TabView t, double sg
 constexpr int kResThreads = 256;
 
 typedef double v16d __attribute__((ext_vector_type(16)));
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 // Two adjacent granules (a 16-byte aligned pair) by ONE store / ONE load.  Every granule carries its
 // own tag and is validated on its own, so all that is needed is that an aligned 8-byte half is never
@@ -3027,8 +3064,6 @@ __device__ __forceinline__ void st_pair(unsigned long long *p, unsigned long lon
     if (LOCAL) asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 2" :: "v"(p), "v"(v) : "memory");
     else       asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" :: "v"(p), "v"(v) : "memory");
 }
-__device__ __forceinline__ unsigned long long pair_lo(const v4u &v) { return ((unsigned long long)v.y << 32) | v.x; }
-__device__ __forceinline__ unsigned long long pair_hi(const v4u &v) { return ((unsigned long long)v.w << 32) | v.z; }
 // N granule pairs + one more pair + one single granule, all loads in flight together, L1 bypassed
 // (sc1: what ld_l2 compiles to); the wait is part of the statement -- the compiler does not count
 // these loads
