@@ -53,7 +53,11 @@ int         mi355x_tune_set_colpart_exchange(int mode);      /* column partition
                                                                 write pricing pairs and the entering
                                                                 column straight into each other's
                                                                 fine-grained buffers (P2P / IPC over
-                                                                xGMI), self-validating granules    */
+                                                                xGMI), self-validating granules; a
+                                                                shard that has its device to itself
+                                                                steps in two launches, 3 the same
+                                                                with the four launches per step of
+                                                                shards that share a stream         */
 /* one process per GPU in exchange mode 2: the ranks' exchange buffers are mapped into each other's
  * address space through IPC handles.  With a communicator (an id from mi355x_rccl_unique_id) the
  * library all-gathers the handles itself when the handle is created; with id128 == NULL no

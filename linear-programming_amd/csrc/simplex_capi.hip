@@ -2037,7 +2037,8 @@ struct mi355x_colpart {
     int     block = kMaxBlock, j = 0;        // pivots per sweep, steps of the current block enqueued
     int     is_max = 1;
     int     timing_stride = 0;               // 0 = no exchange timing, k = every k-th pivot
-    int     exchange = 0;                    // g_cp_exchange when the handle was created
+    int     exchange = 0;                    // g_cp_exchange when the handle was created (3 -> 2 with p2p_merged off)
+    bool    p2p_merged = true;               // mode 2: a shard that has its device to itself steps in two launches
     unsigned xepoch = 0;                     // P2P exchange: pivots exchanged so far (the granules' tags)
     unsigned p2p_spins = 1u << 24;           // polls before a shard gives a peer up (kExchangeLost)
     bool     p2p_connected = false;          // mode 2: every peer's buffer is mapped
@@ -2313,10 +2314,33 @@ int cp_run_rccl(mi355x_colpart *p, CpShard &s, double f, int64_t n, int j0)
         hipEvent_t *e = timed ? &s.ev[(size_t)s.ev_used] : nullptr;
         const unsigned epoch = p->xepoch + (unsigned)i + 1u;     // (mode 2: the tag of this pivot's granules)
         if (p->exchange == 2 && p->block > 1) {
-            // mode 2, blocked: the exchanges are INSIDE the step kernels -- four launches per pivot
-            int rc = cp_fused_p2p_step(p, s, f, j, epoch, 0);
-            if (rc == MI_OK) rc = cp_fused_p2p_step(p, s, f, j, epoch, 1);
-            if (rc == MI_OK) rc = cp_fused_p2p_step(p, s, f, j, epoch, 2);
+            // mode 2, blocked: the exchanges are INSIDE the step kernels -- two launches per pivot where
+            // the shards' kernels run concurrently (this loop: one shard per device or process), four
+            // for the first pivot after an upload and for small shards
+            int rc = MI_OK;
+            mi355x_tab *t = s.t;
+            const int np = (p->p2p_merged && t->n_part > 0 && t->part_is_max == (p->is_max ? 1 : 0)) ? t->n_part : 0;
+            int left = 0;
+            if (np > 0 && t->v.blk && j < kMaxBlock) {
+                P2pArgs x;
+                x.peers = s.d_peers; x.mine = s.xch; x.lay = p->lay; x.rank = s.index; x.epoch = epoch; x.max_spins = p->p2p_spins;
+                rc = use_device(t);
+                if (rc == MI_OK) rc = ensure_dense(t);
+                if (rc != MI_OK) return rc;
+                t->shard_is_max = p->is_max ? 1 : 0;
+                t->v.col_bias = t->v.p2l ? 0 : s.col_begin;
+                left = launch_shard_p2p_step(t->v, j, np, p->world, s.col_begin, f, t->shard_is_max, s.ec, t->stream, x);
+                if (left > 0) {
+                    t->n_part = left;
+                    t->part_is_max = t->shard_is_max;
+                    HIP_TRY(hipGetLastError());
+                }
+            }
+            if (left == 0) {
+                rc = cp_fused_p2p_step(p, s, f, j, epoch, 0);
+                if (rc == MI_OK) rc = cp_fused_p2p_step(p, s, f, j, epoch, 1);
+                if (rc == MI_OK) rc = cp_fused_p2p_step(p, s, f, j, epoch, 2);
+            }
             if (rc != MI_OK) return rc;
             if (++j == p->block) {
                 rc = mi355x_shard_sweep(s.t);
@@ -2521,7 +2545,7 @@ static int cp_create_synthetic(mi355x_colpart **out, int64_t n_vars, int64_t n_c
     *out = nullptr;
     if (world < 1 || n_vars < world || n_cons < 1) return fail(MI_BAD_ARG, "need 1 <= shards <= n_vars and n_cons >= 1");
     const bool mp = rank >= 0;
-    if (mp && (rank >= world || (!id128 && g_cp_exchange != 2)))
+    if (mp && (rank >= world || (!id128 && g_cp_exchange != 2 && g_cp_exchange != 3)))
         return fail(MI_BAD_ARG, "bad rank / id (a NULL id is accepted in exchange mode 2 only: no communicator, "
                                 "the host connects the ranks with mi355x_colpart_p2p_handle / _p2p_connect)");
     if (device_count_checked() <= 0) return fail(MI_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
@@ -2532,7 +2556,8 @@ static int cp_create_synthetic(mi355x_colpart **out, int64_t n_vars, int64_t n_c
     // (world == 1 in the one-process-per-GPU form: device-local exchanges, unless the test hook
     // MI355X_COLPART_FORCE_RCCL=1 asks for the one-rank ncclCommInitRank communicator)
     p->rccl = mp ? (world > 1 || cp_one_device_each(1)) : cp_one_device_each(world);
-    p->exchange = g_cp_exchange;
+    p->exchange = g_cp_exchange == 3 ? 2 : g_cp_exchange;
+    p->p2p_merged = g_cp_exchange != 3;
     p->compact = true;
     p->rows = n_cons + 1;
     p->var_count = n_vars + n_cons;
@@ -2616,7 +2641,8 @@ int mi355x_colpart_create_on(mi355x_colpart **out, int64_t rows, int64_t cols, c
     if (!p) return fail(MI_NO_MEMORY, "host allocation failed");
     p->world = n_devices;
     p->rccl = cp_one_device_each(n_devices);
-    p->exchange = g_cp_exchange;
+    p->exchange = g_cp_exchange == 3 ? 2 : g_cp_exchange;
+    p->p2p_merged = g_cp_exchange != 3;
     p->compact = compact;
     p->rows = rows;
     p->var_count = vc;
@@ -3093,7 +3119,7 @@ int         mi355x_tune_set_compact(int on) { g_compact_enabled = on ? 1 : 0; re
 int         mi355x_tune_set_sweep_impl(int impl) { set_sweep_impl(impl); return impl; }
 int         mi355x_tune_set_shard_la_split(int mode) { set_shard_la_split(mode); return mode; }
 int         mi355x_tune_set_tail_policy(int p) { g_tail_policy = p == 1 ? 1 : 0; return g_tail_policy; }
-int         mi355x_tune_set_colpart_exchange(int mode) { g_cp_exchange = (mode == 1 || mode == 2) ? mode : 0; return g_cp_exchange; }
+int         mi355x_tune_set_colpart_exchange(int mode) { g_cp_exchange = (mode >= 1 && mode <= 3) ? mode : 0; return g_cp_exchange; }
 /* measurement aid: the sweep of the CURRENT pending list launched n more times (the list is not
  * consumed by a sweep); average launch duration by HIP events.  Leaves the tableau meaningless. */
 int         mi355x_debug_repeat_sweep(mi355x_tab *t, int n, double *avg_us)

@@ -199,6 +199,8 @@ void launch_shard_la_contribute(const TabView &t, int j, const double *gathered,
                                 int64_t *ec_out, hipStream_t s, const P2pArgs &x = P2pArgs());
 int  launch_shard_la_prepare(const TabView &t, int j, const double *col, const int64_t *ec_dev,
                              double fp_factor, int is_max, hipStream_t s, const P2pArgs &x = P2pArgs());
+int  launch_shard_p2p_step(const TabView &t, int j, int n_part, int n_shards, int64_t col_offset, double fp_factor,
+                           int is_max, int64_t *ec_dev, hipStream_t s, const P2pArgs &x);
 bool shard_la_split(const TabView &t);     // the look-ahead step of this shard is the multi-workgroup pair
 void set_shard_la_split(int mode);         // tuning / test hook: 0 by size, 1 one workgroup, 2 split over many
 // two-phase hand-over (src/simplex.lisp:437-451)

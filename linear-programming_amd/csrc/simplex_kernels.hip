@@ -1267,6 +1267,148 @@ __global__ __launch_bounds__(kSelThreads) void k_shard_la_prepare(TabView t, int
 //                        slice of that row and of the objective row through the J pending pivots
 //                        (J a template parameter: all operands requested up front), prow_J, the
 //                        objective row through pivot J priced on the way out (per-wave partials).
+// Exchange mode 2 where a shard has its device (or at least its stream and the GPU's scheduler) to
+// itself: pricing pair out, everybody's pairs in, the entering column (chained by its owner and
+// pushed to the peers, or waited for) and the ratio-test partials as ONE launch -- what
+// k_price_only + k_shard_la_contribute + k_shard_la_ratio do in three.  A consumer and the
+// producer it waits for are then the same kernel on different shards, so this form needs the
+// shards' launches to run CONCURRENTLY (one device / process each); logical shards that share a
+// stream keep the three launches, where every producer of an exchange is enqueued before its
+// consumers.  Nobody waits in a cycle: a shard's pair is pushed by its first workgroup before that
+// workgroup waits for anything, and the owner of the column waits for nothing after the pairs.
+// n_part: pricing partials the previous step left (> 0; the first pivot after an upload goes
+// through the three launches).  One ratio partial per workgroup.
+__global__ __launch_bounds__(256) void k_shard_p2p_step(TabView t, int j, int n_part, int n_shards,
+                                                       int64_t col_offset, double price_tol, double ratio_thr,
+                                                       int64_t *ec_out, P2pArgs x)
+{
+    __shared__ double    s_v[256 / 64];
+    __shared__ long long s_i[256 / 64];
+    __shared__ double    s_g[2 * 64];
+    double  *rp_v = t.part_v + t.part_cap / 2;      // ratio partials: upper half of the buffers
+    int64_t *rp_i = t.part_i + t.part_cap / 2;
+    int64_t *rp_s = t.part_s + t.part_cap / 2;
+    Ctl *ctl = t.ctl;
+    const Ctl c0 = *ctl;
+    const bool running = c0.status == kRunning;
+    BlockCtl *blk = t.blk;
+    const int64_t ldv = t.ld >> 1, vcl = t.cols - 1, m = t.rows - 1;
+    const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+    const unsigned long long tg = (unsigned long long)x.epoch << 32;
+    // ---- exchange A, producer (the first workgroup): this shard's pricing pair into slot `rank` of EVERY shard
+    if (blockIdx.x == 0) {
+        const ValIdx e = block_price_partials<256>(t.part_v, t.part_i, t.part_s, n_part, s_v, s_i);
+        const double pk = e.i < 0 ? 0.0 : e.v;
+        const double pc = e.i < 0 ? -1.0 : (e.s == kNanColumn0 ? -2.0 : (double)(e.i + (t.p2l ? 0 : col_offset)));
+        if ((int)threadIdx.x < x.lay.world) {
+            const unsigned long long kb = (unsigned long long)__double_as_longlong(pk), cb = (unsigned long long)__double_as_longlong(pc);
+            unsigned long long *dst = x.peers[threadIdx.x] + x.lay.pair_off(x.epoch & 1u, x.rank);
+            st_sys(dst + 0, tg | (kb & 0xffffffffull));
+            st_sys(dst + 1, tg | (kb >> 32));
+            st_sys(dst + 2, tg | (cb & 0xffffffffull));
+            st_sys(dst + 3, tg | (cb >> 32));
+        }
+    }
+    // ---- exchange A, consumer (every workgroup for itself): every shard's pair of this pivot
+    {
+        int lost = 0;
+        if (running && (int)threadIdx.x < n_shards) {
+            const unsigned long long *src = x.mine + x.lay.pair_off(x.epoch & 1u, (int)threadIdx.x);
+            unsigned long long g[4];
+            for (unsigned spins = 0;; ++spins) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { g[k] = ld_sys(src + k); ok &= (unsigned)(g[k] >> 32) == x.epoch; }
+                if (ok) break;
+                if (spins > x.max_spins) { lost = 1; break; }
+            }
+            s_g[2 * threadIdx.x]     = __longlong_as_double((long long)(((g[1] & 0xffffffffull) << 32) | (g[0] & 0xffffffffull)));
+            s_g[2 * threadIdx.x + 1] = __longlong_as_double((long long)(((g[3] & 0xffffffffull) << 32) | (g[2] & 0xffffffffull)));
+        }
+        if (__syncthreads_or(lost)) {
+            if (threadIdx.x == 0) ctl->status = kExchangeLost;
+            if (gid == 0) *ec_out = -1;
+            if (threadIdx.x == 0) { rp_v[blockIdx.x] = 0.0; rp_i[blockIdx.x] = -1; rp_s[blockIdx.x] = 0; }
+            return;
+        }
+    }
+    if (j == 0) {                                   // a new block starts (whatever the status)
+        if (gid == 0) blk->n_pending = 0;
+        const int64_t n = t.bk_stride > ldv ? t.bk_stride : ldv;
+        for (int64_t idx = gid; idx < n; idx += gsz) {
+            if (idx < t.bk_stride) t.bk_rmask[idx] = 0u;
+            if (idx < ldv)         t.bk_smask[idx] = 0u;
+        }
+    }
+    ValIdx win; win.v = 0.0; win.i = -1; win.s = 0;
+    bool nan0 = false;                              // some shard holds a NaN in global column 0's objective entry
+    for (int k = 0; k < n_shards; ++k) {
+        ValIdx c; c.v = s_g[2 * k]; c.i = (int64_t)s_g[2 * k + 1]; c.s = 0;
+        nan0 |= s_g[2 * k + 1] == -2.0;
+        win = vi_min(win, c);
+    }
+    const int64_t ec = (running && !nan0 && !price_says_optimal(win, price_tol)) ? win.i : -1;
+    const int64_t lc = ec < 0 ? -1 : (t.l2p ? t.l2p[ec] : ec - col_offset);
+    const bool mine = ec >= 0 && lc >= 0 && lc < vcl;
+    const bool live = ec >= 0 && !(c0.max_pivots > 0 && c0.n_pivots >= c0.max_pivots);
+    // (k_shard_la_contribute: the RHS copy is carried from step to step, one link per step)
+    const int64_t crp = j > 0 ? blk->cr[j - 1] : -1;
+    const double  prp = j > 0 ? t.bk_prow[(int64_t)(j - 1) * t.ld + vcl] : 0.0;
+    ValIdx best; best.v = 0.0; best.i = -1; best.s = 0;
+    for (int64_t r = gid; r < t.rows; r += gsz) {
+        if (ec < 0) break;
+        double a = mine ? t.M[r * t.ld + lc] : 0.0;
+        double b = j == 0 ? t.M[r * t.ld + vcl] : t.rhs[r];
+        if (j > 0) b = pend(b, false, r == crp, t.bk_col[(int64_t)(j - 1) * t.bk_stride + r], prp);
+        t.rhs[r] = b;
+        if (mine) {
+            for (int i0 = 0; i0 < j; i0 += 4) {     // four links' operands requested together
+                double ci[4], pi[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + k < j ? i0 + k : j - 1;
+                    ci[k] = t.bk_col[(int64_t)i * t.bk_stride + r];
+                    pi[k] = t.bk_prow[(int64_t)i * t.ld + lc];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (i0 + k < j) a = pend(a, lc == blk->slot[i0 + k], r == blk->cr[i0 + k], ci[k], pi[k]);
+            }
+            // exchange B, producer: the owner writes the column's granules straight into the OTHER shards' buffers
+            const unsigned long long vb = (unsigned long long)__double_as_longlong(a);
+            const int64_t off = x.lay.col_off(x.epoch & 1u) + 2 * r;
+            for (int q = 0; q < x.lay.world; ++q)
+                if (q != x.rank) {
+                    st_sys(x.peers[q] + off, tg | (vb & 0xffffffffull));
+                    st_sys(x.peers[q] + off + 1, tg | (vb >> 32));
+                }
+        } else if (live) {
+            // exchange B, consumer: my row's two granules of this pivot's column, in my own buffer
+            const unsigned long long *src = x.mine + x.lay.col_off(x.epoch & 1u) + 2 * r;
+            unsigned long long lo, hi;
+            for (unsigned spins = 0;; ++spins) {
+                lo = ld_sys(src);
+                hi = ld_sys(src + 1);
+                if ((unsigned)(lo >> 32) == x.epoch && (unsigned)(hi >> 32) == x.epoch) break;
+                if (spins > x.max_spins) { ctl->status = kExchangeLost; lo = hi = 0ull; break; }
+            }
+            a = __longlong_as_double((long long)(((hi & 0xffffffffull) << 32) | (lo & 0xffffffffull)));
+        }
+        if (live) {                                 // (k_shard_la_ratio)
+            t.bk_col[(int64_t)j * t.bk_stride + r] = a;
+            if (t.p2l && !(fabs(a) <= 1.7976931348623157e308)) atomicOr(&ctl->poison, 1);   // compact shard: MI_NONFINITE
+            if (r < m && ratio_thr < a) {
+                const double q = b / a;
+                if (q != q) atomicOr(&ctl->poison, 1);
+                else { ValIdx c; c.v = q; c.i = r; c.s = __double_as_longlong(a); best = vi_min(best, c); }
+            }
+        }
+    }
+    best = block_reduce_min<256>(best, s_v, s_i);
+    if (threadIdx.x == 0) { rp_v[blockIdx.x] = best.v; rp_i[blockIdx.x] = best.i; rp_s[blockIdx.x] = best.s; }
+    if (gid == 0) *ec_out = ec;
+}
+
 __global__ __launch_bounds__(kGatherThreads) void k_shard_la_ratio(TabView t, int j, const double *col_src,
                                                                    const int64_t *ec_dev, double ratio_thr, P2pArgs x)
 {
@@ -3978,6 +4120,26 @@ int launch_shard_la_prepare(const TabView &t, int j, const double *col, const in
                        0.0 + (f / 2.0) * kClEpsilon, x);
     switch (j) {
 #define MI_SLA(J) case J: launch_shard_la_scale_t<J>(t, g2, g1, ec_dev, is_max, s); break;
+        MI_SLA(0) MI_SLA(1) MI_SLA(2) MI_SLA(3) MI_SLA(4) MI_SLA(5) MI_SLA(6) MI_SLA(7)
+        MI_SLA(8) MI_SLA(9) MI_SLA(10) MI_SLA(11) MI_SLA(12) MI_SLA(13) MI_SLA(14) MI_SLA(15)
+#undef MI_SLA
+    }
+    return g2 * (kScaleThreads / 64);
+}
+// the look-ahead step of a large shard in exchange mode 2 as TWO launches (see k_shard_p2p_step);
+// returns the pricing partials it leaves, 0 when this shard / state needs the separate launches
+int launch_shard_p2p_step(const TabView &t, int j, int n_part, int n_shards, int64_t col_offset, double f,
+                          int is_max, int64_t *ec_dev, hipStream_t s, const P2pArgs &x)
+{
+    if (!x.peers || n_part <= 0 || !shard_la_split(t)) return 0;
+    int blocks = (int)((t.rows + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks > t.part_cap / 2) return 0;
+    const int g2 = (int)(((t.ld >> 1) + kScaleThreads - 1) / kScaleThreads);
+    hipLaunchKernelGGL(k_shard_p2p_step, dim3(blocks), dim3(256), 0, s, t, j, n_part, n_shards, col_offset,
+                       (f / 8.0) * kClEpsilon, 0.0 + (f / 2.0) * kClEpsilon, ec_dev, x);
+    switch (j) {
+#define MI_SLA(J) case J: launch_shard_la_scale_t<J>(t, g2, blocks, ec_dev, is_max, s); break;
         MI_SLA(0) MI_SLA(1) MI_SLA(2) MI_SLA(3) MI_SLA(4) MI_SLA(5) MI_SLA(6) MI_SLA(7)
         MI_SLA(8) MI_SLA(9) MI_SLA(10) MI_SLA(11) MI_SLA(12) MI_SLA(13) MI_SLA(14) MI_SLA(15)
 #undef MI_SLA

@@ -20,7 +20,10 @@ def main():
     lp = lp_amd()
     cp = __import__("importlib").import_module("linear-programming_amd.colpart")
     L = lp.capi.lib()
-    L.mi355x_tune_set_colpart_exchange(2)
+    mode = int(sys.argv[6]) if len(sys.argv) > 6 else 2          # 2: two launches per step where it applies, 3: four
+    split = int(sys.argv[7]) if len(sys.argv) > 7 else 0          # 2: the multi-workgroup look-ahead step at any size
+    L.mi355x_tune_set_colpart_exchange(mode)
+    L.mi355x_tune_set_shard_la_split(split)
     tab = cp.NativeColumnPartition.synthetic_rank(n, m, seed, world, rank, 0, None)
     L.mi355x_tune_set_colpart_exchange(0)
     handles = [None] * world

@@ -447,7 +447,8 @@ def test_colpart_c_abi_cap_resume_synthetic_and_dense_fallback():
     tab.close()
 
 
-@pytest.mark.parametrize("exchange", [0, 1, 2], ids=["allreduce", "rooted-broadcast", "p2p-push"])
+@pytest.mark.parametrize("exchange", [0, 1, 2, 12, 13],
+                         ids=["allreduce", "rooted-broadcast", "p2p-push", "p2p-two-launch-step", "p2p-four-launch-step"])
 @pytest.mark.parametrize("entry", ["comm-init-all", "comm-init-rank"])
 def test_colpart_c_abi_over_rccl_single_rank(monkeypatch, entry, exchange):
     """The RCCL code path itself on the one GPU this box has: a single shard forced through its
@@ -466,8 +467,14 @@ def test_colpart_c_abi_over_rccl_single_rank(monkeypatch, entry, exchange):
     M, b = lp.synth.tableau(n, m, seed)
     so, no, trace = oracle.solve(M, b, trace_cap=1 << 14)
     L = lp.capi.lib()
+    # 12 / 13: exchange 2 / 3 with the multi-workgroup look-ahead step of large shards forced at this
+    # size -- 12 is then the two-launch step (k_shard_p2p_step: the shard has its stream to itself),
+    # 13 the same step as four launches
+    split = 2 if exchange >= 10 else 0
+    exchange = exchange % 10
     try:
         L.mi355x_tune_set_colpart_exchange(exchange)
+        L.mi355x_tune_set_shard_la_split(split)
         if entry == "comm-init-rank":
             uid = cp.NativeColumnPartition.rccl_unique_id()
             assert len(uid) == 128 and any(uid)
@@ -478,10 +485,13 @@ def test_colpart_c_abi_over_rccl_single_rank(monkeypatch, entry, exchange):
         L.mi355x_tune_set_colpart_exchange(0)
     assert tab.info() == {"n_shards": 1, "n_devices_used": 1, "uses_rccl": True}
     tab.exchange_timing(4, 64)
-    st, k = tab.solve()
+    try:
+        st, k = tab.solve()
+    finally:
+        L.mi355x_tune_set_shard_la_split(0)
     assert (st, k) == (so, no) and np.array_equal(tab.trace(no), trace)
     ns, ag_us, ar_us = tab.exchange_timing_read()
-    if exchange == 2:
+    if exchange >= 2:
         assert ns == 0                       # no collective to bracket: the exchanges are inside the step kernels
     else:
         assert 0 < ns <= 64 and 0.0 < ag_us < 1e5 and 0.0 < ar_us < 1e5      # both collectives were bracketed

@@ -1081,8 +1081,10 @@ def test_column_partition_logical_shards_bitwise(n_shards, n, m, compact, block)
     cp.destroy_shards(shards)
 
 
+@pytest.mark.parametrize("mode,split", [(2, 0), (2, 2), (3, 2)],
+                         ids=["by-size", "two-launch-step", "four-launch-step"])
 @pytest.mark.parametrize("world,n,m,cap", [(2, 300, 120, 0), (3, 700, 300, 0), (4, 1500, 700, 90)])
-def test_column_partition_p2p_exchange_between_processes(world, n, m, cap, tmp_path):
+def test_column_partition_p2p_exchange_between_processes(world, n, m, cap, mode, split, tmp_path):
     """Exchange mode 2 between real OS processes: every rank owns one shard behind mi355x_colpart_*,
     there is NO communicator (RCCL is not touched), the ranks map each other's fine-grained exchange
     buffers through IPC handles, and the per-pivot loop -- blind enqueue, no host in it -- runs in
@@ -1090,7 +1092,12 @@ def test_column_partition_p2p_exchange_between_processes(world, n, m, cap, tmp_p
     meet only through the self-validating granules they write into each other's buffers.  Every
     rank must end with the oracle's status, pivot sequence, basis and RHS column.  (What this box
     cannot show is the visibility of such stores across xGMI; the protocol, its parities and tags
-    and its freedom from deadlock under real asynchrony are what runs here.)"""
+    and its freedom from deadlock under real asynchrony are what runs here.)
+    two-launch-step: the multi-workgroup look-ahead step of large shards forced at these sizes, in
+    the form a shard with its device to itself uses -- pricing pair, pairs, column and ratio
+    partials as ONE kernel (k_shard_p2p_step), so that a consumer and the producer it waits for are
+    the same kernel in different processes; four-launch-step: the same step as the separate kernels
+    shards on one stream use."""
     import os
     import socket
     import subprocess
@@ -1102,7 +1109,8 @@ def test_column_partition_p2p_exchange_between_processes(world, n, m, cap, tmp_p
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_colpart_p2p_worker.py"),
-                                       str(tmp_path), str(n), str(m), str(seed), str(cap)], env=env, cwd=ROOT))
+                                       str(tmp_path), str(n), str(m), str(seed), str(cap), str(mode), str(split)],
+                                      env=env, cwd=ROOT))
     for p in procs:
         assert p.wait(timeout=600) == 0
     M, b = lp.synth.tableau(n, m, seed)

@@ -15,7 +15,8 @@ K = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 n, m = 65536 // 8, 32768
 seed = lp.synth.seed_for(5)
 for name, force, mode in (("device-local exchanges", "0", 0), ("one-rank RCCL: all-gather + int64 all-reduce", "1", 0),
-                          ("one-rank RCCL: all-gather + rooted broadcast", "1", 1), ("P2P push / poll kernels", "1", 2)):
+                          ("one-rank RCCL: all-gather + rooted broadcast", "1", 1),
+                          ("P2P push, four launches per step", "1", 3), ("P2P push, two launches per step", "1", 2)):
     os.environ["MI355X_COLPART_FORCE_RCCL"] = force
     L.mi355x_tune_set_colpart_exchange(mode)
     tab = cp.NativeColumnPartition.synthetic(n, m, seed, 1)
