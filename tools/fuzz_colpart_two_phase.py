@@ -3,7 +3,9 @@ LPs with <=, >= and = rows (degenerate integer data in half of them, so that art
 at level zero and drive-out pivots happen), 1 .. 8 logical shards, exchange modes 0 (device-local
 sum / all-reduce) and 2 (P2P push), against the oracle bit for bit.  A drive-out pivot on a negative
 element must be DECLINED (MI_UNSUPPORTED) and nothing else may be.
-    python tools/fuzz_colpart_two_phase.py [cases] [first_seed]"""
+    python tools/fuzz_colpart_two_phase.py [cases] [first_seed] [two-launch]
+`two-launch`: every case as ONE shard over the forced one-rank loop in exchange mode 2 with the
+multi-workgroup look-ahead step forced: the two-launch step (k_shard_p2p_step) at these sizes."""
 import ctypes, importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,6 +14,10 @@ import oracle
 from tests.helpers import lp_amd, random_mixed_problem
 lp = lp_amd(); L = lp.capi.lib()
 cp = importlib.import_module("linear-programming_amd.colpart")
+TWO_LAUNCH = len(sys.argv) > 3 and sys.argv[3] == "two-launch"
+if TWO_LAUNCH:
+    os.environ["MI355X_COLPART_FORCE_RCCL"] = "1"
+    L.mi355x_tune_set_shard_la_split(2)
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 meta = np.random.default_rng(seed0)
@@ -22,6 +28,8 @@ for case in range(cases):
     rng = np.random.default_rng(seed)
     shards = int(meta.integers(1, 9))
     mode = int(meta.choice([0, 2]))
+    if TWO_LAUNCH:                      # one shard over a forced one-rank loop: the two-launch P2P step at any size
+        shards, mode = 1, 2
     if meta.integers(0, 2):
         n = int(meta.integers(3, 9))
         names = ["x%d" % i for i in range(n)]
