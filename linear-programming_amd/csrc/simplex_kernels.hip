@@ -3691,11 +3691,9 @@ __global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(Tab
         }
         if (more) RES_RATIO_AHEAD(epoch + 1u, (it + 1) & 1, false);
         RES_T(6);
-        // ---- bookkeeping
-        if (mine && tid == lc) {
-            t.l2p[ec] = -1;
-            t.l2p[leaving] = col0 + lc;
-        }
+        // ---- bookkeeping (the logical -> slot map is rebuilt from lidx / bas at write-back: nothing but
+        // the trace is written to HBM inside the loop)
+        (void)leaving;
         if (leader && t.trace_ec && tn < t.trace_cap) { t.trace_ec[tn] = ec; t.trace_cr[tn] = cr; }
         last_ec = ec; last_cr = cr;
         n_piv += 1; tn += 1;
@@ -3734,9 +3732,13 @@ __global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(Tab
                 if (c + 1 < ncl)  *reinterpret_cast<double2 *>(row + c) = make_double2(a0, a1);
                 else if (c < ncl) row[c] = a0;
             }
-            if (wg == 0) { t.M[r * ld + nnb] = rhs[k]; t.basis[r] = bas[k]; }
+            if (wg == 0) { t.M[r * ld + nnb] = rhs[k]; t.basis[r] = bas[k]; t.l2p[bas[k]] = -1; }
         }
-    if (tid < ncl) { t.M[m * ld + col0 + tid] = obj; t.p2l[col0 + tid] = (int64_t)lidx; }
+    if (tid < ncl) {
+        t.M[m * ld + col0 + tid] = obj;
+        t.p2l[col0 + tid] = (int64_t)lidx;
+        if (lidx >= 0) t.l2p[lidx] = col0 + tid;                  // every logical column is basic or in exactly one strip
+    }
     if (leader) {
         t.M[m * ld + nnb] = objv;
         ctl->ec = last_ec; ctl->cr = last_cr;
