@@ -212,16 +212,23 @@ def other_configs(lp, L, device, block):
     k = ctypes.c_int64(0)
     L.mi355x_tab_solve(hw, 1, 1024.0, 0, ctypes.byref(k))                     # warm: same kernels, another LP
     L.mi355x_tab_destroy(hw)
-    h = ctypes.c_void_p()
-    lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h), n, m, seed, 0, -1, device), "cfg2")
-    lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, 0, 1), "cfg2 prepare")   # representation change outside the timing
-    L.mi355x_tab_sync(h, ctypes.byref(k))
-    resident = bool(L.mi355x_tab_resident(h))
-    L.mi355x_tab_timing_enable(h, 1 if resident else 4)   # (blocked path: every fourth block -- the event records are host work inside the timing)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    rc = L.mi355x_tab_solve(h, 1, 1024.0, 0, ctypes.byref(k))
-    dt = time.perf_counter() - t0
+    # three timed solves on fresh handles of the same LP: the median is reported, all three are listed
+    # (a solve that follows host-side work with large device allocations has been seen to run slow once)
+    runs2 = []
+    for rep_i in range(3):
+        h = ctypes.c_void_p()
+        lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h), n, m, seed, 0, -1, device), "cfg2")
+        lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, 0, 1), "cfg2 prepare")   # representation change outside the timing
+        L.mi355x_tab_sync(h, ctypes.byref(k))
+        resident = bool(L.mi355x_tab_resident(h))
+        L.mi355x_tab_timing_enable(h, 1 if resident else 4)   # (blocked path: every fourth block -- the event records are host work inside the timing)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc = L.mi355x_tab_solve(h, 1, 1024.0, 0, ctypes.byref(k))
+        runs2.append(time.perf_counter() - t0)
+        if rep_i < 2:
+            L.mi355x_tab_destroy(h)
+    dt = sorted(runs2)[1]
     M, b = lp.synth.tableau(n, m, seed)
     so, no, trace = oracle.solve(M, b, trace_cap=1 << 14)
     ec = np.empty(max(no, 1), dtype=np.int64); cr = np.empty(max(no, 1), dtype=np.int64); cnt = ctypes.c_int64(0)
@@ -234,6 +241,7 @@ def other_configs(lp, L, device, block):
     out["cfg2_full_solve"] = {
         "workload": "BASELINE config 2: dense random LP 1024 vars x 512 <=-constraints (513x1537 f64), solved to optimality",
         "value": k.value / dt, "unit": "pivots/s", "pivots": int(k.value), "ms": dt * 1e3, "us_per_pivot": dt / max(k.value, 1) * 1e6,
+        "ms_of_the_three_runs": [x * 1e3 for x in runs2], "reported": "median of three solves on fresh handles",
         "path": "resident: the stored 513x1025 tableau in registers (32 workgroups x 256 threads x 64 doubles), one "
                 "exchange per pivot, no HBM traffic inside the loop" if resident else "blocked: look-ahead + sweep",
         "kernels": ({"k_resident_whole_solve": _events(L, h, 0)} if resident else
@@ -248,13 +256,18 @@ def other_configs(lp, L, device, block):
     warm = lp.TableauBatch.synthetic(nl, n, m, seeds[::-1].copy(), device=device)
     warm.solve()
     del warm
-    batch = lp.TableauBatch.synthetic(nl, n, m, seeds, device=device)
-    lp.capi.check(L.mi355x_batch_prepare(batch._h), "mi355x_batch_prepare")
-    L.mi355x_batch_timing_enable(batch._h, 1)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    st, npv = batch.solve()
-    dt = time.perf_counter() - t0
+    runs4 = []
+    for rep_i in range(3):
+        batch = lp.TableauBatch.synthetic(nl, n, m, seeds, device=device)
+        lp.capi.check(L.mi355x_batch_prepare(batch._h), "mi355x_batch_prepare")
+        L.mi355x_batch_timing_enable(batch._h, 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        st, npv = batch.solve()
+        runs4.append(time.perf_counter() - t0)
+        if rep_i < 2:
+            del batch
+    dt = sorted(runs4)[1]
     nlch, sm, mn = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
     L.mi355x_batch_timing_read(batch._h, ctypes.byref(nlch), ctypes.byref(sm), ctypes.byref(mn))
     checked, same = 16, True
@@ -268,6 +281,7 @@ def other_configs(lp, L, device, block):
         "workload": "BASELINE config 4, one GPU's share: 128 independent LPs of 512 vars x 256 <=-constraints "
                     "(257x769 f64 each), every LP solved to optimality",
         "value": float(npv.sum()) / dt, "unit": "pivots/s (aggregate)", "pivots_total": int(npv.sum()), "ms": dt * 1e3,
+        "ms_of_the_three_runs": [x * 1e3 for x in runs4], "reported": "median of three solves of fresh batches",
         "pivots_per_lp_min_mean_max": [int(npv.min()), float(npv.mean()), int(npv.max())],
         "all_optimal": bool((st == 0).all()),
         "path": "resident: every LP in registers (8 workgroups per LP, 64 LPs in flight), one exchange per pivot"
