@@ -3312,7 +3312,7 @@ __global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(Tab
     bool local = false;
     int it = 0;
 #ifdef MI355X_RES_TIMING
-    unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define RES_T(i) T##i = wall_clock64()
 #else
 #define RES_T(i)
@@ -3703,11 +3703,13 @@ __global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(Tab
             tacc[0] += 1; tacc[1] += T1 - T0; tacc[2] += T2 - T1; tacc[3] += T3 - T2; tacc[4] += T4 - T3;
             tacc[5] += T5 - T4; tacc[6] += T6 - T5; tacc[7] += T7 - T6;
             tacc[8] += T8 - T4; tacc[9] += T9 - T8; tacc[10] += T10 - T9; tacc[11] += T5 - T10;
+            tacc[12] += mine ? 1 : 0;
         }
 #endif
     }
 #ifdef MI355X_RES_TIMING
-    if (leader && t.rhs) for (int k = 0; k < 12; ++k) t.rhs[k] += (double)tacc[k];
+    // (every workgroup's first thread: 16 doubles per workgroup)
+    if (tid == 0 && t.rhs && 16 * (wg + 1) <= t.rows) for (int k = 0; k < 16; ++k) t.rhs[16 * wg + k] += (double)tacc[k];
 #endif
 
     if (lost) {

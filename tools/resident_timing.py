@@ -24,16 +24,21 @@ for rep in range(3):
     npv = ctypes.c_int64(0)
     lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, 0, 1), "prepare")
     L.mi355x_tab_sync(h, ctypes.byref(npv))
-    acc = np.zeros(12)
-    L.mi355x_debug_rhs(h, acc.ctypes.data_as(ctypes.c_void_p), 12, 1)
+    acc = np.zeros(512)
+    L.mi355x_debug_rhs(h, acc.ctypes.data_as(ctypes.c_void_p), 512, 1)
     t0 = time.perf_counter()
     rc = L.mi355x_tab_solve(h, 1, 1024.0, 0, ctypes.byref(npv))
     dt = time.perf_counter() - t0
-    L.mi355x_debug_rhs(h, acc.ctypes.data_as(ctypes.c_void_p), 12, 0)
+    L.mi355x_debug_rhs(h, acc.ctypes.data_as(ctypes.c_void_p), 512, 0)
     L.mi355x_tab_destroy(h)
     c = max(acc[0], 1)
     ph = acc[1:8] / c * 0.01
     print("%d x %d: rc %d, %d pivots in %.3f ms = %.2f us/pivot (%.0f pivots/s) | us per pivot, leader: polls issued + strip update %.2f  records %.2f  column + owner's pivot row %.2f  "
           "prow %.2f  obj+pricing+publish %.2f  rhs + ratio test ahead %.2f  bookkeeping %.2f  = %.2f" % (
               n, m, rc, npv.value, dt * 1e3, dt / max(npv.value, 1) * 1e6, npv.value / dt, *ph, ph.sum()))
+    per = acc.reshape(32, 16)
+    live = per[:, 0] > 0
+    if live.sum() > 1 and rep == 2:
+        print("      per workgroup, us per pivot waiting for records | share of pivots as the owner of the entering column:")
+        print("      " + "  ".join("%d: %.2f|%.0f%%" % (w, per[w, 2] / per[w, 0] * 0.01, 100 * per[w, 12] / per[w, 0]) for w in range(32) if live[w]))
     print("      inside obj+pricing+publish: objective entries %.2f  pricing %.2f  candidate column %.2f  publish %.2f" % tuple(acc[8:12] / c * 0.01))
