@@ -25,11 +25,12 @@ for rep in range(3):
     lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, 0, 1), "prepare")
     L.mi355x_tab_sync(h, ctypes.byref(npv))
     acc = np.zeros(512)
-    L.mi355x_debug_rhs(h, acc.ctypes.data_as(ctypes.c_void_p), 512, 1)
+    nacc = min(512, (m + 1) // 16 * 16)          # (the buffer holds one double per tableau row)
+    L.mi355x_debug_rhs(h, acc.ctypes.data_as(ctypes.c_void_p), nacc, 1)
     t0 = time.perf_counter()
     rc = L.mi355x_tab_solve(h, 1, 1024.0, 0, ctypes.byref(npv))
     dt = time.perf_counter() - t0
-    L.mi355x_debug_rhs(h, acc.ctypes.data_as(ctypes.c_void_p), 512, 0)
+    L.mi355x_debug_rhs(h, acc.ctypes.data_as(ctypes.c_void_p), nacc, 0)
     L.mi355x_tab_destroy(h)
     c = max(acc[0], 1)
     ph = acc[1:8] / c * 0.01
