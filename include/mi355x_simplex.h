@@ -50,6 +50,9 @@ extern "C" {
                                 the reference would spread NaNs over basic columns, which are not
                                 stored there (single tableaux and batches switch to the dense
                                 tableau by themselves and continue) */
+#define MI_CANCELLED     7   /* mi355x_*_cancel was called from another thread: the solve stopped between
+                                two chunks of launches; whole pivots only, the tableau is consistent and a
+                                later solve call carries on from it */
 #define MI_RUNNING     100   /* asynchronous use only: the iterations enqueued so far have not
                                 terminated the solve (mi355x_tab_sync) */
 /* errors */
@@ -123,6 +126,18 @@ int  mi355x_tab_ratio(mi355x_tab *t, int64_t entering_col, double fp_factor, int
  * MI_UNBOUNDED or MI_MAX_PIVOTS; *n_pivots = pivots performed by this call. */
 int  mi355x_tab_solve(mi355x_tab *t, int is_max, double fp_factor, int64_t max_pivots,
                       int64_t *n_pivots);
+/* A way out of a blocking solve.  The reference's loop (src/simplex.lisp:453-461) has no iteration
+ * cap and no anti-cycling rule; in Lisp a cycling LP can be interrupted, a blocking foreign call
+ * cannot.  mi355x_tab_cancel may be called from ANY thread while another thread is inside
+ * mi355x_tab_solve / mi355x_solve_two_phase on the same handle (the one exception to "one thread
+ * at a time"): the solve returns MI_CANCELLED after the chunk of launches in flight -- at most 64
+ * blocks of 16 pivots, 512 per-pivot iterations or one resident launch of 65536 pivots, i.e. well
+ * under a second at every BASELINE size -- with *n_pivots = the pivots done and the tableau whole
+ * (download / trace / a further solve call all work).  The request is sticky: cancelling a handle
+ * nobody is solving cancels its next solve.  For mi355x_solve_two_phase cancel either (or both)
+ * of the two handles.  The other way to keep a host responsive is max_pivots: solve in bounded
+ * chunks and look around in between (what the Lisp glue does). */
+int  mi355x_tab_cancel(mi355x_tab *t);
 /* n-solve-tableau, two-phase branch (src/simplex.lisp:402-452): `art` is the
  * artificial tableau (a min problem), `main_tab` the main tableau with the same
  * row count; both are modified.  n_pivots[0] = phase 1 (incl. drive-out pivots),
@@ -264,6 +279,11 @@ void mi355x_batch_destroy(mi355x_batch *b);
  * single-threaded host -- the Lisp image -- keeps the sub-batches of several GPUs going.) */
 int  mi355x_batch_solve_async(mi355x_batch *b, int is_max, double fp_factor, int64_t max_pivots);
 int  mi355x_batch_sync(mi355x_batch *b, int32_t *status, int64_t *n_pivots);
+/* mi355x_tab_cancel for batches (any thread): the solve in flight -- blocking, or on the library's
+ * worker thread -- returns MI_CANCELLED (mi355x_batch_solve / _sync / mi355x_multibatch_solve)
+ * after its current chunk of launches; status[i] = MI_RUNNING for the LPs it left unfinished,
+ * every tableau whole.  (The per-LP kernels end a launch after 4096 pivots per LP at the latest.) */
+int  mi355x_batch_cancel(mi355x_batch *b);
 
 /* One batch over several devices (config 4 as specified: 1024 LPs over 8 GPUs): LP k lives in
  * sub-batch k / ceil(n_lps / n_devices) (contiguous blocks, one sub-batch per device), independent
@@ -284,6 +304,7 @@ int  mi355x_multibatch_solve(mi355x_multibatch *mb, int is_max, double fp_factor
                              int32_t *status, int64_t *n_pivots);
 int  mi355x_multibatch_download(mi355x_multibatch *mb, int64_t lp_index, double *host_matrix,
                                 int64_t *host_basis, double *last_row, double *last_col);
+int  mi355x_multibatch_cancel(mi355x_multibatch *mb);
 void mi355x_multibatch_destroy(mi355x_multibatch *mb);
 
 /* ---- column-partitioned tableau: per-shard steps (BASELINE config 5) --------------- */
@@ -406,6 +427,11 @@ int  mi355x_colpart_solve_two_phase(mi355x_colpart *art, int64_t main_cols,
 int  mi355x_colpart_solve_async(mi355x_colpart *p, int is_max, double fp_factor, int64_t n_pivots,
                                 int reset);
 int  mi355x_colpart_sync(mi355x_colpart *p, int64_t *n_pivots);
+/* mi355x_tab_cancel for mi355x_colpart_solve (any thread; the one-process forms -- logical shards or
+ * one shard per visible device): MI_CANCELLED after the chunk of 64 .. 256 pivots in flight, every
+ * shard swept.  One process per GPU: MI_UNSUPPORTED (the ranks would have to agree on the chunk, or
+ * the others' collectives never complete) -- bound such solves with max_pivots. */
+int  mi355x_colpart_cancel(mi355x_colpart *p);
 /* read-back as mi355x_tab_download (any pointer may be NULL).  host_matrix (the whole logical
  * tableau) needs every shard in this process; basis, last row and last column are complete in
  * the one-process modes, and basis / last column also on every rank of the multi-process mode. */

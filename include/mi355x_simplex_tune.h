@@ -11,7 +11,7 @@
  * the handle that should run that way; a handle never changes path because another thread turned
  * a knob, so the per-handle thread-safety promise of mi355x_simplex.h holds whatever other threads
  * do with these hooks.  The remaining hooks (update-kernel tiling, sweep shape / implementation,
- * shard look-ahead split, one-XCD placement, poll bounds, resident poll mode, the test faults) are
+ * shard look-ahead split, one-XCD placement, poll bounds, resident poll mode) are
  * process-wide and read at every launch: measurement and test use only, change them while no other
  * thread is inside the library.  Every hook returns the value now in effect.
  */
@@ -80,8 +80,6 @@ int         mi355x_tune_set_resident(int mode);              /* resident solve (
 int         mi355x_tune_set_resident_poll(int mode);         /* who polls the exchange records:
                                                                 0 by size (every wave when an LP has
                                                                 <= 8 workgroups), 1 wave 0, 2 every */
-int         mi355x_tune_set_resident_fault(int on);          /* TEST: the last workgroup of every LP
-                                                                never publishes (co-residency lost) */
 /* 1 when the solve entry points would run this handle (in its current representation) resident */
 int         mi355x_tab_resident(mi355x_tab *t);
 
@@ -90,12 +88,6 @@ int         mi355x_tune_set_la_one_xcd(int on);              /* 1 (default): all
                                                                 one XCD, verified inside the launch */
 int         mi355x_tune_set_la_max_spins(unsigned polls);    /* polls before a workgroup gives up
                                                                 on a record; 0 = default (2^21)  */
-int         mi355x_tune_set_la_fault(int step_plus_1);       /* TEST: > 0: the last workgroup stops
-                                                                publishing from that step on; < 0: it
-                                                                publishes its ratio record of step
-                                                                -step_plus_1 - 1 and then gives up
-                                                                alone (the leader commits a pivot
-                                                                that workgroup never stored)     */
 /* 1 once an exchange of the persistent look-ahead was lost on this handle: the solve carried on
  * (and stays) on the two-launch look-ahead */
 int         mi355x_tab_la_lost(const mi355x_tab *t);
@@ -119,6 +111,21 @@ int         mi355x_debug_repeat_sweep(mi355x_tab *t, int n, double *avg_us);
 /* debugging aid: copies n doubles of the handle's scratch `rhs` buffer (the per-phase clocks of
  * a -DMI355X_LA_TIMING build); clear != 0 zeroes it afterwards */
 int         mi355x_debug_rhs(mi355x_tab *t, double *out, int64_t n, int clear);
+
+/* ---- fault injection: TEST BUILD ONLY ---------------------------------------------------- */
+/* Compiled in with -DMI355X_TEST_HOOKS (libmi355x_simplex_test.so, built next to the product
+ * library by linear-programming_amd/build.py and loaded by the tests that need it); the product
+ * library neither exports these nor contains the code paths behind them. */
+#ifdef MI355X_TEST_HOOKS
+int         mi355x_tune_set_resident_fault(int on);          /* the last workgroup of every LP never
+                                                                publishes (co-residency lost)    */
+int         mi355x_tune_set_la_fault(int step_plus_1);       /* > 0: the last workgroup stops
+                                                                publishing from that step on; < 0: it
+                                                                publishes its ratio record of step
+                                                                -step_plus_1 - 1 and then gives up
+                                                                alone (the leader commits a pivot
+                                                                that workgroup never stored)     */
+#endif
 
 #ifdef __cplusplus
 }

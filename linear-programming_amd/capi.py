@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("MI355X_SIMPLEX_LIB") or os.path.join(HERE, "libmi355x
 MI_OK = MI_OPTIMAL = 0
 MI_UNBOUNDED, MI_INFEASIBLE, MI_MAX_PIVOTS, MI_ART_NONZERO, MI_ART_STUCK = 1, 2, 3, 4, 5
 MI_NONFINITE = 6
+MI_CANCELLED = 7
 MI_RUNNING = 100
 MI_BAD_ARG, MI_HIP_ERROR, MI_RCCL_ERROR, MI_NO_DEVICE, MI_NO_MEMORY, MI_UNSUPPORTED = -1, -2, -3, -4, -5, -6
 
@@ -35,6 +36,7 @@ SIGNATURES = {
     "mi355x_tab_price": (_int, [_p, _int, _dbl, _p]),
     "mi355x_tab_ratio": (_int, [_p, _i64, _dbl, _p]),
     "mi355x_tab_solve": (_int, [_p, _int, _dbl, _i64, _p]),
+    "mi355x_tab_cancel": (_int, [_p]),
     "mi355x_solve_two_phase": (_int, [_p, _p, _int, _dbl, _p]),
     "mi355x_tab_download": (_int, [_p, _p, _p, _p, _p]),
     "mi355x_tab_download_block": (_int, [_p, _i64, _i64, _i64, _i64, _p]),
@@ -76,11 +78,13 @@ SIGNATURES = {
     "mi355x_batch_destroy": (None, [_p]),
     "mi355x_batch_solve_async": (_int, [_p, _int, _dbl, _i64]),
     "mi355x_batch_sync": (_int, [_p, _p, _p]),
+    "mi355x_batch_cancel": (_int, [_p]),
     "mi355x_multibatch_create": (_int, [_pp, _i64, _i64, _i64, _p, _p, _int, _p]),
     "mi355x_multibatch_create_synthetic": (_int, [_pp, _i64, _i64, _i64, _p, _int, _p]),
     "mi355x_multibatch_info": (_int, [_p, _p, _p]),
     "mi355x_multibatch_solve": (_int, [_p, _int, _dbl, _i64, _p, _p]),
     "mi355x_multibatch_download": (_int, [_p, _i64, _p, _p, _p, _p]),
+    "mi355x_multibatch_cancel": (_int, [_p]),
     "mi355x_multibatch_destroy": (None, [_p]),
     "mi355x_shard_set_compact": (_int, [_p, _i64, _p]),
     "mi355x_shard_columns": (_int, [_p, _p]),
@@ -100,6 +104,7 @@ SIGNATURES = {
     "mi355x_colpart_solve_two_phase": (_int, [_p, _i64, _p, _int, _dbl, _p, _pp]),
     "mi355x_colpart_solve_async": (_int, [_p, _int, _dbl, _i64, _int]),
     "mi355x_colpart_sync": (_int, [_p, _p]),
+    "mi355x_colpart_cancel": (_int, [_p]),
     "mi355x_colpart_download": (_int, [_p, _p, _p, _p, _p]),
     "mi355x_colpart_trace": (_int, [_p, _p, _p, _i64, _p]),
     "mi355x_colpart_destroy": (None, [_p]),
@@ -110,7 +115,6 @@ _EXTRA = {
     "mi355x_tune_set_shard_la_split": (_int, [_int]),
     "mi355x_tune_set_tail_policy": (_int, [_int]),
     "mi355x_tune_set_resident": (_int, [_int]),
-    "mi355x_tune_set_resident_fault": (_int, [_int]),
     "mi355x_tune_set_resident_poll": (_int, [_int]),
     "mi355x_tab_resident": (_int, [_p]),
     "mi355x_tune_set_colpart_exchange": (_int, [_int]),
@@ -120,7 +124,6 @@ _EXTRA = {
     "mi355x_colpart_exchange_timing_read": (_int, [_p, _p, _p, _p]),
     "mi355x_tune_set_la_one_xcd": (_int, [_int]),
     "mi355x_tune_set_la_max_spins": (_int, [ctypes.c_uint]),
-    "mi355x_tune_set_la_fault": (_int, [_int]),
     "mi355x_tab_la_lost": (_int, [_p]),
     "mi355x_tab_timing_read_kind": (_int, [_p, _int, _p, _p, _p]),
     "mi355x_debug_rhs": (_int, [_p, _p, _i64, _int]),
@@ -139,6 +142,14 @@ _EXTRA = {
     "mi355x_tune_set_batch_block": (_int, [_int]),
     "mi355x_tune_set_sweep_shape": (_int, [_int, _int]),
 }
+
+# fault injection: only in the TEST build of the library (-DMI355X_TEST_HOOKS,
+# libmi355x_simplex_test.so); the product library does not export them
+_TEST_HOOKS = {
+    "mi355x_tune_set_resident_fault": (_int, [_int]),
+    "mi355x_tune_set_la_fault": (_int, [_int]),
+}
+TEST_LIB_PATH = os.path.join(HERE, "libmi355x_simplex_test.so")
 
 _lib = None
 
@@ -178,14 +189,40 @@ def lib():
                 "%s is missing: build it with `python linear-programming_amd/build.py` "
                 "(there is no CPU fallback)" % LIB_PATH)
         _share_hip_runtime_with_torch()
-        L = ctypes.CDLL(LIB_PATH)
-        for table in (SIGNATURES, _EXTRA):
-            for name, (res, args) in table.items():
-                fn = getattr(L, name)
-                fn.restype = res
-                fn.argtypes = args
-        _lib = L
+        _lib = _load(LIB_PATH, test_hooks=False)
     return _lib
+
+
+def _load(path, test_hooks):
+    L = ctypes.CDLL(path)
+    for table in (SIGNATURES, _EXTRA) + ((_TEST_HOOKS,) if test_hooks else ()):
+        for name, (res, args) in table.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+    return L
+
+
+class test_build:
+    """Context manager (tests only): the TEST build of the library -- the same sources with the
+    fault-injection hooks compiled in -- stands in for the product library inside the block.
+    Handles made inside must be destroyed inside."""
+    _cached = None
+
+    def __enter__(self):
+        global _lib
+        lib()                                     # (HIP runtime shared with torch first)
+        if test_build._cached is None:
+            if not os.path.exists(TEST_LIB_PATH):
+                raise ExtensionMissing("%s is missing: `python linear-programming_amd/build.py`" % TEST_LIB_PATH)
+            test_build._cached = _load(TEST_LIB_PATH, test_hooks=True)
+        self._saved, _lib = _lib, test_build._cached
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._saved
+        return False
 
 
 class Mi355xError(RuntimeError):

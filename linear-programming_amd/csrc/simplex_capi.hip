@@ -146,6 +146,9 @@ struct mi355x_tab {
     std::vector<hipEvent_t> ev0, ev1;     // around the update / sweep launches
     int         n_timed_la = 0;
     std::vector<hipEvent_t> la0, la1;     // around the look-ahead of the same blocks
+    // mi355x_tab_cancel (any thread): consumed by the blocking solve loop that next looks at it --
+    // between two chunks of launches, when everything enqueued has completed
+    std::atomic<int> cancel{0};
 };
 
 struct mi355x_batch {
@@ -658,6 +661,31 @@ int enqueue_resident(mi355x_tab *t, int is_max, double f, int cap)
     return MI_OK;
 }
 
+// A way out of a solve (the reference has no pivot cap and no anti-cycling rule, simplex.lisp:453-461;
+// in Lisp a cycling LP is interruptible, a blocking foreign call is not).  Every blocking solve loop
+// enqueues BOUNDED chunks of launches -- at most 64 blocks, 512 per-pivot iterations, one resident
+// launch of 65536 pivots, 4096 pivots of a per-LP batch kernel -- and looks at this flag whenever it
+// has read the status back, i.e. when everything enqueued has completed and the tableau is whole.
+bool take_cancel(mi355x_tab *t) { return t->cancel.exchange(0, std::memory_order_acq_rel) != 0; }
+// A request is aimed at the solve in flight (or, with none in flight, at the next one): whichever
+// way that solve ends, the request ends with it.
+struct CancelScope {
+    std::atomic<int> &f;
+    explicit CancelScope(std::atomic<int> &flag) : f(flag) {}
+    ~CancelScope() { f.store(0, std::memory_order_release); }
+};
+
+// per-LP outcome of a batch as the host mirror of the control blocks holds it (an LP a cancelled
+// solve left unfinished reports MI_RUNNING; its tableau is whole, a later solve call carries on)
+int batch_report(mi355x_tab *t, int32_t *status, int64_t *n_pivots, int rc)
+{
+    for (int64_t i = 0; i < t->v.n_lps; ++i) {
+        if (status) status[i] = status_to_rc(t->h_ctl[i].status);
+        if (n_pivots) n_pivots[i] = t->h_ctl[i].n_pivots;
+    }
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -945,6 +973,7 @@ int mi355x_tab_solve(mi355x_tab *t, int is_max, double f, int64_t max_pivots, in
 {
     if (!t) return fail(MI_BAD_ARG, "handle is NULL");
     if (max_pivots < 0) return fail(MI_BAD_ARG, "max_pivots < 0");
+    CancelScope cancel_scope(t->cancel);
     int rc = use_device(t);
     if (rc != MI_OK) return rc;
     rc = ensure_compact(t);
@@ -959,7 +988,10 @@ int mi355x_tab_solve(mi355x_tab *t, int is_max, double f, int64_t max_pivots, in
             rc = read_ctl(t);
             if (rc != MI_OK) return rc;
             const int32_t st = t->h_ctl->status;
-            if (st == kRunning) continue;
+            if (st == kRunning) {                     // (a launch ends with the tableau written back)
+                if (take_cancel(t)) { if (n_pivots) *n_pivots = t->h_ctl->n_pivots; return MI_CANCELLED; }
+                continue;
+            }
             if (st == kSyncLost) {                    // its workgroups were not co-resident: nothing happened
                 rc = recover_lost_exchange(t);
                 if (rc != MI_OK) return rc;
@@ -994,6 +1026,8 @@ int mi355x_tab_solve(mi355x_tab *t, int is_max, double f, int64_t max_pivots, in
                 continue;
             }
             if (t->h_ctl->status != kRunning) break;
+            // (every block ends with its sweep: the tableau is whole whenever the host looks)
+            if (take_cancel(t)) { if (n_pivots) *n_pivots = t->h_ctl->n_pivots; return MI_CANCELLED; }
             if (blocks < 64) blocks *= 2;
         }
         if (t->h_ctl->status != kNeedDense) {
@@ -1025,16 +1059,44 @@ int mi355x_tab_solve(mi355x_tab *t, int is_max, double f, int64_t max_pivots, in
             continue;
         }
         if (t->h_ctl->status != kRunning) break;
+        if (take_cancel(t)) {
+            // the chunk ended on a select that chose a pivot (basis, column maps and pivot count
+            // already say so): apply it, then the tableau is whole
+            rc = enqueue_update(t, is_max);
+            if (rc != MI_OK) return rc;
+            HIP_TRY(hipGetLastError());
+            rc = read_ctl(t);
+            if (rc != MI_OK) return rc;
+            if (n_pivots) *n_pivots = t->h_ctl->n_pivots;
+            return MI_CANCELLED;
+        }
         if (chunk < 512) chunk *= 2;
     }
     if (n_pivots) *n_pivots = t->h_ctl->n_pivots;
     return (int)t->h_ctl->status;
 }
 
+int mi355x_tab_cancel(mi355x_tab *t)
+{
+    if (!t) return fail(MI_BAD_ARG, "handle is NULL");
+    t->cancel.store(1, std::memory_order_release);
+    return MI_OK;
+}
+
+static int solve_two_phase_impl(mi355x_tab *art, mi355x_tab *mt, int main_is_max, double f, int64_t *n_pivots);
 int mi355x_solve_two_phase(mi355x_tab *art, mi355x_tab *mt, int main_is_max, double f,
                            int64_t *n_pivots)
 {
     if (!art || !mt) return fail(MI_BAD_ARG, "NULL handle");
+    // mi355x_tab_cancel on EITHER handle stops the call (the caller cannot know which phase is
+    // running, so it cancels both); whatever flag is left over does not outlive the call
+    const int rc = solve_two_phase_impl(art, mt, main_is_max, f, n_pivots);
+    (void)take_cancel(art);
+    (void)take_cancel(mt);
+    return rc;
+}
+static int solve_two_phase_impl(mi355x_tab *art, mi355x_tab *mt, int main_is_max, double f, int64_t *n_pivots)
+{
     if (art->v.rows != mt->v.rows || art->v.cols < mt->v.cols || art->device != mt->device)
         return fail(MI_BAD_ARG, "artificial and main tableau do not match");
     const int64_t m = mt->v.rows - 1, num_vars = mt->v.cols - 1, num_art_vars = art->v.cols - 1;
@@ -1089,6 +1151,8 @@ int mi355x_solve_two_phase(mi355x_tab *art, mi355x_tab *mt, int main_is_max, dou
     mt->n_part = 0;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(art->stream));
+    // (a request that arrived on the main handle during phase 1, or on either between the phases)
+    if (art->cancel.load(std::memory_order_acquire) || mt->cancel.load(std::memory_order_acquire)) return MI_CANCELLED;
     rc = mi355x_tab_solve(mt, main_is_max, f, 0, &n2);                  // simplex.lisp:452
     if (n_pivots) n_pivots[1] = n2;
     return rc;
@@ -1291,6 +1355,7 @@ int mi355x_batch_solve(mi355x_batch *b, int is_max, double f, int64_t max_pivots
     if (!b || !b->t) return fail(MI_BAD_ARG, "batch is NULL");
     if (max_pivots < 0) return fail(MI_BAD_ARG, "max_pivots < 0");
     mi355x_tab *t = b->t;
+    CancelScope cancel_scope(t->cancel);
     int rc = use_device(t);
     if (rc != MI_OK) return rc;
     const int64_t n = t->v.n_lps;
@@ -1320,7 +1385,10 @@ int mi355x_batch_solve(mi355x_batch *b, int is_max, double f, int64_t max_pivots
                 break;
             }
             if (other) break;                         // an LP met an inf / NaN: the established path takes it
-            if (running) continue;
+            if (running) {
+                if (take_cancel(t)) return batch_report(t, status, n_pivots, MI_CANCELLED);
+                continue;
+            }
             for (int64_t i = 0; i < n; ++i) {
                 if (status) status[i] = t->h_ctl[i].status;
                 if (n_pivots) n_pivots[i] = t->h_ctl[i].n_pivots;
@@ -1360,6 +1428,7 @@ int mi355x_batch_solve(mi355x_batch *b, int is_max, double f, int64_t max_pivots
                 }
                 return MI_OK;
             }
+            if (take_cancel(t)) { t->n_part = 0; return batch_report(t, status, n_pivots, MI_CANCELLED); }
             if (blocks < 8) blocks *= 2;
         }
         if (t->compact) {                                      // an LP met an inf / NaN: the established path
@@ -1381,11 +1450,19 @@ int mi355x_batch_solve(mi355x_batch *b, int is_max, double f, int64_t max_pivots
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(t->h_ctl, t->v.ctl, n * sizeof(Ctl), hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));
-            bool need_dense = false;
-            for (int64_t i = 0; i < n && !need_dense; ++i) need_dense = t->h_ctl[i].status == kNeedDense;
-            if (!need_dense) break;
-            rc = fall_back_to_dense(t);               // some LP met an inf / NaN: finish densely
-            if (rc != MI_OK) return rc;
+            bool need_dense = false, running = false;
+            for (int64_t i = 0; i < n; ++i) {
+                need_dense |= t->h_ctl[i].status == kNeedDense;
+                running |= t->h_ctl[i].status == kRunning;
+            }
+            if (need_dense) {
+                rc = fall_back_to_dense(t);           // some LP met an inf / NaN: finish densely
+                if (rc != MI_OK) return rc;
+            } else if (!running) {
+                break;
+            } else if (take_cancel(t)) {              // (a launch ends after kBatchLaunchCap pivots per LP at the latest)
+                return batch_report(t, status, n_pivots, MI_CANCELLED);
+            }
             if (!launch_batch_solve(cur(t), is_max, f, t->stream)) return fail(MI_HIP_ERROR, "batch relaunch failed");
             continue;
         }
@@ -1415,12 +1492,31 @@ int mi355x_batch_solve(mi355x_batch *b, int is_max, double f, int64_t max_pivots
             continue;
         }
         if (!running) break;
+        if (take_cancel(t)) {
+            // the chunk ended on a select: finish the pivots it chose (see above), then report
+            rc = enqueue_update(t, is_max);
+            if (rc != MI_OK) return rc;
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(t->h_ctl, t->v.ctl, n * sizeof(Ctl), hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            return batch_report(t, status, n_pivots, MI_CANCELLED);
+        }
         if (chunk < 256) chunk *= 2;
     }
-    for (int64_t i = 0; i < n; ++i) {
-        if (status) status[i] = t->h_ctl[i].status;
-        if (n_pivots) n_pivots[i] = t->h_ctl[i].n_pivots;
-    }
+    return batch_report(t, status, n_pivots, MI_OK);
+}
+
+int mi355x_batch_cancel(mi355x_batch *b)
+{
+    if (!b || !b->t) return fail(MI_BAD_ARG, "batch is NULL");
+    b->t->cancel.store(1, std::memory_order_release);
+    return MI_OK;
+}
+
+int mi355x_multibatch_cancel(mi355x_multibatch *mb)
+{
+    if (!mb) return fail(MI_BAD_ARG, "handle is NULL");
+    for (mi355x_batch *b : mb->sub) b->t->cancel.store(1, std::memory_order_release);
     return MI_OK;
 }
 
@@ -1506,11 +1602,11 @@ int mi355x_batch_sync(mi355x_batch *b, int32_t *status, int64_t *n_pivots)
     if (!b->running) return fail(MI_BAD_ARG, "no asynchronous solve of this batch is in flight");
     if (b->worker.joinable()) b->worker.join();
     b->running = false;
-    if (b->worker_rc != MI_OK) { g_err = b->worker_err; return b->worker_rc; }
+    if (b->worker_rc < 0) { g_err = b->worker_err; return b->worker_rc; }
     const int64_t n = b->t->v.n_lps;
     if (status) std::copy(b->w_status.begin(), b->w_status.begin() + n, status);
     if (n_pivots) std::copy(b->w_pivots.begin(), b->w_pivots.begin() + n, n_pivots);
-    return MI_OK;
+    return b->worker_rc;                              // MI_OK, or MI_CANCELLED (mi355x_batch_cancel)
 }
 
 // ---- one batch over several devices (BASELINE config 4: 1024 LPs over 8 GPUs) -------------------
@@ -1935,11 +2031,13 @@ __device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // exchange A, producer: my (key, global column) pair into slot `rank` of EVERY shard's buffer
-__global__ __launch_bounds__(64) void k_p2p_push_pair(const double *send2, unsigned long long *const *peers,
+// (only while the solve is running: iterations enqueued blind behind the terminating pivot must
+// not overwrite, with later tags, a pair some peer has not polled yet)
+__global__ __launch_bounds__(64) void k_p2p_push_pair(const Ctl *ctl, const double *send2, unsigned long long *const *peers,
                                                       P2pLayout lay, int rank, unsigned epoch)
 {
     const int r = threadIdx.x;
-    if (r >= lay.world) return;
+    if (ctl->status != kRunning || r >= lay.world) return;
     const unsigned long long kb = (unsigned long long)__double_as_longlong(send2[0]);
     const unsigned long long cb = (unsigned long long)__double_as_longlong(send2[1]);
     unsigned long long *dst = peers[r] + lay.pair_off(epoch & 1u, rank);
@@ -2049,6 +2147,7 @@ struct mi355x_colpart {
     long long *l_bits_all = nullptr, *l_bits_sum = nullptr;
     std::vector<int> thread_rc;
     bool    dead = false;                    // communicators aborted after a failure: only destroy is left
+    std::atomic<int> cancel{0};              // mi355x_colpart_cancel (any thread; one-process forms)
 };
 
 namespace {
@@ -2117,6 +2216,9 @@ int cp_p2p_connect(mi355x_colpart *p, const char *handles)
 // other ranks' buffers are opened -- set-up only, the pivots themselves use no collective.
 int cp_setup_p2p(mi355x_colpart *p)
 {
+    // (the pair kernels index by threadIdx.x < world on one wave and stage 2 x 64 doubles in LDS)
+    if (p->world > 64)
+        return fail(MI_BAD_ARG, "exchange mode 2 (P2P push) supports at most 64 shards, not %d", p->world);
     p->lay.world = p->world;
     p->lay.rows_p = (p->rows + 7) / 8 * 8;
     const size_t bytes = (size_t)p->lay.granules() * sizeof(unsigned long long);
@@ -2176,7 +2278,7 @@ int cp_setup_p2p(mi355x_colpart *p)
 // the two exchanges of one pivot in mode 2, on shard s's stream (epoch = the pivot's tag)
 int cp_p2p_push_pair(mi355x_colpart *p, CpShard &s, unsigned epoch)
 {
-    hipLaunchKernelGGL(k_p2p_push_pair, dim3(1), dim3(64), 0, s.t->stream, s.send, s.d_peers, p->lay, s.index, epoch);
+    hipLaunchKernelGGL(k_p2p_push_pair, dim3(1), dim3(64), 0, s.t->stream, s.t->v.ctl, s.send, s.d_peers, p->lay, s.index, epoch);
     hipLaunchKernelGGL(k_p2p_wait_pairs, dim3(1), dim3(64), 0, s.t->stream, s.t->v.ctl, s.xch, p->lay, epoch, s.gathered,
                        p->p2p_spins);
     HIP_TRY(hipGetLastError());
@@ -2184,7 +2286,7 @@ int cp_p2p_push_pair(mi355x_colpart *p, CpShard &s, unsigned epoch)
 }
 int cp_p2p_push_wait_pairs_split(mi355x_colpart *p, CpShard &s, unsigned epoch, bool push)
 {
-    if (push) hipLaunchKernelGGL(k_p2p_push_pair, dim3(1), dim3(64), 0, s.t->stream, s.send, s.d_peers, p->lay, s.index, epoch);
+    if (push) hipLaunchKernelGGL(k_p2p_push_pair, dim3(1), dim3(64), 0, s.t->stream, s.t->v.ctl, s.send, s.d_peers, p->lay, s.index, epoch);
     else      hipLaunchKernelGGL(k_p2p_wait_pairs, dim3(1), dim3(64), 0, s.t->stream, s.t->v.ctl, s.xch, p->lay, epoch,
                                  s.gathered, p->p2p_spins);
     HIP_TRY(hipGetLastError());
@@ -2393,10 +2495,12 @@ int cp_run_rccl(mi355x_colpart *p, CpShard &s, double f, int64_t n, int j0)
 // shards, so that neither this call's caller nor the destroy path waits on those streams.
 void cp_abort(mi355x_colpart *p)
 {
-    if (!p->rccl || !rccl().ok) return;
+    if (!p->rccl) return;
     const std::string keep = g_err;
+    // (exchange mode 2 without a communicator has nothing to abort, but granules of the failed run
+    // were already pushed under tags a later run would reuse: the handle is dead either way)
     for (CpShard &s : p->sh) {
-        if (s.comm) { (void)hipSetDevice(s.device); (void)rccl().CommAbort(s.comm); s.comm = nullptr; }
+        if (s.comm && rccl().ok) { (void)hipSetDevice(s.device); (void)rccl().CommAbort(s.comm); s.comm = nullptr; }
         s.aborted = true;
     }
     p->dead = true;
@@ -2768,6 +2872,7 @@ int mi355x_colpart_solve(mi355x_colpart *p, int is_max, double f, int64_t max_pi
 {
     if (!p) return fail(MI_BAD_ARG, "handle is NULL");
     if (max_pivots < 0) return fail(MI_BAD_ARG, "max_pivots < 0");
+    CancelScope cancel_scope(p->cancel);
     p->is_max = is_max ? 1 : 0;
     int rc = cp_flush(p);
     if (rc != MI_OK) return rc;
@@ -2781,8 +2886,21 @@ int mi355x_colpart_solve(mi355x_colpart *p, int is_max, double f, int64_t max_pi
         if (rc != MI_OK) return rc;
         const int st = cp_status(p, n_pivots);
         if (st != MI_RUNNING) return st;
+        // (cp_status has applied the pending pivots of an open block: the tableau is whole)
+        if (p->cancel.exchange(0, std::memory_order_acq_rel)) return MI_CANCELLED;
         if (chunk < 256) chunk *= 2;
     }
+}
+
+int mi355x_colpart_cancel(mi355x_colpart *p)
+{
+    if (!p) return fail(MI_BAD_ARG, "handle is NULL");
+    // one process per GPU: the ranks would have to take the decision at the same chunk, or the
+    // collectives of the others never complete -- bound such solves with max_pivots instead
+    if (p->multi_process)
+        return fail(MI_UNSUPPORTED, "cancel is not available on a one-process-per-GPU handle: solve in max_pivots chunks");
+    p->cancel.store(1, std::memory_order_release);
+    return MI_OK;
 }
 
 }  // extern "C"
@@ -2953,6 +3071,17 @@ int mi355x_colpart_solve_two_phase(mi355x_colpart *art, int64_t main_cols, const
     // ---- hand-over (simplex.lisp:437-451): the main tableau's shards are the artificial shards'
     // main-problem columns, gathered slot by slot on each device; the objective row is the main
     // tableau's own, re-eliminated over the basic rows
+    // The column-parallel re-elimination takes every scale from the ORIGINAL objective row; the
+    // reference (simplex.lisp:447) reads it from the row as reduced so far.  The two agree while the
+    // basic columns are exact unit columns AND every product scale * (+0) is +0 -- an inf / NaN
+    // objective coefficient on a basic column would turn later scales into NaNs there.  Declined
+    // like the negative drive-out pivot: the caller solves on one device (sequential form).
+    for (int64_t i = 0; i < m; ++i) {
+        const double sc = main_obj[basis[(size_t)i]];
+        if (!((sc < 0.0 ? -sc : sc) <= 1.7976931348623157e308))
+            return fail(MI_UNSUPPORTED, "non-finite objective coefficient on basic column %lld: the column-parallel "
+                                        "hand-over does not apply", (long long)basis[(size_t)i]);
+    }
     mi355x_colpart *mp = new (std::nothrow) mi355x_colpart;
     if (!mp) return fail(MI_NO_MEMORY, "host allocation failed");
     mp->world = art->world;
@@ -3109,7 +3238,9 @@ int         mi355x_debug_rhs(mi355x_tab *t, double *out, int64_t n, int clear)
 }
 int         mi355x_tune_set_batch_block(int k) { set_batch_block(k); g_batch_block_k = k; return k; }
 int         mi355x_tune_set_resident(int mode) { g_resident_mode = (mode == 1 || mode == 2) ? mode : 0; return g_resident_mode; }
+#ifdef MI355X_TEST_HOOKS
 int         mi355x_tune_set_resident_fault(int on) { set_resident_fault(on); return on; }
+#endif
 int         mi355x_tune_set_resident_poll(int mode) { set_resident_poll(mode); return mode; }
 int         mi355x_tab_resident(mi355x_tab *t) { return (t && resident_mode(t)) ? 1 : 0; }
 int         mi355x_tune_set_lookahead_mode(int mode) { g_la_mode = mode; return g_la_mode; }
@@ -3144,7 +3275,9 @@ int         mi355x_debug_repeat_sweep(mi355x_tab *t, int n, double *avg_us)
 // publishing from step `step_plus_1 - 1` of every block on (0 = off)
 int         mi355x_tune_set_la_one_xcd(int on) { set_la_one_xcd(on); return on; }
 int         mi355x_tune_set_la_max_spins(unsigned n) { set_la_max_spins(n); return (int)n; }
+#ifdef MI355X_TEST_HOOKS
 int         mi355x_tune_set_la_fault(int step_plus_1) { set_la_fault(step_plus_1); return step_plus_1; }
+#endif
 // 1 once an exchange of the persistent look-ahead was lost on this handle (it then stays on the
 // two-launch look-ahead)
 int         mi355x_tab_la_lost(const mi355x_tab *t) { return (t && t->la_lost) ? 1 : 0; }

@@ -589,7 +589,11 @@ __global__ __launch_bounds__(kSelThreads) void k_price_only(TabView t, double sg
         if (out2) { out2[0] = pk; out2[1] = pc; }
         else      t.ctl->ec = price_says_optimal(e, price_tol) ? -1 : e.i;
     }
-    if (x.peers && (int)threadIdx.x < x.lay.world) {         // exchange A, producer: my pair into slot `rank` of EVERY shard
+    // exchange A, producer: my pair into slot `rank` of EVERY shard -- only while the solve is
+    // running: the iterations a host enqueues blind behind a terminating pivot e must stay silent,
+    // or their tags e+2, e+4 ... would overwrite the pair of pivot e in a peer that has not polled
+    // it yet (the consumers of those iterations do not wait, so nothing paces this shard any more)
+    if (x.peers && (int)threadIdx.x < x.lay.world && t.ctl->status == kRunning) {
         const unsigned long long kb = (unsigned long long)__double_as_longlong(pk), cb = (unsigned long long)__double_as_longlong(pc);
         unsigned long long *dst = x.peers[threadIdx.x] + x.lay.pair_off(x.epoch & 1u, x.rank);
         const unsigned long long tg = (unsigned long long)x.epoch << 32;
@@ -1296,7 +1300,8 @@ __global__ __launch_bounds__(256) void k_shard_p2p_step(TabView t, int j, int n_
     const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
     const unsigned long long tg = (unsigned long long)x.epoch << 32;
     // ---- exchange A, producer (the first workgroup): this shard's pricing pair into slot `rank` of EVERY shard
-    if (blockIdx.x == 0) {
+    // (only while running: a finished shard goes silent, see k_price_only)
+    if (blockIdx.x == 0 && running) {
         const ValIdx e = block_price_partials<256>(t.part_v, t.part_i, t.part_s, n_part, s_v, s_i);
         const double pk = e.i < 0 ? 0.0 : e.v;
         const double pc = e.i < 0 ? -1.0 : (e.s == kNanColumn0 ? -2.0 : (double)(e.i + (t.p2l ? 0 : col_offset)));
@@ -1995,6 +2000,9 @@ __global__ __launch_bounds__(kLaThreads) void k_la_block(TabView t, int ksteps, 
     if (leader) { ts_p = tsp; ts_r = tsr; }
 #endif
 
+#ifndef MI355X_TEST_HOOKS
+    fault = 0;                                                   // fault injection exists in the test build only
+#endif
 #pragma unroll 1
     for (int J = 0; J < ksteps; ++J) {
         const unsigned e_price = epoch_base + 2 * J + 1, e_ratio = epoch_base + 2 * J + 2;
@@ -2691,6 +2699,7 @@ __global__ __launch_bounds__(256) void k_sweep16(TabView t, const int tr, const 
 // LPs progress independently and the hardware schedules waiting LPs onto free CUs.  Same
 // arithmetic, same lexicographic reductions => same bits as the lockstep path and the oracle.
 constexpr int kLpThreads = 1024;
+constexpr int64_t kBatchLaunchCap = 4096;   // pivots per LP and launch of the per-LP kernels (a bounded launch: see mi355x_batch_cancel)
 constexpr int kLpUnroll  = 4;   // measured at 128 / 1024 LPs of 257x513: 2 -> 1.76 / 1.49, 4 -> 1.76 / 2.13, 8 -> 1.22 / 1.33 M pivots/s
 
 __global__ __launch_bounds__(kLpThreads) void k_batch_solve(TabView t, double sgn, double price_tol,
@@ -2723,6 +2732,9 @@ __global__ __launch_bounds__(kLpThreads) void k_batch_solve(TabView t, double sg
             if (threadIdx.x == 0) ctl->status = 3;  // MI_MAX_PIVOTS
             break;
         }
+        // a launch is bounded (the host can then honour a cancel between launches; the reference's
+        // loop has no cap and no anti-cycling rule): still kRunning, the host launches again
+        if (n_pivots - c0.n_pivots >= kBatchLaunchCap) break;
         const int64_t ec   = e.i;                   // LOGICAL column
         const int64_t slot = e.s;                   // its physical column
         // gather the entering column into LDS + ratio test
@@ -3138,6 +3150,8 @@ __global__ __launch_bounds__(kBbThreads) void k_batch_block(TabView t, double sg
             }
             __syncthreads();                                   // tableau consistent before the next block reads it
         }
+        // a launch is bounded (see k_batch_solve): still kRunning, the host launches again
+        if (term < 0 && n_pivots - c0.n_pivots >= kBatchLaunchCap) term = kRunning;
     }
     if (tid == 0) {
         ctl->status = term;
@@ -3436,8 +3450,13 @@ __global__ __launch_bounds__(kResThreads, (TR == 1 ? 2 : 1)) void k_resident(Tab
     } while (0)
     price_local();
     RES_COLUMN_OF(lcb, vnext);
-    if (a.G > 1) publish(a.epoch_base + 1u, vnext, obj, a.fault > 0 && wg == a.G - 1);
-    RES_RATIO_AHEAD(a.epoch_base + 1u, 0, a.fault > 0 && wg == a.G - 1);
+#ifdef MI355X_TEST_HOOKS
+    const bool fault_mute = a.fault > 0 && wg == a.G - 1;       // fault injection: the test build only
+#else
+    constexpr bool fault_mute = false;
+#endif
+    if (a.G > 1) publish(a.epoch_base + 1u, vnext, obj, fault_mute);
+    RES_RATIO_AHEAD(a.epoch_base + 1u, 0, fault_mute);
 
     // The strip update of pivot k is the first thing iteration k + 1 does -- AFTER it has asked for
     // the records of pivot k + 1 and before it looks at what came back: the update (pure register /
@@ -4432,7 +4451,9 @@ static int      g_la_one_xcd = 1, g_la_fault = 0;
 static unsigned g_la_max_spins = 1u << 21;
 void set_la_one_xcd(int on) { g_la_one_xcd = on ? 1 : 0; }
 void set_la_max_spins(unsigned n) { g_la_max_spins = n ? n : (1u << 21); }
+#ifdef MI355X_TEST_HOOKS
 void set_la_fault(int step_plus_1) { g_la_fault = step_plus_1; }
+#endif
 
 int la_block_workgroups(const TabView &t)
 {
@@ -4458,7 +4479,9 @@ void launch_la_block(const TabView &t, int ksteps, int is_max, double f, unsigne
 
 // ---- the resident solve
 static int g_res_fault = 0, g_res_poll = 0;
+#ifdef MI355X_TEST_HOOKS
 void set_resident_fault(int on) { g_res_fault = on; }
+#endif
 void set_resident_poll(int mode) { g_res_poll = mode; }     // tuning: 0 / 2 every wave polls (default), 1 wave 0 polls
 
 bool resident_plan(const TabView &c, ResidentPlan *p)

@@ -371,6 +371,22 @@ def _raise_for(rc):
         raise SolverError("Artificial variable still in basis and cannot be replaced")
     if rc == capi.MI_MAX_PIVOTS:
         raise SolverError("pivot cap reached")
+    if rc == capi.MI_CANCELLED:
+        raise SolveCancelled("solve cancelled (mi355x_tab_cancel)")
+
+
+class SolveCancelled(SolverError):
+    """cancel_solve() was called from another thread: the solve stopped between two chunks of
+    launches.  The tableau holds whole pivots only and can be solved further.  (In Lisp the same
+    situation is an interrupt honoured between two bounded foreign calls.)"""
+
+
+def cancel_solve(tableau):
+    """Ask the solve running on `tableau` (in another thread) -- or the next one -- to stop:
+    mi355x_tab_cancel.  The reference's loop has no cap and no anti-cycling rule
+    (src/simplex.lisp:453-461); in Lisp a cycling LP is interruptible, a foreign call is not."""
+    for t in (tableau if isinstance(tableau, (list, tuple)) else [tableau]):
+        capi.check(capi.lib().mi355x_tab_cancel(t._h), "mi355x_tab_cancel")
 
 
 def n_solve_tableau(tableau, max_pivots=0):

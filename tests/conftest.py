@@ -48,3 +48,20 @@ def pytest_sessionstart(session):
 def golden():
     from tests import goldens
     return goldens.load()
+
+
+@pytest.fixture
+def hooks_lib():
+    """The TEST build of the library (fault-injection hooks compiled in, -DMI355X_TEST_HOOKS) in
+    place of the product library for the duration of one test: the product library neither exports
+    the hooks nor holds the code behind them.  Every handle the test makes dies before the swap
+    back."""
+    import gc
+    from tests.helpers import lp_amd
+    ctx = lp_amd().capi.test_build()
+    L = ctx.__enter__()
+    try:
+        yield L
+    finally:
+        gc.collect()
+        ctx.__exit__(None, None, None)

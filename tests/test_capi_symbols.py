@@ -16,9 +16,13 @@ HEADER = os.path.join(ROOT, "include", "mi355x_simplex.h")
 TUNE_HEADER = os.path.join(ROOT, "include", "mi355x_simplex_tune.h")
 
 
-def declared_functions(header=HEADER):
+def declared_functions(header=HEADER, test_hooks=False):
+    """Functions a header declares; the `#ifdef MI355X_TEST_HOOKS` section (fault injection, the
+    test build of the library only) is left out unless test_hooks."""
     src = open(header).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    if not test_hooks:
+        src = re.sub(r"#ifdef MI355X_TEST_HOOKS.*?#endif", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(mi355x_[a-z0-9_]+)\s*\(", src)))
 
 
@@ -54,6 +58,25 @@ def test_tuning_hooks_are_declared_exported_and_bound():
     exported = {l.split()[-1] for l in out.splitlines() if " T " in l and "mi355x_" in l}
     assert exported == set(names) | set(declared_functions()), \
         "undeclared exports: %s" % sorted(exported - set(names) - set(declared_functions()))
+
+
+def test_fault_injection_hooks_exist_in_the_test_build_only():
+    """The fault-injection hooks are compiled in with -DMI355X_TEST_HOOKS only: the product library
+    exports none of them, the test build (same sources) exports exactly the product's symbols plus
+    the hooks, and capi.py binds them only on the test build."""
+    hooks = set(declared_functions(TUNE_HEADER, test_hooks=True)) - set(declared_functions(TUNE_HEADER))
+    assert hooks == set(lp.capi._TEST_HOOKS) and len(hooks) >= 2
+
+    def exports(path):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+        return {l.split()[-1] for l in out.splitlines() if " T " in l and "mi355x_" in l}
+    assert os.path.exists(lp.capi.TEST_LIB_PATH)
+    product, test = exports(lp.capi.LIB_PATH), exports(lp.capi.TEST_LIB_PATH)
+    assert not hooks & product
+    assert test == product | hooks
+    with lp.capi.test_build() as L:
+        assert L is not None and L.mi355x_tune_set_la_fault(0) == 0
+    assert not hasattr(lp.capi.lib(), "_never") and lp.capi.lib() is not L
 
 
 def test_exports_are_plain_c_symbols():

@@ -166,11 +166,11 @@ def test_resident_hands_non_finite_columns_to_the_dense_path():
     assert found >= 3, "no overflowing LP among the seeds"
 
 
-def test_resident_workgroups_not_co_resident_fall_back():
+def test_resident_workgroups_not_co_resident_fall_back(hooks_lib):
     """Test hook: the last workgroup of the LP never publishes its first record (what a workgroup
     that is not resident looks like).  Everybody gives up at the FIRST exchange, nothing has been
     modified, the handle continues (and stays) on the established paths: oracle's pivots and bits."""
-    L = lp.capi.lib()
+    L = hooks_lib
     n, m = 700, 300
     M0, b0 = lp.synth.tableau(n, m, lp.synth.seed_for(2, 99))
     try:
@@ -230,11 +230,11 @@ def test_resident_batches_every_lp_vs_oracle(n, m, nl):
         assert np.array_equal(G.view(np.int64), M.view(np.int64)) and np.array_equal(gb, b), k
 
 
-def test_resident_batch_with_a_lost_member_and_an_overflowing_member():
+def test_resident_batch_with_a_lost_member_and_an_overflowing_member(hooks_lib):
     """One launch, three kinds of LPs: ordinary ones (finished on chip), one whose entries overflow
     (kNeedDense: the batch continues on the dense tableaux) -- and, separately, the co-residency
     test hook (every LP's last workgroup mute): all end where the oracle ends."""
-    L = lp.capi.lib()
+    L = hooks_lib
     n, m, nl = 48, 20, 6
     rng = np.random.default_rng(4)
     Ms, Bs = [], []
