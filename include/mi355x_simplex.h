@@ -73,6 +73,10 @@ int         mi355x_abi_version(void);
 int         mi355x_device_count(void);             /* number of gfx950 devices visible, 0 if none */
 const char *mi355x_last_error(void);               /* thread-local, never NULL */
 double      mi355x_epsilon(void);                  /* CL double-float-epsilon used by the tolerances */
+/* Optional: pay the one-off costs now instead of inside the first solve (the HIP context of
+ * `device`, the library's code object, the pinned staging buffers of the streamed uploads) -- a host
+ * calls it once when it loads the backend.  Idempotent; solves a 1-pivot LP on the device. */
+int         mi355x_init(int device);
 
 /* ---- tableau lifecycle  (tableau struct, src/simplex.lisp:48-58) ------------------- */
 /* Upload a tableau.  host_basis has rows-1 entries (tableau-basis-columns) or is NULL. */

@@ -22,9 +22,9 @@ from .problem import Problem                                    # noqa: F401
 from .simplex import (Tableau, build_tableau, pivot_row, n_pivot_row, solve_tableau,    # noqa: F401
                       n_solve_tableau, copy_tableau, tableau_objective_value,
                       tableau_variable, tableau_reduced_cost, find_entering_column,
-                      find_pivoting_row, simplex_solver, mi355x_simplex_solver,
+                      find_pivoting_row, simplex_solver, mi355x_simplex_solver, mi355x_solve_problems,
                       with_tableau_variables)
-from .solver import (solve_problem, solution_problem, solution_objective_value,         # noqa: F401
+from .solver import (solve_problem, solve_problems, solution_problem, solution_objective_value,         # noqa: F401
                      solution_variable, solution_reduced_cost, with_solution_variables)
 
 __version__ = "0.1.0"

@@ -24,6 +24,7 @@ SIGNATURES = {
     "mi355x_device_count": (_int, []),
     "mi355x_last_error": (ctypes.c_char_p, []),
     "mi355x_epsilon": (_dbl, []),
+    "mi355x_init": (_int, [_int]),
     "mi355x_tab_create": (_int, [_pp, _i64, _i64, _p, _p, _int]),
     "mi355x_tab_create_compact": (_int, [_pp, _i64, _i64, _i64, _p, _p, _p, _int]),
     "mi355x_tab_upload": (_int, [_p, _p, _p]),

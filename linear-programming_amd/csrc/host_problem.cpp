@@ -15,6 +15,12 @@
 #include "../../include/mi355x_simplex.h"
 
 extern "C" void mi355x_set_last_error_(const char *msg);   // simplex_capi.hip (thread-local message)
+// simplex_capi.hip (same library, not exported): a compact handle whose stored rows are PRODUCED
+// chunk by chunk into pinned staging buffers and copied while later rows are being assembled
+extern "C" int mi355x_tab_create_compact_streamed_(mi355x_tab **out, int64_t rows, int64_t var_count, int64_t n_stored,
+                                                   const int64_t *stored_cols, const int64_t *host_basis, int device,
+                                                   void (*produce)(void *ctx, int64_t r0, int64_t r1, double *dst),
+                                                   void *ctx, int n_workers);
 
 #include <algorithm>
 #include <cstdint>
@@ -245,13 +251,22 @@ int hfail(int code, const char *msg) { mi355x_set_last_error_(msg); return code;
 // loop runs on -- the slack identity block is never materialised, on the host or on the device.
 // Same arithmetic as build() entry by entry (rows are independent, so they are filled by a few
 // host threads).  Returns false when the problem needs the general path.
-static bool build_compact(const mi355x_problem &p, std::unique_ptr<double[]> &P, int64_t &rows,
-                          int64_t &ncv_out, std::vector<int64_t> &basis, std::vector<Mapping> &map)
+struct CompactPlan {
+    const mi355x_problem *p = nullptr;
+    std::vector<Constraint> pushed;
+    std::vector<const Constraint *> cons;
+    std::vector<Mapping> map;
+    std::vector<int64_t> basis;
+    int64_t m = 0, ncv = 0;
+};
+
+static bool plan_compact(const mi355x_problem &p, CompactPlan &pl)
 {
     const int64_t n = p.n_vars;
     if (p.constraints.empty()) return false;
+    pl.p = &p;
+    std::vector<Mapping> &map = pl.map;
     map.assign((size_t)n, Mapping());
-    std::vector<Constraint> pushed;
     int64_t ncv = n, column = 0;                                           // :189-212
     for (int64_t v = 0; v < n; ++v) {
         const Bound &bd = p.bounds[(size_t)v];
@@ -261,7 +276,7 @@ static bool build_compact(const mi355x_problem &p, std::unique_ptr<double[]> &P,
             Constraint c;
             if (0.0 <= bd.ub) { c.op = 0; c.rhs = bd.ub; } else { c.op = 1; c.rhs = -bd.ub; }
             c.var = {v}; c.coef = {1.0};
-            pushed.insert(pushed.begin(), c);
+            pl.pushed.insert(pl.pushed.begin(), c);
             map[(size_t)v] = {kPositive, column, bd.lb};
         } else if (bd.has_lb) {
             map[(size_t)v] = {kPositive, column, bd.lb};
@@ -273,12 +288,11 @@ static bool build_compact(const mi355x_problem &p, std::unique_ptr<double[]> &P,
         }
         ++column;
     }
-    std::vector<const Constraint *> cons;
-    for (const auto &c : pushed) cons.push_back(&c);
-    for (const auto &c : p.constraints) cons.push_back(&c);
-    const int64_t m = (int64_t)cons.size();
-    // pass 1: does any row become >= or = (after the sign flip of a negative shifted RHS)?
-    for (const Constraint *c : cons) {
+    for (const auto &c : pl.pushed) pl.cons.push_back(&c);
+    for (const auto &c : p.constraints) pl.cons.push_back(&c);
+    const int64_t m = (int64_t)pl.cons.size();
+    // does any row become >= or = (after the sign flip of a negative shifted RHS)?
+    for (const Constraint *c : pl.cons) {
         double rhs = c->rhs;
         for (size_t k = 0; k < c->var.size(); ++k) {
             const Mapping &mp = map[(size_t)c->var[k]];
@@ -287,46 +301,44 @@ static bool build_compact(const mi355x_problem &p, std::unique_ptr<double[]> &P,
         const int op = (rhs < 0.0) ? (c->op == 0 ? 1 : c->op == 1 ? 0 : 2) : c->op;
         if (op != 0) return false;
     }
-    const int64_t w = ncv + 1;                                             // stored columns + RHS
-    rows = m + 1; ncv_out = ncv;
-    P.reset(new double[(size_t)rows * w]);                                 // rows are zeroed by the
-    basis.resize((size_t)m);                                               // threads that fill them
-    auto fill = [&](int64_t r0, int64_t r1) {
-        for (int64_t row = r0; row < r1; ++row) {                          // :223-268
-            const Constraint &c = *cons[(size_t)row];
-            double *out = P.get() + (size_t)row * w;
-            std::fill(out, out + w, 0.0);
-            out[ncv] = c.rhs;
-            for (size_t k = 0; k < c.var.size(); ++k) {
-                const Mapping &mp = map[(size_t)c.var[k]];
-                const double coef = c.coef[k];
-                if (mp.kind == kPositive)      { out[mp.col] = coef;  out[ncv] = out[ncv] - coef * mp.offset; }
-                else if (mp.kind == kNegative) { out[mp.col] = -coef; out[ncv] = out[ncv] - coef * mp.offset; }
-                else                           { out[mp.col] = coef;  out[mp.col + 1] = -coef; }
-            }
-            if (out[ncv] < 0.0)
-                for (int64_t cc = 0; cc < w; ++cc) out[cc] = -out[cc];
-            basis[(size_t)row] = ncv + row;                                // its slack column
-        }
-    };
-    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    const int64_t nthreads = (m * w > (1 << 22)) ? (int64_t)hw : 1;
-    std::vector<std::thread> pool;
-    for (int64_t k = 0; k < nthreads; ++k) {
-        const int64_t r0 = m * k / nthreads, r1 = m * (k + 1) / nthreads;
-        if (nthreads == 1) fill(r0, r1); else pool.emplace_back(fill, r0, r1);
-    }
-    for (auto &th : pool) th.join();
-    double *obj = P.get() + (size_t)m * w;                                 // :270-283
-    std::fill(obj, obj + w, 0.0);
-    for (size_t k = 0; k < p.obj_var.size(); ++k) {
-        const Mapping &mp = map[(size_t)p.obj_var[k]];
-        const double coef = p.obj_coef[k];
-        if (mp.kind == kPositive)      { obj[mp.col] = -coef; obj[ncv] = obj[ncv] + coef * mp.offset; }
-        else if (mp.kind == kNegative) { obj[mp.col] = coef;  obj[ncv] = obj[ncv] + coef * mp.offset; }
-        else                           { obj[mp.col] = -coef; obj[mp.col + 1] = coef; }
-    }
+    pl.m = m; pl.ncv = ncv;
+    pl.basis.resize((size_t)m);
+    for (int64_t r = 0; r < m; ++r) pl.basis[(size_t)r] = ncv + r;         // every row's slack column
     return true;
+}
+
+// rows [r0, r1) of [structural columns | RHS] (row m = the objective row) into dst, tightly packed;
+// the same arithmetic as build() entry by entry -- rows are independent
+static void produce_compact_rows(void *ctx, int64_t r0, int64_t r1, double *dst)
+{
+    const CompactPlan &pl = *static_cast<const CompactPlan *>(ctx);
+    const int64_t ncv = pl.ncv, w = ncv + 1, m = pl.m;
+    for (int64_t row = r0; row < r1; ++row) {
+        double *out = dst + (size_t)(row - r0) * w;
+        std::fill(out, out + w, 0.0);
+        if (row == m) {                                                    // :270-283
+            const mi355x_problem &p = *pl.p;
+            for (size_t k = 0; k < p.obj_var.size(); ++k) {
+                const Mapping &mp = pl.map[(size_t)p.obj_var[k]];
+                const double coef = p.obj_coef[k];
+                if (mp.kind == kPositive)      { out[mp.col] = -coef; out[ncv] = out[ncv] + coef * mp.offset; }
+                else if (mp.kind == kNegative) { out[mp.col] = coef;  out[ncv] = out[ncv] + coef * mp.offset; }
+                else                           { out[mp.col] = -coef; out[mp.col + 1] = coef; }
+            }
+            continue;
+        }
+        const Constraint &c = *pl.cons[(size_t)row];                       // :223-268
+        out[ncv] = c.rhs;
+        for (size_t k = 0; k < c.var.size(); ++k) {
+            const Mapping &mp = pl.map[(size_t)c.var[k]];
+            const double coef = c.coef[k];
+            if (mp.kind == kPositive)      { out[mp.col] = coef;  out[ncv] = out[ncv] - coef * mp.offset; }
+            else if (mp.kind == kNegative) { out[mp.col] = -coef; out[ncv] = out[ncv] - coef * mp.offset; }
+            else                           { out[mp.col] = coef;  out[mp.col + 1] = -coef; }
+        }
+        if (out[ncv] < 0.0)
+            for (int64_t cc = 0; cc < w; ++cc) out[cc] = -out[cc];
+    }
 }
 
 struct mi355x_solution {
@@ -478,26 +490,26 @@ int mi355x_simplex_solver(const mi355x_problem *p, double fp_tolerance, int devi
     *out = nullptr;
     for (char f : p->is_integer)
         if (f) return hfail(MI_UNSUPPORTED, "integer constraints cannot be handled by the mi355x-simplex solver");
-    {   // single-phase problems: assemble and upload the compact form directly
-        std::unique_ptr<double[]> P;
-        std::vector<int64_t> basis;
-        std::vector<Mapping> map;
-        int64_t rows = 0, ncv = 0;
-        if (build_compact(*p, P, rows, ncv, basis, map)) {
-            const int64_t m = rows - 1, var_count = ncv + m;
+    {   // single-phase problems: the compact form [structural columns | RHS] assembled by a few
+        // host threads straight into pinned staging buffers and uploaded while later rows are still
+        // being assembled (mi355x_tab_create_compact_streamed_)
+        CompactPlan pl;
+        if (plan_compact(*p, pl)) {
+            const int64_t m = pl.m, rows = m + 1, ncv = pl.ncv, var_count = ncv + m;
             mi355x_solution *s = new (std::nothrow) mi355x_solution;
             if (!s) return hfail(MI_NO_MEMORY, "host allocation failed");
             s->rows = rows; s->cols = var_count + 1;
-            s->map = map;
+            s->map = pl.map;
             s->last_row.resize((size_t)var_count + 1);
             s->last_col.resize((size_t)rows);
             s->basis.resize((size_t)m);
             std::vector<int64_t> stored((size_t)ncv);
             for (int64_t j = 0; j < ncv; ++j) stored[(size_t)j] = j;
+            const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+            const int workers = (rows * (ncv + 1) > (1 << 22)) ? (int)hw : 1;
             mi355x_tab *t = nullptr;
-            int rc = mi355x_tab_create_compact(&t, rows, var_count, ncv, P.get(), stored.data(),
-                                               basis.data(), device);
-            P.reset();                                                      // free the host copy early
+            int rc = mi355x_tab_create_compact_streamed_(&t, rows, var_count, ncv, stored.data(), pl.basis.data(),
+                                                         device, produce_compact_rows, &pl, workers);
             if (rc == MI_OK) rc = mi355x_tab_solve(t, p->is_max ? 1 : 0, fp_tolerance, 0, &s->n_pivots[1]);
             int drc = MI_OK;
             if (rc == MI_OPTIMAL)

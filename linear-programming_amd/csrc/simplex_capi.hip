@@ -711,15 +711,15 @@ int mi355x_tab_create(mi355x_tab **out, int64_t rows, int64_t cols, const double
     return MI_OK;
 }
 
-int mi355x_tab_create_compact(mi355x_tab **out, int64_t rows, int64_t var_count, int64_t n_stored,
-                              const double *host_stored, const int64_t *stored_cols,
-                              const int64_t *host_basis, int device)
+// everything of a compact handle but the stored matrix itself: allocations, column maps, basis,
+// zeroed padding, control block -- enqueued on the handle's stream, not waited for
+static int compact_prepare(mi355x_tab **out, int64_t rows, int64_t var_count, int64_t n_stored,
+                           const int64_t *stored_cols, const int64_t *host_basis, int device)
 {
     if (!out) return fail(MI_BAD_ARG, "out is NULL");
     *out = nullptr;
     const int64_t m = rows - 1;
-    if (!host_stored || !stored_cols || !host_basis || m < 1 || n_stored < 1 ||
-        n_stored + m != var_count)
+    if (!stored_cols || !host_basis || m < 1 || n_stored < 1 || n_stored + m != var_count)
         return fail(MI_BAD_ARG, "compact upload needs rows >= 2 and n_stored + (rows-1) == var_count");
     std::vector<int64_t> l2p((size_t)var_count, -2);                 // -2: not yet accounted for
     for (int64_t i = 0; i < m; ++i) {
@@ -744,24 +744,167 @@ int mi355x_tab_create_compact(mi355x_tab **out, int64_t rows, int64_t var_count,
     if (e == hipSuccess) e = hipMalloc((void **)&t->c.p2l, n_stored * sizeof(int64_t));
     if (e == hipSuccess) e = hipMalloc((void **)&t->c.l2p, var_count * sizeof(int64_t));
     if (e == hipSuccess) e = hipMalloc((void **)&t->brow, var_count * sizeof(int64_t));
-    if (e == hipSuccess && t->c.ld != t->c.cols)
-        e = hipMemsetAsync(t->c.M, 0, (size_t)rows * t->c.ld * sizeof(double), t->stream);
-    if (e == hipSuccess)
-        e = hipMemcpy2DAsync(t->c.M, t->c.ld * sizeof(double), host_stored, t->c.cols * sizeof(double),
-                             t->c.cols * sizeof(double), rows, hipMemcpyHostToDevice, t->stream);
+    if (e == hipSuccess && t->c.ld != t->c.cols)                     // (the padding columns only)
+        e = hipMemset2DAsync(t->c.M + t->c.cols, t->c.ld * sizeof(double), 0, (t->c.ld - t->c.cols) * sizeof(double),
+                             rows, t->stream);
+    // (pageable sources: these copies have left the host buffers when the calls return)
     if (e == hipSuccess) e = hipMemcpyAsync(t->c.p2l, stored_cols, n_stored * sizeof(int64_t), hipMemcpyHostToDevice, t->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(t->c.l2p, l2p.data(), var_count * sizeof(int64_t), hipMemcpyHostToDevice, t->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(v.basis, host_basis, m * sizeof(int64_t), hipMemcpyHostToDevice, t->stream);
     if (e == hipSuccess) { launch_ctl_reset(v, 0, 1, t->stream); e = hipGetLastError(); }
-    if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(t->stream);        // l2p is a local
     if (e != hipSuccess) {
         free_tab(t);
         return fail(e == hipErrorOutOfMemory ? MI_NO_MEMORY : MI_HIP_ERROR, "compact upload failed: %s", hipGetErrorString(e));
+    }
+    *out = t;
+    return MI_OK;
+}
+
+int mi355x_tab_create_compact(mi355x_tab **out, int64_t rows, int64_t var_count, int64_t n_stored,
+                              const double *host_stored, const int64_t *stored_cols,
+                              const int64_t *host_basis, int device)
+{
+    if (out) *out = nullptr;
+    if (!host_stored) return fail(MI_BAD_ARG, "host_stored is NULL");
+    mi355x_tab *t = nullptr;
+    int rc = compact_prepare(&t, rows, var_count, n_stored, stored_cols, host_basis, device);
+    if (rc != MI_OK) return rc;
+    hipError_t e = hipMemcpy2DAsync(t->c.M, t->c.ld * sizeof(double), host_stored, t->c.cols * sizeof(double),
+                                    t->c.cols * sizeof(double), rows, hipMemcpyHostToDevice, t->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    if (e != hipSuccess) {
+        free_tab(t);
+        return fail(MI_HIP_ERROR, "compact upload failed: %s", hipGetErrorString(e));
     }
     t->compact = true;
     t->unit_basis = true;
     *out = t;
     return MI_OK;
+}
+
+// ---- the same with the stored matrix PRODUCED chunk by chunk (host_problem.cpp: build-tableau's rows
+// are independent) into pinned staging buffers and copied while later rows are still being assembled:
+// assembly, PCIe and nothing else overlap; no pageable 268 MB intermediate.  The staging pool is
+// process-wide and kept (page-locking memory costs more than the copies it serves).
+namespace {
+struct StagePool {
+    std::mutex mu;
+    std::vector<double *> bufs;
+    size_t bytes_each = 0;
+    ~StagePool() { for (double *b : bufs) (void)hipHostFree(b); }
+};
+StagePool g_stage;
+constexpr size_t kStageBytes = 4u << 20;
+constexpr int    kStageBuffersPerWorker = 2, kStageMaxWorkers = 16;
+
+int stage_pool_reserve(int n_buffers)
+{
+    std::lock_guard<std::mutex> lk(g_stage.mu);
+    g_stage.bytes_each = kStageBytes;
+    while ((int)g_stage.bufs.size() < n_buffers) {
+        double *b = nullptr;
+        HIP_TRY(hipHostMalloc((void **)&b, kStageBytes));
+        g_stage.bufs.push_back(b);
+    }
+    return MI_OK;
+}
+std::mutex g_stream_build_mu;            // one streamed build at a time uses the pool
+}  // namespace
+
+extern "C" __attribute__((visibility("hidden")))
+int mi355x_tab_create_compact_streamed_(mi355x_tab **out, int64_t rows, int64_t var_count, int64_t n_stored,
+                                        const int64_t *stored_cols, const int64_t *host_basis, int device,
+                                        void (*produce)(void *ctx, int64_t r0, int64_t r1, double *dst), void *ctx,
+                                        int n_workers)
+{
+    if (out) *out = nullptr;
+    if (!produce) return fail(MI_BAD_ARG, "no row producer");
+    mi355x_tab *t = nullptr;
+    int rc = compact_prepare(&t, rows, var_count, n_stored, stored_cols, host_basis, device);
+    if (rc != MI_OK) return rc;
+    const int64_t w = n_stored + 1;
+    const int64_t rows_per_chunk = std::max<int64_t>(1, (int64_t)(kStageBytes / (w * sizeof(double))));
+    const int64_t n_chunks = (rows + rows_per_chunk - 1) / rows_per_chunk;
+    n_workers = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(n_workers, kStageMaxWorkers), n_chunks));
+    std::lock_guard<std::mutex> build_lock(g_stream_build_mu);
+    if ((size_t)w * sizeof(double) > kStageBytes ||                 // a row does not fit a staging buffer
+        (rc = stage_pool_reserve(n_workers * kStageBuffersPerWorker)) != MI_OK) {
+        // plain path: assemble everything, one copy
+        std::unique_ptr<double[]> P(new (std::nothrow) double[(size_t)rows * w]);
+        if (!P) { free_tab(t); return fail(MI_NO_MEMORY, "host allocation failed"); }
+        produce(ctx, 0, rows, P.get());
+        hipError_t e = hipMemcpy2DAsync(t->c.M, t->c.ld * sizeof(double), P.get(), w * sizeof(double), w * sizeof(double),
+                                        rows, hipMemcpyHostToDevice, t->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+        if (e != hipSuccess) { free_tab(t); return fail(MI_HIP_ERROR, "compact upload failed: %s", hipGetErrorString(e)); }
+    } else {
+        std::atomic<int64_t> next{0};
+        std::atomic<int> failed{0};
+        auto worker = [&](int wi) {
+            if (hipSetDevice(device) != hipSuccess) { failed = 1; return; }
+            hipStream_t cs = nullptr;
+            hipEvent_t ev[kStageBuffersPerWorker] = {};
+            bool used[kStageBuffersPerWorker] = {};
+            if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { failed = 1; return; }
+            for (auto &e : ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) failed = 1;
+            for (int turn = 0; !failed; ++turn) {
+                const int64_t c = next.fetch_add(1);
+                if (c >= n_chunks) break;
+                const int b = turn % kStageBuffersPerWorker;
+                double *buf = g_stage.bufs[(size_t)(wi * kStageBuffersPerWorker + b)];
+                if (used[b] && hipEventSynchronize(ev[b]) != hipSuccess) { failed = 1; break; }   // its previous copy has left it
+                const int64_t r0 = c * rows_per_chunk, r1 = std::min(rows, r0 + rows_per_chunk);
+                produce(ctx, r0, r1, buf);
+                if (hipMemcpy2DAsync(t->c.M + r0 * t->c.ld, t->c.ld * sizeof(double), buf, w * sizeof(double),
+                                     w * sizeof(double), r1 - r0, hipMemcpyHostToDevice, cs) != hipSuccess ||
+                    hipEventRecord(ev[b], cs) != hipSuccess) { failed = 1; break; }
+                used[b] = true;
+            }
+            if (hipStreamSynchronize(cs) != hipSuccess) failed = 1;
+            for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+            (void)hipStreamDestroy(cs);
+        };
+        std::vector<std::thread> pool;
+        for (int k = 1; k < n_workers; ++k) pool.emplace_back(worker, k);
+        worker(0);
+        for (auto &th : pool) th.join();
+        (void)hipSetDevice(device);
+        if (failed) {
+            (void)hipGetLastError();
+            free_tab(t);
+            return fail(MI_HIP_ERROR, "streamed compact upload failed");
+        }
+    }
+    t->compact = true;
+    t->unit_basis = true;
+    *out = t;
+    return MI_OK;
+}
+
+// Optional: pay the one-off costs now instead of inside the first solve -- the HIP context of
+// `device`, the library's code object (loaded with the first launch), the pinned staging pool of
+// the streamed uploads.  Idempotent.
+int mi355x_init(int device)
+{
+    const int ndev = device_count_checked();
+    if (ndev <= 0) return fail(MI_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(MI_BAD_ARG, "device %d out of range [0,%d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    mi355x_tab *t = nullptr;
+    const double M[6] = {1.0, 1.0, 1.0, -1.0, 0.0, 0.0};            // max x, x <= 1: [A | I | b ; -c | 0 | 0]
+    const int64_t b[1] = {1};
+    int64_t k = 0;
+    int rc = mi355x_tab_create(&t, 2, 3, M, b, device);
+    if (rc != MI_OK) return rc;
+    rc = mi355x_tab_solve(t, 1, 1024.0, 0, &k);
+    mi355x_tab_destroy(t);
+    if (rc != MI_OPTIMAL || k != 1) return rc < 0 ? rc : fail(MI_HIP_ERROR, "warm-up solve ended with status %d after %lld pivots", rc, (long long)k);
+    {
+        std::lock_guard<std::mutex> build_lock(g_stream_build_mu);
+        rc = stage_pool_reserve(kStageMaxWorkers * kStageBuffersPerWorker);
+    }
+    return rc;
 }
 
 int mi355x_tab_upload(mi355x_tab *t, const double *host_matrix, const int64_t *host_basis)

@@ -35,6 +35,7 @@
                 #:solver-error #:unbounded-problem-error #:infeasible-problem-error
                 #:unsupported-constraint-error)
   (:export #:mi355x-simplex-solver
+           #:mi355x-solve-problems
            #:device-count
            #:mi355x-error))
 
@@ -55,6 +56,8 @@
 (defconstant +mi-art-nonzero+ 4)
 (defconstant +mi-art-stuck+ 5)
 (defconstant +mi-nonfinite+ 6)   ; column shards only: the tableau overflowed (see solve-column-partitioned)
+(defconstant +mi-cancelled+ 7)   ; mi355x_*_cancel from another thread (never from this single-threaded glue)
+(defconstant +mi-running+ 100)   ; per-LP status of a batch member a capped / cancelled solve left unfinished
 
 (cffi:defcfun ("mi355x_device_count" device-count) :int)
 (cffi:defcfun ("mi355x_last_error" %last-error) :string)
@@ -85,6 +88,17 @@
   (handle :pointer) (host-matrix :pointer) (host-basis :pointer) (last-row :pointer)
   (last-col :pointer))
 (cffi:defcfun ("mi355x_colpart_destroy" %colpart-destroy) :void (handle :pointer))
+;; a batch of same-shape tableaux over one or several GPUs (include/mi355x_simplex.h, mi355x_multibatch_*)
+(cffi:defcfun ("mi355x_multibatch_create" %multibatch-create) :int
+  (out :pointer) (n-lps :int64) (rows :int64) (cols :int64) (host-matrices :pointer)
+  (host-bases :pointer) (n-devices :int) (device-ids :pointer))
+(cffi:defcfun ("mi355x_multibatch_solve" %multibatch-solve) :int
+  (handle :pointer) (is-max :int) (fp-factor :double) (max-pivots :int64) (status :pointer)
+  (n-pivots :pointer))
+(cffi:defcfun ("mi355x_multibatch_download" %multibatch-download) :int
+  (handle :pointer) (lp-index :int64) (host-matrix :pointer) (host-basis :pointer)
+  (last-row :pointer) (last-col :pointer))
+(cffi:defcfun ("mi355x_multibatch_destroy" %multibatch-destroy) :void (handle :pointer))
 
 (define-condition mi355x-error (solver-error)
   ((code :initarg :code :reader mi355x-error-code)
@@ -332,9 +346,9 @@ one GPU when fewer are visible).  Same pivots, same bits as on one device."
   (multiple-value-bind (flat basis rows cols) (tableau->vectors tableau)
     (let ((handle (colpart-create flat basis rows cols devices)))
       (unwind-protect
-           (let ((status (check (with-foreign-fp-mode
-                                  (%colpart-solve handle (max-problem-p tableau) factor
-                                                  max-pivots n-pivots)))))
+           (let ((status (solve-in-chunks
+                          (lambda (cap) (%colpart-solve handle (max-problem-p tableau) factor cap n-pivots))
+                          rows cols max-pivots n-pivots)))
              ;; A compact column shard cannot do what the reference does with an entering column
              ;; that holds an infinity or a NaN (it would turn basic columns, which a shard does not
              ;; store, into NaNs): the library stops with MI_NONFINITE and the caller, whose tableau
@@ -359,6 +373,36 @@ one GPU when fewer are visible).  Same pivots, same bits as on one device."
 
 (defun max-problem-p (tableau)
   (if (eq 'max (problem-type (tableau-instance-problem tableau))) 1 0))
+
+;;; ------------------------------------------------------------------ a way out of a solve
+;;; The reference's loop has no iteration cap and no anti-cycling rule (src/simplex.lisp:453-461):
+;;; an LP that cycles under Dantzig's rule with lowest-index ties runs for ever.  In Lisp that
+;;; loop can be interrupted (C-c, sb-ext:with-timeout, bt:interrupt-thread); one blocking foreign
+;;; call cannot.  So the glue never makes an unbounded foreign call for a single-phase solve: it
+;;; asks for CHUNK pivots at a time (MI_MAX_PIVOTS = "chunk used up, still running") and is back
+;;; in Lisp -- where pending interrupts are served -- a few times per second.  A solve continued
+;;; call by call takes exactly the pivots of one long call (the cap is a test in the select step;
+;;; pinned by the test-suite through the Python mirror's identical loop).  Other threads can
+;;; also end a blocking call with mi355x_tab_cancel / mi355x_colpart_cancel (MI_CANCELLED).
+(defun chunk-pivots (rows cols)
+  "Pivots per foreign call: about a tenth to half a second of GPU time at every size (one pivot
+moves 16 rows x cols bytes through HBM per 16 pivots; small tableaux cost ~4 us per pivot)."
+  (max 1024 (min 65536 (floor (expt 2 36) (max 1 (* rows cols))))))
+
+(defun solve-in-chunks (solve-fn rows cols max-pivots n-pivots)
+  "Calls (funcall SOLVE-FN cap) -- cap pivots of n-solve-tableau, *N-PIVOTS = pivots of that call
+-- until the status is something else than MI_MAX_PIVOTS or MAX-PIVOTS (0 = no cap) are used up.
+Leaves the total in N-PIVOTS[0] and returns the last status."
+  (let ((chunk (chunk-pivots rows cols))
+        (total 0))
+    (loop
+      (let* ((cap (if (plusp max-pivots) (min chunk (- max-pivots total)) chunk))
+             (status (check (with-foreign-fp-mode (funcall solve-fn cap)))))
+        (incf total (cffi:mem-aref n-pivots :int64 0))
+        (when (or (/= status +mi-max-pivots+)
+                  (and (plusp max-pivots) (>= total max-pivots)))
+          (setf (cffi:mem-aref n-pivots :int64 0) total)
+          (return status))))))
 
 ;;; ------------------------------------------------------------------ the *solver* value
 (defun mi355x-simplex-solver (problem &rest args
@@ -419,19 +463,175 @@ solved `tableau`.  solve-problem forwards these keywords (src/solver.lisp:53-56)
                   (if full-tableau (values nil nil) (upload-tableau-compact tableaus device))
                 (if compact-handle
                     (unwind-protect
-                         (let ((status (check (with-foreign-fp-mode
-                                                (%tab-solve compact-handle (max-problem-p tableaus)
-                                                            factor max-pivots n-pivots)))))
+                         (let ((status (solve-in-chunks
+                                        (lambda (cap) (%tab-solve compact-handle (max-problem-p tableaus)
+                                                                  factor cap n-pivots))
+                                        (1+ (tableau-constraint-count tableaus))
+                                        (1+ (tableau-var-count tableaus)) max-pivots n-pivots)))
                            (signal-outcome status)
                            (download-solution compact-handle tableaus compact-basis))
                       (%tab-destroy compact-handle))
                     (multiple-value-bind (handle flat basis) (upload-tableau tableaus device)
                       (unwind-protect
-                           (let ((status (check (with-foreign-fp-mode
-                                                  (%tab-solve handle (max-problem-p tableaus) factor
-                                                              max-pivots n-pivots)))))
+                           (let ((status (solve-in-chunks
+                                          (lambda (cap) (%tab-solve handle (max-problem-p tableaus) factor
+                                                                    cap n-pivots))
+                                          (1+ (tableau-constraint-count tableaus))
+                                          (1+ (tableau-var-count tableaus)) max-pivots n-pivots)))
                              (signal-outcome status)
                              (if full-tableau
                                  (download-tableau handle tableaus flat basis)
                                  (download-solution handle tableaus basis)))
                         (%tab-destroy handle))))))))))
+
+;;; ------------------------------------------------------------------ many problems at once
+;;; The hook takes ONE problem per call (src/solver.lisp:53-56), so N calls of solve-problem solve
+;;; N small LPs one after the other -- each alone cannot fill the GPU (a 512 x 256 LP occupies 8 of
+;;; 256 CUs).  BASELINE config 4 is exactly that workload; the library solves such LPs side by
+;;; side (mi355x_multibatch_*: every LP resident in the register files of a few CUs, all LPs of a
+;;; sub-batch in one launch, one sub-batch per GPU, no communication).  This is its Lisp entry:
+;;; a LIST of problems in, a list of solved tableaus out, each answering the four solution-*
+;;; generics exactly as the tableau (solve-problem p) returns.
+(defun outcome-condition (status)
+  "The condition SIGNAL-OUTCOME would signal for STATUS, as an object (NIL for MI_OPTIMAL)."
+  (handler-case (progn (signal-outcome status) nil)
+    (error (c) c)))
+
+(defun solve-same-shape-batch (tableaus devices factor max-pivots full-tableau)
+  "TABLEAUS: single-phase tableaus of ONE shape and ONE sense.  Packs them into one multi-device
+batch, solves them side by side and writes every member's results back into its own arrays.
+Returns a list parallel to TABLEAUS: the tableau, or a condition object for a member without a
+solution (unbounded-problem-error ...)."
+  (let* ((n (length tableaus))
+         (first-matrix (tableau-matrix (first tableaus)))
+         (rows (array-dimension first-matrix 0))
+         (cols (array-dimension first-matrix 1))
+         (m (1- rows))
+         (flat (make-array (* n rows cols) :element-type 'double-float))
+         (bases (make-array (max 1 (* n m)) :element-type '(signed-byte 64) :initial-element 0))
+         (n-dev (device-count-of devices))
+         (handle nil))
+    (loop for tab in tableaus for k from 0
+          do (let ((matrix (tableau-matrix tab))
+                   (basis (tableau-basis-columns tab))
+                   (base (* k rows cols)))
+               (dotimes (r rows)
+                 (dotimes (c cols)
+                   (setf (aref flat (+ base (* r cols) c))
+                         (coerce (aref matrix r c) 'double-float))))
+               (dotimes (i m)
+                 (setf (aref bases (+ (* k m) i)) (aref basis i)))))
+    (cffi:with-foreign-objects ((out :pointer) (ids :int (max n-dev 1))
+                                (status :int32 n) (pivots :int64 n))
+      (when (listp devices)
+        (loop for d in devices for i from 0 do (setf (cffi:mem-aref ids :int i) d)))
+      (cffi:with-pointer-to-vector-data (pm flat)
+        (cffi:with-pointer-to-vector-data (pb bases)
+          (check (with-foreign-fp-mode
+                   (%multibatch-create out n rows cols pm pb n-dev
+                                       (if (listp devices) ids (cffi:null-pointer)))))))
+      (setf handle (cffi:mem-ref out :pointer))
+      (unwind-protect
+           (progn
+             ;; bounded foreign calls, as for a single tableau: MI_RUNNING members carry on
+             (let ((chunk (chunk-pivots rows cols))
+                   (done 0))
+               (loop
+                 (let ((cap (if (plusp max-pivots) (min chunk (- max-pivots done)) chunk)))
+                   (check (with-foreign-fp-mode
+                            (%multibatch-solve handle (max-problem-p (first tableaus)) factor cap
+                                               status pivots)))
+                   (incf done cap)
+                   (when (or (and (plusp max-pivots) (>= done max-pivots))
+                             (loop for k below n
+                                   never (= (cffi:mem-aref status :int32 k) +mi-max-pivots+)))
+                     (return)))))
+             (let ((last-row (make-array cols :element-type 'double-float))
+                   (last-col (make-array rows :element-type 'double-float))
+                   (one-flat (when full-tableau (make-array (* rows cols) :element-type 'double-float)))
+                   (one-basis (make-array (max 1 m) :element-type '(signed-byte 64) :initial-element 0)))
+               (loop for tab in tableaus for k from 0
+                     collect
+                     (let ((condition (outcome-condition (cffi:mem-aref status :int32 k))))
+                       (or condition
+                           (let ((matrix (tableau-matrix tab))
+                                 (basis-dst (tableau-basis-columns tab)))
+                             (cffi:with-pointer-to-vector-data (pr last-row)
+                               (cffi:with-pointer-to-vector-data (pc last-col)
+                                 (cffi:with-pointer-to-vector-data (pb one-basis)
+                                   (if full-tableau
+                                       (cffi:with-pointer-to-vector-data (pm one-flat)
+                                         (check (%multibatch-download handle k pm pb pr pc)))
+                                       (check (%multibatch-download handle k (cffi:null-pointer)
+                                                                    pb pr pc))))))
+                             (if full-tableau
+                                 (vectors->tableau tab one-flat one-basis)
+                                 (progn
+                                   (dotimes (r rows) (setf (aref matrix r (1- cols)) (aref last-col r)))
+                                   (dotimes (c cols) (setf (aref matrix (1- rows) c) (aref last-row c)))
+                                   (dotimes (i (length basis-dst))
+                                     (setf (aref basis-dst i) (aref one-basis i)))
+                                   tab))))))))
+        (%multibatch-destroy handle)))))
+
+(defun mi355x-solve-problems (problems &rest args
+                              &key (fp-tolerance 1024) (device 0) (devices 1) (max-pivots 0)
+                                full-tableau (errorp t)
+                              &allow-other-keys)
+  "Solves a LIST of problems and returns the list of their solved tableaus, in order -- what
+  (mapcar #'solve-problem problems) returns, with the independent LPs running side by side on
+the GPU(s) instead of one after the other.
+  * Single-phase problems (every row a <= row after build-tableau's sign normalisation,
+    src/simplex.lisp:243-263) are grouped by tableau shape and sense; a group of two or more is one
+    multi-device batch (mi355x_multibatch_*: DEVICES sub-batches, one per GPU, no communication).
+  * Two-phase problems (build-tableau returned (art main), src/simplex.lisp:326-328) and problems
+    alone in their group go through MI355X-SIMPLEX-SOLVER one by one -- phase 1, the hand-over
+    (src/simplex.lisp:402-452) and phase 2 on DEVICE.
+  * A member without a solution does not abort the others: with :ERRORP NIL its place in the
+    result holds the condition object (unbounded-problem-error, infeasible-problem-error,
+    unsupported-constraint-error ...); with :ERRORP T (default, what mapcar of solve-problem
+    would do) the first such condition is signalled after every member has been attempted.
+Every returned tableau's results are bit-identical to the single-problem path's."
+  (declare (ignore args))
+  (let* ((n (length problems))
+         (results (make-array n :initial-element nil))
+         (groups (make-hash-table :test #'equal))
+         (factor (coerce fp-tolerance 'double-float)))
+    (flet ((solve-alone (k problem)
+             (setf (aref results k)
+                   (handler-case (mi355x-simplex-solver problem :fp-tolerance fp-tolerance
+                                                                :device device :max-pivots max-pivots
+                                                                :full-tableau full-tableau)
+                     (error (c) c)))))
+      ;; build-tableau for every member; two-phase members and integer problems leave the batch
+      (loop for problem in problems for k from 0
+            do (if (problem-integer-vars problem)
+                   (solve-alone k problem)             ; -> unsupported-constraint-error
+                   (let ((tableaus (handler-case
+                                       (build-tableau problem problem :fp-tolerance-factor fp-tolerance)
+                                     (error (c) c))))
+                     (cond
+                       ((typep tableaus 'condition) (setf (aref results k) tableaus))
+                       ((listp tableaus) (solve-alone k problem))
+                       ((not (unit-basis-p tableaus)) (solve-alone k problem))
+                       (t
+                        (let ((matrix (tableau-matrix tableaus)))
+                          (push (cons k tableaus)
+                                (gethash (list (array-dimension matrix 0) (array-dimension matrix 1)
+                                               (max-problem-p tableaus))
+                                         groups))))))))
+      (maphash
+       (lambda (shape members)
+         (declare (ignore shape))
+         (setf members (reverse members))
+         (if (rest members)
+             (loop for (k . nil) in members
+                   for outcome in (solve-same-shape-batch (mapcar #'cdr members) devices factor
+                                                          max-pivots full-tableau)
+                   do (setf (aref results k) outcome))
+             (solve-alone (car (first members)) (nth (car (first members)) problems))))
+       groups))
+    (when errorp
+      (let ((failed (find-if (lambda (r) (typep r 'condition)) results)))
+        (when failed (error failed))))
+    (coerce results 'list)))

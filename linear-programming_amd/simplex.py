@@ -389,9 +389,30 @@ def cancel_solve(tableau):
         capi.check(capi.lib().mi355x_tab_cancel(t._h), "mi355x_tab_cancel")
 
 
-def n_solve_tableau(tableau, max_pivots=0):
+def chunk_pivots(rows, cols):
+    """The glue's `chunk-pivots`: pivots per foreign call, about a tenth to half a second of GPU
+    time at every size, so that a single-threaded host is back in its own code (where interrupts
+    are served) a few times per second."""
+    return max(1024, min(65536, (1 << 36) // max(1, rows * cols)))
+
+
+def _solve_in_chunks(call, rows, cols, max_pivots):
+    """The glue's `solve-in-chunks`: call(cap) -> (status, pivots of that call) until the status is
+    something else than MI_MAX_PIVOTS or max_pivots (0 = no cap) are used up.  A solve continued
+    call by call takes exactly the pivots of one long call."""
+    chunk, total = chunk_pivots(rows, cols), 0
+    while True:
+        cap = min(chunk, max_pivots - total) if max_pivots > 0 else chunk
+        rc, k = call(cap)
+        total += k
+        if rc != capi.MI_MAX_PIVOTS or (max_pivots > 0 and total >= max_pivots):
+            return rc, total
+
+
+def n_solve_tableau(tableau, max_pivots=0, chunked=False):
     """n-solve-tableau (src/simplex.lisp:399-461): a Tableau (single phase) or a list
-    [art, main] (two-phase).  Returns the solved (main) tableau."""
+    [art, main] (two-phase).  Returns the solved (main) tableau.  chunked: bounded foreign calls
+    (what the Lisp glue does, see chunk_pivots)."""
     if isinstance(tableau, (list, tuple)):
         art, main = tableau
         if not isinstance(art, Tableau) or not isinstance(main, Tableau):
@@ -408,12 +429,19 @@ def n_solve_tableau(tableau, max_pivots=0):
     if not isinstance(tableau, Tableau):                    # (check-type tableau tableau) :454
         raise TypeError("%r is not a tableau" % (tableau,))
     n = ctypes.c_int64(0)
-    rc = capi.check(capi.lib().mi355x_tab_solve(tableau._h, int(tableau.is_max),
-                                                float(tableau.fp_tolerance_factor),
-                                                int(max_pivots), ctypes.byref(n)),
-                    "mi355x_tab_solve")
+
+    def call(cap):
+        rc = capi.check(capi.lib().mi355x_tab_solve(tableau._h, int(tableau.is_max),
+                                                    float(tableau.fp_tolerance_factor),
+                                                    int(cap), ctypes.byref(n)),
+                        "mi355x_tab_solve")
+        return rc, int(n.value)
+    if chunked:
+        rc, total = _solve_in_chunks(call, tableau.constraint_count + 1, tableau.var_count + 1, int(max_pivots))
+    else:
+        rc, total = call(max_pivots)
     tableau._touch()
-    tableau.n_pivots = int(n.value)
+    tableau.n_pivots = total
     _raise_for(rc)
     return tableau
 
@@ -438,11 +466,15 @@ def _solve_column_partitioned(tableau, devices, max_pivots=0):
                                        int(devices)), "mi355x_colpart_create")
     try:
         n = ctypes.c_int64(0)
-        rc = capi.check(L.mi355x_colpart_solve(h, int(tableau.is_max), float(tableau.fp_tolerance_factor),
-                                               int(max_pivots), ctypes.byref(n)), "mi355x_colpart_solve")
+
+        def call(cap):
+            rc = capi.check(L.mi355x_colpart_solve(h, int(tableau.is_max), float(tableau.fp_tolerance_factor),
+                                                   int(cap), ctypes.byref(n)), "mi355x_colpart_solve")
+            return rc, int(n.value)
+        rc, total = _solve_in_chunks(call, M.shape[0], M.shape[1], int(max_pivots))
         if rc == capi.MI_NONFINITE:
             return False
-        tableau.n_pivots = int(n.value)
+        tableau.n_pivots = total
         _raise_for(rc)
         G, bg = np.empty_like(M), np.empty_like(b)
         capi.check(L.mi355x_colpart_download(h, _ptr(G), _ptr(bg), None, None), "mi355x_colpart_download")
@@ -516,7 +548,84 @@ def mi355x_simplex_solver(problem, fp_tolerance=1024, device=0, devices=1, **_ig
         return tabs
     if devices > 1 and isinstance(tabs, list) and _solve_two_phase_column_partitioned(tabs[0], tabs[1], devices):
         return tabs[1]
-    return n_solve_tableau(tabs)
+    return n_solve_tableau(tabs, chunked=True)
 
 
 simplex_solver = mi355x_simplex_solver
+
+
+def mi355x_solve_problems(problems, fp_tolerance=1024, device=0, devices=1, max_pivots=0, errorp=True):
+    """The glue's `mi355x-solve-problems`: a LIST of problems -> the list of their solved tableaus,
+    what [solve_problem(p) for p in problems] returns, with the independent LPs side by side on the
+    GPU(s).  Single-phase problems are grouped by tableau shape and sense; a group of two or more
+    is ONE multi-device batch (mi355x_multibatch_create / _solve in bounded chunks / _download per
+    member / _destroy: `devices` sub-batches, no communication).  Two-phase problems
+    (src/simplex.lisp:402-452), integer problems (declined) and problems alone in their group go
+    through mi355x_simplex_solver one by one.  A member without a solution does not abort the
+    others: errorp False leaves the exception object in its place, errorp True raises the first
+    one after every member has been attempted."""
+    from .batch import MultiDeviceBatch
+    results = [None] * len(problems)
+    groups = {}
+
+    def alone(k):
+        try:
+            results[k] = mi355x_simplex_solver(problems[k], fp_tolerance=fp_tolerance, device=device)
+        except SolverError as e:
+            results[k] = e
+
+    for k, p in enumerate(problems):
+        if p.integer_vars:
+            alone(k)
+            continue
+        try:
+            tabs = build_tableau(p, p, fp_tolerance_factor=fp_tolerance, device=device)
+        except SolverError as e:                       # e.g. the unbounded no-constraint special case
+            results[k] = e
+            continue
+        if isinstance(tabs, list) or not _unit_basis(tabs):
+            alone(k)
+        else:
+            groups.setdefault((tabs.matrix.shape, tabs.is_max), []).append((k, tabs))
+    for (shape, is_max), members in groups.items():
+        if len(members) == 1:
+            alone(members[0][0])
+            continue
+        rows, cols = shape
+        mb = MultiDeviceBatch.from_arrays(np.stack([t.matrix for _, t in members]),
+                                          np.stack([t.basis_columns for _, t in members]), n_devices=devices)
+        chunk, done = chunk_pivots(rows, cols), 0
+        while True:
+            cap = min(chunk, max_pivots - done) if max_pivots > 0 else chunk
+            st, npv = mb.solve(is_max=is_max, fp_tolerance=fp_tolerance, max_pivots=cap)
+            done += cap
+            if (max_pivots > 0 and done >= max_pivots) or not (st == capi.MI_MAX_PIVOTS).any():
+                break
+        for q, (k, t) in enumerate(members):
+            try:
+                _raise_for(int(st[q]))
+            except SolverError as e:
+                results[k] = e
+                continue
+            G, gb = mb.download(q)
+            old, t._handle = t._handle, None
+            if old:
+                capi.lib().mi355x_tab_destroy(old)
+            t._matrix, t._basis, t._stale, t._light = G, gb, False, None
+            results[k] = t
+    if errorp:
+        for r in results:
+            if isinstance(r, Exception):
+                raise r
+    return results
+
+
+def _unit_basis(tableau):
+    """The glue's `unit-basis-p`: every basis column is exactly the unit vector of its row."""
+    M, b = tableau.matrix, tableau.basis_columns
+    if len(set(b.tolist())) != len(b) or (len(b) and (b.min() < 0 or b.max() >= M.shape[1] - 1)):
+        return False
+    cols = M[:, b]
+    unit = np.zeros_like(cols)
+    unit[np.arange(len(b)), np.arange(len(b))] = 1.0
+    return bool(np.array_equal(cols, unit) and not np.signbit(cols).any())

@@ -19,6 +19,13 @@ def solve_problem(problem, **kwargs):
     return SOLVER(problem, **kwargs)
 
 
+def solve_problems(problems, **kwargs):
+    """The glue's `mi355x-solve-problems`: what [solve_problem(p) for p in problems] returns, with
+    the independent LPs solved side by side (the hook itself takes one problem per call,
+    src/solver.lisp:53-56)."""
+    return simplex.mi355x_solve_problems(problems, **kwargs)
+
+
 def solution_problem(solution):
     """solution-problem (src/solver.lisp:59-62)."""
     return solution.problem

@@ -45,6 +45,8 @@ int main(void)
             mi355x_multibatch *mb = NULL;
             if (mi355x_multibatch_create(&mb, 1, rows, cols, M, basis, 8, NULL) != MI_NO_DEVICE || mb != NULL) return 21;
             if (mi355x_batch_sync(NULL, NULL, NULL) != MI_BAD_ARG) return 22;
+            if (mi355x_tab_cancel(NULL) != MI_BAD_ARG || mi355x_batch_cancel(NULL) != MI_BAD_ARG ||
+                mi355x_multibatch_cancel(NULL) != MI_BAD_ARG || mi355x_colpart_cancel(NULL) != MI_BAD_ARG) return 36;
         }
         printf("no device: %s\n", mi355x_last_error());
     } else {
@@ -105,6 +107,63 @@ int main(void)
             if (mi355x_colpart_download(mn, NULL, NULL, NULL, lc) != MI_OK || lc[3] != 28.5) return 35;
             mi355x_colpart_destroy(mn);
             mi355x_colpart_destroy(art);
+            mi355x_problem_destroy(q);
+        }
+        {   /* the call sequence of the glue's mi355x-solve-problems on a mixed list: the single-phase
+             * members as ONE batch solved in bounded chunks (cap 1 here: MI_MAX_PIVOTS = "chunk used up",
+             * call again) with the light read-back per member; the two-phase member peeled off to
+             * mi355x_solve_two_phase (t/simplex.lisp:239-275: x + y >= 2 ... objective 57/2 still) */
+            mi355x_multibatch *mb = NULL;
+            double MM[2 * 18], lr[6], lc[3];
+            int64_t bb[4], npv[2], b1[2];
+            int32_t st[2];
+            int calls = 0, running = 1;
+            memcpy(MM, M, sizeof M); memcpy(MM + 18, M, sizeof M);
+            MM[18 + 12] = -3.0;                                   /* second member: max 3x + 4y + 3z */
+            bb[0] = bb[2] = basis[0]; bb[1] = bb[3] = basis[1];
+            if (mi355x_multibatch_create(&mb, 2, rows, cols, MM, bb, 1, NULL) != MI_OK) return 37;
+            while (running) {
+                if (mi355x_multibatch_solve(mb, 1, 1024.0, 1, st, npv) != MI_OK) return 38;
+                running = st[0] == MI_MAX_PIVOTS || st[1] == MI_MAX_PIVOTS;
+                if (++calls > 16) return 39;
+            }
+            if (st[0] != MI_OPTIMAL || st[1] != MI_OPTIMAL || calls < 4) return 40;          /* 2 and 3 pivots, one per call */
+            if (mi355x_multibatch_download(mb, 0, NULL, b1, lr, lc) != MI_OK || lc[2] != 28.5 || lr[5] != 28.5) return 41;
+            if (b1[0] != 0 || b1[1] != 1) return 42;
+            if (mi355x_multibatch_download(mb, 1, NULL, b1, lr, lc) != MI_OK || lc[2] != 33.0) return 43;   /* x = 4, y = 0, z = 7: 12 + 21 */
+            mi355x_multibatch_destroy(mb);
+        }
+        {
+            mi355x_problem *q = NULL;
+            int64_t v3[] = {0, 1};  double c3[] = {1, 1};
+            int64_t ar = 0, ac = 0, mr = 0, mc = 0, npv[2] = {0, 0};
+            double A[4 * 9], Mm[4 * 8], lc[4];
+            int64_t ab[3], mb2[3];
+            mi355x_tab *art = NULL, *mn = NULL;
+            if (mi355x_problem_create(&q, 1, 3) != MI_OK) return 44;
+            mi355x_problem_set_objective(q, ov, oc, 3);
+            mi355x_problem_add_constraint(q, 0, v1, c1, 2, 8.0);
+            mi355x_problem_add_constraint(q, 0, v2, c2, 2, 7.0);
+            mi355x_problem_add_constraint(q, 1, v3, c3, 2, 2.0);
+            if (mi355x_build_tableau(q, 1, &ar, &ac, NULL, NULL, NULL) != MI_OK) return 45;
+            if (mi355x_build_tableau(q, 1, NULL, NULL, A, ab, NULL) != MI_OK) return 46;
+            if (mi355x_build_tableau(q, 0, &mr, &mc, NULL, NULL, NULL) != MI_OK) return 47;
+            if (mi355x_build_tableau(q, 0, NULL, NULL, Mm, mb2, NULL) != MI_OK) return 48;
+            if (mi355x_tab_create(&art, ar, ac, A, ab, 0) != MI_OK) return 49;
+            if (mi355x_tab_create(&mn, mr, mc, Mm, mb2, 0) != MI_OK) return 50;
+            if (mi355x_solve_two_phase(art, mn, 1, 1024.0, npv) != MI_OPTIMAL) return 51;
+            if (mi355x_tab_download(mn, NULL, NULL, NULL, lc) != MI_OK || lc[3] != 28.5) return 52;
+            /* a cancel request with no solve in flight is aimed at the next solve: whole pivots, and
+             * the request ends with that solve */
+            if (mi355x_tab_cancel(mn) != MI_OK) return 53;
+            {
+                int64_t k = 0;
+                const int r1 = mi355x_tab_solve(mn, 1, 1024.0, 0, &k);
+                if (r1 != MI_OPTIMAL && r1 != MI_CANCELLED) return 54;
+                if (mi355x_tab_solve(mn, 1, 1024.0, 0, &k) != MI_OPTIMAL || k != 0) return 55;
+            }
+            mi355x_tab_destroy(mn);
+            mi355x_tab_destroy(art);
             mi355x_problem_destroy(q);
         }
         printf("solved on the GPU: w = %g, x = %g\n", w, x);
