@@ -746,7 +746,7 @@ def main():
             "roofline": roofline,
         }
         if N == 1 and args.workload == "cfg3" and not args.no_per_pivot:
-            rec["per_pivot_kernel"] = per_pivot_record(lp, L, n, m, seed, local_rank, kernel_bytes, args.block or 16)
+            rec["per_pivot_kernel"] = per_pivot_record(lp, L, n, m, seed, local_rank, kernel_bytes, args.block or 0)
         if N == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"], state = cpu_baseline(lp, n, m, seed, args.cpu_pivots)
             rec["parity_in_run"] = parity_in_run(lp, L, n, m, seed, local_rank, state)

@@ -34,7 +34,9 @@ int         mi355x_tune_set_ld_extra(int doubles);           /* extra row paddin
 /* ---- which implementation of the solve loop runs -------------------------------------- */
 int         mi355x_tune_set_select_mode(int mode);           /* 0 auto, 1 one workgroup, 2 split */
 int         mi355x_tune_set_compact(int on);                 /* 1: [non-basic | RHS] (default)   */
-int         mi355x_tune_set_block(int k);                    /* pivots per sweep, 1..16 (1 = off) */
+int         mi355x_tune_set_block(int k);                    /* pivots per sweep: 0 by size (default: 16,
+                                                                or a wide block of 28 where the sweep
+                                                                dominates), 1 off, 2 .. 16, 24, 28    */
 int         mi355x_tune_set_lookahead_mode(int mode);        /* 0 auto, 1 two launches per step,
                                                                 2 one persistent launch per block */
 int         mi355x_tune_set_sweep_shape(int rows_per_workgroup, int nontemporal /* -1 by size */);

@@ -37,7 +37,8 @@ int g_batch_mode = 0;                     // 0 auto, 1 lockstep launch pairs, 2 
                                           // 3 blocked: look-ahead per LP + one sweep launch over all LPs
 int g_tail_policy = 1;                    // a request that is not a whole number of blocks: 0 spread evenly, 1 full blocks + remainder
 int g_la_mode = 0;                        // look-ahead: 0 auto, 1 two launches per step, 2 one persistent launch per block
-int g_block_k = 16;                       // pivots selected ahead and applied per sweep (1 = off)
+int g_block_k = 0;                        // pivots selected ahead and applied per sweep: 0 = by size (16, or a wide
+                                          // block of 28 where the sweep dominates), 1 = off, 2 .. 16, 24, 28
 int g_resident_mode = 0;                  // resident solve (tableau in registers): 0 auto -- whenever the shape fits and
                                           // every other implementation knob is at its default --, 1 never, 2 whenever it fits
 int g_batch_block_k = 0;                  // mirror of the blocked per-LP kernel's knob (0 = default)
@@ -128,6 +129,7 @@ struct mi355x_tab {
     int         n_part = 0;               // pricing partials left by the last update (0 = none)
     int         part_is_max = -1;         // ... and the problem sense they were computed for
     int         shard_is_max = 1;         // sense last given to mi355x_shard_price
+    int         shard_steps = 0;          // look-ahead steps of a shard enqueued since its last sweep
     int         timing_stride = 0;        // 0 = off, k = bracket every k-th update launch
     int64_t     update_launches = 0;
     int64_t     sweeps = 0;               // update launches so far: odd ones sweep bottom-up
@@ -202,6 +204,7 @@ void free_tab(mi355x_tab *t)
     (void)hipFree(t->v.blk);
     (void)hipFree(t->v.bk_rmask);
     (void)hipFree(t->v.bk_smask);
+    (void)hipFree(t->v.bk_smask2);
     (void)hipFree(t->v.la_px);
     (void)hipFree(t->v.la_rx);
     (void)hipFree(t->c.M);
@@ -285,11 +288,12 @@ int alloc_tab(mi355x_tab **out, int64_t rows, int64_t cols, int device, int64_t 
     }
     if (n_lps == 1) {                                 // blocked pivoting
         t->v.bk_stride = (rows + kLdAlign - 1) / kLdAlign * kLdAlign;
-        ALLOC(t->v.bk_col, (size_t)kMaxBlock * t->v.bk_stride * sizeof(double));
-        ALLOC(t->v.bk_prow, (size_t)kMaxBlock * t->v.ld * sizeof(double));
+        ALLOC(t->v.bk_col, (size_t)kWideBlock * t->v.bk_stride * sizeof(double));     // (room for wide blocks)
+        ALLOC(t->v.bk_prow, (size_t)kWideBlock * t->v.ld * sizeof(double));
         ALLOC(t->v.blk, sizeof(BlockCtl));
         ALLOC(t->v.bk_rmask, (size_t)t->v.bk_stride * sizeof(uint32_t));
         ALLOC(t->v.bk_smask, (size_t)t->v.ld * sizeof(uint32_t));
+        ALLOC(t->v.bk_smask2, (size_t)t->v.ld * sizeof(uint32_t));
         ALLOC(t->v.la_px, kMaxLaRecords * sizeof(ExchRec));
         ALLOC(t->v.la_rx, kMaxLaRecords * sizeof(ExchRec));
     }
@@ -325,10 +329,11 @@ int alloc_tab(mi355x_tab **out, int64_t rows, int64_t cols, int device, int64_t 
     if ((n_lps == 1 && ((e = hipMemsetAsync(t->v.blk, 0, sizeof(BlockCtl), t->stream)) != hipSuccess ||
                       (e = hipMemsetAsync(t->v.bk_rmask, 0, t->v.bk_stride * sizeof(uint32_t), t->stream)) != hipSuccess ||
                       (e = hipMemsetAsync(t->v.bk_smask, 0, t->v.ld * sizeof(uint32_t), t->stream)) != hipSuccess ||
+                      (e = hipMemsetAsync(t->v.bk_smask2, 0, t->v.ld * sizeof(uint32_t), t->stream)) != hipSuccess ||
                       (e = hipMemsetAsync(t->v.la_px, 0, kMaxLaRecords * sizeof(ExchRec), t->stream)) != hipSuccess ||
                       (e = hipMemsetAsync(t->v.la_rx, 0, kMaxLaRecords * sizeof(ExchRec), t->stream)) != hipSuccess ||
-                      (e = hipMemsetAsync(t->v.bk_col, 0, (size_t)kMaxBlock * t->v.bk_stride * sizeof(double), t->stream)) != hipSuccess ||
-                      (e = hipMemsetAsync(t->v.bk_prow, 0, (size_t)kMaxBlock * t->v.ld * sizeof(double), t->stream)) != hipSuccess)) ||
+                      (e = hipMemsetAsync(t->v.bk_col, 0, (size_t)kWideBlock * t->v.bk_stride * sizeof(double), t->stream)) != hipSuccess ||
+                      (e = hipMemsetAsync(t->v.bk_prow, 0, (size_t)kWideBlock * t->v.ld * sizeof(double), t->stream)) != hipSuccess)) ||
         (e = hipMemsetAsync(t->v.ctl, 0, n_lps * sizeof(Ctl), t->stream)) != hipSuccess ||
         (e = hipMemsetAsync(t->v.basis, 0, n_lps * nb * sizeof(int64_t), t->stream)) != hipSuccess) {
         free_tab(t);
@@ -514,9 +519,20 @@ int enqueue_iteration(mi355x_tab *t, int is_max, double f)
 }
 
 // ---- blocked pivoting: k look-ahead selects, then one sweep applies them all
+// pivots per sweep of this handle: the knob as it was when the handle was created, or by size --
+// 16 wherever the persistent look-ahead runs (its state lives in LDS), a wide block where the
+// sweep dominates (wide_block_default), 16 otherwise
+int block_size(const mi355x_tab *t)
+{
+    if (t->tn.block_k != 0) return t->tn.block_k;
+    if (t->tn.la_mode != 1 && !t->la_lost && la_block_supported(t->c)) return kMaxBlock;
+    const int w = wide_block_default(t->c);
+    return w ? w : kMaxBlock;
+}
+
 bool block_mode(const mi355x_tab *t)
 {
-    if (t->tn.block_k <= 1 || !t->compact || !block_supported(t->c)) return false;
+    if (t->tn.block_k == 1 || !t->compact || !block_supported(t->c)) return false;
     if (t->tn.select_mode == 1) return false;             // forced: single-workgroup select, per pivot
     if (t->tn.select_mode == 2) return true;
     // the persistent look-ahead pays at every size (a step costs less than the select + update
@@ -532,10 +548,11 @@ int enqueue_block(mi355x_tab *t, int is_max, double f, int k)
     // (a handle that lost an exchange once stays on the two-launch form, forced mode 2 or not:
     // re-launching the persistent kernel for ever on a GPU that cannot co-schedule its workgroups
     // would never return)
-    const bool persistent = t->tn.la_mode != 1 && !t->la_lost && la_block_supported(v);
+    const bool persistent = t->tn.la_mode != 1 && !t->la_lost && k <= kMaxBlock && block_size(t) <= kMaxBlock &&
+                            la_block_supported(v);
     // event pairs around FULL blocks only: the statistics are per (look-ahead of g_block_k
     // pivots, sweep of g_block_k pivots), the partial last block of a run is left out
-    const bool timed = t->timing_stride > 0 && t->n_timed < kTimingCap && k == t->tn.block_k &&
+    const bool timed = t->timing_stride > 0 && t->n_timed < kTimingCap && k == block_size(t) &&
                        (t->update_launches++ % t->timing_stride) == 0;
     auto ensure_events = [](std::vector<hipEvent_t> &a, std::vector<hipEvent_t> &b, int n) -> hipError_t {
         while ((int)a.size() <= n) {
@@ -613,7 +630,7 @@ int status_to_rc(int32_t st) { return st == kRunning ? MI_RUNNING : (int)st; }
 // ---- the resident solve (tableaux that fit the register files; simplex_kernels.hip, k_resident)
 bool knobs_at_default(const TuneSnapshot &k)
 {
-    return k.select_mode == 0 && k.la_mode == 0 && k.block_k == kMaxBlock && k.batch_mode == 0 && k.batch_block_k == 0;
+    return k.select_mode == 0 && k.la_mode == 0 && k.block_k == 0 && k.batch_mode == 0 && k.batch_block_k == 0;
 }
 
 bool resident_mode(const mi355x_tab *t)
@@ -1055,7 +1072,20 @@ int mi355x_tab_solve_async(mi355x_tab *t, int is_max, double f, int64_t n_pivots
         // whole blocks, then the remainder as one shorter block (k_sweep16 for the full ones, a
         // k_sweep with as few links as the remainder needs: 20 pivots 371 us, 40 pivots 627 us), or
         // (g_tail_policy 0) the remainder spread evenly over the blocks (378 / 656 us)
-        const int bk = t->tn.block_k;
+        const int bk = block_size(t);
+        if (bk > kMaxBlock) {
+            // wide blocks: full blocks, then the remainder -- as a block of up to 16 (the sweeps of
+            // short blocks) preceded by one of 16 if it is longer than that
+            int64_t left = n_pivots;
+            while (left > 0) {
+                const int64_t k = left >= bk ? bk : (left > kMaxBlock ? kMaxBlock : left);
+                rc = enqueue_block(t, is_max, f, (int)k);
+                if (rc != MI_OK) return rc;
+                left -= k;
+            }
+            HIP_TRY(hipGetLastError());
+            return MI_OK;
+        }
         const int64_t nblk = (n_pivots + bk - 1) / bk;
         for (int64_t b = 0; b < nblk; ++b) {
             int64_t k = n_pivots / nblk + (b < n_pivots % nblk ? 1 : 0);
@@ -1157,7 +1187,7 @@ int mi355x_tab_solve(mi355x_tab *t, int is_max, double f, int64_t max_pivots, in
         int64_t blocks = 2;
         for (;;) {
             for (int64_t i = 0; i < blocks; ++i) {
-                rc = enqueue_block(t, is_max, f, t->tn.block_k);
+                rc = enqueue_block(t, is_max, f, block_size(t));
                 if (rc != MI_OK) return rc;
             }
             HIP_TRY(hipGetLastError());
@@ -1952,7 +1982,7 @@ static int shard_la_contribute_x(mi355x_tab *t, int j, const double *dev_gathere
                                  double f, int64_t *dev_col_bits, int64_t *dev_ec, const P2pArgs &x)
 {
     if (!t || !dev_gathered || !dev_col_bits || !dev_ec) return fail(MI_BAD_ARG, "NULL argument");
-    if (n_shards < 1 || j < 0 || j >= kMaxBlock) return fail(MI_BAD_ARG, "n_shards < 1 or step outside [0,%d)", kMaxBlock);
+    if (n_shards < 1 || j < 0 || j >= kWideBlock) return fail(MI_BAD_ARG, "n_shards < 1 or step outside [0,%d)", kWideBlock);
     if (!t->v.blk) return fail(MI_UNSUPPORTED, "no block state on this handle");
     int rc = use_device(t);
     if (rc != MI_OK) return rc;
@@ -1973,12 +2003,13 @@ static int shard_la_pivot_x(mi355x_tab *t, int j, const int64_t *dev_col_bits, c
                             const P2pArgs &x)
 {
     if (!t || !dev_col_bits || !dev_ec) return fail(MI_BAD_ARG, "NULL argument");
-    if (j < 0 || j >= kMaxBlock) return fail(MI_BAD_ARG, "step outside [0,%d)", kMaxBlock);
+    if (j < 0 || j >= kWideBlock) return fail(MI_BAD_ARG, "step outside [0,%d)", kWideBlock);
     if (!t->v.blk) return fail(MI_UNSUPPORTED, "no block state on this handle");
     int rc = use_device(t);
     if (rc != MI_OK) return rc;
     rc = ensure_dense(t);
     if (rc != MI_OK) return rc;
+    if (j + 1 > t->shard_steps) t->shard_steps = j + 1;
     // the step prices the local objective-row slice as it will be, for the next mi355x_shard_price
     t->n_part = launch_shard_la_prepare(t->v, j, reinterpret_cast<const double *>(dev_col_bits), dev_ec, f,
                                         t->shard_is_max, t->stream, x);
@@ -2007,7 +2038,9 @@ int mi355x_shard_sweep(mi355x_tab *t)
         }
         HIP_TRY(hipEventRecord(t->ev0[t->n_timed], t->stream));
     }
-    t->n_part = launch_sweep(t->v, kMaxBlock, t->shard_is_max ? 1.0 : -1.0, t->stream);
+    // (as many links as steps were enqueued since the last sweep: a wide block takes k_sweepw)
+    t->n_part = launch_sweep(t->v, t->shard_steps > kMaxBlock ? t->shard_steps : kMaxBlock, t->shard_is_max ? 1.0 : -1.0, t->stream);
+    t->shard_steps = 0;
     t->part_is_max = t->shard_is_max;
     if (timed) {
         HIP_TRY(hipEventRecord(t->ev1[t->n_timed], t->stream));
@@ -2452,6 +2485,14 @@ int cp_p2p_column(mi355x_colpart *p, CpShard &s, unsigned epoch, bool push, bool
 int cp_finish_setup(mi355x_colpart *p, const void *id128, int rank, bool make_comms = true)
 {
     const int nl = (int)p->sh.size();
+    // pivots per sweep of a shard's slice: the knob, or by the size of a shard (the block structure is
+    // local to a shard -- the exchanges are per pivot -- so ranks need not even agree on it)
+    if (g_block_k > 1) p->block = g_block_k;
+    else if (g_block_k == 1) p->block = 1;
+    else {
+        const int w = (nl > 0 && p->sh[0].t) ? wide_block_default(p->sh[0].t->v) : 0;
+        p->block = w ? w : kMaxBlock;
+    }
     if (!p->rccl) {
         HIP_TRY(hipSetDevice(p->sh[0].device));
         HIP_TRY(hipMalloc((void **)&p->l_gathered, 2 * p->world * sizeof(double)));
@@ -2566,7 +2607,7 @@ int cp_run_rccl(mi355x_colpart *p, CpShard &s, double f, int64_t n, int j0)
             mi355x_tab *t = s.t;
             const int np = (p->p2p_merged && t->n_part > 0 && t->part_is_max == (p->is_max ? 1 : 0)) ? t->n_part : 0;
             int left = 0;
-            if (np > 0 && t->v.blk && j < kMaxBlock) {
+            if (np > 0 && t->v.blk && j < kWideBlock) {
                 P2pArgs x;
                 x.peers = s.d_peers; x.mine = s.xch; x.lay = p->lay; x.rank = s.index; x.epoch = epoch; x.max_spins = p->p2p_spins;
                 rc = use_device(t);
@@ -3371,7 +3412,7 @@ int         mi355x_tune_set_handover_mode(int mode) { g_handover_mode = mode; re
 int         mi355x_tune_set_batch_mode(int mode) { g_batch_mode = mode; return g_batch_mode; }
 int         mi355x_tune_set_alternate_sweep(int on) { set_alternate_sweep(on); return on; }
 // pivots one tableau-update launch of this handle applies in its current representation
-int         mi355x_tab_block_size(mi355x_tab *t) { return (t && block_mode(t)) ? t->tn.block_k : 1; }
+int         mi355x_tab_block_size(mi355x_tab *t) { return (t && block_mode(t)) ? block_size(t) : 1; }
 int         mi355x_debug_rhs(mi355x_tab *t, double *out, int64_t n, int clear)
 {
     double *buf = t->v.rhs ? t->v.rhs : t->v.col;          // batches have no rhs buffer: their col buffer
@@ -3387,7 +3428,14 @@ int         mi355x_tune_set_resident_fault(int on) { set_resident_fault(on); ret
 int         mi355x_tune_set_resident_poll(int mode) { set_resident_poll(mode); return mode; }
 int         mi355x_tab_resident(mi355x_tab *t) { return (t && resident_mode(t)) ? 1 : 0; }
 int         mi355x_tune_set_lookahead_mode(int mode) { g_la_mode = mode; return g_la_mode; }
-int         mi355x_tune_set_block(int k) { g_block_k = k < 1 ? 1 : (k > kMaxBlock ? kMaxBlock : k); return g_block_k; }
+int         mi355x_tune_set_block(int k)
+{
+    // 0: by size; 1: off; 2 .. 16; wide blocks: 24 or 28 (anything else above 16 -> the next smaller size)
+    if (k <= 0) g_block_k = 0;
+    else if (k <= kMaxBlock) g_block_k = k;
+    else g_block_k = k >= 28 ? 28 : (k >= 24 ? 24 : kMaxBlock);
+    return g_block_k;
+}
 int         mi355x_tune_set_sweep_shape(int tr, int nt) { set_sweep_shape(tr, nt); return tr; }
 int         mi355x_tune_set_compact(int on) { g_compact_enabled = on ? 1 : 0; return g_compact_enabled; }
 int         mi355x_tune_set_sweep_impl(int impl) { set_sweep_impl(impl); return impl; }
@@ -3402,9 +3450,9 @@ int         mi355x_debug_repeat_sweep(mi355x_tab *t, int n, double *avg_us)
     if (hipSetDevice(t->device) != hipSuccess) return MI_HIP_ERROR;
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return MI_HIP_ERROR;
-    for (int i = 0; i < 3; ++i) (void)launch_sweep(t->c, kMaxBlock, 1.0, t->stream, 0);
+    for (int i = 0; i < 3; ++i) (void)launch_sweep(t->c, block_size(t), 1.0, t->stream, 0);
     (void)hipEventRecord(a, t->stream);
-    for (int i = 0; i < n; ++i) (void)launch_sweep(t->c, kMaxBlock, 1.0, t->stream, 0);
+    for (int i = 0; i < n; ++i) (void)launch_sweep(t->c, block_size(t), 1.0, t->stream, 0);
     (void)hipEventRecord(b, t->stream);
     (void)hipEventSynchronize(b);
     float ms = 0.f;

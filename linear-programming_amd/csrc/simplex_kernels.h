@@ -44,18 +44,26 @@ struct Ctl {
 // stored element in ONE sweep (k rank-1 updates per element, in pivot order, operands and
 // roundings unchanged).  This block lives next to the control block.
 constexpr int kMaxBlock = 16;
+// WIDE blocks (round 4): where the sweep dominates an iteration -- tableaux / column shards of a GB
+// and more, which the persistent look-ahead does not fit anyway -- up to kWideBlock pivots are
+// pending per pass (24 or 28 in practice: what three waves per SIMD can hold of prow operands,
+// kernels_sweep.inc).  The list, the col_i / prow_i buffers and the row masks have room for
+// kWideBlock pivots on every single-tableau handle; pivots 16 .. 31 record their slot hand-overs in
+// a second mask array (bk_smask2, layout of bk_smask).  Everything that lives in LDS (persistent
+// look-ahead, batches) stays at kMaxBlock.
+constexpr int kWideBlock = 32;
 struct BlockCtl {
     int64_t n_pending;            // pivots selected but not yet applied by a sweep
     int64_t stamp;                // persistent look-ahead: epoch base of the launch that wrote the list
-    int64_t cr[kMaxBlock];        // their pivot rows ...
-    int64_t slot[kMaxBlock];      // ... and the physical slots their entering columns gave up
+    int64_t cr[kWideBlock];       // their pivot rows ...
+    int64_t slot[kWideBlock];     // ... and the physical slots their entering columns gave up
     // persistent look-ahead: (stamp << 8 | steps) -- how many steps of the launch with that stamp
     // workgroup w completed (everything it owns of col_i / prow_i stored).  The leader raises
     // n_pending on its own; a workgroup that gave up on an exchange (kSyncLost) may be one step
     // behind it, so the sweep applies min(n_pending, min over w of steps) pivots and the host's
     // recovery takes the bookkeeping of the pivot beyond that back (k_la_rollback).
     int64_t done[32];             // kMaxLaWorkgroups entries
-    int64_t ec[kMaxBlock];        // persistent look-ahead: the logical columns that entered (k_la_rollback)
+    int64_t ec[kWideBlock];       // persistent look-ahead: the logical columns that entered (k_la_rollback)
 };
 
 // Record one workgroup of the persistent look-ahead kernel publishes per exchange: eight
@@ -121,6 +129,7 @@ struct TabView {
     // bit i of bk_rmask[r]: row r is the pivot row of pending pivot i; bits i / 16+i of
     // bk_smask[pair]: the even / odd column of that pair is the slot pending pivot i gave up
     uint32_t *bk_rmask, *bk_smask;
+    uint32_t *bk_smask2;          // slot hand-overs of pending pivots 16 .. 31 (wide blocks; null for batches)
     ExchRec  *la_px, *la_rx;      // kMaxLaRecords pricing / ratio records (persistent look-ahead)
     // batch of n_lps same-shape LPs: per-LP element strides (all zero for a single tableau)
     int64_t  n_lps;
@@ -154,6 +163,10 @@ int  launch_lookahead(const TabView &t, int j, int is_max, double fp_factor, int
 // stamp != 0: apply the pending list only if the look-ahead launch with that epoch base wrote it,
 // and of it only the pivots all la_nw workgroups of that launch completed (BlockCtl::done)
 int  launch_sweep(const TabView &t, int kmax, double sgn, hipStream_t s, unsigned stamp = 0, int la_nw = 0);
+// wide blocks: the block sizes k_sweepw is compiled for, and the one a view of this size should run
+// with (0: stay at kMaxBlock)
+bool wide_block_size_ok(int k);
+int  wide_block_default(const TabView &t);
 // after a lost exchange (kSyncLost): undo the bookkeeping (column maps, basis, pivot count, trace)
 // of the pivots the leader committed but the sweep did not apply
 void launch_la_rollback(const TabView &t, int la_nw, hipStream_t s);

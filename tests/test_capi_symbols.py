@@ -129,7 +129,7 @@ def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "linear-programming_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp", ".lisp", ".asd")):
+            if f.endswith((".py", ".hip", ".h", ".inc", ".cpp", ".lisp", ".asd")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
                 assert "liboracle" not in text and "simplex_oracle" not in text, f

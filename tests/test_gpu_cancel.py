@@ -73,7 +73,7 @@ def path(request):
     knobs = {"default": [], "blocked": [(L.mi355x_tune_set_resident, 1, 0)],
              "two-launch": [(L.mi355x_tune_set_resident, 1, 0), (L.mi355x_tune_set_lookahead_mode, 1, 0),
                             (L.mi355x_tune_set_select_mode, 2, 0)],
-             "per-pivot": [(L.mi355x_tune_set_resident, 1, 0), (L.mi355x_tune_set_block, 1, 16)],
+             "per-pivot": [(L.mi355x_tune_set_resident, 1, 0), (L.mi355x_tune_set_block, 1, 0)],
              "dense": [(L.mi355x_tune_set_compact, 0, 1)]}[request.param]
     for fn, on, _ in knobs:
         fn(on)

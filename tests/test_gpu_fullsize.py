@@ -184,15 +184,17 @@ def test_config5_full_size_64_pivots_rederived():
     L.mi355x_tab_destroy(h)
 
 
-def test_config5_full_size_32_pivots_vs_the_oracle():
+@pytest.mark.timeout(1500, method="thread")
+def test_config5_full_size_64_pivots_vs_the_oracle():
     """The same 32769 x 98305 tableau through the CPU ORACLE (OpenMP row-parallel restatement of
     src/simplex.lisp:337-389, 453-461) on the box's host cores: the dense 25.8 GB tableau the GPU
     generated is downloaded (sampled rows, the whole RHS column and objective row checked against
-    the numpy generator first), the oracle makes 32 pivots on it in host memory, the GPU makes
-    its 32 pivots (two blocks of the default path) in HBM, and then pivot trace, basis and EVERY
-    entry of the tableau must agree bit for bit."""
+    the numpy generator first), the oracle makes 64 pivots on it in host memory, the GPU makes
+    its 64 pivots in HBM -- two WIDE blocks of 28 pivots per sweep, the default at this size since
+    round 4, and the 8 pivots the cap leaves of the third (a block cut short: k_sweepw_rest) --
+    and then pivot trace, basis and EVERY entry of the tableau must agree bit for bit."""
     import time
-    n, m, K = 65536, 32768, 32
+    n, m, K = 65536, 32768, 64
     seed = lp.synth.seed_for(5)
     t = lp.Tableau(None, lp.Problem(type="max"), None, None, n + m, m, {}, _handle=_synthetic_handle(n, m, seed))
     t0 = time.perf_counter()
@@ -220,6 +222,7 @@ def test_config5_full_size_32_pivots_vs_the_oracle():
     t._touch()
     with pytest.raises(lp.SolverError):
         lp.n_solve_tableau(t, max_pivots=K)
+    assert lp.capi.lib().mi355x_tab_block_size(t._h) == 28
     got = t.pivot_trace()
     assert got.shape == trace.shape
     bad = np.where((got != trace).any(axis=1))[0]

@@ -31,7 +31,7 @@ MODES = {
 def _apply(mode):
     L = lp.capi.lib()
     L.mi355x_tune_set_lookahead_mode(mode.get("lookahead", 0))
-    L.mi355x_tune_set_block(mode.get("block", 16))
+    L.mi355x_tune_set_block(mode.get("block", 0))
     L.mi355x_tune_set_compact(mode.get("compact", 1))
     L.mi355x_tune_set_select_mode(mode.get("select", 0))
 

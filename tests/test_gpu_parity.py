@@ -278,7 +278,7 @@ def block_size(request):
     L = lp.capi.lib()
     L.mi355x_tune_set_block(request.param)
     yield request.param
-    L.mi355x_tune_set_block(16)                         # the library default
+    L.mi355x_tune_set_block(0)                         # the library default
 
 
 @pytest.fixture(params=[2, 1], ids=["persistent-lookahead", "two-launches-per-step"])
@@ -289,7 +289,7 @@ def lookahead_mode(request):
     L.mi355x_tune_set_lookahead_mode(0)
 
 
-@pytest.mark.parametrize("block_size", [1, 2, 3, 5, 8, 13, 16], indirect=True)
+@pytest.mark.parametrize("block_size", [1, 2, 3, 5, 8, 13, 16, 24, 28], indirect=True)
 @pytest.mark.parametrize("n,m,seed", [(5, 3, 1), (33, 17, 2), (257, 511, 5), (700, 333, 6),
                                       (2000, 1100, 9)])
 def test_blocked_pivoting_bitwise_vs_oracle(n, m, seed, block_size, lookahead_mode):

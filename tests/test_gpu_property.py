@@ -66,7 +66,7 @@ def test_random_lps_bitwise(n, m, seed, kind, density, degenerate, select_mode, 
         L.mi355x_tune_set_select_mode(0)
         L.mi355x_tune_set_compact(1)
         L.mi355x_tune_set_variant(0)
-        L.mi355x_tune_set_block(16)
+        L.mi355x_tune_set_block(0)
         L.mi355x_tune_set_lookahead_mode(0)
     assert rc == st_o and k.value == npiv
     got = t.pivot_trace()
@@ -313,7 +313,7 @@ def test_tolerance_factor_changes_the_pivot_sequence_and_the_gpu_follows(make, n
                 rc = L.mi355x_tab_solve(t._h, 1, factor, 0, ctypes.byref(k))
                 t._touch()
             finally:
-                L.mi355x_tune_set_block(16)
+                L.mi355x_tune_set_block(0)
                 L.mi355x_tune_set_compact(1)
             assert (rc, k.value) == (so, no), (factor, block, compact)
             assert t.pivot_trace().tolist() == trace.tolist(), (factor, block, compact)

@@ -80,7 +80,7 @@ def test_resident_is_chosen_by_shape_and_by_knobs():
         assert resident() == 1
     finally:
         L.mi355x_tune_set_resident(0)
-        L.mi355x_tune_set_block(16)
+        L.mi355x_tune_set_block(0)
     for n, m in ((8192, 4096), (100, 1025), (2100, 200)):       # too many constraints / strips
         h = ctypes.c_void_p()
         lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h), n, m, 1, 0, -1, 0), "create")

@@ -39,8 +39,9 @@ def audit(extra_flags=()):
     kernel, pending, in_asm, sites, findings = None, set(), False, 0, []
     for ln in lines:
         t = ln.strip()
-        if t.endswith(":") and t.startswith("_Z"):
-            kernel, pending = t[:-1], set()
+        m = re.match(r"^(_Z\w+):", t)                  # (a label may carry a trailing comment)
+        if m:
+            kernel, pending = m.group(1), set()
         if t.startswith(";;#ASMSTART"):
             in_asm = True
             continue
@@ -71,6 +72,6 @@ def audit(extra_flags=()):
 if __name__ == "__main__":
     n, bad = audit()
     for k, ins in bad[:20]:
-        print("%s: %s" % (k[:70], ins))
+        print("%s: %s" % ((k or "?")[:70], ins))
     print("%d hand-issued scalar loads checked, %d instruction(s) touching an in-flight destination" % (n, len(bad)))
     sys.exit(1 if bad or n == 0 else 0)

@@ -81,7 +81,7 @@ for case in range(cases):
             case, name, n, m, seed, lo, hi, rc, st_o, k.value, npiv, got.tolist()[-3:], trace.tolist()[-3:]), flush=True)
         if bad >= 10:
             break
-L.mi355x_tune_set_lookahead_mode(0); L.mi355x_tune_set_block(16); L.mi355x_tune_set_compact(1); L.mi355x_tune_set_select_mode(0)
+L.mi355x_tune_set_lookahead_mode(0); L.mi355x_tune_set_block(0); L.mi355x_tune_set_compact(1); L.mi355x_tune_set_select_mode(0)
 L.mi355x_tune_set_resident(0)
 print("%d cases, %d mismatches, %.0f s" % (case + 1, bad, time.time() - t0), flush=True)
 sys.exit(1 if bad else 0)

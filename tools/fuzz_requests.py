@@ -40,7 +40,7 @@ for case in range(cases):
     st_o, npiv, trace = oracle.solve(M, b, is_max=bool(is_max), max_pivots=total, trace_cap=total)
     if npiv == total:
         st_o = 100        # exactly the requested pivots were made: the device has not looked at the tableau again
-    L.mi355x_tune_set_lookahead_mode(int(meta.choice([0, 0, 1]))); L.mi355x_tune_set_block(int(meta.choice([16, 16, 16, 8, 1])))
+    L.mi355x_tune_set_lookahead_mode(int(meta.choice([0, 0, 1]))); L.mi355x_tune_set_block(int(meta.choice([0, 0, 16, 8, 1])))
     h = ctypes.c_void_p()
     lp.capi.check(L.mi355x_tab_create(ctypes.byref(h), m + 1, n + m + 1, ptr(M0), ptr(b0), 0), "create")
     k = ctypes.c_int64(0)
@@ -60,6 +60,6 @@ for case in range(cases):
         print("MISMATCH case %d: %d x %d seed %d max=%d requests %s: rc %d/%d pivots %d/%d" % (case, n, m, seed, is_max, reqs, rc, st_o, k.value, npiv), flush=True)
         if bad >= 10:
             break
-L.mi355x_tune_set_lookahead_mode(0); L.mi355x_tune_set_block(16)
+L.mi355x_tune_set_lookahead_mode(0); L.mi355x_tune_set_block(0)
 print("%d cases, %d mismatches, %.0f s" % (case + 1, bad, time.time() - t0), flush=True)
 sys.exit(1 if bad else 0)

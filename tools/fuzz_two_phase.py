@@ -23,7 +23,7 @@ for case in range(cases):
     Mm, mb = main.matrix.copy(), main.basis_columns.copy()
     st_o, npv = oracle.solve_two_phase(A, ab, Mm, mb, main_is_max=main.is_max)
     npiv = (ctypes.c_int64 * 2)()
-    L.mi355x_tune_set_lookahead_mode(int(meta.choice([0, 0, 1]))); L.mi355x_tune_set_block(int(meta.choice([16, 16, 4, 1])))
+    L.mi355x_tune_set_lookahead_mode(int(meta.choice([0, 0, 1]))); L.mi355x_tune_set_block(int(meta.choice([0, 16, 4, 1])))
     rc = L.mi355x_solve_two_phase(art._h, main._h, int(main.is_max), 1024.0, npiv)
     art._touch(); main._touch()
     ok = rc == st_o and np.array_equal(art.matrix.view(np.int64), A.view(np.int64))
@@ -37,6 +37,6 @@ for case in range(cases):
             case, n, mle, mge, meq, seed, kind, rc, st_o, npiv[0], npiv[1], npv[0], npv[1]), flush=True)
         if bad >= 10:
             break
-L.mi355x_tune_set_lookahead_mode(0); L.mi355x_tune_set_block(16)
+L.mi355x_tune_set_lookahead_mode(0); L.mi355x_tune_set_block(0)
 print("%d cases, %d mismatches, %.0f s" % (case + 1, bad, time.time() - t0), flush=True)
 sys.exit(1 if bad else 0)

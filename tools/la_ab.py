@@ -46,4 +46,4 @@ run("two launches per step")
 L.mi355x_tune_set_lookahead_mode(0)
 L.mi355x_tune_set_block(1)
 run("per-pivot (block 1)")
-L.mi355x_tune_set_block(16)
+L.mi355x_tune_set_block(0)

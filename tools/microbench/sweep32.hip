@@ -130,6 +130,105 @@ __global__ __launch_bounds__(256) void k_sweep(double *M, const double *prow, co
     }
 }
 
+// pair layout, U = 4: the prow pairs of the first KR links in registers, those of the last K - KR in
+// LDS (re-read once per step of four rows: 16 B per lane and link against 16 f64 instructions)
+template <int K, int KR, bool NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_sweep_mix(double *M, const double *prow, const double *col, int64_t ld,
+                                                   int64_t rows, int64_t col_stride, int tr, int strips)
+{
+    constexpr int U = 4, CP = 4, NCH = K / CP, KL = K - KR;
+    __shared__ vec2d s_p[(KL > 0 ? KL : 1) * 256];
+    const int bx = blockIdx.x % strips, by = blockIdx.x / strips;
+    const int64_t lde = ld / 2;
+    const int64_t e = (int64_t)bx * 256 + threadIdx.x;
+    if (e >= lde) return;
+    const int64_t r0 = (int64_t)by * tr, r1 = r0 + tr < rows ? r0 + tr : rows;
+    vec2d *Mp = reinterpret_cast<vec2d *>(M) + e;
+    auto ld2 = [&](int64_t r) -> vec2d {
+        if constexpr (NT) return __builtin_nontemporal_load(Mp + r * lde);
+        else              return Mp[r * lde];
+    };
+    auto st2 = [&](int64_t r, vec2d v) {
+        if constexpr (NT) __builtin_nontemporal_store(v, Mp + r * lde);
+        else              Mp[r * lde] = v;
+    };
+    vec2d xa[U], xb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { xa[u] = vec2d(0); xb[u] = vec2d(0); if (r0 + u < r1) xa[u] = ld2(r0 + u); }
+    vec2d p[KR > 0 ? KR : 1];
+#pragma unroll
+    for (int i = 0; i < KR; ++i) p[i] = reinterpret_cast<const vec2d *>(prow)[(int64_t)i * lde + e];
+#pragma unroll
+    for (int i = 0; i < KL; ++i) s_p[i * 256 + threadIdx.x] = reinterpret_cast<const vec2d *>(prow)[(int64_t)(KR + i) * lde + e];
+    // (a thread reads back only what it wrote: no barrier)
+    const unsigned o1 = (unsigned)(col_stride * 8);
+    const int64_t chunk_stride = (int64_t)CP * col_stride;
+    auto step = [&](vec2d (&cur)[U], vec2d (&nxt)[U], const int64_t r) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (r + U + u < r1) nxt[u] = ld2(r + U + u);
+        const double *cb = col + r;
+        ColChunk<U> A, B;
+        auto apply = [&](const ColChunk<U> &c, const int i0) {
+#pragma unroll
+            for (int i = 0; i < CP; ++i) {
+                const vec2d pi = (i0 + i < KR) ? p[(i0 + i < KR) ? i0 + i : 0] : s_p[((i0 + i >= KR) ? i0 + i - KR : 0) * 256 + threadIdx.x];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const double cv = c.col(i, u);
+                    const double m0 = cv * pi.x, m1 = cv * pi.y;
+                    cur[u].x = cur[u].x - m0;
+                    cur[u].y = cur[u].y - m1;
+                }
+            }
+        };
+        A.issue(cb, o1);
+        A.wait();
+#pragma unroll
+        for (int c = 0; c < NCH; c += 2) {
+            if (c + 1 < NCH) B.issue(cb + (int64_t)(c + 1) * chunk_stride, o1);
+            apply(A, c * CP);
+            if (c + 1 < NCH) {
+                B.wait();
+                if (c + 2 < NCH) A.issue(cb + (int64_t)(c + 2) * chunk_stride, o1);
+                apply(B, (c + 1) * CP);
+                if (c + 2 < NCH) A.wait();
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (r + u < r1) st2(r + u, cur[u]);
+    };
+    for (int64_t r = r0; r < r1; r += 2 * U) {
+        step(xa, xb, r);
+        if (r + U < r1) step(xb, xa, r + U);
+    }
+}
+
+template <int K, int KR, bool NT>
+static void run_mix(double *M, const double *prow, const double *col, int64_t ld, int64_t rows, int64_t col_stride, int tr)
+{
+    const int strips = (int)((ld / 2 + 255) / 256);
+    const int nb = (int)((rows + tr - 1) / tr);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int reps = rows * ld > (1ll << 28) ? 6 : 20;
+    auto launch = [&]() {
+        hipLaunchKernelGGL((k_sweep_mix<K, KR, NT>), dim3(strips * nb), dim3(256), 0, 0, M, prow, col, ld, rows, col_stride, tr, strips);
+    };
+    for (int i = 0; i < 2; ++i) launch();
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) launch();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / reps, gb = 2.0 * rows * ld * 8 / 1e9;
+    hipFuncAttributes fa;
+    CK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_sweep_mix<K, KR, NT>)));
+    printf("pairs, U=4     K=%2d (%2d in registers, %2d in LDS) nt=%d tr=%4d : %9.1f us  %5.2f TB/s  %7.2f us per pivot   (%d VGPRs, %d B LDS)\n",
+           K, KR, K - KR, (int)NT, tr, us, gb / us * 1e-3, us / K, fa.numRegs, (int)fa.sharedSizeBytes);
+    fflush(stdout);
+}
+
 template <int K, int U, int CPT, bool NT>
 static void run(const char *what, double *M, const double *prow, const double *col, int64_t ld, int64_t rows,
                 int64_t col_stride, int tr)
@@ -153,7 +252,7 @@ static void run(const char *what, double *M, const double *prow, const double *c
     hipFuncAttributes fa;
     CK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_sweep<K, U, CPT, NT>)));
     printf("%-14s K=%2d U=%d cols/thread=%d nt=%d tr=%4d : %9.1f us  %5.2f TB/s  %7.2f us per pivot   (%d VGPRs, %d spilled)\n",
-           what, K, U, CPT, (int)NT, tr, us, gb / us / 1e3, us / K, fa.numRegs, (int)(fa.localSizeBytes / 4));
+           what, K, U, CPT, (int)NT, tr, us, gb / us * 1e-3, us / K, fa.numRegs, (int)(fa.localSizeBytes / 4));
     fflush(stdout);
 }
 
@@ -167,30 +266,22 @@ int main(int argc, char **argv)
     printf("tableau %lld x %lld doubles = %.2f GB stored\n", (long long)rows, (long long)ld, rows * ld * 8 / 1e9);
     const bool big = rows * ld * 8 > (300ll << 20);
 #define RUN(K, U, CPT, TR) do { if (big) run<K, U, CPT, true>("", M, prow, col, ld, rows, cs, TR); else run<K, U, CPT, false>("", M, prow, col, ld, rows, cs, TR); } while (0)
-    // the product's shape and its doubling
-    RUN(16, 4, 2, 32);
-    RUN(16, 4, 2, 64);
-    RUN(16, 4, 2, 128);
-    RUN(32, 4, 2, 32);
-    RUN(32, 4, 2, 128);
-    // one column per thread
-    for (int tr : {32, 64, 128, 256, 512}) {
-        if (tr == 32)  { RUN(32, 8, 1, 32);  RUN(32, 4, 1, 32);  RUN(16, 8, 1, 32); }
-        if (tr == 64)  { RUN(32, 8, 1, 64);  RUN(32, 4, 1, 64);  RUN(16, 8, 1, 64); }
-        if (tr == 128) { RUN(32, 8, 1, 128); RUN(32, 4, 1, 128); RUN(16, 8, 1, 128); }
-        if (tr == 256) { RUN(32, 8, 1, 256); RUN(32, 4, 1, 256); RUN(16, 8, 1, 256); }
-        if (tr == 512) { RUN(32, 8, 1, 512); RUN(32, 4, 1, 512); }
+#define MIX(K, KR, TR) do { if (big) run_mix<K, KR, true>(M, prow, col, ld, rows, cs, TR); else run_mix<K, KR, false>(M, prow, col, ld, rows, cs, TR); } while (0)
+    if (argc > 3) {   // the first survey (round 4): columns per thread, rows per step
+        RUN(16, 4, 2, 32); RUN(32, 4, 2, 32); RUN(32, 8, 1, 64); RUN(32, 4, 1, 64); RUN(16, 8, 1, 64); RUN(24, 4, 2, 64);
+        return 0;
     }
-    // fewer links per pass, same shape (where does the VALU time start to show?)
-    RUN(24, 8, 1, 128);
-    RUN(24, 4, 2, 64);
-    RUN(8, 4, 2, 32);
-    if (big) {       // plain loads / stores instead of non-temporal ones
-        run<32, 8, 1, false>("plain", M, prow, col, ld, rows, cs, 128);
-        run<16, 4, 2, false>("plain", M, prow, col, ld, rows, cs, 32);
-    } else {
-        run<32, 8, 1, true>("nt", M, prow, col, ld, rows, cs, 128);
-        run<16, 4, 2, true>("nt", M, prow, col, ld, rows, cs, 32);
+    for (int tr : {32, 64}) {
+        if (tr == 32) { MIX(16, 16, 32); MIX(20, 20, 32); MIX(24, 24, 32); MIX(28, 28, 32); MIX(32, 32, 32); }
+        else          { MIX(16, 16, 64); MIX(20, 20, 64); MIX(24, 24, 64); MIX(28, 28, 64); MIX(32, 32, 64); }
     }
+    // the last links' prow pairs from LDS
+    MIX(32, 24, 32); MIX(32, 24, 64); MIX(32, 24, 128);
+    MIX(32, 16, 32); MIX(32, 16, 64);
+    MIX(32, 20, 64);
+    MIX(28, 20, 64);
+    MIX(24, 16, 64);
+    MIX(16, 8, 32);
+    MIX(32, 0, 64);
     return 0;
 }

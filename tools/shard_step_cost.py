@@ -11,7 +11,9 @@ import importlib
 lp = importlib.import_module("linear-programming_amd")
 cp = importlib.import_module("linear-programming_amd.colpart")
 L = lp.capi.lib()
-K = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 336                      # (a multiple of 16, 24 and 28)
+if len(sys.argv) > 2:
+    print("pivots per sweep: %d" % L.mi355x_tune_set_block(int(sys.argv[2])), flush=True)
 n, m = 65536 // 8, 32768
 seed = lp.synth.seed_for(5)
 for name, force, mode in (("device-local exchanges", "0", 0), ("one-rank RCCL: all-gather + int64 all-reduce", "1", 0),
@@ -21,7 +23,7 @@ for name, force, mode in (("device-local exchanges", "0", 0), ("one-rank RCCL: a
     L.mi355x_tune_set_colpart_exchange(mode)
     tab = cp.NativeColumnPartition.synthetic(n, m, seed, 1)
     L.mi355x_tune_set_colpart_exchange(0)
-    tab.solve_async(32, reset=True); tab.sync()
+    tab.solve_async(336, reset=True); tab.sync()
     t0 = time.perf_counter()
     tab.solve_async(K); st, done = tab.sync()
     dt = time.perf_counter() - t0
