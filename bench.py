@@ -332,14 +332,47 @@ def other_configs(lp, L, device, block):
     # ---- config 5 as ONE column shard on this GPU (the denominator of the 8-GPU claim)
     try:
         cp = importlib.import_module("linear-programming_amd.colpart")
-        base = cp.one_shard_baseline(65536, 32768, lp.synth.seed_for(5), device, 64, 16)
+        base = cp.one_shard_baseline(65536, 32768, lp.synth.seed_for(5), device, "blocks", 0)
         base["workload"] = ("BASELINE config 5 on ONE GPU: the 32769x98305 f64 tableau (25.8 GB dense, 17.2 GB stored) "
-                            "as one column shard through mi355x_colpart_*, 64 pivots after 16 warm-up pivots")
+                            "as one column shard through mi355x_colpart_*, four full blocks (%d pivots per sweep) after "
+                            "one warm-up block" % base["pivots_per_sweep"])
         base["parity"] = {"identical": None, "checked_against": "nothing in this run: no CPU oracle follows 3.2e9 entries "
                           "in bench time (tests/test_gpu_fullsize.py re-derives 64 pivots of this tableau in numpy)"}
-        out["cfg5_one_shard_64_pivots"] = base
+        out["cfg5_one_shard"] = base
     except BaseException as e:                       # noqa: BLE001 -- a record is owed whatever happens here
-        out["cfg5_one_shard_64_pivots"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out["cfg5_one_shard"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # ---- config 5 SOLVED TO OPTIMALITY on this GPU (~135 000 pivots of the reference's loop at 17 GB)
+    if os.environ.get("BENCH_SKIP_CFG5_FULL") != "1":
+        try:
+            n5, m5 = 65536, 32768
+            h5 = ctypes.c_void_p()
+            lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h5), n5, m5, lp.synth.seed_for(5), 0, -1, device), "cfg5 full")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rc5 = L.mi355x_tab_solve(h5, 1, 1024.0, 0, ctypes.byref(k))
+            dt5 = time.perf_counter() - t0
+            row5, col5, bas5 = np.empty(n5 + m5 + 1), np.empty(m5 + 1), np.empty(m5, dtype=np.int64)
+            lp.capi.check(L.mi355x_tab_download(h5, None, vp(bas5), vp(row5), vp(col5)), "cfg5 read-back")
+            x5 = np.zeros(n5 + m5)
+            x5[bas5] = col5[:m5]
+            c5 = 0.5 + lp.synth.splitmix_u01(lp.synth.seed_for(5), n5 * m5 + m5, n5)
+            out["cfg5_full_solve_one_gpu"] = {
+                "workload": "BASELINE config 5 (65536 vars x 32768 constraints, 25.8 GB dense / 17.2 GB stored) solved to "
+                            "optimality as one tableau on ONE GPU",
+                "status": int(rc5), "optimal": int(rc5) == 0, "pivots": int(k.value), "wall_s": dt5,
+                "value": k.value / dt5, "unit": "pivots/s", "pivots_per_sweep": int(L.mi355x_tab_block_size(h5)),
+                "properties": {"min_reduced_cost": float(row5[:n5 + m5].min()), "dual_feasible": bool(row5[:n5 + m5].min() >= -128 * 1.1102230246251568e-16),
+                               "min_rhs": float(col5[:m5].min()), "primal_feasible": bool(col5[:m5].min() >= 0.0),
+                               "objective": float(col5[m5]),
+                               "ctx_recomputed_rel_err": float(abs(c5 @ x5[:n5] - col5[m5]) / abs(col5[m5]))},
+                "parity": {"identical": None, "checked_against": "size-independent properties here (tests/test_gpu_optimum.py adds "
+                           "Ax <= b with A regenerated); the first 64 pivots bit for bit against the oracle in "
+                           "tests/test_gpu_fullsize.py"}}
+            L.mi355x_tab_destroy(h5)
+            torch.cuda.empty_cache()
+        except BaseException as e:                   # noqa: BLE001
+            out["cfg5_full_solve_one_gpu"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # ---- config 3, steady state: 1 600 pivots = 100 full blocks
     n, m = 8192, 4096

@@ -103,6 +103,7 @@ int         mi355x_tab_timing_read_kind(mi355x_tab *t, int which, int64_t *n_lau
 /* column partition over RCCL: HIP-event brackets around the two per-pivot collectives of every
  * `stride`-th pivot (at most max_samples per shard and per solve call; 0 = off); _read waits for
  * the shards' streams and returns the averages over this process's shards since the last read */
+int         mi355x_colpart_block_size(const mi355x_colpart *p);   /* pivots per sweep of a shard's slice */
 int         mi355x_colpart_exchange_timing_enable(mi355x_colpart *p, int stride, int max_samples);
 int         mi355x_colpart_exchange_timing_read(mi355x_colpart *p, int64_t *n_samples,
                                                 double *allgather_us, double *allreduce_us);

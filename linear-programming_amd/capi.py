@@ -121,6 +121,7 @@ _EXTRA = {
     "mi355x_tune_set_colpart_exchange": (_int, [_int]),
     "mi355x_colpart_p2p_handle": (_int, [_p, _p]),
     "mi355x_colpart_p2p_connect": (_int, [_p, _p]),
+    "mi355x_colpart_block_size": (_int, [_p]),
     "mi355x_colpart_exchange_timing_enable": (_int, [_p, _int, _int]),
     "mi355x_colpart_exchange_timing_read": (_int, [_p, _p, _p, _p]),
     "mi355x_tune_set_la_one_xcd": (_int, [_int]),

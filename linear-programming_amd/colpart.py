@@ -345,6 +345,10 @@ class NativeColumnPartition:
         obj.rows, obj.cols = n_cons + 1, n_vars + n_cons + 1
         return obj
 
+    def block_size(self):
+        """Pivots per sweep of a shard's slice (16, or a wide block of 24 / 28 for large shards)."""
+        return int(capi.lib().mi355x_colpart_block_size(self._h))
+
     def p2p_handle(self):
         """Exchange mode 2, one process per GPU: the 64-byte IPC handle of this rank's exchange buffer."""
         buf = ctypes.create_string_buffer(64)
@@ -477,6 +481,11 @@ def one_shard_baseline(n, m, seed, device, steps, warmup, steady_pivots=0):
     import torch
     tab = NativeColumnPartition.synthetic_rank(n, m, seed, 1, 0, device, bytes(128))
     try:
+        blk = tab.block_size()
+        if steps == "blocks":                     # whole blocks of this handle: 1 warm-up block, 4 timed
+            warmup, steps = blk, 4 * blk
+        if steady_pivots == "auto":
+            steady_pivots = 8 * blk if steps < 4 * blk else 0
         tab.solve_async(warmup, reset=True)
         tab.sync()
         dt, st, done = _timed_pivots(tab, steps, torch, None, 1)
@@ -484,7 +493,8 @@ def one_shard_baseline(n, m, seed, device, steps, warmup, steady_pivots=0):
             raise SystemExit("colpart baseline: LP terminated early (status %d after %d pivots)" % (st, done))
         rec = {"what": "the same %d x %d tableau as ONE shard on one GPU, same driver (mi355x_colpart_*), "
                        "same %d warm-up and %d timed pivots" % (m + 1, n + m + 1, warmup, steps),
-               "value": steps / dt, "unit": "pivots/s", "us_per_pivot": dt / steps * 1e6}
+               "value": steps / dt, "unit": "pivots/s", "us_per_pivot": dt / steps * 1e6,
+               "pivots_per_sweep": blk, "timed_pivots": steps}
         if steady_pivots:
             dt2, st, done = _timed_pivots(tab, steady_pivots, torch, None, 1)
             rec["steady_state_pivots_per_s"] = steady_pivots / dt2
@@ -531,7 +541,7 @@ def bench(args, rank, local_rank, world, progress=None):
     # mi355x_rccl_unique_id -> mi355x_colpart_create_synthetic_rank -> ncclCommInitRank (with
     # MI355X_COLPART_FORCE_RCCL=1 over a one-rank communicator)
     rank_entry = world > 1 or os.environ.get("BENCH_COLPART_RANK_ENTRY") == "1"
-    steady_pivots = 8 * block if args.steps < 4 * block else 0
+    steady_pivots = "auto" if native else (8 * block if args.steps < 4 * block else 0)   # (native: by the handle's block size)
     L = capi.lib()
     baseline = None
     exchange_modes = None
@@ -566,6 +576,8 @@ def bench(args, rank, local_rank, world, progress=None):
             dist.barrier()
         tab = make_native(0)
         info = tab.info()
+        block = tab.block_size()                  # pivots per sweep of this handle's shards (16 / 24 / 28)
+        steady_pivots = 8 * block if args.steps < 4 * block else 0
         tab.solve_async(args.warmup, reset=True)
         st, done = tab.sync()
         if info["uses_rccl"] and not staged:

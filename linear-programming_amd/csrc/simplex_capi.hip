@@ -2617,6 +2617,7 @@ int cp_run_rccl(mi355x_colpart *p, CpShard &s, double f, int64_t n, int j0)
                 t->v.col_bias = t->v.p2l ? 0 : s.col_begin;
                 left = launch_shard_p2p_step(t->v, j, np, p->world, s.col_begin, f, t->shard_is_max, s.ec, t->stream, x);
                 if (left > 0) {
+                    if (j + 1 > t->shard_steps) t->shard_steps = j + 1;     // (what mi355x_shard_la_pivot records)
                     t->n_part = left;
                     t->part_is_max = t->shard_is_max;
                     HIP_TRY(hipGetLastError());
@@ -3004,6 +3005,9 @@ int mi355x_colpart_solve_async(mi355x_colpart *p, int is_max, double f, int64_t 
     }
     return cp_run(p, f, n_pivots);
 }
+
+// pivots per sweep of a shard's slice on this handle (1 = per-pivot updates)
+int mi355x_colpart_block_size(const mi355x_colpart *p) { return p ? p->block : 0; }
 
 int mi355x_colpart_exchange_timing_enable(mi355x_colpart *p, int stride, int max_samples)
 {

@@ -52,6 +52,7 @@ def test_request_sequences_with_wide_blocks(n, m, seed, wide):
     done, first = 0, 1
     for req in (1, wide, wide - 1, wide + 1, 2 * wide, 17, 5, 3 * wide + 19, 16, wide + 16, 100000):
         lp.capi.check(L.mi355x_tab_solve_async(t._h, 1, 1024.0, req, first), "solve_async")
+        assert L.mi355x_tab_block_size(t._h) == wide           # (on the compact representation now)
         first = 0
         k = ctypes.c_int64(0)
         rc = L.mi355x_tab_sync(t._h, ctypes.byref(k))
@@ -67,7 +68,6 @@ def test_request_sequences_with_wide_blocks(n, m, seed, wide):
         assert rc == lp.capi.MI_RUNNING
     else:
         raise AssertionError("the LP did not finish")
-    assert L.mi355x_tab_block_size(t._h) == wide
     M2, b2 = M0.copy(), b0.copy()
     _, _, trace = oracle.solve(M2, b2, trace_cap=1 << 16)
     assert np.array_equal(t.pivot_trace(), trace)
