@@ -41,7 +41,9 @@ int         mi355x_tune_set_lookahead_mode(int mode);        /* 0 auto, 1 two la
                                                                 2 one persistent launch per block */
 int         mi355x_tune_set_sweep_shape(int rows_per_workgroup, int nontemporal /* -1 by size */);
 int         mi355x_tune_set_sweep_impl(int impl);            /* 0 k_sweep16 for full blocks, 1 k_sweep
-                                                                always; 4 / 8: rows per step of k_sweep16 */
+                                                                always, 3 the two-launch form of the wide
+                                                                sweeps (k_sweepw<16> + k_sweepw_rest);
+                                                                4 / 8: rows per step of k_sweep16      */
 int         mi355x_tune_set_shard_la_split(int mode);        /* column shards, local look-ahead step:
                                                                 0 by size, 1 one workgroup, 2 many */
 int         mi355x_tune_set_colpart_exchange(int mode);      /* column partition over RCCL, how the

@@ -14,11 +14,14 @@ L = lp.capi.lib()
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 336                      # (a multiple of 16, 24 and 28)
 if len(sys.argv) > 2:
     print("pivots per sweep: %d" % L.mi355x_tune_set_block(int(sys.argv[2])), flush=True)
+ONLY = sys.argv[3] if len(sys.argv) > 3 else ""                          # substring of the mode's name: that mode only
 n, m = 65536 // 8, 32768
 seed = lp.synth.seed_for(5)
 for name, force, mode in (("device-local exchanges", "0", 0), ("one-rank RCCL: all-gather + int64 all-reduce", "1", 0),
                           ("one-rank RCCL: all-gather + rooted broadcast", "1", 1),
                           ("P2P push, four launches per step", "1", 3), ("P2P push, two launches per step", "1", 2)):
+    if ONLY and ONLY not in name:
+        continue
     os.environ["MI355X_COLPART_FORCE_RCCL"] = force
     L.mi355x_tune_set_colpart_exchange(mode)
     tab = cp.NativeColumnPartition.synthetic(n, m, seed, 1)
