@@ -146,17 +146,18 @@ def test_column_partition_with_wide_blocks(n_shards, exchange, wide):
 
 
 def test_wide_blocks_are_the_default_where_the_sweep_dominates():
-    """A 0.75 GB+ stored tableau that does not fit the persistent look-ahead takes 28 pivots per
-    sweep by default; config 3 (persistent look-ahead) and small tableaux stay at 16."""
+    """A 0.75 GB+ stored tableau that does not fit the persistent look-ahead takes 24 pivots per
+    sweep by default (28 from 8 GB on: config 5, tests/test_gpu_fullsize.py); config 3 (persistent
+    look-ahead) and small tableaux stay at 16."""
     L = lp.capi.lib()
-    for (n, m, want) in ((8192, 4096, 16), (200, 100, 16), (12000, 9000, 28)):
+    for (n, m, want) in ((8192, 4096, 16), (200, 100, 16), (12000, 9000, 24)):
         h = ctypes.c_void_p()
         lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h), n, m, 12345, 0, -1, 0), "create")
         try:
             lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, 0, 1), "to the compact representation")
             L.mi355x_tab_sync(h, None)
             assert L.mi355x_tab_block_size(h) == want, (n, m)
-            if want == 28:                                   # ... and it is the oracle's solve: 100 pivots
+            if want == 24:                                   # ... and it is the oracle's solve: 100 pivots
                 M, b = lp.synth.tableau(n, m, 12345)
                 st, npiv, trace = oracle.solve(M, b, max_pivots=100, trace_cap=100, omp=True)
                 k = ctypes.c_int64(0)

@@ -16,9 +16,11 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_flags.log 2>&1;
 python bench.py --workload cfg4 > $O/bench_cfg4.log 2>&1; echo "bench cfg4 rc=$?"; tail -1 $O/bench_cfg4.log | cut -c1-300
 python bench.py --workload cfg4 --batch-lps 1024 > $O/bench_cfg4_1024.log 2>&1; echo "bench cfg4 x1024 rc=$?"
 python bench.py --workload cfg2 --steps 128 --no-cpu-baseline > $O/bench_cfg2.log 2>&1; echo "bench cfg2 rc=$?"
-python tools/native_end_to_end.py > $O/native_end_to_end.log 2>&1; echo "native end to end rc=$?"; tail -3 $O/native_end_to_end.log
-python bench.py --workload colpart --steps 64 --warmup 16 > $O/bench_colpart_1gpu.log 2>&1; echo "bench colpart rc=$?"
-python tools/shard_step_cost.py 256 2>&1 | grep "us per pivot" > $O/shard_step_cost.log; echo "shard step cost rc=$?"
+python tools/native_end_to_end.py --init > $O/native_end_to_end.log 2>&1; echo "native end to end rc=$?"; tail -4 $O/native_end_to_end.log
+python bench.py --workload colpart --steps 112 --warmup 28 > $O/bench_colpart_1gpu.log 2>&1; echo "bench colpart rc=$?"
+(for b in 16 24 28; do python tools/shard_step_cost.py 336 $b; done) 2>&1 | grep -E "per sweep|us per pivot" > $O/shard_step_cost.log; echo "shard step cost rc=$?"
+python tools/wide_block_ab.py 2>&1 | grep "us per pivot" > $O/wide_block_ab.log; echo "wide block A/B rc=$?"
+(cd tools/microbench && ./sweep32 && ./sweep32 32769 65552 && ./sweep32 4097 8208) > $O/sweep32_microbench.log 2>&1; echo "sweep32 microbench rc=$?"
 (python tools/resident_timing.py; python tools/resident_timing.py 512 256) 2>&1 | grep -E "us/pivot|inside" > $O/resident_timing.log; echo "resident timing rc=$?"
 python tools/resident_ab.py 2>&1 | grep "poll mode" > $O/resident_ab.log; echo "resident A/B rc=$?"
 cd /tmp && export TMPDIR=/tmp
@@ -29,6 +31,11 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_st
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python $R/tools/pmc_probe.py 64 > $O/pmc_$c.log 2>&1; echo "pmc $c rc=$?"
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_perpivot_$c -- python $R/tools/pmc_probe.py 24 1 > $O/pmc_perpivot_$c.log 2>&1; echo "pmc per-pivot $c rc=$?"
+done
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats_cfg5 -- python $R/bench.py --workload colpart --steps 112 --warmup 28 > $O/kernel_stats_cfg5.log 2>&1; echo "rocprof stats cfg5 rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats_shard -- python $R/tools/pmc_probe.py 96 0 0 8192 32768 > $O/kernel_stats_shard.log 2>&1; echo "rocprof stats shard rc=$?"
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_shard_$c -- python $R/tools/pmc_probe.py 96 0 0 8192 32768 > $O/pmc_shard_$c.log 2>&1; echo "pmc shard $c rc=$?"
 done
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_resident_$c -- python $R/tools/pmc_probe_resident.py > $O/pmc_resident_$c.log 2>&1; echo "pmc resident $c rc=$?"

@@ -99,6 +99,51 @@ def main(tag):
             out["kernels"][k] = rec
     json.dump(out, open(os.path.join(PR, tag + "_cfg3_pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
+    # wide blocks (round 4): one 8-GPU-sized shard of config 5 as a single tableau (32769 x 8193 stored,
+    # 2.15 GB), 24 pivots per sweep: k_sweepw<24> + k_sweepw_rest
+    fp = one("pmc_shard_FETCH_SIZE/*/*counter_collection.csv", required=False)
+    wp = one("pmc_shard_WRITE_SIZE/*/*counter_collection.csv", required=False)
+    lg = one("pmc_shard_FETCH_SIZE.log", required=False)
+    if fp and wp and lg:
+        shutil.copy(fp, os.path.join(PR, tag + "_cfg5_shard_pmc_FETCH_SIZE.csv"))
+        shutil.copy(wp, os.path.join(PR, tag + "_cfg5_shard_pmc_WRITE_SIZE.csv"))
+        layout = {}
+        for l in open(lg):
+            if l.startswith("layout"):
+                layout = dict(kv.split("=") for kv in l.split()[1:])
+        rows, cols, ld, dld = int(layout["rows"]), int(layout["stored_cols"]), int(layout["stored_ld"]), int(layout["dense_ld"])
+        cf, cw = max(counter(fp, "copyBuffer")), max(counter(wp, "copyBuffer"))
+        copy_kib = rows * dld * 8 / 1024.0
+        res = {"workload": "one 8-GPU-sized column shard of config 5 as a single tableau (%d x %d stored), %s pivots per sweep"
+                           % (rows, cols, layout.get("block", "?")),
+               "calibration": {"KiB_each_way": copy_kib, "FETCH_SIZE_reported_KiB": cf, "WRITE_SIZE_reported_KiB": cw,
+                               "fetch_factor_measured": copy_kib / cf, "write_factor_measured": copy_kib / cw,
+                               "correction_applied": "FETCH x2 (gfx950), WRITE x1"}, "kernels": {}}
+        for k in ("k_sweepw<", "k_sweepw_rest", "k_la_gather", "k_la_scale"):
+            f, w = counter(fp, k), counter(wp, k)
+            if not f or not w:
+                continue
+            if k == "k_sweepw<":
+                f = [x for x in f if x > 0.5 * max(f)]
+                w = [x for x in w if x > 0.5 * max(w)]
+            favg, wavg = sum(f) / len(f), sum(w) / len(w)
+            rec = {"launches": len(f), "FETCH_SIZE_KiB_avg": favg, "WRITE_SIZE_KiB_avg": wavg,
+                   "hbm_bytes_per_launch": (2 * favg + wavg) * 1024, "stored_rows_cols_ld": [rows, cols, ld]}
+            if k == "k_sweepw<":
+                rec["algorithmic_bytes_per_launch"] = 2 * rows * cols * 8
+                rec["traffic_over_algorithmic"] = rec["hbm_bytes_per_launch"] / rec["algorithmic_bytes_per_launch"]
+            res["kernels"][k.rstrip("<")] = rec
+        json.dump(res, open(os.path.join(PR, tag + "_cfg5_shard_pmc_traffic.json"), "w"), indent=1)
+        print(json.dumps(res, indent=1))
+    for src, dst in (("kernel_stats_cfg5/*/*kernel_stats.csv", "_cfg5_kernel_stats.csv"),
+                     ("kernel_stats_shard/*/*kernel_stats.csv", "_cfg5_shard_kernel_stats.csv")):
+        f = one(src, required=False)
+        if f:
+            shutil.copy(f, os.path.join(PR, tag + dst))
+    for log, dst in (("wide_block_ab.log", "_wide_block_ab.txt"), ("sweep32_microbench.log", "_sweep32_microbench.txt")):
+        f = one(log, required=False)
+        if f and os.path.getsize(f):
+            shutil.copy(f, os.path.join(PR, tag + dst))
     # the resident solve (tools/pmc_probe_resident.py): config 2 as ONE k_resident launch, then a
     # 128-LP config-4 batch as one launch
     fp = one("pmc_resident_FETCH_SIZE/*/*counter_collection.csv", required=False)
