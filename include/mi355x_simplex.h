@@ -308,6 +308,18 @@ int  mi355x_multibatch_solve(mi355x_multibatch *mb, int is_max, double fp_factor
                              int32_t *status, int64_t *n_pivots);
 int  mi355x_multibatch_download(mi355x_multibatch *mb, int64_t lp_index, double *host_matrix,
                                 int64_t *host_basis, double *last_row, double *last_col);
+/* n-solve-tableau, two-phase branch (src/simplex.lisp:402-452), member by member of two matching
+ * batches: member k of `art` is the artificial tableau (a min problem) of the problem whose main
+ * tableau is member k of `main_mb` (same member count, row count and sub-batch layout).  Phase 1 runs
+ * as the batch loop on `art`; the feasibility test (fp= 0 objective) and the hand-over (437-451) run
+ * per member on the devices; phase 2 is the batch loop on `main_mb`.  status[k]: MI_OPTIMAL /
+ * MI_UNBOUNDED / MI_INFEASIBLE as mi355x_solve_two_phase, or MI_UNSUPPORTED for a member whose
+ * degenerate artificials would have to be pivoted out of the basis first (419-434: per-member row
+ * fetches and single pivots) -- solve that problem with mi355x_solve_two_phase from the caller's own
+ * copies.  n_pivots: two entries per member (phase 1, phase 2), may be NULL.  Read results with
+ * mi355x_multibatch_download(main_mb, k, ...). */
+int  mi355x_multibatch_solve_two_phase(mi355x_multibatch *art, mi355x_multibatch *main_mb, int main_is_max,
+                                       double fp_factor, int32_t *status, int64_t *n_pivots);
 int  mi355x_multibatch_cancel(mi355x_multibatch *mb);
 void mi355x_multibatch_destroy(mi355x_multibatch *mb);
 

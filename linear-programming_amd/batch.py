@@ -141,6 +141,17 @@ class MultiDeviceBatch:
                    "mi355x_multibatch_download")
         return M, b
 
+    def solve_two_phase(self, main, main_is_max=True, fp_tolerance=1024):
+        """self = the batch of ARTIFICIAL tableaux, `main` the matching batch of main tableaux
+        (n-solve-tableau's two-phase branch, src/simplex.lisp:402-452, member by member):
+        -> (status per member, pivots (n, 2)).  Status MI_UNSUPPORTED: that member needs drive-out
+        pivots first -- solve it alone."""
+        st = np.zeros(self.n_lps, dtype=np.int32)
+        npv = np.zeros((self.n_lps, 2), dtype=np.int64)
+        capi.check(capi.lib().mi355x_multibatch_solve_two_phase(self._h, main._h, int(bool(main_is_max)), float(fp_tolerance),
+                                                                _ptr(st), _ptr(npv)), "mi355x_multibatch_solve_two_phase")
+        return st, npv
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:

@@ -1920,6 +1920,95 @@ int mi355x_multibatch_download(mi355x_multibatch *mb, int64_t k, double *hm, int
 
 void mi355x_multibatch_destroy(mi355x_multibatch *mb) { mb_free(mb); }
 
+// ---- n-solve-tableau, two-phase branch (src/simplex.lisp:402-452), for a batch -------------------
+// Member k of `art` is the artificial tableau of the problem whose main tableau is member k of
+// `main_mb` (build-tableau's two results, :326-328): phase 1 = the batch loop on `art` (min
+// problems); per member the feasibility test (fp= 0 objective) :405-407 and the hand-over :437-451
+// (mi355x_solve_two_phase's kernels on that member's slices of the two batches); phase 2 = the batch
+// loop on `main_mb`.  A member whose degenerate artificials would have to be driven out of the basis
+// first (:419-434 -- row fetches and single pivots, per member) is DECLINED: status MI_UNSUPPORTED,
+// the caller runs that problem through mi355x_solve_two_phase (its tableaux in the caller's memory
+// are untouched; what the batches hold of it is to be ignored).
+static TabView mb_member_view(const TabView &v, int64_t k)
+{
+    TabView s = v;
+    s.M += k * v.zs_M; s.basis += k * v.zs_basis; s.col += k * v.zs_col; s.prow += k * v.zs_prow;
+    s.ctl += k;
+    s.n_lps = 1;
+    return s;
+}
+
+int mi355x_multibatch_solve_two_phase(mi355x_multibatch *art, mi355x_multibatch *main_mb, int main_is_max, double f,
+                                      int32_t *status, int64_t *n_pivots)
+{
+    if (!art || !main_mb || !status) return fail(MI_BAD_ARG, "NULL argument");
+    if (art->n_lps != main_mb->n_lps || art->rows != main_mb->rows || art->cols < main_mb->cols ||
+        art->sub.size() != main_mb->sub.size() || art->first != main_mb->first)
+        return fail(MI_BAD_ARG, "the artificial and the main batch do not match (members, rows, sub-batches)");
+    for (size_t d = 0; d < art->sub.size(); ++d)
+        if (art->sub[d]->t->device != main_mb->sub[d]->t->device)
+            return fail(MI_BAD_ARG, "sub-batch %zu of the two batches lives on different devices", d);
+    const int64_t n = art->n_lps, rows = art->rows, m = rows - 1, num_vars = main_mb->cols - 1, num_art_vars = art->cols - 1;
+    std::vector<int32_t> st1((size_t)n, 0), st2((size_t)n, 0);
+    std::vector<int64_t> np1((size_t)n, 0), np2((size_t)n, 0);
+    int rc = mi355x_multibatch_solve(art, /*is_max=*/0, f, 0, st1.data(), np1.data());          // :403
+    if (rc != MI_OK) return rc;
+    std::vector<char> go((size_t)n, 0);
+    std::vector<double> obj;
+    std::vector<int64_t> basis;
+    for (size_t d = 0; d < art->sub.size(); ++d) {
+        mi355x_tab *at = art->sub[d]->t, *mt = main_mb->sub[d]->t;
+        const int64_t k0 = art->first[d], nd = art->first[d + 1] - k0;
+        if ((rc = use_device(at)) != MI_OK || (rc = ensure_dense(at)) != MI_OK || (rc = ensure_dense(mt)) != MI_OK) return rc;
+        HIP_TRY(hipStreamSynchronize(mt->stream));
+        obj.resize((size_t)nd);
+        basis.resize((size_t)(nd * std::max<int64_t>(m, 1)));
+        // objective value (last row, last column) and basis of every member of this sub-batch
+        HIP_TRY(hipMemcpy2DAsync(obj.data(), sizeof(double), at->v.M + m * at->v.ld + num_art_vars,
+                                 (size_t)rows * at->v.ld * sizeof(double), sizeof(double), (size_t)nd,
+                                 hipMemcpyDeviceToHost, at->stream));
+        if (m > 0)
+            HIP_TRY(hipMemcpyAsync(basis.data(), at->v.basis, (size_t)(nd * m) * sizeof(int64_t), hipMemcpyDeviceToHost, at->stream));
+        HIP_TRY(hipStreamSynchronize(at->stream));
+        for (int64_t q = 0; q < nd; ++q) {
+            const int64_t k = k0 + q;
+            int32_t out = st1[(size_t)k];
+            if (out == MI_OPTIMAL) {
+                const double diff = 0.0 - obj[(size_t)q];                                        // (fp= 0 objective factor) :405-407
+                if (!((diff < 0.0 ? -diff : diff) <= f * kClEpsilon)) out = MI_INFEASIBLE;
+                else {
+                    bool art_basic = false;
+                    for (int64_t i = 0; i < m && !art_basic; ++i) art_basic = basis[(size_t)(q * m + i)] >= num_vars;
+                    if (art_basic) out = MI_UNSUPPORTED;                                         // drive-out pivots: the one-problem path
+                    else go[(size_t)k] = 1;
+                }
+            }
+            status[k] = out;
+            if (go[(size_t)k]) {
+                launch_handover(mb_member_view(at->v, q), mb_member_view(mt->v, q),
+                                at->unit_basis && at->tn.handover_mode != 1, at->stream);        // :437-451
+            } else {
+                // nothing is handed over: this member's main tableau must not run (the reference's loop
+                // has no cap, and what it holds is no consistent tableau) -- an all-zero objective row
+                // prices as optimal at once
+                HIP_TRY(hipMemsetAsync(mt->v.M + q * mt->v.zs_M + m * mt->v.ld, 0, (size_t)mt->v.ld * sizeof(double), at->stream));
+            }
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(at->stream));
+        mt->n_part = 0;
+        mt->unit_basis = false;
+        mt->compact_failed = false;
+    }
+    rc = mi355x_multibatch_solve(main_mb, main_is_max, f, 0, st2.data(), np2.data());            // :452
+    if (rc != MI_OK) return rc;
+    for (int64_t k = 0; k < n; ++k) {
+        if (go[(size_t)k]) status[k] = st2[(size_t)k];
+        if (n_pivots) { n_pivots[2 * k] = np1[(size_t)k]; n_pivots[2 * k + 1] = go[(size_t)k] ? np2[(size_t)k] : 0; }
+    }
+    return MI_OK;
+}
+
 // ---- column-partitioned shards ------------------------------------------------------
 static int shard_price_x(mi355x_tab *t, int is_max, int64_t col_offset, double *dev_out2, const P2pArgs &x);
 int mi355x_shard_price(mi355x_tab *t, int is_max, int64_t col_offset, double *dev_out2)
@@ -2588,6 +2677,32 @@ int cp_fused_p2p_step(mi355x_colpart *p, CpShard &s, double f, int j, unsigned e
     return mi355x_shard_la_pivot(s.t, j, (const int64_t *)s.bits_in, s.ec, f);
 }
 
+// Exchange mode 2, blocked: the step of shard s as TWO launches (k_shard_p2p_step + k_shard_la_scale)
+// where a consumer and the producer it waits for may be the same kernel on different shards -- a
+// shard that has its device (or at least its stream) to itself, or the only shard there is.
+// Returns > 0: done; 0: this shard / state needs the separate launches; < 0: an error.
+int cp_try_merged_step(mi355x_colpart *p, CpShard &s, double f, int j, unsigned epoch)
+{
+    mi355x_tab *t = s.t;
+    const int np = (p->p2p_merged && t->n_part > 0 && t->part_is_max == (p->is_max ? 1 : 0)) ? t->n_part : 0;
+    if (!(np > 0 && t->v.blk && j < kWideBlock)) return 0;
+    P2pArgs x;
+    x.peers = s.d_peers; x.mine = s.xch; x.lay = p->lay; x.rank = s.index; x.epoch = epoch; x.max_spins = p->p2p_spins;
+    int rc = use_device(t);
+    if (rc == MI_OK) rc = ensure_dense(t);
+    if (rc != MI_OK) return rc;
+    t->shard_is_max = p->is_max ? 1 : 0;
+    t->v.col_bias = t->v.p2l ? 0 : s.col_begin;
+    const int left = launch_shard_p2p_step(t->v, j, np, p->world, s.col_begin, f, t->shard_is_max, s.ec, t->stream, x);
+    if (left > 0) {
+        if (j + 1 > t->shard_steps) t->shard_steps = j + 1;     // (what mi355x_shard_la_pivot records)
+        t->n_part = left;
+        t->part_is_max = t->shard_is_max;
+        HIP_TRY(hipGetLastError());
+    }
+    return left;
+}
+
 // n iterations of shard s over RCCL (its own thread in the one-process form).  j0 = step of the
 // block the first iteration is; every shard runs the same sequence, so they meet in the collectives.
 int cp_run_rccl(mi355x_colpart *p, CpShard &s, double f, int64_t n, int j0)
@@ -2604,25 +2719,8 @@ int cp_run_rccl(mi355x_colpart *p, CpShard &s, double f, int64_t n, int j0)
             // the shards' kernels run concurrently (this loop: one shard per device or process), four
             // for the first pivot after an upload and for small shards
             int rc = MI_OK;
-            mi355x_tab *t = s.t;
-            const int np = (p->p2p_merged && t->n_part > 0 && t->part_is_max == (p->is_max ? 1 : 0)) ? t->n_part : 0;
-            int left = 0;
-            if (np > 0 && t->v.blk && j < kWideBlock) {
-                P2pArgs x;
-                x.peers = s.d_peers; x.mine = s.xch; x.lay = p->lay; x.rank = s.index; x.epoch = epoch; x.max_spins = p->p2p_spins;
-                rc = use_device(t);
-                if (rc == MI_OK) rc = ensure_dense(t);
-                if (rc != MI_OK) return rc;
-                t->shard_is_max = p->is_max ? 1 : 0;
-                t->v.col_bias = t->v.p2l ? 0 : s.col_begin;
-                left = launch_shard_p2p_step(t->v, j, np, p->world, s.col_begin, f, t->shard_is_max, s.ec, t->stream, x);
-                if (left > 0) {
-                    if (j + 1 > t->shard_steps) t->shard_steps = j + 1;     // (what mi355x_shard_la_pivot records)
-                    t->n_part = left;
-                    t->part_is_max = t->shard_is_max;
-                    HIP_TRY(hipGetLastError());
-                }
-            }
+            const int left = cp_try_merged_step(p, s, f, j, epoch);
+            if (left < 0) return left;
             if (left == 0) {
                 rc = cp_fused_p2p_step(p, s, f, j, epoch, 0);
                 if (rc == MI_OK) rc = cp_fused_p2p_step(p, s, f, j, epoch, 1);
@@ -2735,8 +2833,12 @@ int cp_run(mi355x_colpart *p, double f, int64_t n)
         int rc;
         const unsigned epoch = ++p->xepoch;
         if (p->exchange == 2 && p->block > 1) {
-            for (int phase = 0; phase < 3; ++phase)
-                for (CpShard &s : p->sh) if ((rc = cp_fused_p2p_step(p, s, f, p->j, epoch, phase)) != MI_OK) return rc;
+            // ONE shard in all: nobody to wait for, so the two-launch step is safe on this stream too
+            const int left = p->world == 1 ? cp_try_merged_step(p, p->sh[0], f, p->j, epoch) : 0;
+            if (left < 0) return left;
+            if (left == 0)
+                for (int phase = 0; phase < 3; ++phase)
+                    for (CpShard &s : p->sh) if ((rc = cp_fused_p2p_step(p, s, f, p->j, epoch, phase)) != MI_OK) return rc;
             if (++p->j == p->block) {
                 for (CpShard &s : p->sh) if ((rc = mi355x_shard_sweep(s.t)) != MI_OK) return rc;
                 p->j = 0;
@@ -2847,6 +2949,9 @@ static int cp_create_synthetic(mi355x_colpart **out, int64_t n_vars, int64_t n_c
     p->rccl = mp ? (world > 1 || cp_one_device_each(1)) : cp_one_device_each(world);
     p->exchange = g_cp_exchange == 3 ? 2 : g_cp_exchange;
     p->p2p_merged = g_cp_exchange != 3;
+    // (a lone shard without a communicator exchanges with nobody: it takes the self-push form, whose
+    // step is two launches instead of five)
+    if (g_cp_exchange == 0 && p->world == 1 && !p->rccl) p->exchange = 2;
     p->compact = true;
     p->rows = n_cons + 1;
     p->var_count = n_vars + n_cons;
@@ -2932,6 +3037,9 @@ int mi355x_colpart_create_on(mi355x_colpart **out, int64_t rows, int64_t cols, c
     p->rccl = cp_one_device_each(n_devices);
     p->exchange = g_cp_exchange == 3 ? 2 : g_cp_exchange;
     p->p2p_merged = g_cp_exchange != 3;
+    // (a lone shard without a communicator exchanges with nobody: it takes the self-push form, whose
+    // step is two launches instead of five)
+    if (g_cp_exchange == 0 && p->world == 1 && !p->rccl) p->exchange = 2;
     p->compact = compact;
     p->rows = rows;
     p->var_count = vc;

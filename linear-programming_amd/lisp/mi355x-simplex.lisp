@@ -95,6 +95,9 @@
 (cffi:defcfun ("mi355x_multibatch_solve" %multibatch-solve) :int
   (handle :pointer) (is-max :int) (fp-factor :double) (max-pivots :int64) (status :pointer)
   (n-pivots :pointer))
+(cffi:defcfun ("mi355x_multibatch_solve_two_phase" %multibatch-solve-two-phase) :int
+  (art :pointer) (main :pointer) (main-is-max :int) (fp-factor :double) (status :pointer)
+  (n-pivots :pointer))
 (cffi:defcfun ("mi355x_multibatch_download" %multibatch-download) :int
   (handle :pointer) (lp-index :int64) (host-matrix :pointer) (host-basis :pointer)
   (last-row :pointer) (last-col :pointer))
@@ -497,20 +500,16 @@ solved `tableau`.  solve-problem forwards these keywords (src/solver.lisp:53-56)
   (handler-case (progn (signal-outcome status) nil)
     (error (c) c)))
 
-(defun solve-same-shape-batch (tableaus devices factor max-pivots full-tableau)
-  "TABLEAUS: single-phase tableaus of ONE shape and ONE sense.  Packs them into one multi-device
-batch, solves them side by side and writes every member's results back into its own arrays.
-Returns a list parallel to TABLEAUS: the tableau, or a condition object for a member without a
-solution (unbounded-problem-error ...)."
+(defun pack-tableaus (tableaus)
+  "Same-shape tableaus -> (values flat bases rows cols): the matrices coerced to double-float one
+after the other, the bases as (signed-byte 64)."
   (let* ((n (length tableaus))
          (first-matrix (tableau-matrix (first tableaus)))
          (rows (array-dimension first-matrix 0))
          (cols (array-dimension first-matrix 1))
          (m (1- rows))
          (flat (make-array (* n rows cols) :element-type 'double-float))
-         (bases (make-array (max 1 (* n m)) :element-type '(signed-byte 64) :initial-element 0))
-         (n-dev (device-count-of devices))
-         (handle nil))
+         (bases (make-array (max 1 (* n m)) :element-type '(signed-byte 64) :initial-element 0)))
     (loop for tab in tableaus for k from 0
           do (let ((matrix (tableau-matrix tab))
                    (basis (tableau-basis-columns tab))
@@ -521,58 +520,106 @@ solution (unbounded-problem-error ...)."
                          (coerce (aref matrix r c) 'double-float))))
                (dotimes (i m)
                  (setf (aref bases (+ (* k m) i)) (aref basis i)))))
-    (cffi:with-foreign-objects ((out :pointer) (ids :int (max n-dev 1))
-                                (status :int32 n) (pivots :int64 n))
-      (when (listp devices)
-        (loop for d in devices for i from 0 do (setf (cffi:mem-aref ids :int i) d)))
-      (cffi:with-pointer-to-vector-data (pm flat)
-        (cffi:with-pointer-to-vector-data (pb bases)
-          (check (with-foreign-fp-mode
-                   (%multibatch-create out n rows cols pm pb n-dev
-                                       (if (listp devices) ids (cffi:null-pointer)))))))
-      (setf handle (cffi:mem-ref out :pointer))
-      (unwind-protect
-           (progn
-             ;; bounded foreign calls, as for a single tableau: MI_RUNNING members carry on
-             (let ((chunk (chunk-pivots rows cols))
-                   (done 0))
-               (loop
-                 (let ((cap (if (plusp max-pivots) (min chunk (- max-pivots done)) chunk)))
-                   (check (with-foreign-fp-mode
-                            (%multibatch-solve handle (max-problem-p (first tableaus)) factor cap
-                                               status pivots)))
-                   (incf done cap)
-                   (when (or (and (plusp max-pivots) (>= done max-pivots))
-                             (loop for k below n
-                                   never (= (cffi:mem-aref status :int32 k) +mi-max-pivots+)))
-                     (return)))))
-             (let ((last-row (make-array cols :element-type 'double-float))
-                   (last-col (make-array rows :element-type 'double-float))
-                   (one-flat (when full-tableau (make-array (* rows cols) :element-type 'double-float)))
-                   (one-basis (make-array (max 1 m) :element-type '(signed-byte 64) :initial-element 0)))
-               (loop for tab in tableaus for k from 0
-                     collect
-                     (let ((condition (outcome-condition (cffi:mem-aref status :int32 k))))
-                       (or condition
-                           (let ((matrix (tableau-matrix tab))
-                                 (basis-dst (tableau-basis-columns tab)))
-                             (cffi:with-pointer-to-vector-data (pr last-row)
-                               (cffi:with-pointer-to-vector-data (pc last-col)
-                                 (cffi:with-pointer-to-vector-data (pb one-basis)
-                                   (if full-tableau
-                                       (cffi:with-pointer-to-vector-data (pm one-flat)
-                                         (check (%multibatch-download handle k pm pb pr pc)))
-                                       (check (%multibatch-download handle k (cffi:null-pointer)
-                                                                    pb pr pc))))))
-                             (if full-tableau
-                                 (vectors->tableau tab one-flat one-basis)
-                                 (progn
-                                   (dotimes (r rows) (setf (aref matrix r (1- cols)) (aref last-col r)))
-                                   (dotimes (c cols) (setf (aref matrix (1- rows) c) (aref last-row c)))
-                                   (dotimes (i (length basis-dst))
-                                     (setf (aref basis-dst i) (aref one-basis i)))
-                                   tab))))))))
-        (%multibatch-destroy handle)))))
+    (values flat bases rows cols)))
+
+(defun multibatch-create (tableaus devices)
+  "mi355x_multibatch_create over DEVICES (a count or a list of ids): LP k lives in sub-batch
+k / ceil(n / devices)."
+  (multiple-value-bind (flat bases rows cols) (pack-tableaus tableaus)
+    (let ((n-dev (device-count-of devices)))
+      (cffi:with-foreign-objects ((out :pointer) (ids :int (max n-dev 1)))
+        (when (listp devices)
+          (loop for d in devices for i from 0 do (setf (cffi:mem-aref ids :int i) d)))
+        (cffi:with-pointer-to-vector-data (pm flat)
+          (cffi:with-pointer-to-vector-data (pb bases)
+            (check (with-foreign-fp-mode
+                     (%multibatch-create out (length tableaus) rows cols pm pb n-dev
+                                         (if (listp devices) ids (cffi:null-pointer)))))))
+        (cffi:mem-ref out :pointer)))))
+
+(defun multibatch-read-back (handle k tab full-tableau)
+  "Member K of a batch into TAB's own arrays: every entry, or (default) the objective row, the RHS
+column and the basis -- all that tableau-variable & co. read (src/simplex.lisp:74-120)."
+  (let* ((matrix (tableau-matrix tab))
+         (rows (array-dimension matrix 0))
+         (cols (array-dimension matrix 1))
+         (last-row (make-array cols :element-type 'double-float))
+         (last-col (make-array rows :element-type 'double-float))
+         (flat (when full-tableau (make-array (* rows cols) :element-type 'double-float)))
+         (basis (make-array (max 1 (1- rows)) :element-type '(signed-byte 64) :initial-element 0))
+         (basis-dst (tableau-basis-columns tab)))
+    (cffi:with-pointer-to-vector-data (pr last-row)
+      (cffi:with-pointer-to-vector-data (pc last-col)
+        (cffi:with-pointer-to-vector-data (pb basis)
+          (if full-tableau
+              (cffi:with-pointer-to-vector-data (pm flat)
+                (check (%multibatch-download handle k pm pb pr pc)))
+              (check (%multibatch-download handle k (cffi:null-pointer) pb pr pc))))))
+    (if full-tableau
+        (vectors->tableau tab flat basis)
+        (progn
+          (dotimes (r rows) (setf (aref matrix r (1- cols)) (aref last-col r)))
+          (dotimes (c cols) (setf (aref matrix (1- rows) c) (aref last-row c)))
+          (dotimes (i (length basis-dst)) (setf (aref basis-dst i) (aref basis i)))
+          tab))))
+
+(defun solve-two-phase-batch (pairs devices factor full-tableau)
+  "PAIRS: lists (art-tableau main-tableau) of ONE shape each and one sense (build-tableau's results
+for two-phase problems, src/simplex.lisp:326-328).  Phase 1 on the batch of artificial tableaux,
+the feasibility test and the hand-over per member, phase 2 on the batch of main tableaux
+(mi355x_multibatch_solve_two_phase; src/simplex.lisp:402-452).  Returns a list parallel to PAIRS:
+the solved main tableau, a condition object, or :ALONE for a member whose degenerate artificials
+must be pivoted out first (the caller solves that problem through the one-problem hook)."
+  (let* ((n (length pairs))
+         (art-handle (multibatch-create (mapcar #'first pairs) devices))
+         (main-handle nil))
+    (unwind-protect
+         (progn
+           (setf main-handle (multibatch-create (mapcar #'second pairs) devices))
+           (cffi:with-foreign-objects ((status :int32 n) (pivots :int64 (* 2 n)))
+             (check (with-foreign-fp-mode
+                      (%multibatch-solve-two-phase art-handle main-handle
+                                                   (max-problem-p (second (first pairs))) factor
+                                                   status pivots)))
+             (loop for (nil main-tab) in pairs for k from 0
+                   collect (let ((st (cffi:mem-aref status :int32 k)))
+                             (cond
+                               ((= st -6) :alone)               ; MI_UNSUPPORTED: drive-out pivots first
+                               ((outcome-condition st))
+                               (t (multibatch-read-back main-handle k main-tab full-tableau)))))))
+      (when main-handle (%multibatch-destroy main-handle))
+      (%multibatch-destroy art-handle))))
+
+(defun solve-same-shape-batch (tableaus devices factor max-pivots full-tableau)
+  "TABLEAUS: single-phase tableaus of ONE shape and ONE sense.  Packs them into one multi-device
+batch, solves them side by side and writes every member's results back into its own arrays.
+Returns a list parallel to TABLEAUS: the tableau, or a condition object for a member without a
+solution (unbounded-problem-error ...)."
+  (let* ((n (length tableaus))
+         (matrix (tableau-matrix (first tableaus)))
+         (rows (array-dimension matrix 0))
+         (cols (array-dimension matrix 1))
+         (handle (multibatch-create tableaus devices)))
+    (unwind-protect
+         (cffi:with-foreign-objects ((status :int32 n) (pivots :int64 n))
+           ;; bounded foreign calls, as for a single tableau: members a chunk left at MI_MAX_PIVOTS
+           ;; carry on in the next call (finished ones re-price as optimal at once)
+           (let ((chunk (chunk-pivots rows cols))
+                 (done 0))
+             (loop
+               (let ((cap (if (plusp max-pivots) (min chunk (- max-pivots done)) chunk)))
+                 (check (with-foreign-fp-mode
+                          (%multibatch-solve handle (max-problem-p (first tableaus)) factor cap
+                                             status pivots)))
+                 (incf done cap)
+                 (when (or (and (plusp max-pivots) (>= done max-pivots))
+                           (loop for k below n
+                                 never (= (cffi:mem-aref status :int32 k) +mi-max-pivots+)))
+                   (return)))))
+           (loop for tab in tableaus for k from 0
+                 collect (or (outcome-condition (cffi:mem-aref status :int32 k))
+                             (multibatch-read-back handle k tab full-tableau))))
+      (%multibatch-destroy handle))))
 
 (defun mi355x-solve-problems (problems &rest args
                               &key (fp-tolerance 1024) (device 0) (devices 1) (max-pivots 0)
@@ -584,9 +631,11 @@ the GPU(s) instead of one after the other.
   * Single-phase problems (every row a <= row after build-tableau's sign normalisation,
     src/simplex.lisp:243-263) are grouped by tableau shape and sense; a group of two or more is one
     multi-device batch (mi355x_multibatch_*: DEVICES sub-batches, one per GPU, no communication).
-  * Two-phase problems (build-tableau returned (art main), src/simplex.lisp:326-328) and problems
-    alone in their group go through MI355X-SIMPLEX-SOLVER one by one -- phase 1, the hand-over
-    (src/simplex.lisp:402-452) and phase 2 on DEVICE.
+  * Two-phase problems (build-tableau returned (art main), src/simplex.lisp:326-328) are grouped by
+    the shapes of their two tableaux; a group of two or more is a pair of batches -- phase 1, the
+    per-member feasibility test and hand-over (src/simplex.lisp:402-452) and phase 2 on the devices
+    (mi355x_multibatch_solve_two_phase).  Members that need drive-out pivots first, and problems
+    alone in their group, go through MI355X-SIMPLEX-SOLVER one by one.
   * A member without a solution does not abort the others: with :ERRORP NIL its place in the
     result holds the condition object (unbounded-problem-error, infeasible-problem-error,
     unsupported-constraint-error ...); with :ERRORP T (default, what mapcar of solve-problem
@@ -596,6 +645,7 @@ Every returned tableau's results are bit-identical to the single-problem path's.
   (let* ((n (length problems))
          (results (make-array n :initial-element nil))
          (groups (make-hash-table :test #'equal))
+         (groups2 (make-hash-table :test #'equal))          ; two-phase members, by the shapes of (art main)
          (factor (coerce fp-tolerance 'double-float)))
     (flet ((solve-alone (k problem)
              (setf (aref results k)
@@ -612,7 +662,13 @@ Every returned tableau's results are bit-identical to the single-problem path's.
                                      (error (c) c))))
                      (cond
                        ((typep tableaus 'condition) (setf (aref results k) tableaus))
-                       ((listp tableaus) (solve-alone k problem))
+                       ((listp tableaus)
+                        (let ((art (tableau-matrix (first tableaus)))
+                              (main (tableau-matrix (second tableaus))))
+                          (push (cons k tableaus)
+                                (gethash (list (array-dimension art 0) (array-dimension art 1)
+                                               (array-dimension main 1) (max-problem-p (second tableaus)))
+                                         groups2))))
                        ((not (unit-basis-p tableaus)) (solve-alone k problem))
                        (t
                         (let ((matrix (tableau-matrix tableaus)))
@@ -630,7 +686,19 @@ Every returned tableau's results are bit-identical to the single-problem path's.
                                                           max-pivots full-tableau)
                    do (setf (aref results k) outcome))
              (solve-alone (car (first members)) (nth (car (first members)) problems))))
-       groups))
+       groups)
+      (maphash
+       (lambda (shape members)
+         (declare (ignore shape))
+         (setf members (reverse members))
+         (if (rest members)
+             (loop for (k . nil) in members
+                   for outcome in (solve-two-phase-batch (mapcar #'cdr members) devices factor full-tableau)
+                   do (if (eq outcome :alone)
+                          (solve-alone k (nth k problems))
+                          (setf (aref results k) outcome)))
+             (solve-alone (car (first members)) (nth (car (first members)) problems))))
+       groups2))
     (when errorp
       (let ((failed (find-if (lambda (r) (typep r 'condition)) results)))
         (when failed (error failed))))

@@ -560,13 +560,15 @@ def mi355x_solve_problems(problems, fp_tolerance=1024, device=0, devices=1, max_
     GPU(s).  Single-phase problems are grouped by tableau shape and sense; a group of two or more
     is ONE multi-device batch (mi355x_multibatch_create / _solve in bounded chunks / _download per
     member / _destroy: `devices` sub-batches, no communication).  Two-phase problems
-    (src/simplex.lisp:402-452), integer problems (declined) and problems alone in their group go
-    through mi355x_simplex_solver one by one.  A member without a solution does not abort the
+    (src/simplex.lisp:402-452) are grouped by the shapes of their two tableaux; a group of two or more
+    is a pair of batches through mi355x_multibatch_solve_two_phase.  Integer problems (declined),
+    members that need drive-out pivots and problems alone in their group go through
+    mi355x_simplex_solver one by one.  A member without a solution does not abort the
     others: errorp False leaves the exception object in its place, errorp True raises the first
     one after every member has been attempted."""
     from .batch import MultiDeviceBatch
     results = [None] * len(problems)
-    groups = {}
+    groups, groups2 = {}, {}
 
     def alone(k):
         try:
@@ -583,7 +585,10 @@ def mi355x_solve_problems(problems, fp_tolerance=1024, device=0, devices=1, max_
         except SolverError as e:                       # e.g. the unbounded no-constraint special case
             results[k] = e
             continue
-        if isinstance(tabs, list) or not _unit_basis(tabs):
+        if isinstance(tabs, list):                     # two-phase: (art main), src/simplex.lisp:326-328
+            art, main = tabs
+            groups2.setdefault((art.matrix.shape, main.matrix.shape, main.is_max), []).append((k, art, main))
+        elif not _unit_basis(tabs):
             alone(k)
         else:
             groups.setdefault((tabs.matrix.shape, tabs.is_max), []).append((k, tabs))
@@ -612,6 +617,34 @@ def mi355x_solve_problems(problems, fp_tolerance=1024, device=0, devices=1, max_
             if old:
                 capi.lib().mi355x_tab_destroy(old)
             t._matrix, t._basis, t._stale, t._light = G, gb, False, None
+            results[k] = t
+    # two-phase members of one shape: phase 1, the per-member hand-over and phase 2 as batches
+    # (mi355x_multibatch_solve_two_phase); a member that needs drive-out pivots first is declined by
+    # the library and goes through the one-problem hook
+    for (ashape, mshape, is_max), members in groups2.items():
+        if len(members) == 1:
+            alone(members[0][0])
+            continue
+        amb = MultiDeviceBatch.from_arrays(np.stack([a.matrix for _, a, _ in members]),
+                                           np.stack([a.basis_columns for _, a, _ in members]), n_devices=devices)
+        mmb = MultiDeviceBatch.from_arrays(np.stack([t.matrix for _, _, t in members]),
+                                           np.stack([t.basis_columns for _, _, t in members]), n_devices=devices)
+        st, npv = amb.solve_two_phase(mmb, main_is_max=is_max, fp_tolerance=fp_tolerance)
+        for q, (k, a, t) in enumerate(members):
+            if int(st[q]) == capi.MI_UNSUPPORTED:
+                alone(k)
+                continue
+            try:
+                _raise_for(int(st[q]))
+            except SolverError as e:
+                results[k] = e
+                continue
+            G, gb = mmb.download(q)
+            old, t._handle = t._handle, None
+            if old:
+                capi.lib().mi355x_tab_destroy(old)
+            t._matrix, t._basis, t._stale, t._light = G, gb, False, None
+            t.n_pivots = (int(npv[q, 0]), int(npv[q, 1]))
             results[k] = t
     if errorp:
         for r in results:

@@ -149,6 +149,24 @@ int main(void)
             if (mi355x_build_tableau(q, 1, NULL, NULL, A, ab, NULL) != MI_OK) return 46;
             if (mi355x_build_tableau(q, 0, &mr, &mc, NULL, NULL, NULL) != MI_OK) return 47;
             if (mi355x_build_tableau(q, 0, NULL, NULL, Mm, mb2, NULL) != MI_OK) return 48;
+            {   /* the same problem twice as a pair of batches: phase 1, hand-over and phase 2 member by
+                 * member on the device (what mi355x-solve-problems does with two-phase members of one shape) */
+                mi355x_multibatch *ba = NULL, *bm = NULL;
+                double AA[2 * 4 * 9], MM2[2 * 4 * 8], lc2[4];
+                int64_t ab2[6], mb3[6], np2[4] = {0, 0, 0, 0};
+                int32_t st2[2] = {-1, -1};
+                memcpy(AA, A, (size_t)(ar * ac) * sizeof(double)); memcpy(AA + ar * ac, A, (size_t)(ar * ac) * sizeof(double));
+                memcpy(MM2, Mm, (size_t)(mr * mc) * sizeof(double)); memcpy(MM2 + mr * mc, Mm, (size_t)(mr * mc) * sizeof(double));
+                memcpy(ab2, ab, 3 * sizeof(int64_t)); memcpy(ab2 + 3, ab, 3 * sizeof(int64_t));
+                memcpy(mb3, mb2, 3 * sizeof(int64_t)); memcpy(mb3 + 3, mb2, 3 * sizeof(int64_t));
+                if (mi355x_multibatch_create(&ba, 2, ar, ac, AA, ab2, 1, NULL) != MI_OK) return 56;
+                if (mi355x_multibatch_create(&bm, 2, mr, mc, MM2, mb3, 1, NULL) != MI_OK) return 57;
+                if (mi355x_multibatch_solve_two_phase(ba, bm, 1, 1024.0, st2, np2) != MI_OK) return 58;
+                if (st2[0] != MI_OPTIMAL || st2[1] != MI_OPTIMAL || np2[0] != np2[2] || np2[1] != np2[3]) return 59;
+                if (mi355x_multibatch_download(bm, 1, NULL, NULL, NULL, lc2) != MI_OK || lc2[3] != 28.5) return 60;
+                mi355x_multibatch_destroy(bm);
+                mi355x_multibatch_destroy(ba);
+            }
             if (mi355x_tab_create(&art, ar, ac, A, ab, 0) != MI_OK) return 49;
             if (mi355x_tab_create(&mn, mr, mc, Mm, mb2, 0) != MI_OK) return 50;
             if (mi355x_solve_two_phase(art, mn, 1, 1024.0, npv) != MI_OPTIMAL) return 51;

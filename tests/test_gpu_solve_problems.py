@@ -112,3 +112,70 @@ def test_config4_shaped_list_in_bounded_chunks():
     for k, (p, r) in enumerate(zip(ps, got)):
         st, M, b = _oracle_outcome(p)
         assert st == oracle.OPTIMAL and np.array_equal(r.matrix.view(np.int64), M.view(np.int64)), k
+
+
+def _drive_out_problem(seed):
+    """Equality rows with right-hand side 0 whose artificial columns cancel in the phase-1 objective:
+    phase 1 is optimal at once with artificials still basic -- drive-out pivots (src/simplex.lisp:
+    419-434) are needed before the hand-over (seeds searched on the oracle, tests/test_gpu_parity.py)."""
+    rng = np.random.default_rng(seed)
+    n = 5
+    names = ["x%d" % i for i in range(n)]
+    rows = [rng.integers(-2, 3, n).astype(float) for _ in range(3)]
+    cons = [("=", list(zip(names, a.tolist())), 0.0) for a in rows if a.any()]
+    cons.append(("<=", list(zip(names, [1.0] * n)), 5.0))
+    return lp.Problem(type="max", vars=names, objective_var="obj",
+                      objective_func=list(zip(names, rng.integers(1, 4, n).astype(float).tolist())), constraints=cons)
+
+
+@pytest.mark.parametrize("devices", [1, 3])
+def test_two_phase_members_run_as_batches(golden, devices):
+    """Two-phase members of one shape: phase 1, the per-member feasibility test and hand-over
+    (src/simplex.lisp:402-452) and phase 2 as a pair of batches (mi355x_multibatch_solve_two_phase);
+    members that need drive-out pivots are declined by the library and solved alone; infeasible and
+    unbounded members keep their conditions.  Every member against the one-problem hook (pivot counts
+    of both phases included) and the oracle."""
+    ps = [random_mixed_problem(lp, 12, 5, 3, 2, 50 + s) for s in range(7)]            # one shape: a pair of batches of 7
+    ps += [_golden_problem(golden, "equality"), _golden_problem(golden, "equality")]     # t/simplex.lisp:196-237, twice
+    ps += [_golden_problem(golden, "geq"), _golden_problem(golden, "geq")]               # t/simplex.lisp:239-275
+    ps += [_drive_out_problem(s) for s in (282, 957, 959, 1396, 1481, 1610)]             # declined -> alone
+    ps += [random_mixed_problem(lp, 12, 5, 3, 2, 70 + s, kind="min") for s in range(3)]  # the same shape, min
+    ps += [_golden_problem(golden, "infeasible"), _golden_problem(golden, "infeasible")]
+    got = lp.solve_problems(ps, devices=devices, errorp=False)
+    solved = 0
+    for k, (p, r) in enumerate(zip(ps, got)):
+        st, M, b = _oracle_outcome(p)
+        if st == oracle.INFEASIBLE:
+            assert isinstance(r, lp.InfeasibleProblemError), k
+            continue
+        if st == oracle.UNBOUNDED:
+            assert isinstance(r, lp.UnboundedProblemError), k
+            continue
+        assert st == oracle.OPTIMAL and isinstance(r, lp.Tableau), (k, r)
+        assert np.array_equal(r.matrix.view(np.int64), M.view(np.int64)) and np.array_equal(r.basis_columns, b), k
+        one = lp.solve_problem(p)
+        assert np.array_equal(one.matrix.view(np.int64), r.matrix.view(np.int64)), k
+        assert tuple(one.n_pivots) == tuple(r.n_pivots), (k, one.n_pivots, r.n_pivots)
+        solved += 1
+    assert solved >= 18
+    assert lp.solution_objective_value(got[7]) == 28.5
+    assert abs(lp.solution_objective_value(got[9]) - 85 / 3) <= 1e-10 * 85 / 3
+
+
+def test_multibatch_two_phase_entry_point_directly(golden):
+    """mi355x_multibatch_solve_two_phase through ctypes: statuses and pivot counts per member, the
+    declined member (MI_UNSUPPORTED) next to ordinary ones, argument checks."""
+    import ctypes
+    L = lp.capi.lib()
+    ps = [_drive_out_problem(s) for s in (282, 957, 959)]
+    tabs = [lp.build_tableau(p, p) for p in ps]
+    shapes = {(a.matrix.shape, t.matrix.shape) for a, t in tabs}
+    assert len(shapes) == 1
+    amb = lp.MultiDeviceBatch.from_arrays(np.stack([a.matrix for a, _ in tabs]), np.stack([a.basis_columns for a, _ in tabs]), n_devices=2)
+    mmb = lp.MultiDeviceBatch.from_arrays(np.stack([t.matrix for _, t in tabs]), np.stack([t.basis_columns for _, t in tabs]), n_devices=2)
+    st, npv = amb.solve_two_phase(mmb)
+    assert (st == lp.capi.MI_UNSUPPORTED).all() and (npv[:, 1] == 0).all()
+    other = lp.MultiDeviceBatch.from_arrays(np.stack([t.matrix for _, t in tabs]), np.stack([t.basis_columns for _, t in tabs]), n_devices=1)
+    s4 = np.zeros(3, dtype=np.int32)
+    assert L.mi355x_multibatch_solve_two_phase(amb._h, other._h, 1, 1024.0, s4.ctypes.data_as(ctypes.c_void_p), None) == lp.capi.MI_BAD_ARG
+    assert L.mi355x_multibatch_solve_two_phase(None, mmb._h, 1, 1024.0, s4.ctypes.data_as(ctypes.c_void_p), None) == lp.capi.MI_BAD_ARG

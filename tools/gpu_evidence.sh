@@ -24,7 +24,7 @@ python tools/wide_block_ab.py 2>&1 | grep "us per pivot" > $O/wide_block_ab.log;
 (python tools/resident_timing.py; python tools/resident_timing.py 512 256) 2>&1 | grep -E "us/pivot|inside" > $O/resident_timing.log; echo "resident timing rc=$?"
 python tools/resident_ab.py 2>&1 | grep "poll mode" > $O/resident_ab.log; echo "resident A/B rc=$?"
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats -- python $R/bench.py --no-cpu-baseline --no-per-pivot > $O/kernel_stats.log 2>&1; echo "rocprof stats rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats -- python $R/bench.py --no-cpu-baseline --no-per-pivot --no-other-configs > $O/kernel_stats.log 2>&1; echo "rocprof stats rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats_cfg4 -- python $R/bench.py --workload cfg4 > $O/kernel_stats_cfg4.log 2>&1; echo "rocprof stats cfg4 rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats_cfg2 -- python $R/bench.py --workload cfg2 --steps 128 --no-cpu-baseline > $O/kernel_stats_cfg2.log 2>&1; echo "rocprof stats cfg2 rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats_perpivot -- python $R/bench.py --block 1 --steps 320 --no-cpu-baseline --no-per-pivot > $O/kernel_stats_perpivot.log 2>&1; echo "rocprof stats per-pivot rc=$?"
