@@ -23,8 +23,10 @@ extern "C" int mi355x_tab_create_compact_streamed_(mi355x_tab **out, int64_t row
                                                    void *ctx, int n_workers);
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -494,6 +496,7 @@ int mi355x_simplex_solver(const mi355x_problem *p, double fp_tolerance, int devi
         // host threads straight into pinned staging buffers and uploaded while later rows are still
         // being assembled (mi355x_tab_create_compact_streamed_)
         CompactPlan pl;
+        const auto t0 = std::chrono::steady_clock::now();
         if (plan_compact(*p, pl)) {
             const int64_t m = pl.m, rows = m + 1, ncv = pl.ncv, var_count = ncv + m;
             mi355x_solution *s = new (std::nothrow) mi355x_solution;
@@ -508,13 +511,27 @@ int mi355x_simplex_solver(const mi355x_problem *p, double fp_tolerance, int devi
             const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
             const int workers = (rows * (ncv + 1) > (1 << 22)) ? (int)hw : 1;
             mi355x_tab *t = nullptr;
+            // MI355X_E2E_TIMING=1: where the call's time goes, on stderr (tools/native_end_to_end.py)
+            const bool timing = getenv("MI355X_E2E_TIMING") != nullptr;
+            auto now = []() { return std::chrono::steady_clock::now(); };
+            auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+                return std::chrono::duration<double, std::milli>(b - a).count();
+            };
+            const auto t1 = now();
             int rc = mi355x_tab_create_compact_streamed_(&t, rows, var_count, ncv, stored.data(), pl.basis.data(),
                                                          device, produce_compact_rows, &pl, workers);
+            const auto t2 = now();
             if (rc == MI_OK) rc = mi355x_tab_solve(t, p->is_max ? 1 : 0, fp_tolerance, 0, &s->n_pivots[1]);
+            const auto t3 = now();
             int drc = MI_OK;
             if (rc == MI_OPTIMAL)
                 drc = mi355x_tab_download(t, nullptr, s->basis.data(), s->last_row.data(), s->last_col.data());
+            const auto t4 = now();
             mi355x_tab_destroy(t);
+            if (timing)
+                fprintf(stderr, "mi355x_simplex_solver: plan %.1f ms, allocate + assemble + upload (%d workers) %.1f ms, solve %.1f ms "
+                                "(%lld pivots), read-back %.1f ms, destroy %.1f ms\n", ms(t0, t1), workers, ms(t1, t2), ms(t2, t3),
+                        (long long)s->n_pivots[1], ms(t3, t4), ms(t4, now()));
             if (rc != MI_OPTIMAL || drc != MI_OK) { delete s; return rc != MI_OPTIMAL ? rc : drc; }
             *out = s;
             return MI_OPTIMAL;
