@@ -84,6 +84,10 @@ int         mi355x_tune_set_resident(int mode);              /* resident solve (
 int         mi355x_tune_set_resident_poll(int mode);         /* who polls the exchange records:
                                                                 0 by size (every wave when an LP has
                                                                 <= 8 workgroups), 1 wave 0, 2 every */
+int         mi355x_tune_set_resident_lds(int mode);          /* 1: 24 of a strip's 64 columns in LDS (three
+                                                                workgroups per CU; shapes of <= 256
+                                                                constraints) -- measured NOT faster, see
+                                                                kernels_launch.inc; 0 (default): never */
 /* 1 when the solve entry points would run this handle (in its current representation) resident */
 int         mi355x_tab_resident(mi355x_tab *t);
 

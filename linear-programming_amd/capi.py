@@ -118,6 +118,7 @@ _EXTRA = {
     "mi355x_tune_set_tail_policy": (_int, [_int]),
     "mi355x_tune_set_resident": (_int, [_int]),
     "mi355x_tune_set_resident_poll": (_int, [_int]),
+    "mi355x_tune_set_resident_lds": (_int, [_int]),
     "mi355x_tab_resident": (_int, [_p]),
     "mi355x_tune_set_colpart_exchange": (_int, [_int]),
     "mi355x_colpart_p2p_handle": (_int, [_p, _p]),

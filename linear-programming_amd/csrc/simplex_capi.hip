@@ -3538,6 +3538,7 @@ int         mi355x_tune_set_resident(int mode) { g_resident_mode = (mode == 1 ||
 int         mi355x_tune_set_resident_fault(int on) { set_resident_fault(on); return on; }
 #endif
 int         mi355x_tune_set_resident_poll(int mode) { set_resident_poll(mode); return mode; }
+int         mi355x_tune_set_resident_lds(int mode) { mode = mode > 0 ? 1 : 0; set_resident_lds(mode); return mode; }
 int         mi355x_tab_resident(mi355x_tab *t) { return (t && resident_mode(t)) ? 1 : 0; }
 int         mi355x_tune_set_lookahead_mode(int mode) { g_la_mode = mode; return g_la_mode; }
 int         mi355x_tune_set_block(int k)

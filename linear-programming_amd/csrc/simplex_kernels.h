@@ -257,6 +257,7 @@ size_t resident_xbuf_bytes(const TabView &compact);
 bool   launch_resident(const TabView &compact, unsigned long long *xbuf, int is_max, double fp_factor,
                        int cap, unsigned epoch_base, hipStream_t s);
 void   set_resident_fault(int on);      // test hook: the last workgroup of every LP never publishes
+void   set_resident_lds(int mode);      // tuning hook: 1 = part of the strip in LDS (three workgroups per CU), 0 = never
 void   set_resident_poll(int mode);     // tuning hook: who polls the exchange records (0 by size, 1 wave 0, 2 every wave)
 
 int         update_variant_count();

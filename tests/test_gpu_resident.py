@@ -47,8 +47,21 @@ SHAPES = [(1, 1), (5, 3), (63, 10), (64, 30), (65, 30), (129, 255), (300, 256), 
           (1024, 512), (500, 513), (511, 1000), (512, 1024), (2048, 200), (2047, 256)]
 
 
+@pytest.fixture(params=[0, 1], ids=["strip-in-registers", "strip-part-in-lds"])
+def strip_store(request):
+    """Round 4: for shapes of <= 256 constraints the last 24 of a strip's 64 columns can live in LDS
+    (three workgroups per CU instead of two: measured not faster, kept behind the tuning knob).
+    1 = use it for every such shape."""
+    L = lp.capi.lib()
+    assert L.mi355x_tune_set_resident_lds(request.param) == request.param
+    yield request.param
+    L.mi355x_tune_set_resident_lds(0)
+
+
 @pytest.mark.parametrize("n,m", SHAPES)
-def test_resident_solve_bitwise(n, m):
+def test_resident_solve_bitwise(n, m, strip_store):
+    if strip_store and m > 256:
+        pytest.skip("one row per thread only")
     M0, b0 = lp.synth.tableau(n, m, lp.synth.seed_for(2, 7 * n + m))
     t, rc, k = _solve(M0, b0)
     so, no = _check(t, rc, k, M0, b0)
@@ -93,7 +106,7 @@ def test_resident_is_chosen_by_shape_and_by_knobs():
 
 @pytest.mark.parametrize("kind", ["max", "min"])
 @pytest.mark.parametrize("factor", [16.0, 1024.0, float(2 ** 20)])
-def test_resident_senses_tolerances_and_degeneracy(kind, factor):
+def test_resident_senses_tolerances_and_degeneracy(kind, factor, strip_store):
     rng = np.random.default_rng(17)
     for n, m, degenerate in ((90, 40, True), (300, 120, False), (700, 300, True)):
         if degenerate:
@@ -110,11 +123,11 @@ def test_resident_senses_tolerances_and_degeneracy(kind, factor):
         _check(t, rc, k, M0, b0, is_max=(kind == "max"), factor=factor, cap=400)
 
 
-def test_resident_caps_resume_and_async_requests():
+@pytest.mark.parametrize("n,m", [(1024, 512), (1500, 250)])
+def test_resident_caps_resume_and_async_requests(n, m, strip_store):
     """A capped solve stops where the oracle stops; solving on continues from there; sequences of
     solve_async(n) requests (each ONE launch that keeps the tableau on chip) add up to the same."""
     L = lp.capi.lib()
-    n, m = 1024, 512
     seed = lp.synth.seed_for(2, 3)
     M0, b0 = lp.synth.tableau(n, m, seed)
     t, rc, k = _solve(M0, b0, cap=37)
@@ -145,7 +158,7 @@ def test_resident_caps_resume_and_async_requests():
     assert rc == so and kk.value == no
 
 
-def test_resident_hands_non_finite_columns_to_the_dense_path():
+def test_resident_hands_non_finite_columns_to_the_dense_path(strip_store):
     """Entries over hundreds of orders of magnitude: the resident solve stops at the first entering
     column it cannot follow on the compact representation (kNeedDense), writes the tableau back as
     it stands, and the dense per-pivot path takes over -- NaNs in the oracle's places."""
@@ -204,7 +217,7 @@ def test_resident_workgroups_not_co_resident_fall_back(hooks_lib):
 
 
 @pytest.mark.parametrize("n,m,nl", [(512, 256, 40), (60, 30, 19), (300, 40, 9), (700, 300, 11), (130, 600, 5)])
-def test_resident_batches_every_lp_vs_oracle(n, m, nl):
+def test_resident_batches_every_lp_vs_oracle(n, m, nl, strip_store):
     """Batches: every LP on chip with its own group of workgroups, all LPs in ONE launch, each
     progressing and finishing on its own (78 .. 199 pivots per LP at the config-4 shape)."""
     seeds = np.array([lp.synth.seed_for(4, 1000 + 3 * k) for k in range(nl)], dtype=np.uint64)
