@@ -293,15 +293,34 @@ static bool plan_compact(const mi355x_problem &p, CompactPlan &pl)
     for (const auto &c : pl.pushed) pl.cons.push_back(&c);
     for (const auto &c : p.constraints) pl.cons.push_back(&c);
     const int64_t m = (int64_t)pl.cons.size();
-    // does any row become >= or = (after the sign flip of a negative shifted RHS)?
-    for (const Constraint *c : pl.cons) {
-        double rhs = c->rhs;
-        for (size_t k = 0; k < c->var.size(); ++k) {
-            const Mapping &mp = map[(size_t)c->var[k]];
-            if (mp.kind != kSigned) rhs = rhs - c->coef[k] * mp.offset;
+    // does any row become >= or = (after the sign flip of a negative shifted RHS)?  Every
+    // coefficient of the problem is read once for this (537 MB at config 3: 32 ms on one thread of
+    // a 140 ms solve), so large problems are checked by a few threads, rows interleaved
+    auto rows_stay_le = [&](int64_t first, int64_t step) {
+        for (int64_t r = first; r < m; r += step) {
+            const Constraint *c = pl.cons[(size_t)r];
+            double rhs = c->rhs;
+            for (size_t k = 0; k < c->var.size(); ++k) {
+                const Mapping &mp = map[(size_t)c->var[k]];
+                if (mp.kind != kSigned) rhs = rhs - c->coef[k] * mp.offset;
+            }
+            const int op = (rhs < 0.0) ? (c->op == 0 ? 1 : c->op == 1 ? 0 : 2) : c->op;
+            if (op != 0) return false;
         }
-        const int op = (rhs < 0.0) ? (c->op == 0 ? 1 : c->op == 1 ? 0 : 2) : c->op;
-        if (op != 0) return false;
+        return true;
+    };
+    int64_t pairs = 0;
+    for (const Constraint *c : pl.cons) pairs += (int64_t)c->var.size();
+    const int nthr = pairs > (1 << 22) ? (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1;
+    if (nthr == 1) {
+        if (!rows_stay_le(0, 1)) return false;
+    } else {
+        std::vector<char> ok((size_t)nthr, 1);
+        std::vector<std::thread> pool;
+        for (int k = 1; k < nthr; ++k) pool.emplace_back([&, k]() { ok[(size_t)k] = rows_stay_le(k, nthr) ? 1 : 0; });
+        ok[0] = rows_stay_le(0, nthr) ? 1 : 0;
+        for (auto &th : pool) th.join();
+        for (char f : ok) if (!f) return false;
     }
     pl.m = m; pl.ncv = ncv;
     pl.basis.resize((size_t)m);

@@ -34,8 +34,11 @@ for case in range(cases):
     cap = 200
     M, b = M0.copy(), b0.copy()
     st_o, npiv, trace = oracle.solve(M, b, is_max=bool(is_max), max_pivots=cap, trace_cap=cap)
+    blk, exch, split = int(meta.choice([0, 0, 16, 24, 28])), int(meta.choice([0, 0, 2, 3])), int(meta.choice([0, 0, 2]))
+    L.mi355x_tune_set_block(blk); L.mi355x_tune_set_colpart_exchange(exch); L.mi355x_tune_set_shard_la_split(split)
     tab = cp.NativeColumnPartition.from_arrays(M0, b0, nd)
     st, k = tab.solve(is_max=bool(is_max), max_pivots=cap)
+    L.mi355x_tune_set_block(0); L.mi355x_tune_set_colpart_exchange(0); L.mi355x_tune_set_shard_la_split(0)
     got = tab.trace(npiv) if k == npiv else None
     G, bg, _, _ = tab.download()
     tab.close()
@@ -43,7 +46,7 @@ for case in range(cases):
         np.array_equal(G.view(np.int64), M.view(np.int64)) and np.array_equal(bg, b)
     if not ok:
         bad += 1
-        print("MISMATCH case %d: %d x %d seed %d max=%d shards %d: status %d/%d pivots %d/%d" % (case, n, m, seed, is_max, nd, st, st_o, k, npiv), flush=True)
+        print("MISMATCH case %d: %d x %d seed %d max=%d shards %d block %d exchange %d split %d: status %d/%d pivots %d/%d" % (case, n, m, seed, is_max, nd, blk, exch, split, st, st_o, k, npiv), flush=True)
         if bad >= 10:
             break
 print("%d cases, %d mismatches, %.0f s" % (case + 1, bad, time.time() - t0), flush=True)

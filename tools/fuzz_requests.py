@@ -34,13 +34,13 @@ for case in range(cases):
     M0[:m, -1] = bb
     M0[m, :n] = -c if is_max else c
     b0 = np.arange(n, n + m, dtype=np.int64)
-    reqs = [int(x) for x in meta.choice([1, 2, 3, 5, 7, 15, 16, 17, 20, 31, 32, 33, 40, 48, 64, 100], size=int(meta.integers(1, 6)))]
+    reqs = [int(x) for x in meta.choice([1, 2, 3, 5, 7, 15, 16, 17, 20, 23, 24, 25, 27, 28, 29, 31, 32, 33, 40, 48, 56, 64, 100], size=int(meta.integers(1, 6)))]
     total = sum(reqs)
     M, b = M0.copy(), b0.copy()
     st_o, npiv, trace = oracle.solve(M, b, is_max=bool(is_max), max_pivots=total, trace_cap=total)
     if npiv == total:
         st_o = 100        # exactly the requested pivots were made: the device has not looked at the tableau again
-    L.mi355x_tune_set_lookahead_mode(int(meta.choice([0, 0, 1]))); L.mi355x_tune_set_block(int(meta.choice([0, 0, 16, 8, 1])))
+    L.mi355x_tune_set_lookahead_mode(int(meta.choice([0, 0, 1]))); L.mi355x_tune_set_block(int(meta.choice([0, 0, 16, 8, 1, 24, 28])))
     h = ctypes.c_void_p()
     lp.capi.check(L.mi355x_tab_create(ctypes.byref(h), m + 1, n + m + 1, ptr(M0), ptr(b0), 0), "create")
     k = ctypes.c_int64(0)
