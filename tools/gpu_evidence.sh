@@ -16,13 +16,18 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_flags.log 2>&1;
 python bench.py --workload cfg4 > $O/bench_cfg4.log 2>&1; echo "bench cfg4 rc=$?"; tail -1 $O/bench_cfg4.log | cut -c1-300
 python bench.py --workload cfg4 --batch-lps 1024 > $O/bench_cfg4_1024.log 2>&1; echo "bench cfg4 x1024 rc=$?"
 python bench.py --workload cfg2 --steps 128 --no-cpu-baseline > $O/bench_cfg2.log 2>&1; echo "bench cfg2 rc=$?"
-python tools/native_end_to_end.py --init > $O/native_end_to_end.log 2>&1; echo "native end to end rc=$?"; tail -4 $O/native_end_to_end.log
+MI355X_E2E_TIMING=1 python tools/native_end_to_end.py --init > $O/native_end_to_end.log 2>&1; echo "native end to end rc=$?"; tail -4 $O/native_end_to_end.log
 python bench.py --workload colpart --steps 112 --warmup 28 > $O/bench_colpart_1gpu.log 2>&1; echo "bench colpart rc=$?"
 (for b in 16 24 28; do python tools/shard_step_cost.py 336 $b; done) 2>&1 | grep -E "per sweep|us per pivot" > $O/shard_step_cost.log; echo "shard step cost rc=$?"
 python tools/wide_block_ab.py 2>&1 | grep "us per pivot" > $O/wide_block_ab.log; echo "wide block A/B rc=$?"
 (cd tools/microbench && ./sweep32 && ./sweep32 32769 65552 && ./sweep32 4097 8208) > $O/sweep32_microbench.log 2>&1; echo "sweep32 microbench rc=$?"
 (python tools/resident_timing.py; python tools/resident_timing.py 512 256) 2>&1 | grep -E "us/pivot|inside" > $O/resident_timing.log; echo "resident timing rc=$?"
 python tools/resident_ab.py 2>&1 | grep "poll mode" > $O/resident_ab.log; echo "resident A/B rc=$?"
+python tools/resident_lds_ab.py 2>&1 | grep -v "^/opt" > $O/resident_lds_ab.log; echo "resident LDS-strip A/B rc=$?"
+# robustness: the fuzzers on every path (wide blocks, exchange modes, two-phase, batches), totals only
+(timeout 300 python tools/fuzz_requests.py 3000; timeout 300 python tools/fuzz_extreme.py 8000 100 ordinary; timeout 300 python tools/fuzz_extreme.py 12000 107 extreme
+ timeout 300 python tools/fuzz_colpart.py 1500; timeout 300 python tools/fuzz_two_phase.py 2000; timeout 300 python tools/fuzz_batch_extreme.py 200
+ timeout 300 python tools/fuzz_colpart_extreme.py 600; timeout 300 python tools/fuzz_colpart_two_phase.py 600) 2>&1 | grep "cases,\|batches,\|MISMATCH" > $O/fuzz_totals.log; echo "fuzzers done"; cat $O/fuzz_totals.log
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats -- python $R/bench.py --no-cpu-baseline --no-per-pivot --no-other-configs > $O/kernel_stats.log 2>&1; echo "rocprof stats rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats_cfg4 -- python $R/bench.py --workload cfg4 > $O/kernel_stats_cfg4.log 2>&1; echo "rocprof stats cfg4 rc=$?"
@@ -41,3 +46,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_resident_$c -- python $R/tools/pmc_probe_resident.py > $O/pmc_resident_$c.log 2>&1; echo "pmc resident $c rc=$?"
 done
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --kernel-trace --output-format csv -d $O/pmc_SQ -- python $R/tools/pmc_probe.py 64 > $O/pmc_SQ.log 2>&1; echo "pmc SQ rc=$?"
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY SQ_WAVES --kernel-trace --output-format csv -d $O/pmc_resident_SQ -- python $R/tools/pmc_probe_resident.py > $O/pmc_resident_SQ.log 2>&1; echo "pmc resident SQ rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats_shard_step -- python $R/tools/shard_step_cost.py 336 24 "two launches" > $O/kernel_stats_shard_step.log 2>&1; echo "rocprof stats shard step rc=$?"

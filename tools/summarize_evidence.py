@@ -140,7 +140,20 @@ def main(tag):
         f = one(src, required=False)
         if f:
             shutil.copy(f, os.path.join(PR, tag + dst))
-    for log, dst in (("wide_block_ab.log", "_wide_block_ab.txt"), ("sweep32_microbench.log", "_sweep32_microbench.txt")):
+    f = one("kernel_stats_shard_step/*/*kernel_stats.csv", required=False)
+    if f:                                                   # the two-launch step of one 8-GPU-sized shard
+        shutil.copy(f, os.path.join(PR, tag + "_shard_step_kernel_stats.csv"))
+    f = one("pmc_resident_SQ/*/*counter_collection.csv", required=False)
+    if f:                                                   # instruction counters of the resident launches
+        rows_ = list(csv.DictReader(open(f)))
+        keep = [r for r in rows_ if "k_resident" in r["Kernel_Name"]]
+        if keep:
+            with open(os.path.join(PR, tag + "_resident_pmc_SQ.csv"), "w", newline="") as fo:
+                w_ = csv.DictWriter(fo, fieldnames=list(keep[0].keys()))
+                w_.writeheader()
+                w_.writerows(keep)
+    for log, dst in (("wide_block_ab.log", "_wide_block_ab.txt"), ("sweep32_microbench.log", "_sweep32_microbench.txt"),
+                     ("resident_lds_ab.log", "_resident_lds_ab.txt"), ("fuzz_totals.log", "_fuzz_totals.txt")):
         f = one(log, required=False)
         if f and os.path.getsize(f):
             shutil.copy(f, os.path.join(PR, tag + dst))
