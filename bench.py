@@ -701,7 +701,8 @@ def main():
             # contract's literal formula (per-pivot algorithmic bytes x pivots per launch / duration)
             # is `algorithmic_equivalent` and exceeds the peak by construction (the sweep does not
             # re-stream the tableau per pivot).
-            upd_name = "k_sweep16" if block == 16 else ("k_sweep" if block > 1 else L.mi355x_update_kernel_name().decode())
+            upd_name = "k_sweep16" if block == 16 else ("k_sweepw" if block > 16 else
+                                                        ("k_sweep" if block > 1 else L.mi355x_update_kernel_name().decode()))
             ach = kernel_bytes / (upd_avg_ms * 1e-3) / 1e9
             alg = block * kernel_bytes / (upd_avg_ms * 1e-3) / 1e9
             flops = 2.0 * block * R * Cs

@@ -44,6 +44,7 @@ struct Ctl {
 // stored element in ONE sweep (k rank-1 updates per element, in pivot order, operands and
 // roundings unchanged).  This block lives next to the control block.
 constexpr int kMaxBlock = 16;
+constexpr int kLaBlockMax = 24;            // pending pivots one launch of the persistent look-ahead can hold (6 KB of LDS each)
 // WIDE blocks (round 4): where the sweep dominates an iteration -- tableaux / column shards of a GB
 // and more, which the persistent look-ahead does not fit anyway -- up to kWideBlock pivots are
 // pending per pass (24 or 28 in practice: what three waves per SIMD can hold of prow operands,

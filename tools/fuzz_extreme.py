@@ -19,7 +19,7 @@ kind_arg = sys.argv[3] if len(sys.argv) > 3 else "extreme"
 # resident solve at these sizes, "persistent" is the blocked path with the resident solve off
 MODES = [("resident", 0, 16, 1, 0, 0), ("persistent", 0, 16, 1, 0, 1), ("two-launch", 1, 16, 1, 0, 0),
          ("per-pivot", 0, 1, 1, 0, 0), ("dense-1wg", 0, 16, 0, 1, 0), ("dense-split", 0, 16, 0, 2, 0),
-         ("wide-24", 0, 24, 1, 2, 0), ("wide-28", 0, 28, 1, 2, 0)]
+         ("persistent-24", 0, 24, 1, 2, 0), ("two-launch-24", 1, 24, 1, 2, 0), ("wide-28", 0, 28, 1, 2, 0)]
 
 
 def ptr(a):
