@@ -417,8 +417,11 @@ def pmc_traffic(workload, kernel):
                 d = json.load(f)
         except Exception:
             continue
-        for name, rec in d.get("kernels", {}).items():
-            if name.startswith(kernel) or kernel.startswith(name):
+        recs = d.get("kernels", {})
+        if kernel in recs:                                   # (exact name first: k_sweepw is not k_sweep)
+            return recs[kernel]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+        for name, rec in recs.items():
+            if name.startswith(kernel + " ") or name.startswith(kernel + "<"):
                 return rec["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
         if "kernels" not in d and (d.get("kernel", "").startswith(kernel) or kernel.startswith(d.get("kernel", "?"))):
             return d["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)

@@ -61,7 +61,8 @@ def main(tag):
             shutil.copy(f, os.path.join(PR, tag + dst))
     out = {"workload": "cfg3", "kernels": {}}
     dense_ld = (8192 + 4096 + 1 + 15) // 16 * 16
-    for variant, kernels in (("", ("k_sweep16", "k_la_block")), ("perpivot_", ("k_update", "k_select_gather", "k_select_scale"))):
+    for variant, kernels in (("", ("k_sweepw<", "k_sweepw_rest", "k_sweep16", "k_la_block")),
+                             ("perpivot_", ("k_update", "k_select_gather", "k_select_scale"))):
         fp = one("pmc_%sFETCH_SIZE/*/*counter_collection.csv" % variant, required=False)
         wp = one("pmc_%sWRITE_SIZE/*/*counter_collection.csv" % variant, required=False)
         lg = one("pmc_%sFETCH_SIZE.log" % variant, required=False)
@@ -85,7 +86,7 @@ def main(tag):
             f, w = counter(fp, k), counter(wp, k)
             if not f or not w:
                 continue
-            if k in ("k_sweep16", "k_update"):           # steady state: drop launches that did nothing
+            if k in ("k_sweepw<", "k_sweep16", "k_update"):   # steady state: drop launches that did nothing
                 f = [x for x in f if x > 0.5 * max(f)]
                 w = [x for x in w if x > 0.5 * max(w)]
             favg, wavg = sum(f) / len(f), sum(w) / len(w)
@@ -93,10 +94,10 @@ def main(tag):
                    "hbm_bytes_per_launch": (2 * favg + wavg) * 1024,
                    "representation": "compact" if int(layout["compact"]) else "dense",
                    "stored_rows_cols_ld": [rows, cols, ld]}
-            if k in ("k_sweep16", "k_update"):
+            if k in ("k_sweepw<", "k_sweep16", "k_update"):
                 rec["algorithmic_bytes_per_launch"] = 2 * rows * cols * 8
                 rec["traffic_over_algorithmic"] = rec["hbm_bytes_per_launch"] / rec["algorithmic_bytes_per_launch"]
-            out["kernels"][k] = rec
+            out["kernels"][k.rstrip("<")] = rec
     json.dump(out, open(os.path.join(PR, tag + "_cfg3_pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
     # wide blocks (round 4): one 8-GPU-sized shard of config 5 as a single tableau (32769 x 8193 stored,
