@@ -26,20 +26,20 @@ lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h), n, m, lp.synth.seed
 npv = ctypes.c_int64(0)
 lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, 64, 1), "warm")
 L.mi355x_tab_sync(h, ctypes.byref(npv))
-NS = 16 * 24
+NS = 24 * 24
 out = np.zeros(NS)
 L.mi355x_debug_rhs(h, out.ctypes.data_as(ctypes.c_void_p), NS, 1)
 L.mi355x_tab_timing_enable(h, 1)
-lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, 1600, 0), "run")
+lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, 1680, 0), "run")
 L.mi355x_tab_sync(h, ctypes.byref(npv))
 L.mi355x_debug_rhs(h, out.ctypes.data_as(ctypes.c_void_p), NS, 0)
-d = out.reshape(16, 24)
+d = out.reshape(24, 24)
 if d[:, 0].sum() == 0:
     sys.exit("no samples: the library was built without -DMI355X_LA_TIMING")
 print("one_xcd=%d  %d x %d   us per step (leader thread):" % (one_xcd, n, m))
 print(" J     n | price-xchg column+chain ratio-xchg row+chain+bk |  total || price: ->published  ->records in  ->result  extra polls || ratio: ...")
 tot = 0.0
-for J in range(16):
+for J in range(24):
     c = d[J, 0]
     if c == 0:
         continue
@@ -49,7 +49,7 @@ for J in range(16):
     rx = [d[J, k] / c * 0.01 for k in (9, 10, 11)] + [d[J, 12] / c]
     print("%2d %5d | " % (J, int(c)) + " ".join("%7.2f" % x for x in row) + " | %6.2f || " % sum(row)
           + " ".join("%5.2f" % x for x in px) + " || " + " ".join("%5.2f" % x for x in rx))
-print("sum over the 16 steps: %.1f us per block" % tot)
+print("sum over the steps of a block: %.1f us" % tot)
 for kind, name in ((1, "look-ahead"), (0, "sweep")):
     nl, sm, mn = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
     L.mi355x_tab_timing_read_kind(h, kind, ctypes.byref(nl), ctypes.byref(sm), ctypes.byref(mn))
