@@ -148,7 +148,7 @@ def test_column_partition_with_wide_blocks(n_shards, exchange, wide):
 def test_wide_blocks_are_the_default_where_the_sweep_dominates():
     """A 0.75 GB+ stored tableau that does not fit the persistent look-ahead takes 24 pivots per
     sweep by default (28 from 8 GB on: config 5, tests/test_gpu_fullsize.py); so does config 3 --
-    the persistent look-ahead holds up to 24 pending pivots, and from 200 MB of stored tableau on
+    the persistent look-ahead holds up to 24 pending pivots, and from 100 MB of stored tableau on
     the sweep is a pass over HBM; smaller tableaux stay at 16."""
     L = lp.capi.lib()
     for (n, m, want) in ((8192, 4096, 24), (200, 100, 16), (3000, 2000, 16), (12000, 9000, 24)):
