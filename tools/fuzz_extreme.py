@@ -26,10 +26,27 @@ def ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+def free_mb():
+    """free device memory (a leak of handles' buffers shows up here long before an allocation fails)"""
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        f, tot = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(tot))
+        return f.value / 1e6
+    except OSError:
+        return float("nan")
+
+
 bad = 0
+mem0 = None
 t0 = time.time()
 meta = np.random.default_rng(seed0)
 for case in range(cases):
+    if case % 2000 == 1999:
+        if mem0 is None:
+            mem0 = free_mb()
+        else:
+            print("   case %d: free device memory %+.0f MB since case 2000" % (case + 1, free_mb() - mem0), flush=True)
     seed = int(meta.integers(0, 2 ** 31 - 1))
     rng = np.random.default_rng(seed)
     is_max, cap, lo, hi = 1, 60, 0, 0
