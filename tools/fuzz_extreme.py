@@ -29,7 +29,15 @@ def ptr(a):
 def free_mb():
     """free device memory (a leak of handles' buffers shows up here long before an allocation fails)"""
     try:
-        hip = ctypes.CDLL("libamdhip64.so")
+        hip = None
+        for name in ("libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"):
+            try:
+                hip = ctypes.CDLL(name)
+                break
+            except OSError:
+                pass
+        if hip is None:
+            return float("nan")
         f, tot = ctypes.c_size_t(0), ctypes.c_size_t(0)
         hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(tot))
         return f.value / 1e6
