@@ -30,12 +30,13 @@ def free_mb():
     """free device memory (a leak of handles' buffers shows up here long before an allocation fails)"""
     try:
         hip = None
-        for name in ("libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"):
+        for name in (None, "libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"):   # (None: the runtime this process has loaded)
             try:
                 hip = ctypes.CDLL(name)
+                hip.hipMemGetInfo                            # (AttributeError: not in this one)
                 break
-            except OSError:
-                pass
+            except (OSError, AttributeError):
+                hip = None
         if hip is None:
             return float("nan")
         f, tot = ctypes.c_size_t(0), ctypes.c_size_t(0)
