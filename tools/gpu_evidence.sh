@@ -27,7 +27,7 @@ python tools/resident_lds_ab.py 2>&1 | grep -v "^/opt" > $O/resident_lds_ab.log;
 # robustness: the fuzzers on every path (wide blocks, exchange modes, two-phase, batches), totals only
 (timeout 300 python tools/fuzz_requests.py 3000; timeout 300 python tools/fuzz_extreme.py 8000 100 ordinary; timeout 300 python tools/fuzz_extreme.py 12000 107 extreme
  timeout 300 python tools/fuzz_colpart.py 1500; timeout 300 python tools/fuzz_two_phase.py 2000; timeout 300 python tools/fuzz_batch_extreme.py 200
- timeout 300 python tools/fuzz_colpart_extreme.py 600; timeout 300 python tools/fuzz_colpart_two_phase.py 600; timeout 300 python tools/fuzz_solve_problems.py 300) 2>&1 | grep "cases,\|batches,\|MISMATCH" > $O/fuzz_totals.log; echo "fuzzers done"; cat $O/fuzz_totals.log
+ timeout 300 python tools/fuzz_colpart_extreme.py 600; timeout 300 python tools/fuzz_colpart_two_phase.py 600; timeout 300 python tools/fuzz_solve_problems.py 300) 2>&1 | grep "cases,\|batches,\|lists,\|MISMATCH" > $O/fuzz_totals.log; echo "fuzzers done"; cat $O/fuzz_totals.log
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats -- python $R/bench.py --no-cpu-baseline --no-per-pivot --no-other-configs > $O/kernel_stats.log 2>&1; echo "rocprof stats rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats_cfg4 -- python $R/bench.py --workload cfg4 > $O/kernel_stats_cfg4.log 2>&1; echo "rocprof stats cfg4 rc=$?"
