@@ -67,6 +67,7 @@ typedef struct mi355x_tab   mi355x_tab;     /* one tableau resident in HBM      
 typedef struct mi355x_batch mi355x_batch;   /* a batch of same-shape tableaux in HBM    */
 typedef struct mi355x_problem  mi355x_problem;   /* a parsed LP, src/problem.lisp:45-53 (host)  */
 typedef struct mi355x_solution mi355x_solution;  /* what the read-back needs of a solved tableau */
+typedef struct mi355x_solve    mi355x_solve;     /* a problem on its way to a solution (resumable)  */
 
 /* ---- library / device ------------------------------------------------------------- */
 int         mi355x_abi_version(void);
@@ -149,6 +150,15 @@ int  mi355x_tab_cancel(mi355x_tab *t);
  * MI_ART_NONZERO / MI_ART_STUCK. */
 int  mi355x_solve_two_phase(mi355x_tab *art, mi355x_tab *main_tab, int main_is_max,
                             double fp_factor, int64_t *n_pivots);
+/* The step BETWEEN the phases on its own (src/simplex.lisp:405-451), for a caller that drives the
+ * phases itself in bounded chunks (mi355x_tab_solve(art, 0, f, cap, ..) until it is no longer
+ * MI_MAX_PIVOTS, this, then mi355x_tab_solve(main_tab, ..) likewise -- what the Lisp glue and
+ * mi355x_simplex_solver_step do): `art` holds the optimal artificial tableau; the feasibility test
+ * (fp= 0 objective), the drive-out pivots of artificial variables still basic, rows and basis into
+ * `main_tab`, its objective row re-eliminated.  *n_driveout = drive-out pivots made.  Returns MI_OK
+ * (main_tab is ready for phase 2), MI_INFEASIBLE, MI_ART_NONZERO or MI_ART_STUCK. */
+int  mi355x_two_phase_handover(mi355x_tab *art, mi355x_tab *main_tab, double fp_factor,
+                               int64_t *n_driveout);
 
 /* ---- read-back (src/simplex.lisp:74-120 needs last row, last column, basis) -------- */
 /* Any pointer may be NULL.  host_matrix: rows*cols, host_basis: rows-1,
@@ -244,6 +254,23 @@ int  mi355x_var_mapping(const mi355x_problem *p, int64_t var, int *kind, int64_t
  * MI_INFEASIBLE / MI_UNSUPPORTED (integer variables) / an error. */
 int  mi355x_simplex_solver(const mi355x_problem *p, double fp_tolerance, int device,
                            mi355x_solution **out);
+/* The same solve as a resumable job, for a host that must never sit in an unbounded foreign call
+ * (the reference's loop has no pivot cap and no anti-cycling rule, src/simplex.lisp:453-461; a Lisp
+ * thread inside a foreign call cannot serve an interrupt).  begin: build-tableau + upload (declines
+ * integer problems with MI_UNSUPPORTED, reports the unbounded no-constraint case as MI_UNBOUNDED).
+ * step: at most max_pivots pivots (0 = no cap) of n-solve-tableau, across the phases of a two-phase
+ * problem; *n_pivots = pivots of this call.  Returns MI_MAX_PIVOTS while the solve is still running
+ * (call again: the continuation takes exactly the pivots one long call would), otherwise the final
+ * status -- MI_OPTIMAL / MI_UNBOUNDED / MI_INFEASIBLE / MI_ART_NONZERO / MI_ART_STUCK, MI_CANCELLED
+ * after mi355x_simplex_solver_cancel from another thread (a further step carries on).  finish: the
+ * light read-back into a solution object (only after MI_OPTIMAL; MI_BAD_ARG otherwise) -- it always
+ * consumes the job, as does abandon.  mi355x_simplex_solver = begin, step(0), finish. */
+int  mi355x_simplex_solver_begin(const mi355x_problem *p, double fp_tolerance, int device,
+                                 mi355x_solve **out);
+int  mi355x_simplex_solver_step(mi355x_solve *job, int64_t max_pivots, int64_t *n_pivots);
+int  mi355x_simplex_solver_cancel(mi355x_solve *job);
+int  mi355x_simplex_solver_finish(mi355x_solve *job, mi355x_solution **out);
+void mi355x_simplex_solver_abandon(mi355x_solve *job);
 /* tableau-objective-value / tableau-variable / tableau-reduced-cost (src/simplex.lisp:74-120).
  * reduced_cost fails with MI_BAD_ARG for a variable without a lower bound, as the reference. */
 int  mi355x_solution_objective_value(const mi355x_solution *s, double *out);

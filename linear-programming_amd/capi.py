@@ -39,6 +39,7 @@ SIGNATURES = {
     "mi355x_tab_solve": (_int, [_p, _int, _dbl, _i64, _p]),
     "mi355x_tab_cancel": (_int, [_p]),
     "mi355x_solve_two_phase": (_int, [_p, _p, _int, _dbl, _p]),
+    "mi355x_two_phase_handover": (_int, [_p, _p, _dbl, _p]),
     "mi355x_tab_download": (_int, [_p, _p, _p, _p, _p]),
     "mi355x_tab_download_block": (_int, [_p, _i64, _i64, _i64, _i64, _p]),
     "mi355x_tab_trace": (_int, [_p, _p, _p, _i64, _p]),
@@ -64,6 +65,11 @@ SIGNATURES = {
     "mi355x_build_tableau": (_int, [_p, _int, _p, _p, _p, _p, _p]),
     "mi355x_var_mapping": (_int, [_p, _i64, _p, _p, _p]),
     "mi355x_simplex_solver": (_int, [_p, _dbl, _int, _pp]),
+    "mi355x_simplex_solver_begin": (_int, [_p, _dbl, _int, _pp]),
+    "mi355x_simplex_solver_step": (_int, [_p, _i64, _p]),
+    "mi355x_simplex_solver_cancel": (_int, [_p]),
+    "mi355x_simplex_solver_finish": (_int, [_p, _pp]),
+    "mi355x_simplex_solver_abandon": (None, [_p]),
     "mi355x_solution_objective_value": (_int, [_p, _p]),
     "mi355x_solution_variable": (_int, [_p, _i64, _p]),
     "mi355x_solution_reduced_cost": (_int, [_p, _i64, _p]),

@@ -22,6 +22,10 @@ extern "C" int mi355x_tab_create_compact_streamed_(mi355x_tab **out, int64_t row
                                                    void (*produce)(void *ctx, int64_t r0, int64_t r1, double *dst),
                                                    void *ctx, int n_workers);
 
+// simplex_capi.hip (same library, not exported): cancel plumbing of a two-phase job
+extern "C" void mi355x_tab_link_cancel_(mi355x_tab *a, mi355x_tab *b);
+extern "C" void mi355x_tab_clear_cancel_(mi355x_tab *t);
+
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
@@ -371,6 +375,24 @@ struct mi355x_solution {
     int64_t n_pivots[2] = {0, 0};
 };
 
+struct mi355x_solve {
+    enum State { kPhase1, kHandover, kPhase2, kDone };
+    mi355x_tab *mt = nullptr, *at = nullptr;          // main / artificial tableau on the device
+    mi355x_solution *sol = nullptr;                   // sized at begin, filled at finish
+    State  state = kPhase2;
+    int    status = MI_RUNNING;                       // the final status once state == kDone
+    int    is_max = 1;
+    double f = 1024.0;
+    bool   timing = false;                            // MI355X_E2E_TIMING=1: where the time goes, on stderr
+    ~mi355x_solve()
+    {
+        mi355x_tab_link_cancel_(at, nullptr);
+        mi355x_tab_destroy(at);
+        mi355x_tab_destroy(mt);
+        delete sol;
+    }
+};
+
 extern "C" {
 
 int mi355x_problem_create(mi355x_problem **out, int is_max, int64_t n_vars)
@@ -504,22 +526,28 @@ int mi355x_var_mapping(const mi355x_problem *p, int64_t var, int *kind, int64_t 
     return MI_OK;
 }
 
-int mi355x_simplex_solver(const mi355x_problem *p, double fp_tolerance, int device,
-                          mi355x_solution **out)
+// ---- simplex-solver for LPs as a resumable job: begin (build + upload), step (bounded chunks of
+// n-solve-tableau across the phases), finish (light read-back).  mi355x_simplex_solver is the three
+// in a row.
+int mi355x_simplex_solver_begin(const mi355x_problem *p, double fp_tolerance, int device, mi355x_solve **out)
 {
     if (!p || !out) return hfail(MI_BAD_ARG, "NULL argument");
     *out = nullptr;
     for (char f : p->is_integer)
         if (f) return hfail(MI_UNSUPPORTED, "integer constraints cannot be handled by the mi355x-simplex solver");
+    std::unique_ptr<mi355x_solve> job(new (std::nothrow) mi355x_solve);
+    std::unique_ptr<mi355x_solution> s(new (std::nothrow) mi355x_solution);
+    if (!job || !s) return hfail(MI_NO_MEMORY, "host allocation failed");
+    job->is_max = p->is_max ? 1 : 0;
+    job->f = fp_tolerance;
+    job->timing = getenv("MI355X_E2E_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     {   // single-phase problems: the compact form [structural columns | RHS] assembled by a few
         // host threads straight into pinned staging buffers and uploaded while later rows are still
         // being assembled (mi355x_tab_create_compact_streamed_)
         CompactPlan pl;
-        const auto t0 = std::chrono::steady_clock::now();
         if (plan_compact(*p, pl)) {
             const int64_t m = pl.m, rows = m + 1, ncv = pl.ncv, var_count = ncv + m;
-            mi355x_solution *s = new (std::nothrow) mi355x_solution;
-            if (!s) return hfail(MI_NO_MEMORY, "host allocation failed");
             s->rows = rows; s->cols = var_count + 1;
             s->map = pl.map;
             s->last_row.resize((size_t)var_count + 1);
@@ -529,60 +557,123 @@ int mi355x_simplex_solver(const mi355x_problem *p, double fp_tolerance, int devi
             for (int64_t j = 0; j < ncv; ++j) stored[(size_t)j] = j;
             const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
             const int workers = (rows * (ncv + 1) > (1 << 22)) ? (int)hw : 1;
-            mi355x_tab *t = nullptr;
-            // MI355X_E2E_TIMING=1: where the call's time goes, on stderr (tools/native_end_to_end.py)
-            const bool timing = getenv("MI355X_E2E_TIMING") != nullptr;
-            auto now = []() { return std::chrono::steady_clock::now(); };
-            auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-                return std::chrono::duration<double, std::milli>(b - a).count();
-            };
-            const auto t1 = now();
-            int rc = mi355x_tab_create_compact_streamed_(&t, rows, var_count, ncv, stored.data(), pl.basis.data(),
-                                                         device, produce_compact_rows, &pl, workers);
-            const auto t2 = now();
-            if (rc == MI_OK) rc = mi355x_tab_solve(t, p->is_max ? 1 : 0, fp_tolerance, 0, &s->n_pivots[1]);
-            const auto t3 = now();
-            int drc = MI_OK;
-            if (rc == MI_OPTIMAL)
-                drc = mi355x_tab_download(t, nullptr, s->basis.data(), s->last_row.data(), s->last_col.data());
-            const auto t4 = now();
-            mi355x_tab_destroy(t);
-            if (timing)
-                fprintf(stderr, "mi355x_simplex_solver: plan %.1f ms, allocate + assemble + upload (%d workers) %.1f ms, solve %.1f ms "
-                                "(%lld pivots), read-back %.1f ms, destroy %.1f ms\n", ms(t0, t1), workers, ms(t1, t2), ms(t2, t3),
-                        (long long)s->n_pivots[1], ms(t3, t4), ms(t4, now()));
-            if (rc != MI_OPTIMAL || drc != MI_OK) { delete s; return rc != MI_OPTIMAL ? rc : drc; }
-            *out = s;
-            return MI_OPTIMAL;
+            const auto t1 = std::chrono::steady_clock::now();
+            const int rc = mi355x_tab_create_compact_streamed_(&job->mt, rows, var_count, ncv, stored.data(), pl.basis.data(),
+                                                               device, produce_compact_rows, &pl, workers);
+            if (job->timing)
+                fprintf(stderr, "mi355x_simplex_solver: plan %.1f ms, allocate + assemble + upload (%d workers) %.1f ms\n",
+                        std::chrono::duration<double, std::milli>(t1 - t0).count(), workers,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+            if (rc != MI_OK) return rc;
+            job->state = mi355x_solve::kPhase2;
+            job->sol = s.release();
+            *out = job.release();
+            return MI_OK;
         }
     }
     Built b = build(*p);
     if (b.status != MI_OK) return b.status;
-    mi355x_solution *s = new (std::nothrow) mi355x_solution;
-    if (!s) return hfail(MI_NO_MEMORY, "host allocation failed");
     HostTableau &t = b.main_tab;
     s->rows = t.rows; s->cols = t.cols;
     s->map = b.map;
     s->last_row.resize((size_t)t.cols);
     s->last_col.resize((size_t)t.rows);
     s->basis.resize((size_t)std::max<int64_t>(t.rows - 1, 0));
-    mi355x_tab *mt = nullptr, *at = nullptr;
-    int rc = mi355x_tab_create(&mt, t.rows, t.cols, t.M.data(), t.basis.empty() ? nullptr : t.basis.data(), device);
+    int rc = mi355x_tab_create(&job->mt, t.rows, t.cols, t.M.data(), t.basis.empty() ? nullptr : t.basis.data(), device);
     if (rc == MI_OK && b.two_phase)
-        rc = mi355x_tab_create(&at, b.art.rows, b.art.cols, b.art.M.data(), b.art.basis.data(), device);
-    if (rc == MI_OK) {
-        if (b.two_phase) rc = mi355x_solve_two_phase(at, mt, p->is_max ? 1 : 0, fp_tolerance, s->n_pivots);
-        else             rc = mi355x_tab_solve(mt, p->is_max ? 1 : 0, fp_tolerance, 0, &s->n_pivots[1]);
+        rc = mi355x_tab_create(&job->at, b.art.rows, b.art.cols, b.art.M.data(), b.art.basis.data(), device);
+    if (rc != MI_OK) return rc;                      // (the job's destructor releases what was created)
+    if (b.two_phase) mi355x_tab_link_cancel_(job->at, job->mt);
+    job->state = b.two_phase ? mi355x_solve::kPhase1 : mi355x_solve::kPhase2;
+    job->sol = s.release();
+    *out = job.release();
+    return MI_OK;
+}
+
+int mi355x_simplex_solver_step(mi355x_solve *job, int64_t max_pivots, int64_t *n_pivots)
+{
+    if (n_pivots) *n_pivots = 0;
+    if (!job) return hfail(MI_BAD_ARG, "job is NULL");
+    if (max_pivots < 0) return hfail(MI_BAD_ARG, "max_pivots < 0");
+    if (job->state == mi355x_solve::kDone) return job->status;
+    int64_t done = 0;
+    // whichever way this step ends, a cancel request aimed at it ends with it
+    struct Clear { mi355x_solve *j; ~Clear() { mi355x_tab_clear_cancel_(j->at); mi355x_tab_clear_cancel_(j->mt); } } clear{job};
+    auto finished = [&](int rc) { job->state = mi355x_solve::kDone; job->status = rc; if (n_pivots) *n_pivots = done; return rc; };
+    auto paused = [&](int rc) { if (n_pivots) *n_pivots = done; return rc; };
+    const auto t0 = std::chrono::steady_clock::now();
+    if (job->state == mi355x_solve::kPhase1) {                              // simplex.lisp:403
+        int64_t k = 0;
+        const int rc = mi355x_tab_solve(job->at, /*is_max=*/0, job->f, max_pivots, &k);
+        done += k; job->sol->n_pivots[0] += k;
+        if (rc == MI_MAX_PIVOTS || rc == MI_CANCELLED) return paused(rc);
+        if (rc != MI_OPTIMAL) return finished(rc);
+        job->state = mi355x_solve::kHandover;
     }
-    int drc = MI_OK;
-    if (rc == MI_OPTIMAL)
-        drc = mi355x_tab_download(mt, nullptr, s->basis.empty() ? nullptr : s->basis.data(),
-                                  s->last_row.data(), s->last_col.data());
-    mi355x_tab_destroy(at);
-    mi355x_tab_destroy(mt);
-    if (rc != MI_OPTIMAL || drc != MI_OK) { delete s; return rc != MI_OPTIMAL ? rc : drc; }
+    if (job->state == mi355x_solve::kHandover) {                            // simplex.lisp:405-451
+        int64_t nd = 0;
+        const int rc = mi355x_two_phase_handover(job->at, job->mt, job->f, &nd);
+        done += nd; job->sol->n_pivots[0] += nd;
+        if (rc != MI_OK) return finished(rc);
+        job->state = mi355x_solve::kPhase2;
+        if (max_pivots && done >= max_pivots) return paused(MI_MAX_PIVOTS);
+    }
+    int64_t k = 0;                                                          // simplex.lisp:452 / 453-461
+    const int rc = mi355x_tab_solve(job->mt, job->is_max, job->f, max_pivots ? max_pivots - done : 0, &k);
+    done += k; job->sol->n_pivots[1] += k;
+    if (job->timing)
+        fprintf(stderr, "mi355x_simplex_solver: step %.1f ms (%lld pivots, status %d)\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), (long long)done, rc);
+    if (rc == MI_MAX_PIVOTS || rc == MI_CANCELLED) return paused(rc);
+    return finished(rc);
+}
+
+int mi355x_simplex_solver_cancel(mi355x_solve *job)
+{
+    if (!job) return hfail(MI_BAD_ARG, "job is NULL");
+    // (the two tableaux of a two-phase job look at each other's flag: one request reaches whichever
+    // phase is running)
+    return mi355x_tab_cancel(job->mt);
+}
+
+void mi355x_simplex_solver_abandon(mi355x_solve *job) { delete job; }
+
+int mi355x_simplex_solver_finish(mi355x_solve *job, mi355x_solution **out)
+{
+    if (out) *out = nullptr;
+    if (!job) return hfail(MI_BAD_ARG, "job is NULL");
+    std::unique_ptr<mi355x_solve> owner(job);                               // consumed whatever happens
+    if (!out) return hfail(MI_BAD_ARG, "out is NULL");
+    if (job->state != mi355x_solve::kDone || job->status != MI_OPTIMAL)
+        return hfail(MI_BAD_ARG, "the job has not ended with MI_OPTIMAL: there is no solution to read");
+    mi355x_solution *s = job->sol;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = mi355x_tab_download(job->mt, nullptr, s->basis.empty() ? nullptr : s->basis.data(),
+                                       s->last_row.data(), s->last_col.data());
+    const auto t1 = std::chrono::steady_clock::now();
+    if (rc != MI_OK) return rc;
+    job->sol = nullptr;
+    mi355x_tab_destroy(job->at); job->at = nullptr;
+    mi355x_tab_destroy(job->mt); job->mt = nullptr;
+    if (job->timing)
+        fprintf(stderr, "mi355x_simplex_solver: read-back %.1f ms, destroy %.1f ms\n",
+                std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
     *out = s;
     return MI_OPTIMAL;
+}
+
+int mi355x_simplex_solver(const mi355x_problem *p, double fp_tolerance, int device,
+                          mi355x_solution **out)
+{
+    if (!p || !out) return hfail(MI_BAD_ARG, "NULL argument");
+    *out = nullptr;
+    mi355x_solve *job = nullptr;
+    int rc = mi355x_simplex_solver_begin(p, fp_tolerance, device, &job);
+    if (rc != MI_OK) return rc;
+    rc = mi355x_simplex_solver_step(job, 0, nullptr);
+    if (rc != MI_OPTIMAL) { mi355x_simplex_solver_abandon(job); return rc; }
+    return mi355x_simplex_solver_finish(job, out);
 }
 
 void mi355x_solution_destroy(mi355x_solution *s) { delete s; }

@@ -151,6 +151,10 @@ struct mi355x_tab {
     // mi355x_tab_cancel (any thread): consumed by the blocking solve loop that next looks at it --
     // between two chunks of launches, when everything enqueued has completed
     std::atomic<int> cancel{0};
+    // mi355x_solve_two_phase: the call's two handles look at each other's flag too (a caller cannot
+    // know which phase is running), and the flags are cleared when the CALL ends, not a phase
+    std::atomic<int> *cancel_peer = nullptr;
+    bool        cancel_scoped_outside = false;
 };
 
 struct mi355x_batch {

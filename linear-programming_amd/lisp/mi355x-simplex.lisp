@@ -9,12 +9,22 @@
 ;;;; or (setf linear-programming:*solver* 'mi355x-simplex:mi355x-simplex-solver), after which
 ;;;; solve-problem / with-solved-problem / with-solution-variables work unchanged.
 ;;;;
-;;;; What stays in Lisp: the DSL parser, build-tableau (src/simplex.lisp:142-328, called here
-;;;; through its exported name), the var-mapping based read-back (tableau-variable etc.,
-;;;; src/simplex.lisp:74-120) and the four solution-* generics, which keep working because this
-;;;; backend returns an ordinary `tableau` whose matrix / basis arrays hold the solved values.
-;;;; What moves to the GPU: n-solve-tableau (src/simplex.lisp:399-461) -- pricing, ratio test,
-;;;; rank-1 update and the two-phase hand-over -- in double-float arithmetic.
+;;;; Two routes from a `problem` to a solution object:
+;;;;  * NATIVE (the default for problems whose numbers are double-floats / integers): the parsed
+;;;;    problem (src/problem.lisp:45-53) is marshalled straight into the library (mi355x_problem_*),
+;;;;    which assembles the tableau in C++ (= build-tableau, src/simplex.lisp:142-328, in double-float;
+;;;;    single-phase problems never exist as a dense tableau on either side), solves it on the GPU and
+;;;;    keeps a light solution (objective row, RHS column, basis, var-mapping: all that
+;;;;    src/simplex.lisp:74-120 read).  The Lisp side holds a MI355X-SOLUTION with methods on the
+;;;;    four solution-* generics (src/solver.lisp:59-80).  No boxed R x C matrix, no per-element
+;;;;    coerce.
+;;;;  * BUILD-TABLEAU route (:full-tableau t, :devices > 1, :native nil, or numbers the double-float
+;;;;    assembly would not reproduce bit for bit -- ratios, single-floats): the reference's exported
+;;;;    build-tableau, the tableau coerced and uploaded, the solved values written back into the
+;;;;    same `tableau`, which the reference's own methods (src/solver.lisp:61-80) serve.
+;;;; What stays in Lisp either way: the DSL parser, the hook, the generics.  What moves to the GPU:
+;;;; n-solve-tableau (src/simplex.lisp:399-461) -- pricing, ratio test, rank-1 update and the
+;;;; two-phase hand-over -- in double-float arithmetic.
 ;;;;
 ;;;; Scope: LP, double-float.  Problems with integer / binary variables are declined with
 ;;;; unsupported-constraint-error (src/conditions.lisp:69-77) as the hook's contract expects of
@@ -30,12 +40,20 @@
                 #:build-tableau #:tableau-matrix #:tableau-basis-columns
                 #:tableau-var-count #:tableau-constraint-count #:tableau-instance-problem)
   (:import-from :linear-programming/problem
-                #:problem-type #:problem-integer-vars)
+                #:problem-type #:problem-vars #:problem-objective-var #:problem-objective-func
+                #:problem-integer-vars #:problem-var-bounds #:problem-constraints)
+  (:import-from :linear-programming/solver
+                #:solution-problem #:solution-objective-value #:solution-variable
+                #:solution-reduced-cost)
   (:import-from :linear-programming/conditions
                 #:solver-error #:unbounded-problem-error #:infeasible-problem-error
                 #:unsupported-constraint-error)
   (:export #:mi355x-simplex-solver
            #:mi355x-solve-problems
+           #:mi355x-solution
+           #:solution-pivots
+           #:free-solution
+           #:native-var-mapping
            #:device-count
            #:mi355x-error))
 
@@ -72,6 +90,8 @@
   (tab :pointer) (is-max :int) (fp-factor :double) (max-pivots :int64) (n-pivots :pointer))
 (cffi:defcfun ("mi355x_solve_two_phase" %solve-two-phase) :int
   (art :pointer) (main :pointer) (main-is-max :int) (fp-factor :double) (n-pivots :pointer))
+(cffi:defcfun ("mi355x_two_phase_handover" %two-phase-handover) :int
+  (art :pointer) (main :pointer) (fp-factor :double) (n-driveout :pointer))
 (cffi:defcfun ("mi355x_tab_download" %tab-download) :int
   (tab :pointer) (host-matrix :pointer) (host-basis :pointer) (last-row :pointer)
   (last-col :pointer))
@@ -102,6 +122,40 @@
   (handle :pointer) (lp-index :int64) (host-matrix :pointer) (host-basis :pointer)
   (last-row :pointer) (last-col :pointer))
 (cffi:defcfun ("mi355x_multibatch_destroy" %multibatch-destroy) :void (handle :pointer))
+
+;; the native route: problem -> (C++ build-tableau, GPU solve) -> light solution
+;; (include/mi355x_simplex.h, "native host side of the hook")
+(cffi:defcfun ("mi355x_problem_create" %problem-create) :int
+  (out :pointer) (is-max :int) (n-vars :int64))
+(cffi:defcfun ("mi355x_problem_set_objective" %problem-set-objective) :int
+  (problem :pointer) (vars :pointer) (coefs :pointer) (nnz :int64))
+(cffi:defcfun ("mi355x_problem_set_bounds" %problem-set-bounds) :int
+  (problem :pointer) (var :int64) (has-lb :int) (lb :double) (has-ub :int) (ub :double))
+(cffi:defcfun ("mi355x_problem_set_integer" %problem-set-integer) :int
+  (problem :pointer) (var :int64))
+(cffi:defcfun ("mi355x_problem_add_constraint" %problem-add-constraint) :int
+  (problem :pointer) (op :int) (vars :pointer) (coefs :pointer) (nnz :int64) (rhs :double))
+(cffi:defcfun ("mi355x_problem_destroy" %problem-destroy) :void (problem :pointer))
+(cffi:defcfun ("mi355x_var_mapping" %var-mapping) :int
+  (problem :pointer) (var :int64) (kind :pointer) (col :pointer) (offset :pointer))
+(cffi:defcfun ("mi355x_simplex_solver" %simplex-solver) :int
+  (problem :pointer) (fp-tolerance :double) (device :int) (out :pointer))
+(cffi:defcfun ("mi355x_simplex_solver_begin" %solver-begin) :int
+  (problem :pointer) (fp-tolerance :double) (device :int) (out :pointer))
+(cffi:defcfun ("mi355x_simplex_solver_step" %solver-step) :int
+  (job :pointer) (max-pivots :int64) (n-pivots :pointer))
+(cffi:defcfun ("mi355x_simplex_solver_finish" %solver-finish) :int
+  (job :pointer) (out :pointer))
+(cffi:defcfun ("mi355x_simplex_solver_abandon" %solver-abandon) :void (job :pointer))
+(cffi:defcfun ("mi355x_solution_objective_value" %solution-objective-value) :int
+  (solution :pointer) (out :pointer))
+(cffi:defcfun ("mi355x_solution_variable" %solution-variable) :int
+  (solution :pointer) (var :int64) (out :pointer))
+(cffi:defcfun ("mi355x_solution_reduced_cost" %solution-reduced-cost) :int
+  (solution :pointer) (var :int64) (out :pointer))
+(cffi:defcfun ("mi355x_solution_pivots" %solution-pivots) :int
+  (solution :pointer) (phase1 :pointer) (phase2 :pointer))
+(cffi:defcfun ("mi355x_solution_destroy" %solution-destroy) :void (solution :pointer))
 
 (define-condition mi355x-error (solver-error)
   ((code :initarg :code :reader mi355x-error-code)
@@ -407,25 +461,255 @@ Leaves the total in N-PIVOTS[0] and returns the last status."
           (setf (cffi:mem-aref n-pivots :int64 0) total)
           (return status))))))
 
+;;; ------------------------------------------------------------------ the native route
+;;; SURVEY 8(f) rows 2-3: at 8192 x 4096 the reference's build-tableau conses a boxed 4097 x 12289
+;;; (simple-array real 2) -- 5e7 boxed entries -- and the build-tableau route then coerces every one
+;;; of them.  Here the parsed problem itself crosses the C ABI: one foreign call per constraint with
+;;; its coefficients in two specialised vectors, the tableau is assembled by the library's host
+;;; threads straight into pinned staging buffers (csrc/host_problem.cpp), and what comes back is a
+;;; handle to (objective row, RHS column, basis, var-mapping).
+(defclass mi355x-solution ()
+  ((problem :initarg :problem :reader mi355x-solution-problem
+            :documentation "The problem instance the solution answers (solution-problem).")
+   (handle :initarg :handle :accessor mi355x-solution-handle
+           :documentation "mi355x_solution*; a null pointer once FREE-SOLUTION has run.")
+   (var-index :initarg :var-index :reader mi355x-solution-var-index
+              :documentation "eq hash table: variable symbol -> its index in problem-vars, the
+name the C ABI knows the variable by."))
+  (:documentation "What MI355X-SIMPLEX-SOLVER returns on the native route: the light solution
+object of the library behind the four solution-* generics (src/solver.lisp:59-80).  Holds
+O(rows + cols) doubles on the C side; released by the garbage collector's finalizer (SBCL) or
+explicitly by FREE-SOLUTION."))
+
+(defun make-solution (problem handle var-index)
+  (let ((solution (make-instance 'mi355x-solution :problem problem :handle handle
+                                                  :var-index var-index)))
+    ;; the finalizer must not close over SOLUTION itself (it would never become garbage)
+    #+sbcl (sb-ext:finalize solution (lambda () (%solution-destroy handle)) :dont-save t)
+    solution))
+
+(defun free-solution (solution)
+  "Releases the C side of SOLUTION now instead of at some later garbage collection.  Idempotent;
+the solution answers no generic afterwards."
+  (let ((handle (mi355x-solution-handle solution)))
+    (unless (cffi:null-pointer-p handle)
+      #+sbcl (sb-ext:cancel-finalization solution)
+      (setf (mi355x-solution-handle solution) (cffi:null-pointer))
+      (%solution-destroy handle)))
+  nil)
+
+(defun live-handle (solution)
+  (let ((handle (mi355x-solution-handle solution)))
+    (when (cffi:null-pointer-p handle)
+      (error "~S has been released with free-solution" solution))
+    handle))
+
+(defun solution-var-index (solution variable)
+  "Index of VARIABLE in problem-vars, or the reference's error for a stranger
+(src/simplex.lisp:85-86, 115-116)."
+  (or (gethash variable (mi355x-solution-var-index solution))
+      (error "~S is not a variable in the tableau" variable)))
+
+(defmethod solution-problem ((solution mi355x-solution))          ; src/solver.lisp:59-62
+  (mi355x-solution-problem solution))
+
+(defmethod solution-objective-value ((solution mi355x-solution))  ; src/solver.lisp:64-67, simplex.lisp:74-78
+  (cffi:with-foreign-object (out :double)
+    (check (%solution-objective-value (live-handle solution) out))
+    (cffi:mem-ref out :double)))
+
+(defmethod solution-variable ((solution mi355x-solution) variable) ; src/solver.lisp:69-72, simplex.lisp:81-107
+  (if (eq variable (problem-objective-var (mi355x-solution-problem solution)))
+      (solution-objective-value solution)
+      (let ((index (solution-var-index solution variable)))
+        (cffi:with-foreign-object (out :double)
+          (check (%solution-variable (live-handle solution) index out))
+          (cffi:mem-ref out :double)))))
+
+(defmethod solution-reduced-cost ((solution mi355x-solution) variable) ; src/solver.lisp:74-80, simplex.lisp:111-120
+  (let ((index (solution-var-index solution variable)))
+    (cffi:with-foreign-object (out :double)
+      (let ((status (%solution-reduced-cost (live-handle solution) index out)))
+        ;; MI_BAD_ARG with a valid index: the variable's mapping is not `positive`
+        (when (= status -1)
+          (error "~S has no lower bound" variable))                 ; src/simplex.lisp:117-118
+        (check status)
+        (cffi:mem-ref out :double)))))
+
+(defun solution-pivots (solution)
+  "(values phase-1-pivots phase-2-pivots) the solve took (drive-out pivots count as phase 1)."
+  (cffi:with-foreign-objects ((p1 :int64) (p2 :int64))
+    (check (%solution-pivots (live-handle solution) p1 p2))
+    (values (cffi:mem-ref p1 :int64) (cffi:mem-ref p2 :int64))))
+
+(defun call-with-linear-expression (alist var-index fn)
+  "ALIST: a linear expression ((var . coef) ...) as the parser leaves it (src/problem.lisp:45-53).
+Calls FN with pointers to its variable indices (int64) and coefficients (double) and their count;
+the vectors are pinned for the length of the call only (the library copies)."
+  (let* ((nnz (length alist))
+         (vars (make-array (max nnz 1) :element-type '(signed-byte 64) :initial-element 0))
+         (coefs (make-array (max nnz 1) :element-type 'double-float :initial-element 0d0)))
+    (loop for (var . coef) in alist for k from 0
+          do (setf (aref vars k) (or (gethash var var-index)
+                                     (error "~S is not a variable of the problem" var))
+                   (aref coefs k) (coerce coef 'double-float)))
+    (cffi:with-pointer-to-vector-data (pv vars)
+      (cffi:with-pointer-to-vector-data (pc coefs)
+        (funcall fn pv pc nnz)))))
+
+(defun marshal-problem (problem)
+  "PROBLEM (src/problem.lisp:45-53) -> (values mi355x_problem* var-index): variables named by
+their index in problem-vars, every number coerced to double-float.  The caller destroys the
+handle (mi355x_problem_destroy)."
+  (let* ((vars (problem-vars problem))
+         (var-index (make-hash-table :test #'eq :size (max 1 (length vars)))))
+    (loop for var across vars for i from 0 do (setf (gethash var var-index) i))
+    (cffi:with-foreign-object (out :pointer)
+      (check (%problem-create out (if (eq 'max (problem-type problem)) 1 0) (length vars)))
+      (let ((handle (cffi:mem-ref out :pointer))
+            (complete nil))
+        (unwind-protect
+             (progn
+               (call-with-linear-expression
+                (problem-objective-func problem) var-index
+                (lambda (pv pc nnz) (check (%problem-set-objective handle pv pc nnz))))
+               ;; (var . (lb . ub)), NIL = unbounded on that side; a variable without an entry
+               ;; is >= 0 (src/simplex.lisp:189-212)
+               (loop for (var . (lb . ub)) in (problem-var-bounds problem)
+                     do (check (%problem-set-bounds
+                                handle (or (gethash var var-index)
+                                           (error "~S is not a variable of the problem" var))
+                                (if lb 1 0) (if lb (coerce lb 'double-float) 0d0)
+                                (if ub 1 0) (if ub (coerce ub 'double-float) 0d0))))
+               (dolist (var (problem-integer-vars problem))
+                 (check (%problem-set-integer handle (gethash var var-index))))
+               ;; (op alist rhs), op one of <= >= = (src/problem.lisp:45-53)
+               (loop for (op expression rhs) in (problem-constraints problem)
+                     do (call-with-linear-expression
+                         expression var-index
+                         (lambda (pv pc nnz)
+                           (check (%problem-add-constraint handle (ecase op (<= 0) (>= 1) (= 2))
+                                                           pv pc nnz (coerce rhs 'double-float))))))
+               (setf complete t)
+               (values handle var-index))
+          (unless complete (%problem-destroy handle)))))))
+
+(defun native-var-mapping (problem variable)
+  "The var-mapping entry the library's build-tableau gives VARIABLE, in the reference's form
+(src/simplex.lisp:44-46): (positive col offset), (negative col offset) or (signed col)."
+  (multiple-value-bind (handle var-index) (marshal-problem problem)
+    (unwind-protect
+         (cffi:with-foreign-objects ((kind :int) (col :int64) (offset :double))
+           (check (%var-mapping handle (or (gethash variable var-index)
+                                           (error "~S is not a variable of the problem" variable))
+                                kind col offset))
+           (ecase (cffi:mem-ref kind :int)
+             (0 (list 'positive (cffi:mem-ref col :int64) (cffi:mem-ref offset :double)))
+             (1 (list 'negative (cffi:mem-ref col :int64) (cffi:mem-ref offset :double)))
+             (2 (list 'signed (cffi:mem-ref col :int64)))))
+      (%problem-destroy handle))))
+
+(defun native-number-p (x)
+  "Numbers the library's double-float build-tableau treats exactly as the reference's generic
+arithmetic followed by the glue's coerce would: double-floats, and integers a double holds
+exactly.  (A ratio or a single-float is combined in its own type first by the reference --
+rhs - coef * lb at src/simplex.lisp:235-238 -- and rounded to double afterwards.)"
+  (or (typep x 'double-float)
+      (and (integerp x) (<= (abs x) (expt 2 53)))))
+
+(defun native-numbers-p (problem)
+  (flet ((expression-ok (alist) (every (lambda (term) (native-number-p (cdr term))) alist)))
+    (and (expression-ok (problem-objective-func problem))
+         (every (lambda (entry)
+                  (destructuring-bind (lb . ub) (cdr entry)
+                    (and (or (null lb) (native-number-p lb)) (or (null ub) (native-number-p ub)))))
+                (problem-var-bounds problem))
+         (every (lambda (constraint)
+                  (and (expression-ok (second constraint)) (native-number-p (third constraint))))
+                (problem-constraints problem)))))
+
+(defun solve-natively (problem factor device max-pivots)
+  "simplex-solver for an LP (src/simplex.lisp:506-542 without branch-and-bound) entirely behind
+the C ABI: marshal, mi355x_simplex_solver_begin (build-tableau + upload), ..._step in bounded
+chunks (never an unbounded foreign call; the phases of a two-phase problem included), ..._finish.
+Returns a MI355X-SOLUTION or signals the reference's conditions."
+  (multiple-value-bind (problem-handle var-index) (marshal-problem problem)
+    (unwind-protect
+         (cffi:with-foreign-objects ((out :pointer) (n-pivots :int64))
+           (let ((status (with-foreign-fp-mode (%solver-begin problem-handle factor device out))))
+             ;; the no-constraint special case decides unboundedness while building
+             ;; (src/simplex.lisp:170, 174)
+             (when (= status +mi-unbounded+) (error 'unbounded-problem-error))
+             (check status))
+           (let ((job (cffi:mem-ref out :pointer))
+                 (consumed nil)
+                 (rows (1+ (length (problem-constraints problem)))))
+             (unwind-protect
+                  (let ((status (solve-in-chunks
+                                 (lambda (cap) (%solver-step job cap n-pivots))
+                                 rows (+ rows (length (problem-vars problem))) max-pivots n-pivots)))
+                    (signal-outcome status)
+                    (setf consumed t)                ; finish consumes the job whatever it returns
+                    (check (%solver-finish job out))
+                    (make-solution problem (cffi:mem-ref out :pointer) var-index))
+               (unless consumed (%solver-abandon job)))))
+      (%problem-destroy problem-handle))))
+
 ;;; ------------------------------------------------------------------ the *solver* value
+(defun solve-two-phase-in-chunks (art-handle main-handle rows cols main-is-max factor max-pivots
+                                  n-pivots)
+  "n-solve-tableau's two-phase branch (src/simplex.lisp:402-452) without an unbounded foreign call:
+phase 1 in chunks on the artificial tableau, the step between the phases
+(mi355x_two_phase_handover: feasibility test, drive-out pivots, hand-over -- bounded by the row
+count), phase 2 in chunks on the main tableau.  Same pivots, same bits as mi355x_solve_two_phase.
+ROWS x COLS: the artificial tableau's shape (chunk size).  MAX-PIVOTS (0 = none) caps the two
+phases together.  Returns the final status."
+  (let* ((used 0)
+         (status (solve-in-chunks (lambda (cap) (%tab-solve art-handle 0 factor cap n-pivots))
+                                  rows cols max-pivots n-pivots)))
+    (incf used (cffi:mem-aref n-pivots :int64 0))
+    (cond
+      ((/= status +mi-optimal+) status)
+      (t
+       (setf status (check (with-foreign-fp-mode
+                             (%two-phase-handover art-handle main-handle factor n-pivots))))
+       (incf used (cffi:mem-aref n-pivots :int64 0))
+       (cond
+         ((/= status +mi-optimal+) status)         ; MI_INFEASIBLE / MI_ART_NONZERO / MI_ART_STUCK
+         ((and (plusp max-pivots) (>= used max-pivots)) +mi-max-pivots+)
+         (t (solve-in-chunks (lambda (cap) (%tab-solve main-handle main-is-max factor cap n-pivots))
+                             rows cols (if (plusp max-pivots) (- max-pivots used) 0)
+                             n-pivots)))))))
+
 (defun mi355x-simplex-solver (problem &rest args
                               &key (fp-tolerance 1024) (device 0) (devices 1) (max-pivots 0)
-                                full-tableau
+                                full-tableau (native :auto)
                               &allow-other-keys)
   "Solver interface function for the MI355X backend (the value of
 linear-programming:*solver*, src/solver.lisp:39-49).  Takes a problem and backend keyword
 arguments -- :fp-tolerance (as the built-in solver, src/simplex.lisp:506-511), :device,
 :devices (a count > 1 or a list of device ids: the tableau -- for a two-phase problem the
 artificial tableau, with phase 1, the hand-over and phase 2 all on the partition -- is
-column-partitioned over those GPUs of the node), :max-pivots, :full-tableau (write every entry
-of the solved tableau back instead of only what the solution-* generics read) -- and returns a
-solved `tableau`.  solve-problem forwards these keywords (src/solver.lisp:53-56):
+column-partitioned over those GPUs of the node), :max-pivots, :full-tableau (return a `tableau`
+with every entry of the solved tableau written back), :native (:auto, the default: the native
+route whenever the problem's numbers are double-floats / integers and neither :full-tableau nor
+:devices asks for the tableau itself; T: the native route also for ratios and single-floats, which
+are then rounded to double BEFORE build-tableau's arithmetic instead of after; NIL: always the
+build-tableau route) -- and returns a solution object answering solution-problem,
+solution-objective-value, solution-variable and solution-reduced-cost (src/solver.lisp:40-45): a
+MI355X-SOLUTION on the native route, a solved `tableau` otherwise.  solve-problem forwards these
+keywords (src/solver.lisp:53-56):
   (solve-problem problem :devices 8)        (solve-problem problem :devices '(4 5 6 7))"
   (declare (ignore args))
   (when (problem-integer-vars problem)
     (error 'unsupported-constraint-error
            :constraint (cons 'integer (problem-integer-vars problem))
            :solver-name "mi355x-simplex"))
+  (when (and native (not full-tableau) (<= (device-count-of devices) 1)
+             (plusp (length (problem-vars problem)))
+             (or (eq native t) (native-numbers-p problem)))
+    (return-from mi355x-simplex-solver
+      (solve-natively problem (coerce fp-tolerance 'double-float) device max-pivots)))
   (let ((tableaus (build-tableau problem problem :fp-tolerance-factor fp-tolerance))
         (factor (coerce fp-tolerance 'double-float)))
     (cffi:with-foreign-object (n-pivots :int64 2)
@@ -443,10 +727,11 @@ solved `tableau`.  solve-problem forwards these keywords (src/solver.lisp:53-56)
                    (multiple-value-bind (main-handle main-flat main-basis)
                        (upload-tableau main-tab device)
                      (unwind-protect
-                          (let ((status (check (with-foreign-fp-mode
-                                                 (%solve-two-phase art-handle main-handle
-                                                                   (max-problem-p main-tab)
-                                                                   factor n-pivots)))))
+                          (let ((status (solve-two-phase-in-chunks
+                                         art-handle main-handle
+                                         (array-dimension (tableau-matrix art-tab) 0)
+                                         (array-dimension (tableau-matrix art-tab) 1)
+                                         (max-problem-p main-tab) factor max-pivots n-pivots)))
                             (signal-outcome status)
                             (if full-tableau
                                 (download-tableau main-handle main-tab main-flat main-basis)

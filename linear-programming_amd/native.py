@@ -74,6 +74,36 @@ class NativeProblem:
         kind = ("positive", "negative", "signed")[k.value]
         return (kind, c.value) if kind == "signed" else (kind, c.value, o.value)
 
+    def solve_in_chunks(self, fp_tolerance=1024, device=0, max_pivots=0, chunk=None):
+        """The Lisp glue's `solve-natively`, call for call: mi355x_simplex_solver_begin, ..._step in
+        bounded chunks (`solve-in-chunks`; the phases of a two-phase problem included), ..._finish;
+        the job is abandoned on every other way out."""
+        from .simplex import _solve_in_chunks, _raise_for
+        L = capi.lib()
+        job, s, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64(0)
+        rc = L.mi355x_simplex_solver_begin(self._h, float(fp_tolerance), device, ctypes.byref(job))
+        if rc == capi.MI_UNBOUNDED:                    # the no-constraint special case, simplex.lisp:170,174
+            raise UnboundedProblemError()
+        if rc == capi.MI_UNSUPPORTED:
+            raise UnsupportedConstraintError(("integer",) + tuple(self.problem.integer_vars),
+                                             "mi355x-simplex")
+        capi.check(rc, "mi355x_simplex_solver_begin")
+        consumed = False
+        try:
+            def call(cap):
+                rc = capi.check(L.mi355x_simplex_solver_step(job, int(cap), ctypes.byref(n)),
+                                "mi355x_simplex_solver_step")
+                return rc, int(n.value)
+            rows = len(self.problem.constraints) + 1
+            rc, _ = _solve_in_chunks(call, rows, rows + len(self.problem.vars), int(max_pivots), chunk=chunk)
+            _raise_for(rc)
+            consumed = True
+            capi.check(L.mi355x_simplex_solver_finish(job, ctypes.byref(s)), "mi355x_simplex_solver_finish")
+            return NativeSolution(self, s)
+        finally:
+            if not consumed:
+                L.mi355x_simplex_solver_abandon(job)
+
     def solve(self, fp_tolerance=1024, device=0):
         """mi355x_simplex_solver: returns a NativeSolution or raises the reference's errors."""
         s = ctypes.c_void_p()
@@ -97,8 +127,12 @@ class NativeProblem:
 
 
 class NativeSolution:
+    """The glue's MI355X-SOLUTION: the library's light solution object (objective row, RHS column,
+    basis, var-mapping) behind the four solution-* generics (src/solver.lisp:59-80)."""
+
     def __init__(self, nproblem, handle):
         self.nproblem, self._h = nproblem, handle
+        self.problem = nproblem.problem                 # solution-problem
 
     def objective_value(self):
         x = ctypes.c_double(0)

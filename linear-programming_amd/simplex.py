@@ -396,11 +396,11 @@ def chunk_pivots(rows, cols):
     return max(1024, min(65536, (1 << 36) // max(1, rows * cols)))
 
 
-def _solve_in_chunks(call, rows, cols, max_pivots):
+def _solve_in_chunks(call, rows, cols, max_pivots, chunk=None):
     """The glue's `solve-in-chunks`: call(cap) -> (status, pivots of that call) until the status is
     something else than MI_MAX_PIVOTS or max_pivots (0 = no cap) are used up.  A solve continued
-    call by call takes exactly the pivots of one long call."""
-    chunk, total = chunk_pivots(rows, cols), 0
+    call by call takes exactly the pivots of one long call.  (chunk: tests force a small one.)"""
+    chunk, total = chunk or chunk_pivots(rows, cols), 0
     while True:
         cap = min(chunk, max_pivots - total) if max_pivots > 0 else chunk
         rc, k = call(cap)
@@ -409,7 +409,41 @@ def _solve_in_chunks(call, rows, cols, max_pivots):
             return rc, total
 
 
-def n_solve_tableau(tableau, max_pivots=0, chunked=False):
+def _solve_two_phase_in_chunks(art, main, max_pivots=0, chunk=None):
+    """The glue's `solve-two-phase-in-chunks`: phase 1 in chunks on the artificial tableau,
+    mi355x_two_phase_handover, phase 2 in chunks on the main tableau -- the pivots and bits of
+    mi355x_solve_two_phase without an unbounded foreign call; max_pivots caps the phases together."""
+    L = capi.lib()
+    n = ctypes.c_int64(0)
+    f = float(main.fp_tolerance_factor)
+    rows, cols = art.constraint_count + 1, art.var_count + 1
+
+    def phase(t, is_max):
+        def call(cap):
+            rc = capi.check(L.mi355x_tab_solve(t._h, int(is_max), f, int(cap), ctypes.byref(n)), "mi355x_tab_solve")
+            return rc, int(n.value)
+        return call
+    try:
+        rc, n1 = _solve_in_chunks(phase(art, 0), rows, cols, int(max_pivots), chunk=chunk)
+        main.n_pivots = (n1, 0)
+        if rc != capi.MI_OPTIMAL:
+            return rc
+        rc = capi.check(L.mi355x_two_phase_handover(art._h, main._h, f, ctypes.byref(n)), "mi355x_two_phase_handover")
+        n1 += int(n.value)
+        main.n_pivots = (n1, 0)
+        if rc != capi.MI_OK:
+            return rc
+        if max_pivots > 0 and n1 >= max_pivots:
+            return capi.MI_MAX_PIVOTS
+        rc, n2 = _solve_in_chunks(phase(main, main.is_max), rows, cols, max_pivots - n1 if max_pivots > 0 else 0, chunk=chunk)
+        main.n_pivots = (n1, n2)
+        return rc
+    finally:
+        art._touch()
+        main._touch()
+
+
+def n_solve_tableau(tableau, max_pivots=0, chunked=False, chunk=None):
     """n-solve-tableau (src/simplex.lisp:399-461): a Tableau (single phase) or a list
     [art, main] (two-phase).  Returns the solved (main) tableau.  chunked: bounded foreign calls
     (what the Lisp glue does, see chunk_pivots)."""
@@ -417,6 +451,10 @@ def n_solve_tableau(tableau, max_pivots=0, chunked=False):
         art, main = tableau
         if not isinstance(art, Tableau) or not isinstance(main, Tableau):
             raise TypeError("expected tableaus")
+        if chunked:
+            rc = _solve_two_phase_in_chunks(art, main, int(max_pivots), chunk=chunk)
+            _raise_for(rc)
+            return main
         npv = (ctypes.c_int64 * 2)()
         rc = capi.check(capi.lib().mi355x_solve_two_phase(
             art._h, main._h, int(main.is_max), float(main.fp_tolerance_factor), npv),
@@ -437,7 +475,7 @@ def n_solve_tableau(tableau, max_pivots=0, chunked=False):
                         "mi355x_tab_solve")
         return rc, int(n.value)
     if chunked:
-        rc, total = _solve_in_chunks(call, tableau.constraint_count + 1, tableau.var_count + 1, int(max_pivots))
+        rc, total = _solve_in_chunks(call, tableau.constraint_count + 1, tableau.var_count + 1, int(max_pivots), chunk=chunk)
     else:
         rc, total = call(max_pivots)
     tableau._touch()
@@ -531,10 +569,34 @@ def _solve_two_phase_column_partitioned(art, main, devices):
     return True
 
 
-def mi355x_simplex_solver(problem, fp_tolerance=1024, device=0, devices=1, **_ignored):
+def _native_number(x):
+    """The glue's `native-number-p`: numbers the library's double-float build-tableau treats exactly
+    as generic arithmetic followed by a coerce would -- doubles and integers a double holds exactly
+    (a Fraction, like a Lisp ratio, is combined exactly first and rounded afterwards)."""
+    if isinstance(x, bool):
+        return False
+    if isinstance(x, int):
+        return abs(x) <= 2 ** 53
+    return isinstance(x, float)
+
+
+def _native_numbers(problem):
+    ok = all(_native_number(c) for _, c in problem.objective_func)
+    ok = ok and all((lb is None or _native_number(lb)) and (ub is None or _native_number(ub))
+                    for _, (lb, ub) in problem.var_bounds)
+    return ok and all(all(_native_number(c) for _, c in e) and _native_number(rhs)
+                      for _, e, rhs in problem.constraints)
+
+
+def mi355x_simplex_solver(problem, fp_tolerance=1024, device=0, devices=1, max_pivots=0,
+                          full_tableau=False, native="auto", chunk=None, **_ignored):
     """What the Lisp glue installs as `*solver*` (src/solver.lisp:39-56): takes a problem and
-    backend keyword arguments, returns a solved tableau answering the four solution-*
-    generics.  LP only: integer/binary variables are declined the way a backend must
+    backend keyword arguments, returns a solution object answering the four solution-*
+    generics -- on the NATIVE route (default whenever the problem's numbers are floats / integers
+    and neither full_tableau nor devices > 1 asks for the tableau itself; native=True forces it,
+    native=False never takes it) a NativeSolution (the glue's MI355X-SOLUTION: problem marshalled
+    through mi355x_problem_*, mi355x_simplex_solver_begin / _step in bounded chunks / _finish), on
+    the build-tableau route a solved Tableau.  LP only: integer/binary variables are declined the way a backend must
     (unsupported-constraint-error, src/conditions.lisp:69-77); branch-and-bound
     (src/simplex.lisp:506-542) stays with the reference's own solver.  devices > 1: the tableau
     (single-phase problems) or the artificial tableau (two-phase problems: phase 1, the hand-over
@@ -543,12 +605,17 @@ def mi355x_simplex_solver(problem, fp_tolerance=1024, device=0, devices=1, **_ig
     if problem.integer_vars:
         raise UnsupportedConstraintError(("integer",) + tuple(problem.integer_vars),
                                          "mi355x-simplex")
+    if native and not full_tableau and devices <= 1 and len(problem.vars) > 0 and \
+            (native is True or _native_numbers(problem)):
+        from .native import NativeProblem
+        return NativeProblem(problem).solve_in_chunks(fp_tolerance=fp_tolerance, device=device,
+                                                      max_pivots=max_pivots, chunk=chunk)
     tabs = build_tableau(problem, problem, fp_tolerance_factor=fp_tolerance, device=device)
-    if devices > 1 and isinstance(tabs, Tableau) and _solve_column_partitioned(tabs, devices):
+    if devices > 1 and isinstance(tabs, Tableau) and _solve_column_partitioned(tabs, devices, max_pivots):
         return tabs
     if devices > 1 and isinstance(tabs, list) and _solve_two_phase_column_partitioned(tabs[0], tabs[1], devices):
         return tabs[1]
-    return n_solve_tableau(tabs, chunked=True)
+    return n_solve_tableau(tabs, max_pivots=max_pivots, chunked=True, chunk=chunk)
 
 
 simplex_solver = mi355x_simplex_solver

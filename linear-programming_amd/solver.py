@@ -3,11 +3,14 @@ the `*solver*` hook and the four solution-* generics.
 
 In the Lisp deployment nothing in src/solver.lisp changes: the glue's
 `mi355x-simplex-solver` is simply the value of `linear-programming:*solver*`
-(`(let ((*solver* 'mi355x-simplex-solver)) (solve-problem problem))`) and returns a `tableau`,
-so the reference's own methods at src/solver.lisp:61-80 serve the generics.  This module
-restates that contract for the Python-side tests.
+(`(let ((*solver* 'mi355x-simplex-solver)) (solve-problem problem))`).  On the native route it
+returns a MI355X-SOLUTION, for which the glue adds one method to each of the four generics
+(lisp/mi355x-simplex.lisp); on the build-tableau route it returns a `tableau`, served by the
+reference's own methods at src/solver.lisp:61-80.  This module restates that two-class dispatch
+for the Python-side tests.
 """
 from . import simplex
+from .native import NativeSolution
 
 #: `*solver*` (src/solver.lisp:39-49): a function taking a problem and backend-specific keyword
 #: arguments and returning a solution object.  Defaults to the MI355X backend here.
@@ -33,16 +36,22 @@ def solution_problem(solution):
 
 def solution_objective_value(solution):
     """solution-objective-value (src/solver.lisp:64-67)."""
+    if isinstance(solution, NativeSolution):          # (defmethod ... ((solution mi355x-solution)))
+        return solution.objective_value()
     return simplex.tableau_objective_value(solution)
 
 
 def solution_variable(solution, variable):
     """solution-variable (src/solver.lisp:69-72)."""
+    if isinstance(solution, NativeSolution):
+        return solution.variable(variable)
     return simplex.tableau_variable(solution, variable)
 
 
 def solution_reduced_cost(solution, variable):
     """solution-reduced-cost (src/solver.lisp:74-80)."""
+    if isinstance(solution, NativeSolution):
+        return solution.reduced_cost(variable)
     return simplex.tableau_reduced_cost(solution, variable)
 
 

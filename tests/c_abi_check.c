@@ -35,6 +35,14 @@ int main(void)
         rc = mi355x_tab_create(&t, rows, cols, M, basis, 0);
         if (rc != MI_NO_DEVICE || t != NULL) return 10;
         if (mi355x_simplex_solver(p, 1024.0, 0, &s) != MI_NO_DEVICE || s != NULL) return 11;
+        {   /* the resumable form fails the same way, and its argument checks need no device */
+            mi355x_solve *job = NULL;
+            if (mi355x_simplex_solver_begin(p, 1024.0, 0, &job) != MI_NO_DEVICE || job != NULL) return 61;
+            if (mi355x_simplex_solver_step(NULL, 0, NULL) != MI_BAD_ARG || mi355x_simplex_solver_cancel(NULL) != MI_BAD_ARG ||
+                mi355x_simplex_solver_finish(NULL, &s) != MI_BAD_ARG || s != NULL) return 62;
+            if (mi355x_two_phase_handover(NULL, NULL, 1024.0, NULL) != MI_BAD_ARG) return 63;
+            mi355x_simplex_solver_abandon(NULL);
+        }
         {   /* the multi-device entry points fail the same way (and never touch RCCL) */
             mi355x_colpart *cp = NULL;
             if (mi355x_colpart_create(&cp, rows, cols, M, basis, 8) != MI_NO_DEVICE || cp != NULL) return 14;
@@ -57,6 +65,26 @@ int main(void)
         mi355x_solution_variable(s, 0, &x);
         if (w != 28.5 || x != 0.5) return 13;                                                /* README.md:58-62 */
         mi355x_solution_destroy(s);
+        {   /* the Lisp glue's native route (solve-natively), call for call: begin, step in bounded
+             * chunks (cap 1: MI_MAX_PIVOTS = "chunk used up, still running"), finish, the read-back
+             * behind the four solution-* generics, destroy */
+            mi355x_solve *job = NULL;
+            mi355x_solution *s2 = NULL;
+            int64_t k = 0, total = 0, p1 = -1, p2 = -1;
+            double v = 0;
+            int calls = 0;
+            if (mi355x_simplex_solver_begin(p, 1024.0, 0, &job) != MI_OK || !job) return 64;
+            while ((rc = mi355x_simplex_solver_step(job, 1, &k)) == MI_MAX_PIVOTS) { total += k; if (++calls > 16) return 65; }
+            total += k;
+            if (rc != MI_OPTIMAL || total != 2) return 66;                                   /* t/simplex.lisp:190: two pivots */
+            if (mi355x_simplex_solver_finish(job, &s2) != MI_OPTIMAL || !s2) return 67;
+            if (mi355x_solution_objective_value(s2, &v) != MI_OK || v != 28.5) return 68;
+            if (mi355x_solution_variable(s2, 1, &v) != MI_OK || v != 7.0) return 69;
+            if (mi355x_solution_reduced_cost(s2, 2, &v) != MI_OK || v != 0.5) return 70;       /* README.md:58-62 */
+            if (mi355x_solution_variable(s2, 3, &v) != MI_BAD_ARG) return 71;                  /* "not a variable in the tableau" */
+            if (mi355x_solution_pivots(s2, &p1, &p2) != MI_OK || p1 != 0 || p2 != 2) return 72;
+            mi355x_solution_destroy(s2);
+        }
         {   /* the same tableau column-partitioned over 2 shards (logical shards on one GPU),
              * what the Lisp glue does for :devices 2 -- t/simplex.lisp:170-194: objective 57/2 */
             mi355x_colpart *cp = NULL;
@@ -167,9 +195,31 @@ int main(void)
                 mi355x_multibatch_destroy(bm);
                 mi355x_multibatch_destroy(ba);
             }
+            {   /* the glue's solve-two-phase-in-chunks: phase 1 in bounded calls, the hand-over on its
+                 * own, phase 2 in bounded calls -- the pivots of the one-call form below */
+                mi355x_tab *a2 = NULL, *m2 = NULL;
+                int64_t k = 0, n1 = 0, n2 = 0, nd = -1;
+                if (mi355x_tab_create(&a2, ar, ac, A, ab, 0) != MI_OK) return 73;
+                if (mi355x_tab_create(&m2, mr, mc, Mm, mb2, 0) != MI_OK) return 74;
+                while ((rc = mi355x_tab_solve(a2, 0, 1024.0, 1, &k)) == MI_MAX_PIVOTS) n1 += k;
+                n1 += k;
+                if (rc != MI_OPTIMAL) return 75;
+                if (mi355x_two_phase_handover(a2, m2, 1024.0, &nd) != MI_OK || nd != 0) return 76;
+                while ((rc = mi355x_tab_solve(m2, 1, 1024.0, 1, &k)) == MI_MAX_PIVOTS) n2 += k;
+                n2 += k;
+                if (rc != MI_OPTIMAL) return 77;
+                if (mi355x_tab_download(m2, NULL, NULL, NULL, lc) != MI_OK || lc[3] != 28.5) return 78;
+                npv[0] = n1; npv[1] = n2;
+                mi355x_tab_destroy(m2);
+                mi355x_tab_destroy(a2);
+            }
             if (mi355x_tab_create(&art, ar, ac, A, ab, 0) != MI_OK) return 49;
             if (mi355x_tab_create(&mn, mr, mc, Mm, mb2, 0) != MI_OK) return 50;
-            if (mi355x_solve_two_phase(art, mn, 1, 1024.0, npv) != MI_OPTIMAL) return 51;
+            {
+                int64_t n12[2] = {0, 0};
+                if (mi355x_solve_two_phase(art, mn, 1, 1024.0, n12) != MI_OPTIMAL) return 51;
+                if (n12[0] != npv[0] || n12[1] != npv[1]) return 79;
+            }
             if (mi355x_tab_download(mn, NULL, NULL, NULL, lc) != MI_OK || lc[3] != 28.5) return 52;
             /* a cancel request with no solve in flight is aimed at the next solve: whole pivots, and
              * the request ends with that solve */

@@ -190,3 +190,68 @@ def test_lisp_glue_is_well_formed_and_binds_only_declared_entry_points():
         macro = "MI_" + m.group(1).upper().replace("-", "_")
         decl = re.search(r"#define\s+%s\s+(-?\d+)" % macro, header)
         assert decl and int(decl.group(1)) == int(m.group(2)), "%s = %s in the glue" % (macro, m.group(2))
+
+
+def _glue_source():
+    return open(os.path.join(ROOT, "linear-programming_amd", "lisp", "mi355x-simplex.lisp")).read()
+
+
+def test_lisp_glue_binds_the_native_route_and_has_a_method_on_every_generic():
+    """SURVEY section 8 f-2 / f-3 from the reference's host language: the glue binds the whole
+    problem -> solution path (mi355x_problem_*, the resumable solver job, mi355x_solution_*), has one
+    method per solution-* generic of src/solver.lisp:59-80 on its own solution class, signals the
+    reference's errors in the read-back (src/simplex.lisp:85-86, 117-118), and every foreign
+    function it CALLS is one it binds."""
+    src = _glue_source()
+    code = re.sub(r";[^\n]*", "", src)
+    bound_c = set(re.findall(r'\(cffi:defcfun \("(mi355x_\w+)"', src))
+    for name in ("mi355x_problem_create", "mi355x_problem_set_objective", "mi355x_problem_set_bounds",
+                 "mi355x_problem_set_integer", "mi355x_problem_add_constraint", "mi355x_problem_destroy",
+                 "mi355x_simplex_solver", "mi355x_simplex_solver_begin", "mi355x_simplex_solver_step",
+                 "mi355x_simplex_solver_finish", "mi355x_simplex_solver_abandon", "mi355x_var_mapping",
+                 "mi355x_solution_objective_value", "mi355x_solution_variable", "mi355x_solution_reduced_cost",
+                 "mi355x_solution_pivots", "mi355x_solution_destroy", "mi355x_two_phase_handover"):
+        assert name in bound_c, "%s is not bound by the glue" % name
+    # every %foreign-function the glue calls is bound, and every binding (but the documented one-shot
+    # conveniences) is used
+    bound_lisp = set(re.findall(r'\(cffi:defcfun \("mi355x_\w+" (%?[\w-]+)\)', src))
+    body = re.sub(r'\(cffi:defcfun \("mi355x_\w+" %?[\w-]+\)', "", code)
+    called = set(re.findall(r"\((%[\w-]+)[\s)]", body))
+    assert called <= bound_lisp, "called but never bound: %s" % sorted(called - bound_lisp)
+    unused = {n for n in bound_lisp if n.startswith("%")} - called
+    assert unused <= {"%simplex-solver", "%solve-two-phase"}, "bound but never called: %s" % sorted(unused)
+    # the four generics of src/solver.lisp:59-80, imported from the reference's package and specialised
+    assert "(:import-from :linear-programming/solver" in src
+    for generic, params in (("solution-problem", r"\(\(solution mi355x-solution\)\)"),
+                            ("solution-objective-value", r"\(\(solution mi355x-solution\)\)"),
+                            ("solution-variable", r"\(\(solution mi355x-solution\) variable\)"),
+                            ("solution-reduced-cost", r"\(\(solution mi355x-solution\) variable\)")):
+        assert re.search(r"#:%s\b" % generic, src), "%s is not imported" % generic
+        assert re.search(r"\(defmethod %s %s" % (generic, params), src), "no method on %s" % generic
+    assert "(defclass mi355x-solution" in src and "sb-ext:finalize" in src and "(defun free-solution" in src
+    # the reference's error texts of the read-back
+    assert '"~S is not a variable in the tableau"' in src and '"~S has no lower bound"' in src
+    # the solver takes the native route by default and keeps the build-tableau route
+    solver = src[src.index("(defun mi355x-simplex-solver"):src.index(";;; ------------------------------------------------------------------ many problems at once")]
+    assert "(native :auto)" in solver and "(solve-natively problem" in solver and "(build-tableau problem problem" in solver
+    assert solver.index("(solve-natively problem") < solver.index("(build-tableau problem problem")
+    # never an unbounded foreign solve: every solve entry point is called with a cap through solve-in-chunks
+    for fn in ("%tab-solve", "%colpart-solve", "%solver-step"):
+        for m in re.finditer(r"\(%s " % re.escape(fn), body):
+            ctx = body[max(0, m.start() - 120):m.start()]
+            assert "(lambda (cap)" in ctx, "%s is called outside solve-in-chunks" % fn
+
+
+def test_python_mirror_replays_the_glue_call_for_call():
+    """The C entry points the glue's native route calls are exactly those NativeProblem (marshal) +
+    NativeProblem.solve_in_chunks (begin / step / finish / abandon) + NativeSolution (read-back) call:
+    the GPU tests of the native route (tests/test_gpu_native_route.py) exercise the glue's sequence."""
+    src = _glue_source()
+    native = src[src.index(";;; ------------------------------------------------------------------ the native route"):
+                 src.index("(defun solve-two-phase-in-chunks")]
+    lisp_to_c = dict((l, c) for c, l in re.findall(r'\(cffi:defcfun \("(mi355x_\w+)" (%[\w-]+)\)', src))
+    glue_calls = {lisp_to_c[n] for n in set(re.findall(r"\((%[\w-]+)[\s)]", re.sub(r";[^\n]*", "", native)))}
+    py = open(os.path.join(ROOT, "linear-programming_amd", "native.py")).read()
+    py_calls = set(re.findall(r"\b(mi355x_(?:problem|simplex_solver|solution|var_mapping)\w*)\(", py))
+    py_calls -= {"mi355x_problem_read_mps", "mi355x_problem_to_json", "mi355x_simplex_solver"}   # (the MPS reader, the one-shot form)
+    assert glue_calls == py_calls, (sorted(glue_calls - py_calls), sorted(py_calls - glue_calls))

@@ -264,3 +264,85 @@ def test_colpart_cancel_leaves_every_shard_swept(n_shards, exchange):
         assert np.array_equal(G.view(np.int64), M.view(np.int64)) and np.array_equal(gb, b)
     finally:
         L.mi355x_colpart_destroy(h)
+
+
+# ---- two-phase: a request on EITHER handle ends the call, whichever phase is running ------------
+def _two_phase_cycling():
+    """Beale's cycling LP plus one variable pinned by an equality row (y = 1): build-tableau returns
+    (art main); phase 1 ends after the pivot that brings y in, phase 2 cycles for ever."""
+    names = ["x1", "x2", "x3", "x4", "y"]
+    p = lp.Problem(type="max", vars=names, objective_var="z",
+                   objective_func=[("x1", 0.75), ("x2", -20.0), ("x3", 0.5), ("x4", -6.0)],
+                   constraints=[("<=", [("x1", 0.25), ("x2", -8.0), ("x3", -1.0), ("x4", 9.0)], 0.0),
+                                ("<=", [("x1", 0.5), ("x2", -12.0), ("x3", -0.5), ("x4", 3.0)], 0.0),
+                                ("<=", [("x3", 1.0)], 1.0),
+                                ("=", [("y", 1.0)], 1.0)])
+    tabs = lp.build_tableau(p, p)
+    assert isinstance(tabs, list)
+    return tabs
+
+
+@pytest.mark.parametrize("which", ["art", "main"])
+def test_two_phase_cancel_on_either_handle_during_phase_2(which):
+    """(round-4 advisor finding) phase 2 polled only the main handle's flag: a request on the
+    artificial handle was never seen and a cycling phase 2 could not be ended through it."""
+    L = lp.capi.lib()
+    art, main = _two_phase_cycling()
+    ha, hm = art._h, main._h
+    npv = (ctypes.c_int64 * 2)()
+    th = _cancel_after(lambda: L.mi355x_tab_cancel(ha if which == "art" else hm), 0.4)
+    t0 = time.perf_counter()
+    rc = L.mi355x_solve_two_phase(ha, hm, 1, 1024.0, npv)
+    dt = time.perf_counter() - t0
+    th.join()
+    art._touch(); main._touch()
+    assert rc == lp.capi.MI_CANCELLED and dt < 10.0, (rc, dt)
+    assert npv[0] >= 1 and npv[1] > 0                       # phase 1 done, phase 2 was running
+    # whole pivots: the main tableau is what the phases driven one by one (mi355x_tab_solve on the
+    # artificial tableau, mi355x_two_phase_handover, mi355x_tab_solve with a cap on the main one -- each
+    # pinned against the oracle elsewhere) leave after exactly that many phase-2 pivots
+    a2, m2 = _two_phase_cycling()
+    k = ctypes.c_int64(0)
+    assert L.mi355x_tab_solve(a2._h, 0, 1024.0, 0, ctypes.byref(k)) == lp.capi.MI_OPTIMAL
+    lp.capi.check(L.mi355x_two_phase_handover(a2._h, m2._h, 1024.0, ctypes.byref(k)), "handover")
+    assert L.mi355x_tab_solve(m2._h, 1, 1024.0, int(npv[1]), ctypes.byref(k)) == lp.capi.MI_MAX_PIVOTS
+    a2._touch(); m2._touch()
+    assert np.array_equal(main.matrix.view(np.int64), m2.matrix.view(np.int64))
+    assert np.array_equal(main.basis_columns, m2.basis_columns)
+    # the request ended with the call: neither handle keeps a stale flag
+    k = ctypes.c_int64(0)
+    assert L.mi355x_tab_solve(hm, 1, 1024.0, 12, ctypes.byref(k)) == lp.capi.MI_MAX_PIVOTS and k.value == 12
+    assert L.mi355x_tab_solve(ha, 0, 1024.0, 12, ctypes.byref(k)) == lp.capi.MI_OPTIMAL and k.value == 0
+
+
+@pytest.mark.parametrize("which", ["art", "main", "both"])
+def test_two_phase_cancel_requested_before_the_call(which):
+    """A request with no solve in flight is aimed at the next one -- on either handle of the pair.
+    The call ends with MI_CANCELLED before phase 2 makes a pivot (at the latest between the phases),
+    and a second call runs to the oracle's optimum."""
+    from tests.helpers import random_mixed_problem
+    L = lp.capi.lib()
+    p = random_mixed_problem(lp, 150, 60, 40, 20, 9)
+    art, main = lp.build_tableau(p, p)
+    if which in ("art", "both"):
+        L.mi355x_tab_cancel(art._h)
+    if which in ("main", "both"):
+        L.mi355x_tab_cancel(main._h)
+    npv = (ctypes.c_int64 * 2)()
+    rc = L.mi355x_solve_two_phase(art._h, main._h, 1, 1024.0, npv)
+    assert rc == lp.capi.MI_CANCELLED and npv[1] == 0, (rc, list(npv))
+    # nothing is left over: fresh tableaux of the same problem solve to the end, bit for bit
+    art2, main2 = lp.build_tableau(p, p)
+    lp.n_solve_tableau([art2, main2])
+    sol = lp.NativeProblem(p).solve()
+    assert lp.solution_objective_value(main2) == sol.objective_value()
+    # ... and the cancelled pair itself carries on: phase 1 is (or gets) finished, the hand-over and
+    # phase 2 follow, ending in the same optimum
+    k = ctypes.c_int64(0)
+    rc1 = L.mi355x_tab_solve(art._h, 0, 1024.0, 0, ctypes.byref(k))
+    assert rc1 == lp.capi.MI_OPTIMAL
+    lp.capi.check(L.mi355x_two_phase_handover(art._h, main._h, 1024.0, ctypes.byref(k)), "handover")
+    assert L.mi355x_tab_solve(main._h, 1, 1024.0, 0, ctypes.byref(k)) == lp.capi.MI_OPTIMAL
+    art._touch(); main._touch()
+    assert np.array_equal(main.matrix.view(np.int64), main2.matrix.view(np.int64))
+    assert np.array_equal(main.basis_columns, main2.basis_columns)

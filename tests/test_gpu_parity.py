@@ -1284,7 +1284,7 @@ def test_solver_hook_devices_keyword(devices):
     p = lp.Problem(type="max", vars=["x", "y", "z"], objective_var="w",          # README.md:43-47
                    objective_func=[("x", 1), ("y", 4), ("z", 3)],
                    constraints=[("<=", [("x", 2), ("y", 1)], 8), ("<=", [("y", 1), ("z", 1)], 7)])
-    one = lp.solve_problem(p)
+    one = lp.solve_problem(p, native=False)
     many = lp.solve_problem(p, devices=devices)
     assert lp.solution_variable(many, "w") == 28.5 and lp.solution_variable(many, "x") == 0.5
     assert np.array_equal(many.matrix.view(np.int64), one.matrix.view(np.int64))
@@ -1299,13 +1299,13 @@ def test_solver_hook_devices_keyword(devices):
     cons = [("<=", list(zip(names, A[i].tolist())), float(rng.uniform(5, 9))) for i in range(m)]
     q = lp.Problem(type="max", vars=names, objective_var="obj",
                    objective_func=list(zip(names, rng.uniform(0.5, 1.5, n).tolist())), constraints=cons)
-    one, many = lp.solve_problem(q), lp.solve_problem(q, devices=devices)
+    one, many = lp.solve_problem(q, native=False), lp.solve_problem(q, devices=devices)
     assert np.array_equal(many.matrix.view(np.int64), one.matrix.view(np.int64))
     assert lp.solution_objective_value(many) == lp.solution_objective_value(one)
     # two-phase problem (>= and = rows): phase 1, hand-over and phase 2 on the partition, same bits
     from tests.helpers import random_mixed_problem
     r = random_mixed_problem(lp, 12, 5, 3, 2, 77)
-    one, many = lp.solve_problem(r), lp.solve_problem(r, devices=devices)
+    one, many = lp.solve_problem(r, native=False), lp.solve_problem(r, devices=devices)
     assert np.array_equal(many.matrix.view(np.int64), one.matrix.view(np.int64))
     assert np.array_equal(many.basis_columns, one.basis_columns) and many.n_pivots == one.n_pivots
     assert lp.solution_objective_value(many) == lp.solution_objective_value(one)
@@ -1338,7 +1338,7 @@ def test_solver_hook_devices_falls_back_when_the_tableau_overflows():
             continue
         found += 1
         outcomes = []
-        for kw in ({}, {"devices": 3}):
+        for kw in ({"native": False}, {"devices": 3}):
             try:
                 s = lp.solve_problem(q, **kw)
                 G = s.matrix

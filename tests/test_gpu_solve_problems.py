@@ -74,8 +74,10 @@ def test_mixed_list_every_member_vs_single_solves_and_the_oracle(golden, devices
         assert st == oracle.OPTIMAL and isinstance(r, lp.Tableau), (k, r)
         assert np.array_equal(r.matrix.view(np.int64), M.view(np.int64)), k
         assert np.array_equal(r.basis_columns, b), k
-        one = lp.solve_problem(p)                                              # the one-problem hook
+        one = lp.solve_problem(p, native=False)                                # the one-problem hook, build-tableau route
         assert np.array_equal(one.matrix.view(np.int64), r.matrix.view(np.int64)), k
+        nat = lp.solve_problem(p, native=True)                                 # ... and its native route
+        assert isinstance(nat, lp.NativeSolution) and lp.solution_objective_value(nat) == lp.solution_objective_value(one)
         assert lp.solution_objective_value(r) == lp.solution_objective_value(one)
         for v in p.vars:
             assert lp.solution_variable(r, v) == lp.solution_variable(one, v), (k, v)
@@ -153,9 +155,13 @@ def test_two_phase_members_run_as_batches(golden, devices):
             continue
         assert st == oracle.OPTIMAL and isinstance(r, lp.Tableau), (k, r)
         assert np.array_equal(r.matrix.view(np.int64), M.view(np.int64)) and np.array_equal(r.basis_columns, b), k
-        one = lp.solve_problem(p)
+        one = lp.solve_problem(p, native=False)
         assert np.array_equal(one.matrix.view(np.int64), r.matrix.view(np.int64)), k
         assert tuple(one.n_pivots) == tuple(r.n_pivots), (k, one.n_pivots, r.n_pivots)
+        nat = lp.solve_problem(p, native=True)
+        assert nat.pivots() == tuple(one.n_pivots) and lp.solution_objective_value(nat) == lp.solution_objective_value(one)
+        for v in p.vars:
+            assert lp.solution_variable(nat, v) == lp.solution_variable(one, v), (k, v)
         solved += 1
     assert solved >= 18
     assert lp.solution_objective_value(got[7]) == 28.5

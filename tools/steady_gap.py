@@ -1,0 +1,78 @@
+"""Where does the time between the kernels of a config-3 block go?  (Round-4 review: the driver's
+box showed 16.5 us per pivot in steady state where the kernels add up to 12.9.)
+
+Runs the steady-state leg of bench.py (1 600 pivots on a warm config-3 tableau) and prints, per
+run: how long the host needed to ENQUEUE the request (mi355x_tab_solve_async returning), how long
+the request took in total, the event-timed kernel averages and the gap per block = (total -
+sum of kernel time) / blocks.  If enqueue ~= total the run is bound by the host's launch rate.
+With --load N, N busy-loop processes per host core keep the host cores occupied meanwhile.
+
+    python tools/steady_gap.py [--load 2] [--pivots 1600] [--events 0|1] [--repeat 3]
+"""
+import argparse
+import ctypes
+import os
+import signal
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from tests.helpers import lp_amd  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--load", type=int, default=0, help="busy-loop processes per host core")
+ap.add_argument("--pivots", type=int, default=1600)
+ap.add_argument("--events", type=int, default=1, help="event pairs around every 4th block (as bench.py)")
+ap.add_argument("--repeat", type=int, default=3)
+args = ap.parse_args()
+
+lp = lp_amd()
+L = lp.capi.lib()
+n, m = 8192, 4096
+
+burners = []
+if args.load:
+    ncpu = os.cpu_count() or 1
+    for _ in range(args.load * ncpu):
+        burners.append(subprocess.Popen(["sh", "-c", "while :; do :; done"], preexec_fn=os.setsid))
+    time.sleep(1.0)
+
+try:
+    for rep in range(args.repeat):
+        h = ctypes.c_void_p()
+        k = ctypes.c_int64(0)
+        lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h), n, m, lp.synth.seed_for(3, 500 + rep), 0, -1, 0), "create")
+        lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, 64, 1), "warm")
+        L.mi355x_tab_sync(h, ctypes.byref(k))
+        if args.events:
+            L.mi355x_tab_timing_enable(h, 4)
+        bk = L.mi355x_tab_block_size(h)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, args.pivots, 0), "run")
+        t1 = time.perf_counter()
+        rc = L.mi355x_tab_sync(h, ctypes.byref(k))
+        t2 = time.perf_counter()
+        blocks = -(-args.pivots // bk)
+        ev = {}
+        for kind, name in ((1, "la"), (0, "sweep")):
+            nl, sm, mn = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+            L.mi355x_tab_timing_read_kind(h, kind, ctypes.byref(nl), ctypes.byref(sm), ctypes.byref(mn))
+            ev[name] = sm.value / nl.value * 1e3 if nl.value else float("nan")
+        tot_us = (t2 - t0) * 1e6
+        kern = (ev["la"] + ev["sweep"]) * blocks
+        print("load=%d events=%d block=%d: enqueue %.2f ms, total %.2f ms = %.2f us/pivot (%.0f pivots/s); "
+              "kernels la %.1f + sweep %.1f us per block; gap_us_per_block %.1f; lost=%d rc=%d"
+              % (args.load, args.events, bk, (t1 - t0) * 1e3, tot_us / 1e3, tot_us / args.pivots,
+                 args.pivots / (t2 - t0), ev["la"], ev["sweep"], (tot_us - kern) / blocks,
+                 L.mi355x_tab_la_lost(h), rc), flush=True)
+        L.mi355x_tab_destroy(h)
+finally:
+    for p in burners:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except OSError:
+            pass
