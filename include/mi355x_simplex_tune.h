@@ -96,9 +96,18 @@ int         mi355x_tune_set_la_one_xcd(int on);              /* 1 (default): all
                                                                 one XCD, verified inside the launch */
 int         mi355x_tune_set_la_max_spins(unsigned polls);    /* polls before a workgroup gives up
                                                                 on a record; 0 = default (2^21)  */
-/* 1 once an exchange of the persistent look-ahead was lost on this handle: the solve carried on
- * (and stays) on the two-launch look-ahead */
+/* How often an exchange of the persistent look-ahead was lost on this handle (0 = never).  After a
+ * loss the solve carries on on the two-launch look-ahead; the persistent form is re-armed after 1024
+ * clean blocks (four times as many after each further loss).  mi355x_debug_set_la_rearm overrides the
+ * number of clean blocks left (tests). */
 int         mi355x_tab_la_lost(const mi355x_tab *t);
+int         mi355x_debug_set_la_rearm(mi355x_tab *t, int64_t blocks);
+/* Which implementation the dispatcher actually enqueued on this handle so far, launches by class:
+ * out8[0] per-pivot updates (k_update), [1] persistent look-ahead blocks (k_la_block), [2] two-launch
+ * look-ahead blocks (k_la_gather / k_la_scale per step), [3] k_sweep16 sweeps, [4] wide sweeps
+ * (k_sweepw + k_sweepw_rest), [5] short sweeps (k_sweep), [6] resident launches (k_resident),
+ * [7] split selects (k_select_gather + k_select_scale). */
+int         mi355x_tab_path_counts(const mi355x_tab *t, int64_t *out8);
 
 /* ---- measurement ------------------------------------------------------------------------ */
 /* HIP-event brackets on the handle's stream (what `mi355x_tab_timing_*` of the main header

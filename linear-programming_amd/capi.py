@@ -135,6 +135,8 @@ _EXTRA = {
     "mi355x_tune_set_la_one_xcd": (_int, [_int]),
     "mi355x_tune_set_la_max_spins": (_int, [ctypes.c_uint]),
     "mi355x_tab_la_lost": (_int, [_p]),
+    "mi355x_debug_set_la_rearm": (_int, [_p, _i64]),
+    "mi355x_tab_path_counts": (_int, [_p, _p]),
     "mi355x_tab_timing_read_kind": (_int, [_p, _int, _p, _p, _p]),
     "mi355x_debug_rhs": (_int, [_p, _p, _i64, _int]),
     "mi355x_debug_repeat_sweep": (_int, [_p, _int, _p]),

@@ -141,9 +141,14 @@ struct mi355x_tab {
     unsigned    res_epoch = 1;
     bool        res_lost = false;
     bool        last_was_resident = false;  // kind of the launch enqueued last (what a kSyncLost status refers to)
-    bool        la_lost = false;          // an exchange of the persistent look-ahead was lost once
-                                          // (its workgroups were not co-resident): this handle
-                                          // stays on the two-launch look-ahead
+    bool        la_lost = false;          // an exchange of the persistent look-ahead was lost (its
+                                          // workgroups were not co-resident): the handle runs the
+                                          // two-launch look-ahead -- until la_rearm_in clean blocks have
+                                          // gone by, then the persistent form gets another try
+    int         la_losses = 0;            // how often that happened on this handle
+    int64_t     la_rearm_in = 0;          // two-launch blocks left before the next try
+    // which implementation the dispatcher actually enqueued, per launch class (mi355x_tab_path_counts)
+    int64_t     path_counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int         n_timed = 0;
     std::vector<hipEvent_t> ev0, ev1;     // around the update / sweep launches
     int         n_timed_la = 0;

@@ -1,0 +1,212 @@
+"""The dispatcher at its thresholds (round-4 review, "What's weak" 2).  Which implementation a
+solve runs is decided by shape alone -- csrc/capi_tab_impl.inc (`block_size`, `block_mode`,
+`resident_mode`, `enqueue_select`), csrc/kernels_launch.inc (`la_block_supported`,
+`wide_block_default`, `resident_plan`):
+
+  * persistent look-ahead (k_la_block): max(rows, stored_ld / 2) <= 8192, i.e. <= 32 workgroups;
+  * pivots per sweep behind it: 16 below 100 MiB of stored tableau, 24 from there on;
+  * without it: 16 below 768 MiB stored, 24 from there on, 28 from 8e9 bytes on;
+  * resident (k_resident): <= 1024 constraints and <= 32 column strips of 64 / 32 / 16 columns;
+  * dense tableaux (basis not unit columns): single-workgroup select up to 1024 rows and a row pitch
+    of 4096 doubles, split select beyond.
+
+A wrong hand-off at such a switch is a wrong pending list, i.e. a wrong pivot.  Every shape below
+straddles one switch; the handle is created with DEFAULT knobs, solves K pivots = three full blocks
+and a block cut short by the cap, and must (i) have enqueued the intended implementation and no
+other (mi355x_tab_path_counts) and (ii) agree with the oracle bit for bit: pivot trace, basis, RHS
+column, objective row and every entry of the tableau."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle
+from tests.helpers import lp_amd
+
+pytestmark = pytest.mark.gpu
+lp = lp_amd()
+
+PER_PIVOT, LA_PERSISTENT, LA_TWO_LAUNCH, SWEEP16, SWEEP_WIDE, SWEEP_SHORT, RESIDENT, SELECT_SPLIT = range(8)
+NAMES = ["per-pivot", "la-persistent", "la-two-launch", "sweep16", "sweep-wide", "sweep-short", "resident", "select-split"]
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _counts(h):
+    out = np.zeros(8, dtype=np.int64)
+    lp.capi.check(lp.capi.lib().mi355x_tab_path_counts(h, _ptr(out)), "path_counts")
+    return out
+
+
+def _stored_bytes(n, m):
+    ld = (n + 1 + 15) // 16 * 16
+    return (m + 1) * ld * 8
+
+
+def _la_workgroups(n, m):
+    ld = (n + 1 + 15) // 16 * 16
+    return (max(m + 1, ld // 2) + 255) // 256
+
+
+def _run(n, m, seed, expect_block, expect_paths, full_compare=True):
+    """Synthetic LP of n variables x m constraints on a default-knob handle: K pivots against the
+    oracle.  expect_paths: the launch classes that must have run (all others must not)."""
+    L = lp.capi.lib()
+    h = ctypes.c_void_p()
+    lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h), n, m, seed, 0, -1, 0), "create_synthetic")
+    t = lp.Tableau(None, lp.Problem(type="max"), None, None, n + m, m, {}, _handle=h)
+    M = t.matrix                                           # the initial tableau as the GPU holds it
+    b = t.basis_columns.copy()
+    if n * m <= 40_000_000:                                # ... which is the generator's (numpy form: small sizes only)
+        M0, b0 = lp.synth.tableau(n, m, seed)
+        assert np.array_equal(M.view(np.int64), M0.view(np.int64)) and np.array_equal(b, b0)
+        del M0
+    K = 3 * max(expect_block, 1) + 7 if RESIDENT not in expect_paths else 55
+    st, npiv, trace = oracle.solve(M, b, max_pivots=K, trace_cap=K, omp=True)
+    assert (st, npiv) == (oracle.MAX_PIVOTS, K), (st, npiv)
+    t._touch()
+    k = ctypes.c_int64(0)
+    rc = L.mi355x_tab_solve(h, 1, 1024.0, K, ctypes.byref(k))
+    assert (rc, k.value) == (lp.capi.MI_MAX_PIVOTS, K)
+    # (i) the intended implementation ran, and nothing else
+    got = _counts(h)
+    ran = {i for i in range(8) if got[i] > 0}
+    assert ran == set(expect_paths), "ran %s, expected %s (counts %s)" % (
+        sorted(NAMES[i] for i in ran), sorted(NAMES[i] for i in expect_paths), got.tolist())
+    assert L.mi355x_tab_block_size(h) == expect_block
+    assert L.mi355x_tab_resident(h) == int(RESIDENT in expect_paths) and L.mi355x_tab_la_lost(h) == 0
+    # (ii) the oracle's pivots and bits
+    tr = t.pivot_trace()
+    assert tr.shape == trace.shape
+    bad = np.where((tr != trace).any(axis=1))[0]
+    assert not len(bad), "first differing pivots %s: got %s, oracle %s" % (bad[:4], tr[bad[:4]], trace[bad[:4]])
+    last_row, last_col, basis = np.empty(n + m + 1), np.empty(m + 1), np.empty(m, dtype=np.int64)
+    lp.capi.check(L.mi355x_tab_download(h, None, _ptr(basis), _ptr(last_row), _ptr(last_col)), "download")
+    assert np.array_equal(basis, b)
+    assert np.array_equal(last_col.view(np.int64), M[:, -1].view(np.int64))
+    assert np.array_equal(last_row.view(np.int64), M[m].view(np.int64))
+    if full_compare:
+        t._touch()
+        G = t.matrix
+        for r0 in range(0, m + 1, 2048):
+            assert np.array_equal(G[r0:r0 + 2048].view(np.int64), M[r0:r0 + 2048].view(np.int64)), r0
+
+
+# ---- persistent look-ahead: 31 / 32 / 33 workgroups, by rows and by column pairs -----------------
+@pytest.mark.parametrize("n,m,wg,persistent", [
+    (600, 7935, 31, True), (600, 8191, 32, True), (600, 8192, 33, False),          # rows = m + 1
+    (15871, 600, 31, True), (16383, 600, 32, True), (16384, 600, 33, False),       # pairs = padded(n + 1) / 2
+], ids=["rows-31wg", "rows-32wg", "rows-33wg", "pairs-31wg", "pairs-32wg", "pairs-33wg"])
+def test_persistent_lookahead_limit(n, m, wg, persistent):
+    assert _la_workgroups(n, m) == wg and _stored_bytes(n, m) < (100 << 20)
+    _run(n, m, lp.synth.seed_for(3, 7000 + wg), 16, [LA_PERSISTENT if persistent else LA_TWO_LAUNCH, SWEEP16])
+
+
+# ---- behind the persistent look-ahead: 16 pivots per sweep below 100 MiB stored, 24 from there on
+@pytest.mark.parametrize("n,m,block", [(4079, 3200, 16), (4095, 3200, 24)], ids=["99.6MiB", "100.03MiB"])
+def test_block_size_switch_at_100_mib(n, m, block):
+    assert (_stored_bytes(n, m) >= (100 << 20)) == (block == 24) and _la_workgroups(n, m) <= 32
+    assert abs(_stored_bytes(n, m) - (100 << 20)) < (1 << 20)
+    _run(n, m, lp.synth.seed_for(3, 7100 + block), block, [LA_PERSISTENT, SWEEP_WIDE if block == 24 else SWEEP16])
+
+
+# ---- without it: 16 below 768 MiB stored, 24 from there on (two-launch look-ahead, wide sweep)
+@pytest.mark.parametrize("n,m,block", [(12271, 8200, 16), (12287, 8200, 24)], ids=["767.8MiB", "768.8MiB"])
+def test_wide_block_switch_at_768_mib(n, m, block):
+    assert _la_workgroups(n, m) > 32
+    assert (_stored_bytes(n, m) >= 768 * 1024 * 1024) == (block == 24)
+    assert abs(_stored_bytes(n, m) - 768 * 1024 * 1024) < (1 << 20)
+    _run(n, m, lp.synth.seed_for(3, 7200 + block), block, [LA_TWO_LAUNCH, SWEEP_WIDE if block == 24 else SWEEP16])
+
+
+# ---- one shape in the middle of the band no BASELINE configuration falls into (268 MB ... 17 GB)
+@pytest.mark.timeout(900, method="thread")
+def test_mid_band_shape_2_3_gb():
+    n, m = 24000, 12000
+    assert 2.2e9 < _stored_bytes(n, m) < 2.4e9
+    _run(n, m, lp.synth.seed_for(3, 7300), 24, [LA_TWO_LAUNCH, SWEEP_WIDE])
+
+
+# ---- 24 -> 28 pivots per sweep at 8e9 bytes stored
+@pytest.mark.timeout(1500, method="thread")
+@pytest.mark.parametrize("n,m,block", [(49000, 20000, 24), (50100, 20000, 28)], ids=["7.84e9", "8.02e9"])
+def test_wide_block_switch_at_8e9_bytes(n, m, block):
+    assert (_stored_bytes(n, m) >= 8e9) == (block == 28) and abs(_stored_bytes(n, m) - 8e9) < 0.2e9
+    _run(n, m, lp.synth.seed_for(3, 7400 + block), block, [LA_TWO_LAUNCH, SWEEP_WIDE])
+
+
+# ---- the resident solve: 1024 / 1025 constraints, 32 / 33 column strips
+@pytest.mark.parametrize("n,m,resident", [
+    (512, 1024, True), (512, 1025, False), (513, 1024, False),        # 16-column strips (TR = 4)
+    (1024, 512, True), (1025, 512, False),                            # 32-column strips (TR = 2)
+    (2048, 256, True), (2049, 256, False),                            # 64-column strips (TR = 1)
+], ids=["m1024-32strips", "m1025", "m1024-33strips", "m512-32strips", "m512-33strips", "m256-32strips", "m256-33strips"])
+def test_resident_limits(n, m, resident):
+    # (mi355x_tab_block_size: what the blocked path WOULD apply per sweep; the resident launch never sweeps)
+    _run(n, m, lp.synth.seed_for(2, 7500 + n + m), 16, [RESIDENT] if resident else [LA_PERSISTENT, SWEEP16])
+
+
+# ---- dense tableaux (the basis is not a set of unit columns): single-workgroup select up to 1024
+# rows / a pitch of 4096 doubles, split select beyond -- per-pivot k_update either way
+@pytest.mark.parametrize("n,m,split", [(100, 1023, False), (100, 1024, True), (3000, 1000, False), (3100, 1000, True)],
+                         ids=["rows-1024", "rows-1025", "pitch-4016", "pitch-4112"])
+def test_dense_select_switch(n, m, split):
+    L = lp.capi.lib()
+    M0, b0 = lp.synth.tableau(n, m, lp.synth.seed_for(2, 7600 + n + m))
+    M0[:m, n:n + m] *= 2.0                                   # basis columns 2 e_i: the tableau stays dense
+    t = lp.Tableau(None, lp.Problem(type="max"), M0, b0, n + m, m, {})
+    M, b = M0.copy(), b0.copy()
+    K = 40
+    st, npiv, trace = oracle.solve(M, b, max_pivots=K, trace_cap=K, omp=True)
+    assert (st, npiv) == (oracle.MAX_PIVOTS, K)
+    k = ctypes.c_int64(0)
+    assert (L.mi355x_tab_solve(t._h, 1, 1024.0, K, ctypes.byref(k)), k.value) == (lp.capi.MI_MAX_PIVOTS, K)
+    t._touch()
+    got = _counts(t._h)
+    ran = {i for i in range(8) if got[i] > 0}
+    assert ran == ({PER_PIVOT, SELECT_SPLIT} if split else {PER_PIVOT}), got.tolist()
+    assert np.array_equal(t.pivot_trace(), trace)
+    assert np.array_equal(t.matrix.view(np.int64), M.view(np.int64)) and np.array_equal(t.basis_columns, b)
+
+
+# ---- a demoted handle gets the persistent look-ahead back (round-4 review, "What's weak" 10)
+def test_persistent_lookahead_is_rearmed_after_clean_blocks(hooks_lib):
+    """A lost exchange (test build: the last workgroup stops publishing) demotes the handle to the
+    two-launch look-ahead; after the clean blocks left on its counter (1024 by default, set to 3 here)
+    the persistent form runs again -- and every pivot on the way is the oracle's."""
+    L = hooks_lib
+    if True:
+        n, m = 1500, 700
+        seed = lp.synth.seed_for(3, 7700)
+        h = ctypes.c_void_p()
+        lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h), n, m, seed, 0, -1, 0), "create")
+        out = np.zeros(8, dtype=np.int64)
+        M, b = lp.synth.tableau(n, m, seed)
+        K = 16 * 12
+        st, npiv, trace = oracle.solve(M, b, max_pivots=K, trace_cap=K)
+        k = ctypes.c_int64(0)
+        L.mi355x_tune_set_la_max_spins(20000)
+        L.mi355x_tune_set_la_fault(4)                         # from step 3 of every block on
+        try:
+            assert L.mi355x_tab_solve(h, 1, 1024.0, 32, ctypes.byref(k)) == lp.capi.MI_MAX_PIVOTS and k.value == 32
+        finally:
+            L.mi355x_tune_set_la_max_spins(0)
+            L.mi355x_tune_set_la_fault(0)
+        assert L.mi355x_tab_la_lost(h) == 1
+        L.mi355x_tab_path_counts(h, _ptr(out))
+        persistent_before, two_launch_before = int(out[LA_PERSISTENT]), int(out[LA_TWO_LAUNCH])
+        assert persistent_before >= 1 and two_launch_before >= 1
+        lp.capi.check(L.mi355x_debug_set_la_rearm(h, 3), "set_la_rearm")
+        assert L.mi355x_tab_solve(h, 1, 1024.0, K - 32, ctypes.byref(k)) == lp.capi.MI_MAX_PIVOTS and k.value == K - 32
+        L.mi355x_tab_path_counts(h, _ptr(out))
+        assert out[LA_TWO_LAUNCH] >= two_launch_before + 2 and out[LA_PERSISTENT] > persistent_before, out.tolist()
+        assert L.mi355x_tab_la_lost(h) == 1                   # no further loss
+        ec, cr, cnt = np.empty(K, dtype=np.int64), np.empty(K, dtype=np.int64), ctypes.c_int64(0)
+        lp.capi.check(L.mi355x_tab_trace(h, _ptr(ec), _ptr(cr), K, ctypes.byref(cnt)), "trace")
+        assert cnt.value == K and np.array_equal(np.stack([ec, cr], axis=1), trace)
+        G, gb = np.empty_like(M), np.empty_like(b)
+        lp.capi.check(L.mi355x_tab_download(h, _ptr(G), _ptr(gb), None, None), "download")
+        assert np.array_equal(G.view(np.int64), M.view(np.int64)) and np.array_equal(gb, b)
+        L.mi355x_tab_destroy(h)

@@ -23,7 +23,7 @@ import torch  # noqa: E402
 from tests.helpers import lp_amd  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--load", type=int, default=0, help="busy-loop processes per host core")
+ap.add_argument("--load", type=float, default=0, help="busy-loop processes per host core (may be a fraction)")
 ap.add_argument("--pivots", type=int, default=1600)
 ap.add_argument("--events", type=int, default=1, help="event pairs around every 4th block (as bench.py)")
 ap.add_argument("--repeat", type=int, default=3)
@@ -32,11 +32,15 @@ args = ap.parse_args()
 lp = lp_amd()
 L = lp.capi.lib()
 n, m = 8192, 4096
+for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+    if os.path.exists(f):
+        print("%s: %s (a quota throttles the whole container once the burners have used it up: waits then end "
+              "on 100 ms period boundaries)" % (f, open(f).read().strip()), flush=True)
 
 burners = []
 if args.load:
     ncpu = os.cpu_count() or 1
-    for _ in range(args.load * ncpu):
+    for _ in range(int(args.load * ncpu)):
         burners.append(subprocess.Popen(["sh", "-c", "while :; do :; done"], preexec_fn=os.setsid))
     time.sleep(1.0)
 
@@ -50,12 +54,18 @@ try:
         if args.events:
             L.mi355x_tab_timing_enable(h, 4)
         bk = L.mi355x_tab_block_size(h)
+        lp.capi.check(L.mi355x_tab_set_stream(h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), 0), "set_stream")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        e0.record()
         lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, args.pivots, 0), "run")
+        e1.record()
         t1 = time.perf_counter()
         rc = L.mi355x_tab_sync(h, ctypes.byref(k))
         t2 = time.perf_counter()
+        torch.cuda.synchronize()
+        gpu_us = e0.elapsed_time(e1) * 1e3
         blocks = -(-args.pivots // bk)
         ev = {}
         for kind, name in ((1, "la"), (0, "sweep")):
@@ -64,10 +74,12 @@ try:
             ev[name] = sm.value / nl.value * 1e3 if nl.value else float("nan")
         tot_us = (t2 - t0) * 1e6
         kern = (ev["la"] + ev["sweep"]) * blocks
-        print("load=%d events=%d block=%d: enqueue %.2f ms, total %.2f ms = %.2f us/pivot (%.0f pivots/s); "
-              "kernels la %.1f + sweep %.1f us per block; gap_us_per_block %.1f; lost=%d rc=%d"
+        print("load=%g events=%d block=%d: enqueue %.2f ms; WALL %.2f ms = %.2f us/pivot (%.0f pivots/s); GPU CLOCK %.2f ms = "
+              "%.2f us/pivot (%.0f pivots/s); host wait after the GPU %.2f ms; kernels la %.1f + sweep %.1f us per block; "
+              "gap_us_per_block (GPU clock) %.1f; lost=%d rc=%d"
               % (args.load, args.events, bk, (t1 - t0) * 1e3, tot_us / 1e3, tot_us / args.pivots,
-                 args.pivots / (t2 - t0), ev["la"], ev["sweep"], (tot_us - kern) / blocks,
+                 args.pivots / (t2 - t0), gpu_us / 1e3, gpu_us / args.pivots, args.pivots / (gpu_us * 1e-6),
+                 (tot_us - gpu_us) / 1e3, ev["la"], ev["sweep"], (gpu_us - kern) / blocks,
                  L.mi355x_tab_la_lost(h), rc), flush=True)
         L.mi355x_tab_destroy(h)
 finally:
