@@ -338,13 +338,21 @@ int  mi355x_multibatch_download(mi355x_multibatch *mb, int64_t lp_index, double 
 /* n-solve-tableau, two-phase branch (src/simplex.lisp:402-452), member by member of two matching
  * batches: member k of `art` is the artificial tableau (a min problem) of the problem whose main
  * tableau is member k of `main_mb` (same member count, row count and sub-batch layout).  Phase 1 runs
- * as the batch loop on `art`; the feasibility test (fp= 0 objective) and the hand-over (437-451) run
- * per member on the devices; phase 2 is the batch loop on `main_mb`.  status[k]: MI_OPTIMAL /
- * MI_UNBOUNDED / MI_INFEASIBLE as mi355x_solve_two_phase, or MI_UNSUPPORTED for a member whose
- * degenerate artificials would have to be pivoted out of the basis first (419-434: per-member row
- * fetches and single pivots) -- solve that problem with mi355x_solve_two_phase from the caller's own
- * copies.  n_pivots: two entries per member (phase 1, phase 2), may be NULL.  Read results with
- * mi355x_multibatch_download(main_mb, k, ...). */
+ * as the batch loop on `art`; the feasibility test (fp= 0 objective), the drive-out pivots of
+ * artificial variables still basic (419-434: row fetches and single pivots on that member inside the
+ * batch) and the hand-over (437-451) run per member on the devices; phase 2 is the batch loop on
+ * `main_mb`.  status[k]: MI_OPTIMAL / MI_UNBOUNDED / MI_INFEASIBLE / MI_ART_NONZERO / MI_ART_STUCK as
+ * mi355x_solve_two_phase.  n_pivots: two entries per member (phase 1 incl. drive-out pivots, phase
+ * 2), may be NULL.  Read results with mi355x_multibatch_download(main_mb, k, ...).
+ * mi355x_multibatch_two_phase_handover is the step between the phases on its own, for a caller that
+ * drives both phases in bounded chunks (mi355x_multibatch_solve with a cap, what the Lisp glue does):
+ * phase1_status = the per-member statuses phase 1 ended with (NULL: all MI_OPTIMAL); status[k] = MI_OK
+ * when member k of main_mb is ready for phase 2, otherwise that member's final outcome (its main
+ * tableau is then neutralised so that the batch loop of phase 2 passes over it); n_driveout per
+ * member, may be NULL. */
+int  mi355x_multibatch_two_phase_handover(mi355x_multibatch *art, mi355x_multibatch *main_mb,
+                                          double fp_factor, const int32_t *phase1_status,
+                                          int32_t *status, int64_t *n_driveout);
 int  mi355x_multibatch_solve_two_phase(mi355x_multibatch *art, mi355x_multibatch *main_mb, int main_is_max,
                                        double fp_factor, int32_t *status, int64_t *n_pivots);
 int  mi355x_multibatch_cancel(mi355x_multibatch *mb);

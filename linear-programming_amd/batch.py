@@ -141,11 +141,22 @@ class MultiDeviceBatch:
                    "mi355x_multibatch_download")
         return M, b
 
+    def two_phase_handover(self, main, fp_tolerance=1024, phase1_status=None):
+        """The step between the phases, member by member (mi355x_multibatch_two_phase_handover):
+        self = the batch of artificial tableaux after phase 1.  -> (status per member: MI_OK = ready
+        for phase 2, otherwise final; drive-out pivots per member)."""
+        st = np.zeros(self.n_lps, dtype=np.int32)
+        nd = np.zeros(self.n_lps, dtype=np.int64)
+        p1 = None if phase1_status is None else np.ascontiguousarray(phase1_status, dtype=np.int32)
+        capi.check(capi.lib().mi355x_multibatch_two_phase_handover(self._h, main._h, float(fp_tolerance),
+                                                                   None if p1 is None else _ptr(p1), _ptr(st), _ptr(nd)),
+                   "mi355x_multibatch_two_phase_handover")
+        return st, nd
+
     def solve_two_phase(self, main, main_is_max=True, fp_tolerance=1024):
         """self = the batch of ARTIFICIAL tableaux, `main` the matching batch of main tableaux
-        (n-solve-tableau's two-phase branch, src/simplex.lisp:402-452, member by member):
-        -> (status per member, pivots (n, 2)).  Status MI_UNSUPPORTED: that member needs drive-out
-        pivots first -- solve it alone."""
+        (n-solve-tableau's two-phase branch, src/simplex.lisp:402-452, member by member, drive-out
+        pivots included): -> (status per member, pivots (n, 2))."""
         st = np.zeros(self.n_lps, dtype=np.int32)
         npv = np.zeros((self.n_lps, 2), dtype=np.int64)
         capi.check(capi.lib().mi355x_multibatch_solve_two_phase(self._h, main._h, int(bool(main_is_max)), float(fp_tolerance),

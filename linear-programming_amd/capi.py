@@ -92,6 +92,7 @@ SIGNATURES = {
     "mi355x_multibatch_solve": (_int, [_p, _int, _dbl, _i64, _p, _p]),
     "mi355x_multibatch_download": (_int, [_p, _i64, _p, _p, _p, _p]),
     "mi355x_multibatch_solve_two_phase": (_int, [_p, _p, _int, _dbl, _p, _p]),
+    "mi355x_multibatch_two_phase_handover": (_int, [_p, _p, _dbl, _p, _p, _p]),
     "mi355x_multibatch_cancel": (_int, [_p]),
     "mi355x_multibatch_destroy": (None, [_p]),
     "mi355x_shard_set_compact": (_int, [_p, _i64, _p]),

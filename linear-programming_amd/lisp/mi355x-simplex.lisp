@@ -118,6 +118,9 @@
 (cffi:defcfun ("mi355x_multibatch_solve_two_phase" %multibatch-solve-two-phase) :int
   (art :pointer) (main :pointer) (main-is-max :int) (fp-factor :double) (status :pointer)
   (n-pivots :pointer))
+(cffi:defcfun ("mi355x_multibatch_two_phase_handover" %multibatch-two-phase-handover) :int
+  (art :pointer) (main :pointer) (fp-factor :double) (phase1-status :pointer) (status :pointer)
+  (n-driveout :pointer))
 (cffi:defcfun ("mi355x_multibatch_download" %multibatch-download) :int
   (handle :pointer) (lp-index :int64) (host-matrix :pointer) (host-basis :pointer)
   (last-row :pointer) (last-col :pointer))
@@ -848,30 +851,53 @@ column and the basis -- all that tableau-variable & co. read (src/simplex.lisp:7
           (dotimes (i (length basis-dst)) (setf (aref basis-dst i) (aref basis i)))
           tab))))
 
-(defun solve-two-phase-batch (pairs devices factor full-tableau)
+(defun multibatch-solve-in-chunks (handle is-max factor rows cols max-pivots n status pivots)
+  "mi355x_multibatch_solve in bounded foreign calls, as for a single tableau: members a chunk left
+at MI_MAX_PIVOTS carry on in the next call (finished ones re-price as optimal at once).  STATUS
+(int32 x N) holds the members' statuses afterwards.  Returns the pivot budget used (chunk caps)."
+  (let ((chunk (chunk-pivots rows cols))
+        (done 0))
+    (loop
+      (let ((cap (if (plusp max-pivots) (min chunk (- max-pivots done)) chunk)))
+        (check (with-foreign-fp-mode
+                 (%multibatch-solve handle is-max factor cap status pivots)))
+        (incf done cap)
+        (when (or (and (plusp max-pivots) (>= done max-pivots))
+                  (loop for k below n
+                        never (= (cffi:mem-aref status :int32 k) +mi-max-pivots+)))
+          (return done))))))
+
+(defun solve-two-phase-batch (pairs devices factor max-pivots full-tableau)
   "PAIRS: lists (art-tableau main-tableau) of ONE shape each and one sense (build-tableau's results
-for two-phase problems, src/simplex.lisp:326-328).  Phase 1 on the batch of artificial tableaux,
-the feasibility test and the hand-over per member, phase 2 on the batch of main tableaux
-(mi355x_multibatch_solve_two_phase; src/simplex.lisp:402-452).  Returns a list parallel to PAIRS:
-the solved main tableau, a condition object, or :ALONE for a member whose degenerate artificials
-must be pivoted out first (the caller solves that problem through the one-problem hook)."
+for two-phase problems, src/simplex.lisp:326-328).  Phase 1 on the batch of artificial tableaux in
+bounded calls, the step between the phases per member on the devices
+(mi355x_multibatch_two_phase_handover: feasibility test, drive-out pivots, hand-over;
+src/simplex.lisp:405-451), phase 2 on the batch of main tableaux in bounded calls.  MAX-PIVOTS (0 =
+none) caps each phase.  Returns a list parallel to PAIRS: the solved main tableau or a condition
+object."
   (let* ((n (length pairs))
+         (art-matrix (tableau-matrix (first (first pairs))))
+         (rows (array-dimension art-matrix 0))
+         (cols (array-dimension art-matrix 1))
          (art-handle (multibatch-create (mapcar #'first pairs) devices))
          (main-handle nil))
     (unwind-protect
          (progn
            (setf main-handle (multibatch-create (mapcar #'second pairs) devices))
-           (cffi:with-foreign-objects ((status :int32 n) (pivots :int64 (* 2 n)))
+           (cffi:with-foreign-objects ((status1 :int32 n) (between :int32 n) (status2 :int32 n)
+                                       (pivots :int64 n))
+             (multibatch-solve-in-chunks art-handle 0 factor rows cols max-pivots n status1 pivots)
              (check (with-foreign-fp-mode
-                      (%multibatch-solve-two-phase art-handle main-handle
-                                                   (max-problem-p (second (first pairs))) factor
-                                                   status pivots)))
+                      (%multibatch-two-phase-handover art-handle main-handle factor status1 between
+                                                      (cffi:null-pointer))))
+             (multibatch-solve-in-chunks main-handle (max-problem-p (second (first pairs))) factor
+                                         rows cols max-pivots n status2 pivots)
              (loop for (nil main-tab) in pairs for k from 0
-                   collect (let ((st (cffi:mem-aref status :int32 k)))
-                             (cond
-                               ((= st -6) :alone)               ; MI_UNSUPPORTED: drive-out pivots first
-                               ((outcome-condition st))
-                               (t (multibatch-read-back main-handle k main-tab full-tableau)))))))
+                   collect (let ((st (if (= (cffi:mem-aref between :int32 k) +mi-optimal+)
+                                         (cffi:mem-aref status2 :int32 k)
+                                         (cffi:mem-aref between :int32 k))))
+                             (or (outcome-condition st)
+                                 (multibatch-read-back main-handle k main-tab full-tableau))))))
       (when main-handle (%multibatch-destroy main-handle))
       (%multibatch-destroy art-handle))))
 
@@ -887,20 +913,8 @@ solution (unbounded-problem-error ...)."
          (handle (multibatch-create tableaus devices)))
     (unwind-protect
          (cffi:with-foreign-objects ((status :int32 n) (pivots :int64 n))
-           ;; bounded foreign calls, as for a single tableau: members a chunk left at MI_MAX_PIVOTS
-           ;; carry on in the next call (finished ones re-price as optimal at once)
-           (let ((chunk (chunk-pivots rows cols))
-                 (done 0))
-             (loop
-               (let ((cap (if (plusp max-pivots) (min chunk (- max-pivots done)) chunk)))
-                 (check (with-foreign-fp-mode
-                          (%multibatch-solve handle (max-problem-p (first tableaus)) factor cap
-                                             status pivots)))
-                 (incf done cap)
-                 (when (or (and (plusp max-pivots) (>= done max-pivots))
-                           (loop for k below n
-                                 never (= (cffi:mem-aref status :int32 k) +mi-max-pivots+)))
-                   (return)))))
+           (multibatch-solve-in-chunks handle (max-problem-p (first tableaus)) factor rows cols
+                                       max-pivots n status pivots)
            (loop for tab in tableaus for k from 0
                  collect (or (outcome-condition (cffi:mem-aref status :int32 k))
                              (multibatch-read-back handle k tab full-tableau))))
@@ -908,7 +922,7 @@ solution (unbounded-problem-error ...)."
 
 (defun mi355x-solve-problems (problems &rest args
                               &key (fp-tolerance 1024) (device 0) (devices 1) (max-pivots 0)
-                                full-tableau (errorp t)
+                                full-tableau (errorp t) native
                               &allow-other-keys)
   "Solves a LIST of problems and returns the list of their solved tableaus, in order -- what
   (mapcar #'solve-problem problems) returns, with the independent LPs running side by side on
@@ -918,9 +932,10 @@ the GPU(s) instead of one after the other.
     multi-device batch (mi355x_multibatch_*: DEVICES sub-batches, one per GPU, no communication).
   * Two-phase problems (build-tableau returned (art main), src/simplex.lisp:326-328) are grouped by
     the shapes of their two tableaux; a group of two or more is a pair of batches -- phase 1, the
-    per-member feasibility test and hand-over (src/simplex.lisp:402-452) and phase 2 on the devices
-    (mi355x_multibatch_solve_two_phase).  Members that need drive-out pivots first, and problems
-    alone in their group, go through MI355X-SIMPLEX-SOLVER one by one.
+    per-member feasibility test, drive-out pivots and hand-over (src/simplex.lisp:402-452) and phase 2
+    on the devices, each phase in bounded foreign calls (mi355x_multibatch_solve with a cap,
+    mi355x_multibatch_two_phase_handover between them).  Problems alone in their group go through
+    MI355X-SIMPLEX-SOLVER one by one.
   * A member without a solution does not abort the others: with :ERRORP NIL its place in the
     result holds the condition object (unbounded-problem-error, infeasible-problem-error,
     unsupported-constraint-error ...); with :ERRORP T (default, what mapcar of solve-problem
@@ -934,9 +949,12 @@ Every returned tableau's results are bit-identical to the single-problem path's.
          (factor (coerce fp-tolerance 'double-float)))
     (flet ((solve-alone (k problem)
              (setf (aref results k)
+                   ;; (:native NIL, the default here, keeps the result list homogeneous -- every member
+                   ;; a `tableau`; :native :auto lets a member solved alone take the native route)
                    (handler-case (mi355x-simplex-solver problem :fp-tolerance fp-tolerance
                                                                 :device device :max-pivots max-pivots
-                                                                :full-tableau full-tableau)
+                                                                :full-tableau full-tableau
+                                                                :native native)
                      (error (c) c)))))
       ;; build-tableau for every member; two-phase members and integer problems leave the batch
       (loop for problem in problems for k from 0
@@ -978,10 +996,9 @@ Every returned tableau's results are bit-identical to the single-problem path's.
          (setf members (reverse members))
          (if (rest members)
              (loop for (k . nil) in members
-                   for outcome in (solve-two-phase-batch (mapcar #'cdr members) devices factor full-tableau)
-                   do (if (eq outcome :alone)
-                          (solve-alone k (nth k problems))
-                          (setf (aref results k) outcome)))
+                   for outcome in (solve-two-phase-batch (mapcar #'cdr members) devices factor
+                                                         max-pivots full-tableau)
+                   do (setf (aref results k) outcome))
              (solve-alone (car (first members)) (nth (car (first members)) problems))))
        groups2))
     (when errorp

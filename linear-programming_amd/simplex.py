@@ -621,16 +621,17 @@ def mi355x_simplex_solver(problem, fp_tolerance=1024, device=0, devices=1, max_p
 simplex_solver = mi355x_simplex_solver
 
 
-def mi355x_solve_problems(problems, fp_tolerance=1024, device=0, devices=1, max_pivots=0, errorp=True):
+def mi355x_solve_problems(problems, fp_tolerance=1024, device=0, devices=1, max_pivots=0, errorp=True, native=False):
     """The glue's `mi355x-solve-problems`: a LIST of problems -> the list of their solved tableaus,
     what [solve_problem(p) for p in problems] returns, with the independent LPs side by side on the
     GPU(s).  Single-phase problems are grouped by tableau shape and sense; a group of two or more
     is ONE multi-device batch (mi355x_multibatch_create / _solve in bounded chunks / _download per
     member / _destroy: `devices` sub-batches, no communication).  Two-phase problems
     (src/simplex.lisp:402-452) are grouped by the shapes of their two tableaux; a group of two or more
-    is a pair of batches through mi355x_multibatch_solve_two_phase.  Integer problems (declined),
-    members that need drive-out pivots and problems alone in their group go through
-    mi355x_simplex_solver one by one.  A member without a solution does not abort the
+    is a pair of batches: phase 1 and phase 2 through mi355x_multibatch_solve in bounded chunks, the
+    per-member feasibility test, drive-out pivots and hand-over through
+    mi355x_multibatch_two_phase_handover.  Integer problems (declined) and problems alone in their
+    group go through mi355x_simplex_solver one by one; max_pivots caps every phase.  A member without a solution does not abort the
     others: errorp False leaves the exception object in its place, errorp True raises the first
     one after every member has been attempted."""
     from .batch import MultiDeviceBatch
@@ -639,7 +640,10 @@ def mi355x_solve_problems(problems, fp_tolerance=1024, device=0, devices=1, max_
 
     def alone(k):
         try:
-            results[k] = mi355x_simplex_solver(problems[k], fp_tolerance=fp_tolerance, device=device)
+            # (native: what the one-problem hook may return for a member solved alone -- False keeps the
+            # list homogeneous, every member a Tableau; "auto" lets lone members take the native route)
+            results[k] = mi355x_simplex_solver(problems[k], fp_tolerance=fp_tolerance, device=device,
+                                               max_pivots=max_pivots, native=native)
         except SolverError as e:
             results[k] = e
 
@@ -659,6 +663,26 @@ def mi355x_solve_problems(problems, fp_tolerance=1024, device=0, devices=1, max_
             alone(k)
         else:
             groups.setdefault((tabs.matrix.shape, tabs.is_max), []).append((k, tabs))
+    def batch_in_chunks(mb, is_max, rows, cols):
+        """The glue's `multibatch-solve-in-chunks`: bounded calls until no member is left at
+        MI_MAX_PIVOTS (or max_pivots are used up); -> (statuses, pivots per member)."""
+        chunk, done = chunk_pivots(rows, cols), 0
+        total = np.zeros(mb.n_lps, dtype=np.int64)
+        while True:
+            cap = min(chunk, max_pivots - done) if max_pivots > 0 else chunk
+            st, npv = mb.solve(is_max=is_max, fp_tolerance=fp_tolerance, max_pivots=cap)
+            total += npv
+            done += cap
+            if (max_pivots > 0 and done >= max_pivots) or not (st == capi.MI_MAX_PIVOTS).any():
+                return st, total
+
+    def adopt(t, mb, q):
+        G, gb = mb.download(q)
+        old, t._handle = t._handle, None
+        if old:
+            capi.lib().mi355x_tab_destroy(old)
+        t._matrix, t._basis, t._stale, t._light = G, gb, False, None
+
     for (shape, is_max), members in groups.items():
         if len(members) == 1:
             alone(members[0][0])
@@ -666,28 +690,19 @@ def mi355x_solve_problems(problems, fp_tolerance=1024, device=0, devices=1, max_
         rows, cols = shape
         mb = MultiDeviceBatch.from_arrays(np.stack([t.matrix for _, t in members]),
                                           np.stack([t.basis_columns for _, t in members]), n_devices=devices)
-        chunk, done = chunk_pivots(rows, cols), 0
-        while True:
-            cap = min(chunk, max_pivots - done) if max_pivots > 0 else chunk
-            st, npv = mb.solve(is_max=is_max, fp_tolerance=fp_tolerance, max_pivots=cap)
-            done += cap
-            if (max_pivots > 0 and done >= max_pivots) or not (st == capi.MI_MAX_PIVOTS).any():
-                break
+        st, npv = batch_in_chunks(mb, is_max, rows, cols)
         for q, (k, t) in enumerate(members):
             try:
                 _raise_for(int(st[q]))
             except SolverError as e:
                 results[k] = e
                 continue
-            G, gb = mb.download(q)
-            old, t._handle = t._handle, None
-            if old:
-                capi.lib().mi355x_tab_destroy(old)
-            t._matrix, t._basis, t._stale, t._light = G, gb, False, None
+            adopt(t, mb, q)
+            t.n_pivots = int(npv[q])
             results[k] = t
-    # two-phase members of one shape: phase 1, the per-member hand-over and phase 2 as batches
-    # (mi355x_multibatch_solve_two_phase); a member that needs drive-out pivots first is declined by
-    # the library and goes through the one-problem hook
+    # two-phase members of one shape: phase 1 in bounded calls on the batch of artificial tableaux, the
+    # per-member step between the phases (feasibility test, drive-out pivots, hand-over:
+    # mi355x_multibatch_two_phase_handover), phase 2 in bounded calls on the batch of main tableaux
     for (ashape, mshape, is_max), members in groups2.items():
         if len(members) == 1:
             alone(members[0][0])
@@ -696,22 +711,18 @@ def mi355x_solve_problems(problems, fp_tolerance=1024, device=0, devices=1, max_
                                            np.stack([a.basis_columns for _, a, _ in members]), n_devices=devices)
         mmb = MultiDeviceBatch.from_arrays(np.stack([t.matrix for _, _, t in members]),
                                            np.stack([t.basis_columns for _, _, t in members]), n_devices=devices)
-        st, npv = amb.solve_two_phase(mmb, main_is_max=is_max, fp_tolerance=fp_tolerance)
+        st1, np1 = batch_in_chunks(amb, False, ashape[0], ashape[1])
+        between, nd = amb.two_phase_handover(mmb, fp_tolerance=fp_tolerance, phase1_status=st1)
+        st2, np2 = batch_in_chunks(mmb, is_max, ashape[0], ashape[1])
         for q, (k, a, t) in enumerate(members):
-            if int(st[q]) == capi.MI_UNSUPPORTED:
-                alone(k)
-                continue
+            st = int(st2[q]) if int(between[q]) == capi.MI_OK else int(between[q])
             try:
-                _raise_for(int(st[q]))
+                _raise_for(st)
             except SolverError as e:
                 results[k] = e
                 continue
-            G, gb = mmb.download(q)
-            old, t._handle = t._handle, None
-            if old:
-                capi.lib().mi355x_tab_destroy(old)
-            t._matrix, t._basis, t._stale, t._light = G, gb, False, None
-            t.n_pivots = (int(npv[q, 0]), int(npv[q, 1]))
+            adopt(t, mmb, q)
+            t.n_pivots = (int(np1[q] + nd[q]), int(np2[q]))
             results[k] = t
     if errorp:
         for r in results:

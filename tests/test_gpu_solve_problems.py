@@ -134,13 +134,13 @@ def _drive_out_problem(seed):
 def test_two_phase_members_run_as_batches(golden, devices):
     """Two-phase members of one shape: phase 1, the per-member feasibility test and hand-over
     (src/simplex.lisp:402-452) and phase 2 as a pair of batches (mi355x_multibatch_solve_two_phase);
-    members that need drive-out pivots are declined by the library and solved alone; infeasible and
+    members that need drive-out pivots get them inside the batch; infeasible and
     unbounded members keep their conditions.  Every member against the one-problem hook (pivot counts
     of both phases included) and the oracle."""
     ps = [random_mixed_problem(lp, 12, 5, 3, 2, 50 + s) for s in range(7)]            # one shape: a pair of batches of 7
     ps += [_golden_problem(golden, "equality"), _golden_problem(golden, "equality")]     # t/simplex.lisp:196-237, twice
     ps += [_golden_problem(golden, "geq"), _golden_problem(golden, "geq")]               # t/simplex.lisp:239-275
-    ps += [_drive_out_problem(s) for s in (282, 957, 959, 1396, 1481, 1610)]             # declined -> alone
+    ps += [_drive_out_problem(s) for s in (282, 957, 959, 1396, 1481, 1610)]             # drive-out pivots inside the batch
     ps += [random_mixed_problem(lp, 12, 5, 3, 2, 70 + s, kind="min") for s in range(3)]  # the same shape, min
     ps += [_golden_problem(golden, "infeasible"), _golden_problem(golden, "infeasible")]
     got = lp.solve_problems(ps, devices=devices, errorp=False)
@@ -169,8 +169,9 @@ def test_two_phase_members_run_as_batches(golden, devices):
 
 
 def test_multibatch_two_phase_entry_point_directly(golden):
-    """mi355x_multibatch_solve_two_phase through ctypes: statuses and pivot counts per member, the
-    declined member (MI_UNSUPPORTED) next to ordinary ones, argument checks."""
+    """mi355x_multibatch_solve_two_phase / _two_phase_handover through ctypes: statuses and pivot
+    counts per member, members that need drive-out pivots (src/simplex.lisp:419-434) solved inside the
+    batch, argument checks."""
     import ctypes
     L = lp.capi.lib()
     ps = [_drive_out_problem(s) for s in (282, 957, 959)]
@@ -180,7 +181,43 @@ def test_multibatch_two_phase_entry_point_directly(golden):
     amb = lp.MultiDeviceBatch.from_arrays(np.stack([a.matrix for a, _ in tabs]), np.stack([a.basis_columns for a, _ in tabs]), n_devices=2)
     mmb = lp.MultiDeviceBatch.from_arrays(np.stack([t.matrix for _, t in tabs]), np.stack([t.basis_columns for _, t in tabs]), n_devices=2)
     st, npv = amb.solve_two_phase(mmb)
-    assert (st == lp.capi.MI_UNSUPPORTED).all() and (npv[:, 1] == 0).all()
+    # (round 4: such members were declined with MI_UNSUPPORTED) the drive-out pivots of
+    # src/simplex.lisp:419-434 now run on the member inside the batch: outcome, pivot counts of both
+    # phases and every bit of the solved main tableau as mi355x_solve_two_phase on that problem alone
+    for q, p in enumerate(ps):
+        one_tabs = lp.build_tableau(p, p)
+        try:
+            one = lp.n_solve_tableau(one_tabs)
+            want = lp.capi.MI_OPTIMAL
+        except lp.UnboundedProblemError:
+            one, want = one_tabs[1], lp.capi.MI_UNBOUNDED
+        assert int(st[q]) == want, (q, st)
+        assert tuple(npv[q]) == tuple(one.n_pivots), (q, npv[q], one.n_pivots)
+        assert npv[q, 0] >= 1                                   # phase 1 itself made no pivot: these ARE drive-out pivots
+        if want == lp.capi.MI_OPTIMAL:
+            G, gb = mmb.download(q)
+            assert np.array_equal(G.view(np.int64), one.matrix.view(np.int64)) and np.array_equal(gb, one.basis_columns), q
+    # the same through the step-by-step form (what the glue drives in bounded chunks)
+    amb2 = lp.MultiDeviceBatch.from_arrays(np.stack([a.matrix for a, _ in tabs]), np.stack([a.basis_columns for a, _ in tabs]), n_devices=2)
+    mmb2 = lp.MultiDeviceBatch.from_arrays(np.stack([t.matrix for _, t in tabs]), np.stack([t.basis_columns for _, t in tabs]), n_devices=2)
+    st1, np1 = amb2.solve(is_max=False)
+    between, nd = amb2.two_phase_handover(mmb2, phase1_status=st1)
+    st2, np2 = mmb2.solve(is_max=True)
+    assert (between == lp.capi.MI_OK).all() and (nd >= 1).all() and np.array_equal(np1 + nd, npv[:, 0]) and np.array_equal(np2, npv[:, 1])
+    assert np.array_equal(st2, st)
+    for q in range(len(ps)):
+        A, _ = mmb.download(q)
+        B, _ = mmb2.download(q)
+        assert np.array_equal(A.view(np.int64), B.view(np.int64)), q
+    # a member whose phase 1 did not end optimal keeps that status and its main tableau is passed over
+    p1 = st1.copy(); p1[1] = lp.capi.MI_MAX_PIVOTS
+    amb3 = lp.MultiDeviceBatch.from_arrays(np.stack([a.matrix for a, _ in tabs]), np.stack([a.basis_columns for a, _ in tabs]), n_devices=2)
+    mmb3 = lp.MultiDeviceBatch.from_arrays(np.stack([t.matrix for _, t in tabs]), np.stack([t.basis_columns for _, t in tabs]), n_devices=2)
+    amb3.solve(is_max=False)
+    b3, _ = amb3.two_phase_handover(mmb3, phase1_status=p1)
+    assert b3[1] == lp.capi.MI_MAX_PIVOTS and b3[0] == lp.capi.MI_OK and b3[2] == lp.capi.MI_OK
+    s3, n3 = mmb3.solve(is_max=True)
+    assert n3[1] == 0 and s3[1] == lp.capi.MI_OPTIMAL           # all-zero objective row: priced as optimal at once
     other = lp.MultiDeviceBatch.from_arrays(np.stack([t.matrix for _, t in tabs]), np.stack([t.basis_columns for _, t in tabs]), n_devices=1)
     s4 = np.zeros(3, dtype=np.int32)
     assert L.mi355x_multibatch_solve_two_phase(amb._h, other._h, 1, 1024.0, s4.ctypes.data_as(ctypes.c_void_p), None) == lp.capi.MI_BAD_ARG
