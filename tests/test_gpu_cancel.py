@@ -322,7 +322,7 @@ def test_two_phase_cancel_requested_before_the_call(which):
     and a second call runs to the oracle's optimum."""
     from tests.helpers import random_mixed_problem
     L = lp.capi.lib()
-    p = random_mixed_problem(lp, 80, 30, 20, 10, 3)
+    p = random_mixed_problem(lp, 80, 30, 20, 10, 5)
     art, main = lp.build_tableau(p, p)
     if which in ("art", "both"):
         L.mi355x_tab_cancel(art._h)

@@ -131,7 +131,7 @@ def test_dispatch_rule_follows_the_numbers(golden):
     assert isinstance(lp.solve_problem(big), lp.Tableau)
 
 
-@pytest.mark.parametrize("n,mle,mge,meq,seed", [(12, 5, 3, 2, 77), (60, 20, 15, 8, 5), (80, 30, 20, 10, 3)])
+@pytest.mark.parametrize("n,mle,mge,meq,seed", [(12, 5, 3, 2, 77), (60, 20, 15, 8, 5), (80, 30, 20, 10, 5)])
 def test_stepped_job_takes_the_pivots_of_one_long_call(n, mle, mge, meq, seed):
     """A two-phase job stepped with caps that fall inside phase 1, on the hand-over and inside phase
     2 ends in the bits of the one-call solver and of the oracle; the pivot counts add up."""
