@@ -235,6 +235,15 @@ int64_t mi355x_problem_to_json(const mi355x_problem *p, char *buf, int64_t cap);
  * recently read by the calling thread, in problem-vars order: mi355x_mps_var_name. */
 int  mi355x_problem_read_mps(const char *text, int64_t len, int default_is_max, const char *rhs_id,
                              int read_case, mi355x_problem **out);
+/* The same with options.  flags = 0 is mi355x_problem_read_mps: single-variable rows are folded into
+ * bounds exactly as the reference's loop does it (src/external-formats.lisp:312-323, quirks included:
+ * a `<=` row writes (lb-max ub bound) into the upper bound, a `>=` row turns the variable integer, the
+ * coefficient's sign is ignored, the constraint after a folded row is skipped).
+ * MI_MPS_SINGLE_VARIABLE_ROWS_AS_MEANT: fold them the way the rows read instead (`<=` tightens the
+ * upper bound, `>=` the lower bound, the sense flips for a negative coefficient, `=` fixes). */
+#define MI_MPS_SINGLE_VARIABLE_ROWS_AS_MEANT 1
+int  mi355x_problem_read_mps_ex(const char *text, int64_t len, int default_is_max, const char *rhs_id,
+                                int read_case, int flags, mi355x_problem **out);
 int64_t     mi355x_mps_var_count(void);
 const char *mi355x_mps_var_name(int64_t i);
 const char *mi355x_mps_objective_name(void);

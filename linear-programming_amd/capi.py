@@ -59,6 +59,7 @@ SIGNATURES = {
     "mi355x_problem_destroy": (None, [_p]),
     "mi355x_problem_to_json": (_i64, [_p, ctypes.c_char_p, _i64]),
     "mi355x_problem_read_mps": (_int, [ctypes.c_char_p, _i64, _int, ctypes.c_char_p, _int, _pp]),
+    "mi355x_problem_read_mps_ex": (_int, [ctypes.c_char_p, _i64, _int, ctypes.c_char_p, _int, _int, _pp]),
     "mi355x_mps_var_count": (_i64, []),
     "mi355x_mps_var_name": (ctypes.c_char_p, [_i64]),
     "mi355x_mps_objective_name": (ctypes.c_char_p, []),

@@ -12,12 +12,14 @@
 // been meant as written, none is exercised by its tests):
 //   * RANGES looks rows up by name (the reference interns the name as a symbol and then
 //     searches a string-keyed table, :253-258, which can never match);
-//   * a single-variable `<=` row tightens the UPPER bound and a `>=` row the LOWER bound
-//     (the reference writes lb-max into the upper-bound slot and ub-min into the integer flag,
-//     :313-318), with the sense reversed for a negative coefficient;
+//   * (opt-in, MI_MPS_SINGLE_VARIABLE_ROWS_AS_MEANT) a single-variable `<=` row tightens the UPPER
+//     bound and a `>=` row the LOWER bound, with the sense reversed for a negative coefficient.  By
+//     default such rows are handled as the reference handles them (:312-323: lb-max into the
+//     upper-bound slot, ub-min into the integer flag, the row after a folded one skipped);
 //   * numbers are read with strtod (the reference's hand-written exponent parsing, :150-161,
 //     discards the exponent); plain decimals such as 4.5 give the same double;
-//   * row / variable order is file order (the reference iterates hash tables).
+//   * variable order is file order (the reference iterates hash tables); constraints come out in file
+//     order with the opt-in above, in the reference's push order (reverse of the rows) by default.
 #include "../../include/mi355x_simplex.h"
 
 #include <algorithm>
@@ -112,6 +114,12 @@ extern "C" {
 
 int mi355x_problem_read_mps(const char *text, int64_t len, int default_is_max, const char *rhs_id_in,
                             int read_case, mi355x_problem **out)
+{
+    return mi355x_problem_read_mps_ex(text, len, default_is_max, rhs_id_in, read_case, 0, out);
+}
+
+int mi355x_problem_read_mps_ex(const char *text, int64_t len, int default_is_max, const char *rhs_id_in,
+                               int read_case, int flags, mi355x_problem **out)
 {
     if (!text || len < 0 || !out) return mfail(MI_BAD_ARG, "bad arguments");
     *out = nullptr;
@@ -245,22 +253,69 @@ int mi355x_problem_read_mps(const char *text, int64_t len, int default_is_max, c
     }
     // single-variable rows become bounds, negative right-hand sides are flipped, :312-335
     std::vector<Row> kept;
-    for (Row &c : cons) {
-        if (c.var.size() == 1 && c.coef[0] != 0.0) {
-            VarInfo &vi = vinfo[(size_t)c.var[0]];
-            const double bound = c.rhs / c.coef[0];
-            int op = c.type;
-            if (c.coef[0] < 0 && op != 2) op = 1 - op;
-            if (op == 0 || op == 2) { vi.ub = vi.has_ub ? std::min(vi.ub, bound) : bound; vi.has_ub = true; }
-            if (op == 1 || op == 2) { vi.lb = vi.has_lb ? std::max(vi.lb, bound) : bound; vi.has_lb = true; }
-            continue;
+    if (flags & MI_MPS_SINGLE_VARIABLE_ROWS_AS_MEANT) {
+        // opt-in: what such a row MEANS -- `<=` tightens the upper bound, `>=` the lower bound, the
+        // sense flips for a negative coefficient, `=` fixes the variable; every row is looked at
+        for (Row &c : cons) {
+            if (c.var.size() == 1 && c.coef[0] != 0.0) {
+                VarInfo &vi = vinfo[(size_t)c.var[0]];
+                const double bound = c.rhs / c.coef[0];
+                int op = c.type;
+                if (c.coef[0] < 0 && op != 2) op = 1 - op;
+                if (op == 0 || op == 2) { vi.ub = vi.has_ub ? std::min(vi.ub, bound) : bound; vi.has_ub = true; }
+                if (op == 1 || op == 2) { vi.lb = vi.has_lb ? std::max(vi.lb, bound) : bound; vi.has_lb = true; }
+                continue;
+            }
+            if (c.rhs < 0) {
+                for (auto &x : c.coef) x = -x;
+                c.rhs = -c.rhs;
+                c.type = c.type == 0 ? 1 : c.type == 1 ? 0 : 2;
+            }
+            kept.push_back(c);
         }
-        if (c.rhs < 0) {
-            for (auto &x : c.coef) x = -x;
-            c.rhs = -c.rhs;
-            c.type = c.type == 0 ? 1 : c.type == 1 ? 0 : 2;
+    } else {
+        // default: the reference's loop as written (:312-335).  `constraints` is the list PUSH left --
+        // the rows in reverse (hash tables iterated in insertion order, as SBCL does), a RANGES
+        // companion ahead of its row.  A single-variable row (info = (lb ub integer-flag), :313-318):
+        //   <=   ub   := (lb-max ub bound)        nil -> bound, else the LARGER one; the sign of the
+        //   >=   flag := (ub-min flag bound)      coefficient is not looked at; the integer flag becomes
+        //   =    both                             a number, i.e. true: the variable turns integer
+        // and is then spliced out by copying the NEXT cell over it (:320-321) -- the loop moves on to the
+        // cell after that, so the constraint that followed a single-variable row is neither folded nor
+        // has its negative right-hand side flipped; a single-variable row at the END of the list leaves
+        // NIL in its place.
+        std::vector<Row> L(cons.rbegin(), cons.rend());
+        std::vector<char> flag_is_number(vinfo.size(), 0);
+        size_t i = 0;
+        while (i < L.size()) {
+            Row &c = L[i];
+            if (c.var.size() == 1) {
+                const size_t v = (size_t)c.var[0];
+                VarInfo &vi = vinfo[v];
+                if (c.coef[0] == 0.0) return mfail(MI_BAD_ARG, "single-variable row with a zero coefficient: the reference divides by it (:315)");
+                const double bound = c.rhs / c.coef[0];
+                if (c.type == 0 || c.type == 2) { vi.ub = vi.has_ub ? std::max(vi.ub, bound) : bound; vi.has_ub = true; }
+                if (c.type == 1 || c.type == 2) {
+                    if (vi.integer && !flag_is_number[v])
+                        return mfail(MI_BAD_ARG, "a >= / = single-variable row on an integer variable: the reference calls (min t bound) (:317-318)");
+                    vi.integer = true;
+                    flag_is_number[v] = 1;
+                }
+                if (i + 1 == L.size())
+                    return mfail(MI_UNSUPPORTED, "a single-variable row ends the reference's constraint list: it leaves NIL among the "
+                                                 "problem's constraints (:320-321), which no solver accepts");
+                L.erase(L.begin() + (std::ptrdiff_t)i);           // the next cell's contents move here ...
+                i += 1;                                            // ... and are stepped over
+                continue;
+            }
+            if (c.rhs < 0) {
+                for (auto &x : c.coef) x = -x;
+                c.rhs = -c.rhs;
+                c.type = c.type == 0 ? 1 : c.type == 1 ? 0 : 2;
+            }
+            i += 1;
         }
-        kept.push_back(c);
+        kept = L;
     }
 
     mi355x_problem *p = nullptr;

@@ -173,21 +173,23 @@ class NativeSolution:
 _READ_CASE = {"upcase": 0, "downcase": 1, "preserve": 2, "invert": 3}
 
 
-def read_mps(text, problem_type=None, rhs_id=None, read_case="upcase"):
+def read_mps(text, problem_type=None, rhs_id=None, read_case="upcase", single_variable_rows="reference"):
     """read-mps (src/external-formats.lisp:78-348) through the native reader
     (csrc/mps_reader.cpp): fixed-width MPS text -> `Problem`.  problem_type: 'max' / 'min' /
-    None (the file's OBJSENSE section decides)."""
+    None (the file's OBJSENSE section decides).  single_variable_rows: "reference" (default: folded
+    into bounds exactly as src/external-formats.lisp:312-323 does, quirks included) or "as-meant"."""
     import json
     from .conditions import ParsingError
     from .problem import Problem
     L = capi.lib()
     data = text.encode("utf-8") if isinstance(text, str) else bytes(text)
     h = ctypes.c_void_p()
-    rc = L.mi355x_problem_read_mps(data, len(data),
-                                   {None: -1, "max": 1, "min": 0}[problem_type],
-                                   None if rhs_id is None else rhs_id.encode("utf-8"),
-                                   _READ_CASE[read_case], ctypes.byref(h))
-    if rc == capi.MI_BAD_ARG:
+    rc = L.mi355x_problem_read_mps_ex(data, len(data),
+                                      {None: -1, "max": 1, "min": 0}[problem_type],
+                                      None if rhs_id is None else rhs_id.encode("utf-8"),
+                                      _READ_CASE[read_case],
+                                      {"reference": 0, "as-meant": 1}[single_variable_rows], ctypes.byref(h))
+    if rc in (capi.MI_BAD_ARG, capi.MI_UNSUPPORTED):
         raise ParsingError(L.mi355x_last_error().decode("utf-8", "replace"))
     capi.check(rc, "mi355x_problem_read_mps")
     try:

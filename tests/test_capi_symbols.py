@@ -253,5 +253,5 @@ def test_python_mirror_replays_the_glue_call_for_call():
     glue_calls = {lisp_to_c[n] for n in set(re.findall(r"\((%[\w-]+)[\s)]", re.sub(r";[^\n]*", "", native)))}
     py = open(os.path.join(ROOT, "linear-programming_amd", "native.py")).read()
     py_calls = set(re.findall(r"\b(mi355x_(?:problem|simplex_solver|solution|var_mapping)\w*)\(", py))
-    py_calls -= {"mi355x_problem_read_mps", "mi355x_problem_to_json", "mi355x_simplex_solver"}   # (the MPS reader, the one-shot form)
+    py_calls -= {"mi355x_problem_read_mps", "mi355x_problem_read_mps_ex", "mi355x_problem_to_json", "mi355x_simplex_solver"}   # (the MPS reader, the one-shot form)
     assert glue_calls == py_calls, (sorted(glue_calls - py_calls), sorted(py_calls - glue_calls))

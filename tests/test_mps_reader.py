@@ -94,7 +94,7 @@ BOUNDS
 ENDATA
 this text after ENDATA is not part of the problem
 """
-    p = read_mps(text, "max", read_case="preserve")
+    p = read_mps(text, "max", read_case="preserve", single_variable_rows="as-meant")
     assert p.vars == ["x", "y", "z"] and p.integer_vars == ["x"]
     b = dict(p.var_bounds)
     assert b["x"] == (1.0, 3.0)            # LI 1, and the single-variable row 2x <= 6
@@ -103,6 +103,16 @@ this text after ENDATA is not part of the problem
                                           (">=", [("x", 1.0), ("y", 1.0)], 1.5),     # range 2.5
                                           (">=", [("x", 1.0), ("z", 1.0)], 1.0),
                                           ("=", [("y", 1.0), ("z", -1.0)], 7.0)])     # flipped
+    # the default = the reference's loop as written (src/external-formats.lisp:312-335).  Its
+    # constraint list is (onlyx eq1 lim2 lim1-range lim1) -- push order; `onlyx` is folded into x's upper
+    # bound and spliced out by copying `eq1` over it, and the loop steps past that cell: eq1 keeps its
+    # negative right-hand side
+    q = read_mps(text, "max", read_case="preserve")
+    assert q.vars == p.vars and q.integer_vars == ["x"] and dict(q.var_bounds) == b
+    assert q.constraints == [("=", [("y", -1.0), ("z", 1.0)], -7.0),                 # NOT flipped: skipped
+                             (">=", [("x", 1.0), ("z", 1.0)], 1.0),
+                             (">=", [("x", 1.0), ("y", 1.0)], 1.5),
+                             ("<=", [("x", 1.0), ("y", 1.0)], 4.0)]
 
 
 @pytest.mark.gpu
@@ -116,13 +126,7 @@ def test_mps_to_solution_on_gpu():
     assert abs(sol.variable("Z") - 3.5) < 1e-12
 
 
-def test_single_variable_rows_deliberate_deviation_from_the_reference():
-    """Single-variable rows become bounds.  The reference (src/external-formats.lisp:312-323)
-    writes a `<=` row's bound with lb-max into the UPPER-bound slot, a `>=` row's bound into the
-    INTEGER-flag slot, and ignores the coefficient's sign; this reader does what the row means
-    (documented in csrc/mps_reader.cpp and INTEGRATION.md): `<=` tightens the upper bound, `>=`
-    the lower bound, the sense flips for a negative coefficient, `=` fixes the variable."""
-    text = """NAME          t
+SINGLE_VARIABLE_TEXT = """NAME          t
 ROWS
  N  cost
  L  both
@@ -148,7 +152,12 @@ RHS
     r         fixw      10              negv      -8
 ENDATA
 """
-    p = read_mps(text, "max", read_case="preserve")
+
+
+def test_single_variable_rows_as_meant_is_opt_in():
+    """MI_MPS_SINGLE_VARIABLE_ROWS_AS_MEANT: `<=` tightens the upper bound, `>=` the lower bound, the
+    sense flips for a negative coefficient, `=` fixes the variable, every row is looked at."""
+    p = read_mps(SINGLE_VARIABLE_TEXT, "max", read_case="preserve", single_variable_rows="as-meant")
     b = dict(p.var_bounds)
     assert b["v"] == (0.0, 4.0)            # -2v >= -8  <=>  v <= 4 (sense flipped by the sign)
     assert b["x"] == (0.0, 3.0)            # 2x <= 6
@@ -157,3 +166,68 @@ ENDATA
     assert b["w"] == (2.0, 2.0)            # 5w = 10
     assert p.integer_vars == []            # nothing leaks into the integer flags
     assert _cset(p.constraints) == _cset([("<=", [("x", 1.0), ("y", 1.0), ("z", 1.0), ("v", 1.0), ("w", 1.0)], 100.0)])
+    # the reference on the same text: its list is (fixw negv negz loy upx both); fixw turns w integer
+    # with upper bound 2 and is spliced out, negv is stepped over, negz writes 8 / -2 = -4 into z's UPPER
+    # bound (the coefficient's sign is not looked at) -> (0 . -4) -> invalid-bounds-error (:343)
+    with pytest.raises(lp.ParsingError, match="invalid bounds"):
+        read_mps(SINGLE_VARIABLE_TEXT, "max", read_case="preserve")
+
+
+def _mps(rows, columns, rhs):
+    return "NAME          t\nROWS\n N  cost\n%sCOLUMNS\n%sRHS\n%sENDATA\n" % (rows, columns, rhs)
+
+
+def test_single_variable_rows_as_the_reference_folds_them():
+    """src/external-formats.lisp:312-323 by hand.  Rows both, keep, upx, loy, fixw -> the list push
+    leaves is (fixw loy upx keep both):
+      fixw  5w = 10   ub(w) := (lb-max nil 2) = 2, flag(w) := (ub-min nil 2) = 2: w is integer now; spliced
+                      out by copying loy over it, the loop steps past that cell
+      loy             stepped over: stays a CONSTRAINT 4y >= 2
+      upx   2x <= 6   ub(x) := 3; spliced out, keep is copied over it
+      keep            stepped over: x + y >= -3 keeps its negative right-hand side
+      both            an ordinary row."""
+    text = _mps(" L  both\n G  keep\n L  upx\n G  loy\n E  fixw\n",
+                "    x         cost      1               both      1\n"
+                "    x         keep      1               upx       2\n"
+                "    y         cost      1               both      1\n"
+                "    y         keep      1               loy       4\n"
+                "    w         cost      1               both      1\n"
+                "    w         fixw      5\n",
+                "    r         both      100             keep      -3\n"
+                "    r         upx       6               loy       2\n"
+                "    r         fixw      10\n")
+    p = read_mps(text, "max", read_case="preserve")
+    assert p.vars == ["x", "y", "w"] and p.integer_vars == ["w"]
+    assert dict(p.var_bounds) == {"x": (0.0, 3.0), "w": (0.0, 2.0)}
+    assert p.constraints == [(">=", [("y", 4.0)], 2.0),
+                             (">=", [("x", 1.0), ("y", 1.0)], -3.0),
+                             ("<=", [("x", 1.0), ("y", 1.0), ("w", 1.0)], 100.0)]
+    # a `>=` row that IS looked at turns its variable integer and leaves the bounds alone (:317)
+    text = _mps(" L  both\n G  loy\n",
+                "    x         cost      1               both      1\n"
+                "    y         cost      1               both      1\n"
+                "    y         loy       4\n",
+                "    r         both      100             loy       2\n")
+    p = read_mps(text, "max", read_case="preserve")
+    assert p.integer_vars == ["y"] and p.var_bounds == [] and p.constraints == [("<=", [("x", 1.0), ("y", 1.0)], 100.0)]
+    # lb-max into the upper bound: of two `<=` rows on x the LARGER bound survives (:316)
+    text = _mps(" L  both\n L  up1\n L  mid\n L  up2\n",
+                "    x         cost      1               both      1\n"
+                "    x         up1       1               up2       1\n"
+                "    x         mid       1\n"
+                "    y         cost      1               both      1\n"
+                "    y         mid       1\n",
+                "    r         both      100             up1       3\n"
+                "    r         up2       7               mid       50\n")
+    p = read_mps(text, "max", read_case="preserve")          # list (up2 mid up1 both): up2 folded, mid stepped over, up1 folded
+    assert dict(p.var_bounds) == {"x": (0.0, 7.0)}
+    assert p.constraints == [("<=", [("x", 1.0), ("y", 1.0)], 50.0), ("<=", [("x", 1.0), ("y", 1.0)], 100.0)]
+    # a single-variable row at the END of the list leaves NIL among the constraints (:320-321)
+    text = _mps(" G  loy\n L  both\n",
+                "    x         cost      1               both      1\n"
+                "    y         cost      1               both      1\n"
+                "    y         loy       4\n",
+                "    r         both      100             loy       2\n")
+    with pytest.raises(lp.ParsingError, match="NIL"):
+        read_mps(text, "max", read_case="preserve")
+    assert read_mps(text, "max", read_case="preserve", single_variable_rows="as-meant").var_bounds == [("y", (0.5, None))]
