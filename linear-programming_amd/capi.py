@@ -122,6 +122,7 @@ SIGNATURES = {
 # tuning / measurement / test hooks: include/mi355x_simplex_tune.h (not the drop-in boundary)
 _EXTRA = {
     "mi355x_tune_set_sweep_impl": (_int, [_int]),
+    "mi355x_tune_set_sweepw_ring": (_int, [_int]),
     "mi355x_tune_set_shard_la_split": (_int, [_int]),
     "mi355x_tune_set_tail_policy": (_int, [_int]),
     "mi355x_tune_set_resident": (_int, [_int]),

@@ -21,13 +21,18 @@ def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-@pytest.fixture(params=[24, 28])
+@pytest.fixture(params=[(24, 1), (28, 1), (24, 0), (28, 0)], ids=["24-ring", "28-ring", "24-registers", "28-registers"])
 def wide(request):
+    """Pivots per pass, and the form of the streaming kernel: the tile's rows through a per-wave LDS
+    ring (k_sweepw_ring, the default since round 5) or through two register sets (k_sweepw)."""
     L = lp.capi.lib()
-    assert L.mi355x_tune_set_block(request.param) == request.param
+    k, ring = request.param
+    assert L.mi355x_tune_set_block(k) == k
+    L.mi355x_tune_set_sweepw_ring(ring)
     L.mi355x_tune_set_select_mode(2)                    # small shapes too: the blocked path
-    yield request.param
+    yield k
     L.mi355x_tune_set_block(0)
+    L.mi355x_tune_set_sweepw_ring(1)
     L.mi355x_tune_set_select_mode(0)
 
 
