@@ -70,7 +70,9 @@ struct BlockCtl {
 // Record one workgroup of the persistent look-ahead kernel publishes per exchange: eight
 // self-validating granules {tag = 32-bit epoch, 32 bits of payload}, each written by one 8-byte
 // store (a reduction candidate (value, index, payload), a flag and two doubles; layout in
-// simplex_kernels.hip, la_exchange).  One record per 64-byte line.
+// simplex_kernels.hip, la_exchange).  Since round 5 the buffer of kMaxLaRecords records is laid out
+// TRANSPOSED -- granule j of record R at 8-byte word j * kMaxLaRecords + R -- so that the collecting
+// wave reads consecutive granules with consecutive lanes; ExchRec only sizes the buffer.
 struct ExchRec {
     unsigned long long g[8];
 };
