@@ -47,7 +47,9 @@ int         mi355x_tune_set_sweep_impl(int impl);            /* 0 k_sweep16 for 
 int         mi355x_tune_set_sweepw_ring(int on);             /* wide sweeps (k > 16 pivots per pass): 1
                                                                 (default) the tile's rows travel through a
                                                                 per-wave LDS ring (k_sweepw_ring), 0 the
-                                                                register form of round 4 (k_sweepw)      */
+                                                                register form of round 4 (k_sweepw); A/B of
+                                                                the ring's cache policy: 2 no non-temporal
+                                                                access, 3 non-temporal stores only        */
 int         mi355x_tune_set_shard_la_split(int mode);        /* column shards, local look-ahead step:
                                                                 0 by size, 1 one workgroup, 2 many */
 int         mi355x_tune_set_colpart_exchange(int mode);      /* column partition over RCCL, how the
