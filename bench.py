@@ -67,6 +67,8 @@ def parse():
                     help="tuning: pivots selected ahead and applied per sweep (0 = library default, 1 = off)")
     ap.add_argument("--batch-block", type=int, default=0,
                     help="tuning, cfg4: pivots per pass of the blocked per-LP kernel (0 = default, 1 = off)")
+    ap.add_argument("--sweepw-ring", type=int, default=1,
+                    help="tuning: wide sweeps through the per-wave LDS ring (1, default) or the register form of round 4 (0)")
     ap.add_argument("--sweep-tr", type=int, default=0, help="tuning: rows per sweep workgroup")
     ap.add_argument("--sweep-nt", type=int, default=-1, help="tuning: non-temporal sweep accesses (0/1)")
     ap.add_argument("--multi-gpu", default="colpart", choices=["colpart", "independent"],
@@ -447,7 +449,7 @@ def pmc_traffic(workload, kernel):
     WRITE_SIZE in separate runs, FETCH doubled per the gfx950 correction, calibrated on a copy of
     the same buffer -- profiles/rNN_cfg3_pmc_traffic.json).  PMC counters cannot be collected
     from inside this process, so the number is the last profiled one for this kernel, or None."""
-    for tag in ("r04", "r03", "r02", "r01"):
+    for tag in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_%s_pmc_traffic.json" % (tag, workload))
         try:
             with open(path) as f:
@@ -600,6 +602,8 @@ def main():
         L.mi355x_tune_set_block(args.block)
     if args.sweep_tr or args.sweep_nt >= 0:
         L.mi355x_tune_set_sweep_shape(args.sweep_tr, args.sweep_nt)
+    if not args.sweepw_ring:
+        L.mi355x_tune_set_sweepw_ring(0)
     # One LP supports only so many pivots before it is optimal (config 3: 5 700-6 100, config 2:
     # 189-416 with these seeds).  If more timed steps are asked for than one LP safely provides,
     # further LPs of the same shape are generated in HBM BEFORE the timed region and the timed
@@ -741,7 +745,7 @@ def main():
             # contract's literal formula (per-pivot algorithmic bytes x pivots per launch / duration)
             # is `algorithmic_equivalent` and exceeds the peak by construction (the sweep does not
             # re-stream the tableau per pivot).
-            upd_name = "k_sweep16" if block == 16 else ("k_sweepw" if block > 16 else
+            upd_name = "k_sweep16" if block == 16 else (("k_sweepw_ring" if args.sweepw_ring else "k_sweepw") if block > 16 else
                                                         ("k_sweep" if block > 1 else L.mi355x_update_kernel_name().decode()))
             ach = kernel_bytes / (upd_avg_ms * 1e-3) / 1e9
             alg = block * kernel_bytes / (upd_avg_ms * 1e-3) / 1e9

@@ -61,7 +61,7 @@ def main(tag):
             shutil.copy(f, os.path.join(PR, tag + dst))
     out = {"workload": "cfg3", "kernels": {}}
     dense_ld = (8192 + 4096 + 1 + 15) // 16 * 16
-    for variant, kernels in (("", ("k_sweepw<", "k_sweepw_rest", "k_sweep16", "k_la_block")),
+    for variant, kernels in (("", ("k_sweepw_ring<", "k_sweepw<", "k_sweepw_rest", "k_sweep16", "k_la_block")),
                              ("perpivot_", ("k_update", "k_select_gather", "k_select_scale"))):
         fp = one("pmc_%sFETCH_SIZE/*/*counter_collection.csv" % variant, required=False)
         wp = one("pmc_%sWRITE_SIZE/*/*counter_collection.csv" % variant, required=False)
@@ -86,7 +86,7 @@ def main(tag):
             f, w = counter(fp, k), counter(wp, k)
             if not f or not w:
                 continue
-            if k in ("k_sweepw<", "k_sweep16", "k_update"):   # steady state: drop launches that did nothing
+            if k in ("k_sweepw_ring<", "k_sweepw<", "k_sweep16", "k_update"):   # steady state: drop launches that did nothing
                 f = [x for x in f if x > 0.5 * max(f)]
                 w = [x for x in w if x > 0.5 * max(w)]
             favg, wavg = sum(f) / len(f), sum(w) / len(w)
@@ -94,7 +94,7 @@ def main(tag):
                    "hbm_bytes_per_launch": (2 * favg + wavg) * 1024,
                    "representation": "compact" if int(layout["compact"]) else "dense",
                    "stored_rows_cols_ld": [rows, cols, ld]}
-            if k in ("k_sweepw<", "k_sweep16", "k_update"):
+            if k in ("k_sweepw_ring<", "k_sweepw<", "k_sweep16", "k_update"):
                 rec["algorithmic_bytes_per_launch"] = 2 * rows * cols * 8
                 rec["traffic_over_algorithmic"] = rec["hbm_bytes_per_launch"] / rec["algorithmic_bytes_per_launch"]
             out["kernels"][k.rstrip("<")] = rec
@@ -120,17 +120,17 @@ def main(tag):
                "calibration": {"KiB_each_way": copy_kib, "FETCH_SIZE_reported_KiB": cf, "WRITE_SIZE_reported_KiB": cw,
                                "fetch_factor_measured": copy_kib / cf, "write_factor_measured": copy_kib / cw,
                                "correction_applied": "FETCH x2 (gfx950), WRITE x1"}, "kernels": {}}
-        for k in ("k_sweepw<", "k_sweepw_rest", "k_la_gather", "k_la_scale"):
+        for k in ("k_sweepw_ring<", "k_sweepw<", "k_sweepw_rest", "k_la_gather", "k_la_scale"):
             f, w = counter(fp, k), counter(wp, k)
             if not f or not w:
                 continue
-            if k == "k_sweepw<":
+            if k in ("k_sweepw<", "k_sweepw_ring<"):
                 f = [x for x in f if x > 0.5 * max(f)]
                 w = [x for x in w if x > 0.5 * max(w)]
             favg, wavg = sum(f) / len(f), sum(w) / len(w)
             rec = {"launches": len(f), "FETCH_SIZE_KiB_avg": favg, "WRITE_SIZE_KiB_avg": wavg,
                    "hbm_bytes_per_launch": (2 * favg + wavg) * 1024, "stored_rows_cols_ld": [rows, cols, ld]}
-            if k == "k_sweepw<":
+            if k in ("k_sweepw<", "k_sweepw_ring<"):
                 rec["algorithmic_bytes_per_launch"] = 2 * rows * cols * 8
                 rec["traffic_over_algorithmic"] = rec["hbm_bytes_per_launch"] / rec["algorithmic_bytes_per_launch"]
             res["kernels"][k.rstrip("<")] = rec
@@ -153,7 +153,8 @@ def main(tag):
                 w_ = csv.DictWriter(fo, fieldnames=list(keep[0].keys()))
                 w_.writeheader()
                 w_.writerows(keep)
-    for log, dst in (("wide_block_ab.log", "_wide_block_ab.txt"), ("sweep32_microbench.log", "_sweep32_microbench.txt"),
+    for log, dst in (("steady_gap.log", "_steady_gap.txt"), ("la_timing.log", "_la_timing.txt"), ("sweep_lds_microbench.log", "_sweep_lds_microbench.txt"),
+                     ("ring_ab_kernel_stats.log", "_ring_ab_kernel_stats.txt"), ("wide_block_ab.log", "_wide_block_ab.txt"), ("sweep32_microbench.log", "_sweep32_microbench.txt"),
                      ("resident_lds_ab.log", "_resident_lds_ab.txt"), ("fuzz_totals.log", "_fuzz_totals.txt")):
         f = one(log, required=False)
         if f and os.path.getsize(f):
