@@ -68,6 +68,7 @@ typedef struct mi355x_batch mi355x_batch;   /* a batch of same-shape tableaux in
 typedef struct mi355x_problem  mi355x_problem;   /* a parsed LP, src/problem.lisp:45-53 (host)  */
 typedef struct mi355x_solution mi355x_solution;  /* what the read-back needs of a solved tableau */
 typedef struct mi355x_solve    mi355x_solve;     /* a problem on its way to a solution (resumable)  */
+typedef struct mi355x_solve_many mi355x_solve_many; /* a LIST of problems on their way to solutions   */
 
 /* ---- library / device ------------------------------------------------------------- */
 int         mi355x_abi_version(void);
@@ -280,6 +281,22 @@ int  mi355x_simplex_solver_step(mi355x_solve *job, int64_t max_pivots, int64_t *
 int  mi355x_simplex_solver_cancel(mi355x_solve *job);
 int  mi355x_simplex_solver_finish(mi355x_solve *job, mi355x_solution **out);
 void mi355x_simplex_solver_abandon(mi355x_solve *job);
+/* A LIST of problems (the hook takes one per call, src/solver.lisp:53-56; N small LPs one after the
+ * other leave the GPU almost empty -- BASELINE config 4): what mi355x_simplex_solver returns for every
+ * member, with the members solved side by side.  begin: build-tableau per member in C++, members of one
+ * tableau shape and sense packed into ONE batch over n_devices GPUs (device_ids NULL = 0 .. n_devices-1;
+ * two-phase members: a pair of batches), a member alone in its group as an ordinary job on the first
+ * device; integer members are declined (MI_UNSUPPORTED) and unbounded no-constraint members decided here.
+ * step: at most max_pivots pivots per member and phase (0 = no cap); returns MI_MAX_PIVOTS while some
+ * member is still running (call again), MI_OK when every member has its final status.  status (n
+ * entries, may be NULL): MI_RUNNING while undecided, then MI_OPTIMAL / MI_UNBOUNDED / MI_INFEASIBLE /
+ * MI_ART_NONZERO / MI_ART_STUCK / MI_UNSUPPORTED.  finish: out[k] = the solution of member k (light
+ * read-back) or NULL for a member without one; consumes the job, as does abandon. */
+int  mi355x_simplex_solver_many_begin(const mi355x_problem *const *problems, int64_t n, double fp_tolerance,
+                                      int n_devices, const int *device_ids, mi355x_solve_many **out);
+int  mi355x_simplex_solver_many_step(mi355x_solve_many *job, int64_t max_pivots, int32_t *status);
+int  mi355x_simplex_solver_many_finish(mi355x_solve_many *job, int32_t *status, mi355x_solution **out);
+void mi355x_simplex_solver_many_abandon(mi355x_solve_many *job);
 /* tableau-objective-value / tableau-variable / tableau-reduced-cost (src/simplex.lisp:74-120).
  * reduced_cost fails with MI_BAD_ARG for a variable without a lower bound, as the reference. */
 int  mi355x_solution_objective_value(const mi355x_solution *s, double *out);

@@ -71,6 +71,10 @@ SIGNATURES = {
     "mi355x_simplex_solver_cancel": (_int, [_p]),
     "mi355x_simplex_solver_finish": (_int, [_p, _pp]),
     "mi355x_simplex_solver_abandon": (None, [_p]),
+    "mi355x_simplex_solver_many_begin": (_int, [_p, _i64, _dbl, _int, _p, _pp]),
+    "mi355x_simplex_solver_many_step": (_int, [_p, _i64, _p]),
+    "mi355x_simplex_solver_many_finish": (_int, [_p, _p, _p]),
+    "mi355x_simplex_solver_many_abandon": (None, [_p]),
     "mi355x_solution_objective_value": (_int, [_p, _p]),
     "mi355x_solution_variable": (_int, [_p, _i64, _p]),
     "mi355x_solution_reduced_cost": (_int, [_p, _i64, _p]),

@@ -28,6 +28,8 @@ extern "C" void mi355x_tab_clear_cancel_(mi355x_tab *t);
 
 #include <algorithm>
 #include <chrono>
+#include <map>
+#include <tuple>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -675,6 +677,200 @@ int mi355x_simplex_solver(const mi355x_problem *p, double fp_tolerance, int devi
     if (rc != MI_OPTIMAL) { mi355x_simplex_solver_abandon(job); return rc; }
     return mi355x_simplex_solver_finish(job, out);
 }
+
+// ---- a LIST of problems (the glue's mi355x-solve-problems, natively) ---------------------------
+// The hook takes one problem per call (src/solver.lisp:53-56); N small LPs solved one after the other
+// leave the GPU almost empty (BASELINE config 4).  Here the library itself groups the members: same
+// tableau shape and sense -> ONE multi-device batch (mi355x_multibatch_*; single-phase groups one batch,
+// two-phase groups a pair of batches with the per-member step between the phases on the devices); a
+// member alone in its group is an ordinary solver job.  Everything is stepped in bounded chunks, so the
+// host language never sits in an unbounded foreign call.  Results are those of mi355x_simplex_solver on
+// every member, bit for bit.
+struct ManyUnit {
+    std::vector<int64_t> members;                     // indices into the list
+    mi355x_solve *single = nullptr;                   // a member alone in its group
+    mi355x_multibatch *main_mb = nullptr, *art_mb = nullptr;
+    int    is_max = 1;
+    int    phase = 2;                                 // 1: phase 1 running (art_mb), 2: phase 2 / single phase, 3: done
+    std::vector<int32_t> st1;                         // statuses phase 1 ended with (two-phase groups)
+    std::vector<int32_t> between;                     // MI_OK or the member's final outcome after the hand-over
+    std::vector<int64_t> np1, np2;
+};
+struct mi355x_solve_many {
+    int64_t n = 0;
+    double  f = 1024.0;
+    std::vector<int32_t> status;                      // per member: MI_RUNNING until decided
+    std::vector<std::unique_ptr<mi355x_solution>> sol;
+    std::vector<ManyUnit> units;
+    ~mi355x_solve_many()
+    {
+        for (ManyUnit &u : units) {
+            delete u.single;
+            mi355x_multibatch_destroy(u.art_mb);
+            mi355x_multibatch_destroy(u.main_mb);
+        }
+    }
+};
+
+int mi355x_simplex_solver_many_begin(const mi355x_problem *const *problems, int64_t n, double fp_tolerance,
+                                     int n_devices, const int *device_ids, mi355x_solve_many **out)
+{
+    if (!problems || n < 1 || !out || n_devices < 1) return hfail(MI_BAD_ARG, "bad arguments");
+    *out = nullptr;
+    for (int64_t k = 0; k < n; ++k) if (!problems[k]) return hfail(MI_BAD_ARG, "a problem of the list is NULL");
+    std::unique_ptr<mi355x_solve_many> job(new (std::nothrow) mi355x_solve_many);
+    if (!job) return hfail(MI_NO_MEMORY, "host allocation failed");
+    job->n = n; job->f = fp_tolerance;
+    job->status.assign((size_t)n, MI_RUNNING);
+    job->sol.resize((size_t)n);
+    std::vector<Built> built((size_t)n);
+    // group key -> unit index
+    struct Key { int two; int64_t r, c, mc; int is_max; bool operator<(const Key &o) const {
+        return std::tie(two, r, c, mc, is_max) < std::tie(o.two, o.r, o.c, o.mc, o.is_max); } };
+    std::map<Key, size_t> groups;
+    for (int64_t k = 0; k < n; ++k) {
+        const mi355x_problem &p = *problems[k];
+        bool integer = false;
+        for (char fl : p.is_integer) integer |= fl != 0;
+        if (integer) { job->status[(size_t)k] = MI_UNSUPPORTED; continue; }
+        built[(size_t)k] = build(p);
+        Built &b = built[(size_t)k];
+        if (b.status != MI_OK) { job->status[(size_t)k] = b.status; continue; }      // the unbounded no-constraint case
+        if (b.main_tab.rows < 2) {                                                   // no constraint rows: nothing to batch
+            groups[Key{2, k, 0, 0, 0}] = job->units.size();
+            job->units.push_back(ManyUnit());
+            job->units.back().members.push_back(k);
+            continue;
+        }
+        const Key key = b.two_phase ? Key{1, b.art.rows, b.art.cols, b.main_tab.cols, p.is_max ? 1 : 0}
+                                    : Key{0, b.main_tab.rows, b.main_tab.cols, 0, p.is_max ? 1 : 0};
+        auto it = groups.find(key);
+        if (it == groups.end()) { it = groups.emplace(key, job->units.size()).first; job->units.push_back(ManyUnit()); }
+        job->units[it->second].members.push_back(k);
+    }
+    for (ManyUnit &u : job->units) {
+        const int64_t g = (int64_t)u.members.size();
+        const Built &b0 = built[(size_t)u.members[0]];
+        u.is_max = problems[u.members[0]]->is_max ? 1 : 0;
+        for (int64_t k : u.members) {
+            std::unique_ptr<mi355x_solution> s(new (std::nothrow) mi355x_solution);
+            if (!s) return hfail(MI_NO_MEMORY, "host allocation failed");
+            const HostTableau &t = built[(size_t)k].main_tab;
+            s->rows = t.rows; s->cols = t.cols; s->map = built[(size_t)k].map;
+            s->last_row.resize((size_t)t.cols); s->last_col.resize((size_t)t.rows);
+            s->basis.resize((size_t)std::max<int64_t>(t.rows - 1, 0));
+            job->sol[(size_t)k] = std::move(s);
+        }
+        if (g == 1) {                                  // alone in its group: the one-problem job
+            const int rc = mi355x_simplex_solver_begin(problems[u.members[0]], fp_tolerance, device_ids ? device_ids[0] : 0, &u.single);
+            if (rc != MI_OK) return rc;
+            continue;
+        }
+        auto pack = [&](bool art, mi355x_multibatch **mb) -> int {
+            const HostTableau &t0 = art ? b0.art : b0.main_tab;
+            std::vector<double>  M((size_t)(g * t0.rows * t0.cols));
+            std::vector<int64_t> B((size_t)(g * (t0.rows - 1)));
+            for (int64_t q = 0; q < g; ++q) {
+                const Built &b = built[(size_t)u.members[(size_t)q]];
+                const HostTableau &t = art ? b.art : b.main_tab;
+                std::memcpy(M.data() + (size_t)q * t0.rows * t0.cols, t.M.data(), t.M.size() * sizeof(double));
+                std::memcpy(B.data() + (size_t)q * (t0.rows - 1), t.basis.data(), t.basis.size() * sizeof(int64_t));
+            }
+            return mi355x_multibatch_create(mb, g, t0.rows, t0.cols, M.data(), B.data(), n_devices, device_ids);
+        };
+        int rc = pack(false, &u.main_mb);
+        if (rc == MI_OK && b0.two_phase) { rc = pack(true, &u.art_mb); u.phase = 1; }
+        if (rc != MI_OK) return rc;
+        u.st1.assign((size_t)g, MI_RUNNING); u.between.assign((size_t)g, MI_OK);
+        u.np1.assign((size_t)g, 0); u.np2.assign((size_t)g, 0);
+    }
+    *out = job.release();
+    return MI_OK;
+}
+
+int mi355x_simplex_solver_many_step(mi355x_solve_many *job, int64_t max_pivots, int32_t *status)
+{
+    if (!job) return hfail(MI_BAD_ARG, "job is NULL");
+    if (max_pivots < 0) return hfail(MI_BAD_ARG, "max_pivots < 0");
+    bool running = false;
+    for (ManyUnit &u : job->units) {
+        if (u.phase == 3) continue;
+        const int64_t g = (int64_t)u.members.size();
+        if (u.single) {
+            const int rc = mi355x_simplex_solver_step(u.single, max_pivots, nullptr);
+            if (rc < 0) return rc;
+            if (rc == MI_MAX_PIVOTS && max_pivots > 0) { running = true; continue; }
+            job->status[(size_t)u.members[0]] = rc;
+            u.phase = 3;
+            continue;
+        }
+        std::vector<int32_t> st((size_t)g);
+        std::vector<int64_t> np((size_t)g);
+        if (u.phase == 1) {                                                  // simplex.lisp:403, all members
+            const int rc = mi355x_multibatch_solve(u.art_mb, 0, job->f, max_pivots, st.data(), np.data());
+            if (rc != MI_OK) return rc;
+            bool more = false;
+            for (int64_t q = 0; q < g; ++q) { u.np1[(size_t)q] += np[(size_t)q]; u.st1[(size_t)q] = st[(size_t)q]; more |= st[(size_t)q] == MI_MAX_PIVOTS; }
+            if (more && max_pivots > 0) { running = true; continue; }
+            std::vector<int64_t> nd((size_t)g, 0);                           // :405-451, per member on the devices
+            const int hrc = mi355x_multibatch_two_phase_handover(u.art_mb, u.main_mb, job->f, u.st1.data(), u.between.data(), nd.data());
+            if (hrc != MI_OK) return hrc;
+            for (int64_t q = 0; q < g; ++q) u.np1[(size_t)q] += nd[(size_t)q];
+            u.phase = 2;
+            if (max_pivots > 0) { running = true; continue; }                // phase 2 in the next call (the chunk is used up)
+        }
+        const int rc = mi355x_multibatch_solve(u.main_mb, u.is_max, job->f, max_pivots, st.data(), np.data());   // :452 / :453-461
+        if (rc != MI_OK) return rc;
+        bool more = false;
+        for (int64_t q = 0; q < g; ++q) {
+            u.np2[(size_t)q] += np[(size_t)q];
+            const bool went = u.between[(size_t)q] == MI_OK;
+            if (went && st[(size_t)q] == MI_MAX_PIVOTS && max_pivots > 0) { more = true; continue; }
+            job->status[(size_t)u.members[(size_t)q]] = went ? st[(size_t)q] : u.between[(size_t)q];
+        }
+        if (more) running = true; else u.phase = 3;
+    }
+    if (status) for (int64_t k = 0; k < job->n; ++k) status[k] = job->status[(size_t)k];
+    return running ? MI_MAX_PIVOTS : MI_OK;
+}
+
+int mi355x_simplex_solver_many_finish(mi355x_solve_many *job, int32_t *status, mi355x_solution **out)
+{
+    if (!job) return hfail(MI_BAD_ARG, "job is NULL");
+    std::unique_ptr<mi355x_solve_many> owner(job);                          // consumed whatever happens
+    if (!out) return hfail(MI_BAD_ARG, "out is NULL");
+    for (int64_t k = 0; k < job->n; ++k) out[k] = nullptr;
+    for (ManyUnit &u : job->units) {
+        const int64_t g = (int64_t)u.members.size();
+        if (u.single) {
+            const int64_t k = u.members[0];
+            if (u.phase == 3 && job->status[(size_t)k] == MI_OPTIMAL) {
+                mi355x_solution *s = nullptr;
+                const int rc = mi355x_simplex_solver_finish(u.single, &s);
+                u.single = nullptr;                                          // consumed
+                if (rc != MI_OPTIMAL) return rc;
+                job->sol[(size_t)k].reset(s);
+            }
+            continue;
+        }
+        for (int64_t q = 0; q < g; ++q) {
+            const int64_t k = u.members[(size_t)q];
+            if (job->status[(size_t)k] != MI_OPTIMAL) continue;
+            mi355x_solution &s = *job->sol[(size_t)k];
+            const int rc = mi355x_multibatch_download(u.main_mb, q, nullptr, s.basis.empty() ? nullptr : s.basis.data(),
+                                                      s.last_row.data(), s.last_col.data());
+            if (rc != MI_OK) return rc;
+            s.n_pivots[0] = u.np1[(size_t)q]; s.n_pivots[1] = u.np2[(size_t)q];
+        }
+    }
+    for (int64_t k = 0; k < job->n; ++k) {
+        if (status) status[k] = job->status[(size_t)k];
+        if (job->status[(size_t)k] == MI_OPTIMAL) out[k] = job->sol[(size_t)k].release();
+    }
+    return MI_OK;
+}
+
+void mi355x_simplex_solver_many_abandon(mi355x_solve_many *job) { delete job; }
 
 void mi355x_solution_destroy(mi355x_solution *s) { delete s; }
 

@@ -150,6 +150,14 @@
 (cffi:defcfun ("mi355x_simplex_solver_finish" %solver-finish) :int
   (job :pointer) (out :pointer))
 (cffi:defcfun ("mi355x_simplex_solver_abandon" %solver-abandon) :void (job :pointer))
+(cffi:defcfun ("mi355x_simplex_solver_many_begin" %solver-many-begin) :int
+  (problems :pointer) (n :int64) (fp-tolerance :double) (n-devices :int) (device-ids :pointer)
+  (out :pointer))
+(cffi:defcfun ("mi355x_simplex_solver_many_step" %solver-many-step) :int
+  (job :pointer) (max-pivots :int64) (status :pointer))
+(cffi:defcfun ("mi355x_simplex_solver_many_finish" %solver-many-finish) :int
+  (job :pointer) (status :pointer) (out :pointer))
+(cffi:defcfun ("mi355x_simplex_solver_many_abandon" %solver-many-abandon) :void (job :pointer))
 (cffi:defcfun ("mi355x_solution_objective_value" %solution-objective-value) :int
   (solution :pointer) (out :pointer))
 (cffi:defcfun ("mi355x_solution_variable" %solution-variable) :int
@@ -658,6 +666,60 @@ Returns a MI355X-SOLUTION or signals the reference's conditions."
                (unless consumed (%solver-abandon job)))))
       (%problem-destroy problem-handle))))
 
+(defun solve-problems-natively (problems factor devices max-pivots)
+  "A LIST of problems entirely behind the C ABI: every problem marshalled (mi355x_problem_*), ONE job of
+the library for the list (mi355x_simplex_solver_many_begin groups the members by tableau shape and
+sense into multi-device batches; two-phase members as pairs of batches with the step between the
+phases on the devices), stepped in bounded foreign calls, the light solutions read back.  Returns a
+list parallel to PROBLEMS: a MI355X-SOLUTION, or the condition object the one-problem hook would
+signal for that member.  No boxed tableau exists for any member (BASELINE config 4 from Lisp: 1 024
+build-tableau results would be 2e8 boxed entries)."
+  (let* ((n (length problems))
+         (marshalled (mapcar (lambda (problem) (multiple-value-list (marshal-problem problem))) problems))
+         (n-dev (device-count-of devices))
+         (rows (1+ (reduce #'max problems :key (lambda (p) (length (problem-constraints p))))))
+         (cols (+ rows (reduce #'max problems :key (lambda (p) (length (problem-vars p))))))
+         (chunk (chunk-pivots rows cols)))
+    (unwind-protect
+         (cffi:with-foreign-objects ((handles :pointer n) (ids :int (max n-dev 1)) (out :pointer)
+                                     (status :int32 n) (solutions :pointer n))
+           (loop for (handle nil) in marshalled for k from 0
+                 do (setf (cffi:mem-aref handles :pointer k) handle))
+           (when (listp devices)
+             (loop for d in devices for i from 0 do (setf (cffi:mem-aref ids :int i) d)))
+           (check (with-foreign-fp-mode
+                    (%solver-many-begin handles n factor n-dev
+                                        (if (listp devices) ids (cffi:null-pointer)) out)))
+           (let ((job (cffi:mem-ref out :pointer))
+                 (consumed nil)
+                 (done 0))
+             (unwind-protect
+                  (progn
+                    (loop
+                      (let* ((cap (if (plusp max-pivots) (min chunk (- max-pivots done)) chunk))
+                             (rc (check (with-foreign-fp-mode (%solver-many-step job cap status)))))
+                        (incf done cap)
+                        (when (or (/= rc +mi-max-pivots+)
+                                  (and (plusp max-pivots) (>= done max-pivots)))
+                          (return))))
+                    (setf consumed t)                ; finish consumes the job whatever it returns
+                    (check (%solver-many-finish job status solutions))
+                    (loop for problem in problems
+                          for (nil var-index) in marshalled
+                          for k from 0
+                          collect (let ((st (cffi:mem-aref status :int32 k)))
+                                    (cond
+                                      ((= st +mi-optimal+)
+                                       (make-solution problem (cffi:mem-aref solutions :pointer k) var-index))
+                                      ((= st -6)                         ; MI_UNSUPPORTED: integer variables
+                                       (make-condition 'unsupported-constraint-error
+                                                       :constraint (cons 'integer (problem-integer-vars problem))
+                                                       :solver-name "mi355x-simplex"))
+                                      ((= st +mi-running+) (outcome-condition +mi-max-pivots+))
+                                      (t (outcome-condition st))))))
+               (unless consumed (%solver-many-abandon job)))))
+      (loop for (handle nil) in marshalled do (%problem-destroy handle)))))
+
 ;;; ------------------------------------------------------------------ the *solver* value
 (defun solve-two-phase-in-chunks (art-handle main-handle rows cols main-is-max factor max-pivots
                                   n-pivots)
@@ -940,8 +1002,22 @@ the GPU(s) instead of one after the other.
     result holds the condition object (unbounded-problem-error, infeasible-problem-error,
     unsupported-constraint-error ...); with :ERRORP T (default, what mapcar of solve-problem
     would do) the first such condition is signalled after every member has been attempted.
-Every returned tableau's results are bit-identical to the single-problem path's."
+  * :NATIVE :MANY hands the whole list to the library instead (mi355x_simplex_solver_many_*: the
+    problems marshalled as they are, tableaux assembled, grouped and batched in C++): the result list
+    then holds MI355X-SOLUTION objects -- the way to solve BASELINE config 4's 1 024 LPs from Lisp
+    without 1 024 boxed tableaux.  (:NATIVE NIL, the default, keeps every member a `tableau`.)
+Every returned solution object's results are bit-identical to the single-problem path's."
   (declare (ignore args))
+  (when (and (eq native :many) (not full-tableau) problems)
+    ;; the whole list behind ONE job of the library: no build-tableau, no boxed matrices; the members
+    ;; come back as MI355X-SOLUTION objects
+    (let ((results (solve-problems-natively problems (coerce fp-tolerance 'double-float)
+                                            (if (and (integerp devices) (<= devices 1)) (list device) devices)
+                                            max-pivots)))
+      (when errorp
+        (let ((failed (find-if (lambda (r) (typep r 'condition)) results)))
+          (when failed (error failed))))
+      (return-from mi355x-solve-problems results)))
   (let* ((n (length problems))
          (results (make-array n :initial-element nil))
          (groups (make-hash-table :test #'equal))

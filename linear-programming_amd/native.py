@@ -170,6 +170,58 @@ class NativeSolution:
             capi.lib().mi355x_solution_destroy(h)
 
 
+def solve_many(problems, fp_tolerance=1024, devices=1, device_ids=None, max_pivots=0, chunk=None):
+    """The glue's native `mi355x-solve-problems`, call for call: every problem marshalled
+    (mi355x_problem_*), ONE mi355x_simplex_solver_many_begin for the list (the library groups the
+    members by tableau shape and sense into multi-device batches), ..._many_step in bounded chunks,
+    ..._many_finish.  Returns a list parallel to `problems`: a NativeSolution or the exception the
+    one-problem hook would raise for that member."""
+    from .simplex import _raise_for, chunk_pivots
+    L = capi.lib()
+    nps = [NativeProblem(p) for p in problems]
+    n = len(nps)
+    arr = (ctypes.c_void_p * n)(*[q._h.value for q in nps])
+    ids = None if device_ids is None else (ctypes.c_int * len(device_ids))(*[int(d) for d in device_ids])
+    job = ctypes.c_void_p()
+    capi.check(L.mi355x_simplex_solver_many_begin(arr, n, float(fp_tolerance), int(devices), ids, ctypes.byref(job)),
+               "mi355x_simplex_solver_many_begin")
+    status = (ctypes.c_int32 * n)()
+    consumed = False
+    try:
+        rows = max(len(p.constraints) for p in problems) + 1
+        cols = rows + max(len(p.vars) for p in problems)
+        step = chunk or chunk_pivots(rows, cols)
+        done = 0
+        while True:
+            cap = min(step, max_pivots - done) if max_pivots > 0 else step
+            rc = capi.check(L.mi355x_simplex_solver_many_step(job, int(cap), status), "mi355x_simplex_solver_many_step")
+            done += cap
+            if rc != capi.MI_MAX_PIVOTS or (max_pivots > 0 and done >= max_pivots):
+                break
+        out = (ctypes.c_void_p * n)()
+        consumed = True
+        capi.check(L.mi355x_simplex_solver_many_finish(job, status, out), "mi355x_simplex_solver_many_finish")
+    finally:
+        if not consumed:
+            L.mi355x_simplex_solver_many_abandon(job)
+    results = []
+    for k in range(n):
+        st = int(status[k])
+        if st == capi.MI_OPTIMAL:
+            results.append(NativeSolution(nps[k], ctypes.c_void_p(out[k])))
+            continue
+        try:
+            if st == capi.MI_UNSUPPORTED:
+                raise UnsupportedConstraintError(("integer",) + tuple(problems[k].integer_vars), "mi355x-simplex")
+            if st == capi.MI_RUNNING:
+                st = capi.MI_MAX_PIVOTS
+            _raise_for(st)
+            raise SolverError("status %d" % st)
+        except SolverError as e:
+            results.append(e)
+    return results
+
+
 _READ_CASE = {"upcase": 0, "downcase": 1, "preserve": 2, "invert": 3}
 
 

@@ -635,6 +635,16 @@ def mi355x_solve_problems(problems, fp_tolerance=1024, device=0, devices=1, max_
     others: errorp False leaves the exception object in its place, errorp True raises the first
     one after every member has been attempted."""
     from .batch import MultiDeviceBatch
+    if native == "many":
+        # the whole list behind ONE job of the library (mi355x_simplex_solver_many_*): members come
+        # back as NativeSolution objects (the glue's :native :many)
+        from .native import solve_many
+        results = solve_many(problems, fp_tolerance=fp_tolerance, devices=devices, max_pivots=max_pivots)
+        if errorp:
+            for r in results:
+                if isinstance(r, Exception):
+                    raise r
+        return results
     results = [None] * len(problems)
     groups, groups2 = {}, {}
 

@@ -222,3 +222,87 @@ def test_multibatch_two_phase_entry_point_directly(golden):
     s4 = np.zeros(3, dtype=np.int32)
     assert L.mi355x_multibatch_solve_two_phase(amb._h, other._h, 1, 1024.0, s4.ctypes.data_as(ctypes.c_void_p), None) == lp.capi.MI_BAD_ARG
     assert L.mi355x_multibatch_solve_two_phase(None, mmb._h, 1, 1024.0, s4.ctypes.data_as(ctypes.c_void_p), None) == lp.capi.MI_BAD_ARG
+
+
+# ---- the whole list behind ONE job of the library (the glue's :native :many) ----------------------
+def _same_outcome(a, b, p):
+    """Two results of one problem: the same exception type, or solutions equal bit for bit."""
+    if isinstance(a, Exception) or isinstance(b, Exception):
+        return type(a) is type(b)
+    if lp.solution_objective_value(a) != lp.solution_objective_value(b) or a.pivots() != b.pivots():
+        return False
+    for v in p.vars:
+        if lp.solution_variable(a, v) != lp.solution_variable(b, v):
+            return False
+        ra, rb = [], []
+        for s, out in ((a, ra), (b, rb)):
+            try:
+                out.append(lp.solution_reduced_cost(s, v))
+            except ValueError as e:
+                out.append(str(e))
+        if ra != rb:
+            return False
+    return True
+
+
+def _one_native(p):
+    try:
+        return lp.NativeProblem(p).solve_in_chunks()
+    except lp.SolverError as e:
+        return e
+
+
+@pytest.mark.parametrize("chunk", [None, 3])
+@pytest.mark.parametrize("devices", [1, 3])
+def test_native_list_entry_equals_the_one_problem_job_member_by_member(golden, devices, chunk):
+    """mi355x_simplex_solver_many_begin / _step / _finish on a mixed list -- single-phase groups, two-phase
+    groups (incl. members that need drive-out pivots), members alone in their group, unbounded,
+    infeasible and integer members: every member's outcome is the one-problem job's, bit for bit
+    (objective, every variable, every reduced cost, pivot counts of both phases).  chunk = 3: every
+    phase of every group is stepped three pivots per foreign call."""
+    solve_many = lp.native.solve_many
+    ps = _mixed_list(golden)
+    ps += [_drive_out_problem(s) for s in (282, 957, 959)]
+    ps += [random_mixed_problem(lp, 12, 5, 3, 2, 50 + s) for s in range(4)]
+    q = lp.Problem(type="max", vars=["x", "y"], objective_var="w", objective_func=[("x", 1), ("y", 1)],
+                   integer_vars=["x"], constraints=[("<=", [("x", 1), ("y", 2)], 4)])
+    ps.append(q)
+    ps.append(lp.Problem(type="max", vars=["x"], objective_var="w", objective_func=[("x", 1.0)]))      # no constraints: unbounded while building
+    got = solve_many(ps, devices=devices, chunk=chunk)
+    assert len(got) == len(ps)
+    n_solved = 0
+    for k, (p, r) in enumerate(zip(ps, got)):
+        if p.integer_vars:
+            assert isinstance(r, lp.UnsupportedConstraintError), k
+            continue
+        one = _one_native(p)
+        assert _same_outcome(r, one, p), (k, r, one)
+        n_solved += not isinstance(r, Exception)
+    assert n_solved >= 20
+    assert lp.solution_objective_value(got[0]) == 28.5 and lp.solution_variable(got[0], "x") == 0.5    # README.md:58-62
+    # through the list entry of the mirror (the glue's (mi355x-solve-problems problems :native :many))
+    again = lp.solve_problems(ps, devices=devices, native="many", errorp=False)
+    assert all(_same_outcome(a, b, p) for a, b, p in zip(again, got, ps) if not p.integer_vars)
+    with pytest.raises(lp.SolverError):
+        lp.solve_problems(ps, native="many")                                                        # errorp: the first failure
+
+
+def test_native_list_entry_config4_shaped():
+    """64 LPs of 48 x 24 as ONE job over 8 (logical) sub-batches, stepped in chunks of 7 pivots, against the oracle."""
+    solve_many = lp.native.solve_many
+    ps = [_random_le_problem(48, 24, 100 + s) for s in range(64)]
+    got = solve_many(ps, devices=8, chunk=7)
+    for k, (p, r) in enumerate(zip(ps, got)):
+        st, M, b = _oracle_outcome(p)
+        assert st == oracle.OPTIMAL and isinstance(r, lp.NativeSolution), k
+        assert np.float64(lp.solution_objective_value(r)).view(np.int64) == M[-1, -1:].view(np.int64)[0], k
+    # a cap that ends the job early leaves the unfinished members at "pivot cap reached"
+    capped = solve_many(ps[:8], devices=2, max_pivots=2)
+    assert all(isinstance(r, lp.SolverError) and "pivot cap" in str(r) for r in capped)
+    # argument checks
+    import ctypes
+    L = lp.capi.lib()
+    job = ctypes.c_void_p()
+    assert L.mi355x_simplex_solver_many_begin(None, 1, 1024.0, 1, None, ctypes.byref(job)) == lp.capi.MI_BAD_ARG
+    assert L.mi355x_simplex_solver_many_step(None, 0, None) == lp.capi.MI_BAD_ARG
+    L.mi355x_simplex_solver_many_abandon(None)
