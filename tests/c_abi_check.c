@@ -41,6 +41,8 @@ int main(void)
             if (mi355x_simplex_solver_step(NULL, 0, NULL) != MI_BAD_ARG || mi355x_simplex_solver_cancel(NULL) != MI_BAD_ARG ||
                 mi355x_simplex_solver_finish(NULL, &s) != MI_BAD_ARG || s != NULL) return 62;
             if (mi355x_two_phase_handover(NULL, NULL, 1024.0, NULL) != MI_BAD_ARG) return 63;
+            if (mi355x_simplex_solver_many_step(NULL, 0, NULL) != MI_BAD_ARG) return 86;
+            mi355x_simplex_solver_many_abandon(NULL);
             mi355x_simplex_solver_abandon(NULL);
         }
         {   /* the multi-device entry points fail the same way (and never touch RCCL) */
@@ -84,6 +86,32 @@ int main(void)
             if (mi355x_solution_variable(s2, 3, &v) != MI_BAD_ARG) return 71;                  /* "not a variable in the tableau" */
             if (mi355x_solution_pivots(s2, &p1, &p2) != MI_OK || p1 != 0 || p2 != 2) return 72;
             mi355x_solution_destroy(s2);
+        }
+        {   /* a LIST of problems as ONE job (the glue's :native :many): the README LP twice (one batch of
+             * two) next to a two-phase problem alone in its group, stepped one pivot per call */
+            mi355x_problem *q = NULL;
+            const mi355x_problem *list[3];
+            mi355x_solve_many *job = NULL;
+            mi355x_solution *sols[3] = {NULL, NULL, NULL};
+            int32_t st[3] = {-1, -1, -1};
+            int64_t v3[] = {0, 1};  double c3[] = {1, 1};
+            double v = 0;
+            int calls = 0;
+            if (mi355x_problem_create(&q, 1, 3) != MI_OK) return 80;
+            mi355x_problem_set_objective(q, ov, oc, 3);
+            mi355x_problem_add_constraint(q, 0, v1, c1, 2, 8.0);
+            mi355x_problem_add_constraint(q, 0, v2, c2, 2, 7.0);
+            mi355x_problem_add_constraint(q, 1, v3, c3, 2, 2.0);
+            list[0] = p; list[1] = q; list[2] = p;
+            if (mi355x_simplex_solver_many_begin(list, 3, 1024.0, 2, NULL, &job) != MI_OK || !job) return 81;
+            while ((rc = mi355x_simplex_solver_many_step(job, 1, st)) == MI_MAX_PIVOTS) if (++calls > 64) return 82;
+            if (rc != MI_OK || st[0] != MI_OPTIMAL || st[1] != MI_OPTIMAL || st[2] != MI_OPTIMAL) return 83;
+            if (mi355x_simplex_solver_many_finish(job, st, sols) != MI_OK || !sols[0] || !sols[1] || !sols[2]) return 84;
+            for (int k = 0; k < 3; ++k) {
+                if (mi355x_solution_objective_value(sols[k], &v) != MI_OK || v != 28.5) return 85;
+                mi355x_solution_destroy(sols[k]);
+            }
+            mi355x_problem_destroy(q);
         }
         {   /* the same tableau column-partitioned over 2 shards (logical shards on one GPU),
              * what the Lisp glue does for :devices 2 -- t/simplex.lisp:170-194: objective 57/2 */
