@@ -29,6 +29,7 @@ ap.add_argument("--events", type=int, default=1, help="event pairs around every 
 ap.add_argument("--repeat", type=int, default=3)
 ap.add_argument("--n", type=int, default=8192)
 ap.add_argument("--m", type=int, default=4096)
+ap.add_argument("--block", type=int, default=0, help="pivots per sweep (0 = by size)")
 ap.add_argument("--tr", type=int, default=0, help="rows per sweep workgroup (0 = default)")
 ap.add_argument("--nt", type=int, default=-1, help="non-temporal sweep accesses (0 / 1, -1 = by size)")
 ap.add_argument("--ring", type=int, default=1, help="wide sweeps through the LDS ring (1, default) or the register form (0)")
@@ -38,6 +39,8 @@ lp = lp_amd()
 L = lp.capi.lib()
 n, m = args.n, args.m
 L.mi355x_tune_set_sweepw_ring(args.ring)
+if args.block:
+    L.mi355x_tune_set_block(args.block)
 if args.tr or args.nt >= 0:
     L.mi355x_tune_set_sweep_shape(args.tr, args.nt)
 for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
