@@ -50,6 +50,15 @@ int         mi355x_tune_set_sweepw_ring(int on);             /* wide sweeps (k >
                                                                 register form of round 4 (k_sweepw); A/B of
                                                                 the ring's cache policy: 2 no non-temporal
                                                                 access, 3 non-temporal stores only        */
+int         mi355x_tune_set_prime(int on);                   /* 1 (default): a handle's first block is
+                                                                preceded by one EMPTY block of every kernel
+                                                                form its requests can pick, so that no later
+                                                                request pays a kernel's first launch; 0 off */
+int         mi355x_tune_set_ctl_wait(int mode);              /* how a status read-back waits: 2 (default) a
+                                                                kernel publishes the control block to pinned
+                                                                memory and the host polls its sequence number,
+                                                                1 copy + polled hipStreamQuery, 0 copy +
+                                                                hipStreamSynchronize                      */
 int         mi355x_tune_set_shard_la_split(int mode);        /* column shards, local look-ahead step:
                                                                 0 by size, 1 one workgroup, 2 many */
 int         mi355x_tune_set_colpart_exchange(int mode);      /* column partition over RCCL, how the

@@ -119,6 +119,8 @@ struct mi355x_tab {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     Ctl        *h_ctl = nullptr;          // pinned host mirror of the control block
+    unsigned long long *h_seq = nullptr;  // pinned: sequence number of the last control block k_ctl_publish handed over (read_ctls)
+    unsigned long long  seq_next = 0;
     TabView     c{};                      // compact view [non-basic columns | RHS]; shares
                                           // basis / col / prow / ctl / trace / partials with v
     bool        compact = false;          // which representation currently holds the tableau
@@ -150,6 +152,7 @@ struct mi355x_tab {
     int64_t     la_rearm_in = 0;          // two-launch blocks left before the next try
     // which implementation the dispatcher actually enqueued, per launch class (mi355x_tab_path_counts)
     int64_t     path_counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool        primed = false;           // every (look-ahead, sweep) form this handle's requests can pick was launched once (prime_block_kernels)
     int         n_timed = 0;
     std::vector<hipEvent_t> ev0, ev1;     // around the update / sweep launches
     int         n_timed_la = 0;

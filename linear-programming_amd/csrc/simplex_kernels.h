@@ -183,6 +183,10 @@ int  la_block_workgroups(const TabView &t);
 bool la_block_supported(const TabView &t);
 void launch_la_block(const TabView &t, int ksteps, int is_max, double fp_factor,
                      unsigned epoch_base, hipStream_t s);
+// the same with the kernel picked by `form` (a block size: <= kMaxBlock the 16-step look-ahead, above
+// it the 24-step one) instead of by ksteps -- prime_block_kernels launches each with 0 steps
+void launch_la_block_form(const TabView &t, int form, int ksteps, int is_max, double fp_factor,
+                          unsigned epoch_base, hipStream_t s);
 // tuning / test hooks of the persistent look-ahead: all its workgroups on one XCD (default on),
 // polls before a workgroup gives up waiting (kSyncLost), a workgroup that stops publishing
 void set_la_one_xcd(int on);
@@ -237,6 +241,9 @@ void launch_compact(const TabView &dense, const TabView &compact, hipStream_t s)
 void launch_expand(const TabView &dense, const TabView &compact, int64_t *brow, hipStream_t s);
 void launch_ctl_reset(const TabView &t, int64_t max_pivots, int reset_trace, hipStream_t s);
 void launch_ctl_finish(const TabView &t, hipStream_t s);
+// the first n control blocks -> pinned coherent host memory, then `seq` -> *host_seq (system-scope release)
+void launch_ctl_publish(const TabView &t, int64_t n, void *host_dst, unsigned long long *host_seq,
+                        unsigned long long seq, hipStream_t s);
 // `from` -> kRunning (kNeedDense: after the host has rebuilt the dense tableau; kSyncLost: after
 // it has switched the handle to the two-launch look-ahead)
 void launch_ctl_resume(const TabView &t, hipStream_t s, int32_t from);

@@ -32,6 +32,7 @@ ap.add_argument("--m", type=int, default=4096)
 ap.add_argument("--block", type=int, default=0, help="pivots per sweep (0 = by size)")
 ap.add_argument("--tr", type=int, default=0, help="rows per sweep workgroup (0 = default)")
 ap.add_argument("--nt", type=int, default=-1, help="non-temporal sweep accesses (0 / 1, -1 = by size)")
+ap.add_argument("--wait", type=int, default=2, help="status read-back: 2 published control block + memory poll (default), 1 polled stream query, 0 hipStreamSynchronize")
 ap.add_argument("--ring", type=int, default=1, help="wide sweeps through the LDS ring (1, default) or the register form (0)")
 args = ap.parse_args()
 
@@ -39,6 +40,7 @@ lp = lp_amd()
 L = lp.capi.lib()
 n, m = args.n, args.m
 L.mi355x_tune_set_sweepw_ring(args.ring)
+L.mi355x_tune_set_ctl_wait(args.wait)
 if args.block:
     L.mi355x_tune_set_block(args.block)
 if args.tr or args.nt >= 0:
@@ -60,13 +62,14 @@ try:
         h = ctypes.c_void_p()
         k = ctypes.c_int64(0)
         lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h), n, m, lp.synth.seed_for(3, 500 + rep), 0, -1, 0), "create")
+        lp.capi.check(L.mi355x_tab_set_stream(h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), 0), "set_stream")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); e1.record()                       # (their first use is not the run's business)
         lp.capi.check(L.mi355x_tab_solve_async(h, 1, 1024.0, 64, 1), "warm")
         L.mi355x_tab_sync(h, ctypes.byref(k))
         if args.events:
             L.mi355x_tab_timing_enable(h, 4)
         bk = L.mi355x_tab_block_size(h)
-        lp.capi.check(L.mi355x_tab_set_stream(h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), 0), "set_stream")
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         e0.record()
@@ -85,10 +88,10 @@ try:
             ev[name] = sm.value / nl.value * 1e3 if nl.value else float("nan")
         tot_us = (t2 - t0) * 1e6
         kern = (ev["la"] + ev["sweep"]) * blocks
-        print("load=%g events=%d block=%d: enqueue %.2f ms; WALL %.2f ms = %.2f us/pivot (%.0f pivots/s); GPU CLOCK %.2f ms = "
+        print("load=%g wait=%d events=%d block=%d: enqueue %.2f ms; WALL %.2f ms = %.2f us/pivot (%.0f pivots/s); GPU CLOCK %.2f ms = "
               "%.2f us/pivot (%.0f pivots/s); host wait after the GPU %.2f ms; kernels la %.1f + sweep %.1f us per block; "
               "gap_us_per_block (GPU clock) %.1f; lost=%d rc=%d"
-              % (args.load, args.events, bk, (t1 - t0) * 1e3, tot_us / 1e3, tot_us / args.pivots,
+              % (args.load, args.wait, args.events, bk, (t1 - t0) * 1e3, tot_us / 1e3, tot_us / args.pivots,
                  args.pivots / (t2 - t0), gpu_us / 1e3, gpu_us / args.pivots, args.pivots / (gpu_us * 1e-6),
                  (tot_us - gpu_us) / 1e3, ev["la"], ev["sweep"], (gpu_us - kern) / blocks,
                  L.mi355x_tab_la_lost(h), rc), flush=True)
