@@ -170,6 +170,7 @@ int  launch_sweep(const TabView &t, int kmax, double sgn, hipStream_t s, unsigne
 // with (0: stay at kMaxBlock)
 bool wide_block_size_ok(int k);
 int  wide_block_default(const TabView &t);
+void set_sweep_xmap(int on);               // k_sweepw_ring: workgroup -> (strip, tile) by XCD (see the kernel)
 void set_sweepw_ring(int on);              // wide sweeps through the LDS ring (default) or the register form
 int  sweep_kind(int kmax);                 // 2 wide pair, 1 k_sweep16, 0 k_sweep<..>: what launch_sweep picks
 // after a lost exchange (kSyncLost): undo the bookkeeping (column maps, basis, pivot count, trace)

@@ -134,6 +134,64 @@ __device__ __forceinline__ void links8(vec2d (&cur)[4], const vec2d pa, const ve
           "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "scc");
 }
 
+// The CONTINUOUS chain (round 5, second half): a statement never waits for a load it has just issued.
+// On entry the first chunk (pivots i0 .. i0+3, s[68:99] -- the HIGHEST registers: the compiler knows them
+// only as clobbers and takes the lowest free ones for what it needs between two statements) is already on its way -- requested by the
+// statement before this one (or the prologue); it asks for the second chunk, applies the first, and at
+// its end asks for the NEXT statement's first chunk (nbase: the next pivots of these rows, or pivots
+// 0 .. 3 of the next step's rows), which travels while the second chunk is applied.
+__device__ __forceinline__ void links8c(vec2d (&cur)[4], const vec2d pa, const vec2d pb, const vec2d pc, const vec2d pd,
+                                        const vec2d pe, const vec2d pf, const vec2d pg, const vec2d ph,
+                                        const double *base2, const double *nbase, unsigned o1, unsigned o2)
+{
+    double t0, t1;
+    asm volatile(
+        "s_add_u32 s34, %[o1], %[o2]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_load_dwordx8 s[36:43], %[base2], 0x0\n\t"
+        "s_load_dwordx8 s[44:51], %[base2], %[o1]\n\t"
+        "s_load_dwordx8 s[52:59], %[base2], %[o2]\n\t"
+        "s_load_dwordx8 s[60:67], %[base2], s34\n\t"
+        MI_W4_LINK("s[68:69]", "s[70:71]", "s[72:73]", "s[74:75]", "pax", "pay")
+        MI_W4_LINK("s[76:77]", "s[78:79]", "s[80:81]", "s[82:83]", "pbx", "pby")
+        MI_W4_LINK("s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]", "pcx", "pcy")
+        MI_W4_LINK("s[92:93]", "s[94:95]", "s[96:97]", "s[98:99]", "pdx", "pdy")
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_load_dwordx8 s[68:75], %[nbase], 0x0\n\t"
+        "s_load_dwordx8 s[76:83], %[nbase], %[o1]\n\t"
+        "s_load_dwordx8 s[84:91], %[nbase], %[o2]\n\t"
+        "s_load_dwordx8 s[92:99], %[nbase], s34\n\t"
+        MI_W4_LINK("s[36:37]", "s[38:39]", "s[40:41]", "s[42:43]", "pex", "pey")
+        MI_W4_LINK("s[44:45]", "s[46:47]", "s[48:49]", "s[50:51]", "pfx", "pfy")
+        MI_W4_LINK("s[52:53]", "s[54:55]", "s[56:57]", "s[58:59]", "pgx", "pgy")
+        MI_W4_LINK("s[60:61]", "s[62:63]", "s[64:65]", "s[66:67]", "phx", "phy")
+        : [x0] "+v"(cur[0].x), [y0] "+v"(cur[0].y), [x1] "+v"(cur[1].x), [y1] "+v"(cur[1].y),
+          [x2] "+v"(cur[2].x), [y2] "+v"(cur[2].y), [x3] "+v"(cur[3].x), [y3] "+v"(cur[3].y),
+          [t0] "=&v"(t0), [t1] "=&v"(t1)
+        : [pax] "v"(pa.x), [pay] "v"(pa.y), [pbx] "v"(pb.x), [pby] "v"(pb.y),
+          [pcx] "v"(pc.x), [pcy] "v"(pc.y), [pdx] "v"(pd.x), [pdy] "v"(pd.y),
+          [pex] "v"(pe.x), [pey] "v"(pe.y), [pfx] "v"(pf.x), [pfy] "v"(pf.y),
+          [pgx] "v"(pg.x), [pgy] "v"(pg.y), [phx] "v"(ph.x), [phy] "v"(ph.y),
+          [base2] "s"(base2), [nbase] "s"(nbase), [o1] "s"(o1), [o2] "s"(o2)
+        : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
+          "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",
+          "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83",
+          "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s34", "scc", "memory");
+}
+// the chain's first request (a tile's prologue): pivots 0 .. 3 of the first step's rows
+__device__ __forceinline__ void links_first(const double *base, unsigned o1, unsigned o2)
+{
+    asm volatile(
+        "s_add_u32 s34, %[o1], %[o2]\n\t"
+        "s_load_dwordx8 s[68:75], %[base], 0x0\n\t"
+        "s_load_dwordx8 s[76:83], %[base], %[o1]\n\t"
+        "s_load_dwordx8 s[84:91], %[base], %[o2]\n\t"
+        "s_load_dwordx8 s[92:99], %[base], s34\n\t"
+        :: [base] "s"(base), [o1] "s"(o1), [o2] "s"(o2)
+        : "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83",
+          "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s34", "scc", "memory");
+}
+
 // ---- variant R: the product's structure (k_sweepw without masks / slots)
 template <int K, bool NT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8)))
@@ -262,7 +320,14 @@ void k_lds(double *M, const double *prow, const double *col, int64_t ld, int64_t
         if (s + D < nsteps) issue(s + D);                     // into the slot just read
         const int64_t r = r0 + (int64_t)s * U;
         const double *cb = col + r;
-        if constexpr (MODE != 1 && L8 == 2) {
+        if constexpr (MODE != 1 && L8 == 3) {
+            if (s == 0) links_first(cb, o1, o2);
+#pragma unroll
+            for (int i0 = 0; i0 < K; i0 += 8)
+                links8c(cur, p[i0], p[i0 + 1], p[i0 + 2], p[i0 + 3], p[i0 + 4], p[i0 + 5], p[i0 + 6], p[i0 + 7],
+                        cb + (int64_t)(i0 / 4 + 1) * group_stride,
+                        i0 + 8 < K ? cb + (int64_t)(i0 / 4 + 2) * group_stride : cb + U, o1, o2);
+        } else if constexpr (MODE != 1 && L8 == 2) {
 #pragma unroll
             for (int i0 = 0; i0 < K; i0 += 4)
                 links4t8(cur, p[i0], p[i0 + 1], p[i0 + 2], p[i0 + 3], cb + (int64_t)(i0 / 4) * group_stride, o1, o2, o3);
@@ -288,6 +353,7 @@ void k_lds(double *M, const double *prow, const double *col, int64_t ld, int64_t
             for (int u = 0; u < U; ++u) if (r + u < r1) st2(r + u, cur[u]);
         }
     }
+    if constexpr (L8 == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
 static std::vector<double> g_ref;
@@ -342,6 +408,7 @@ static void run_lds_mode(const Setup &S, int tr, const char *what)
     const size_t lds = (size_t)4 * D * 4 * 1024;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lds<K, D, NT, MODE, WMAX, L8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     auto launch = [&]() { hipLaunchKernelGGL((k_lds<K, D, NT, MODE, WMAX, L8>), grid, dim3(256), lds, 0, S.M, S.prow, S.col, S.ld, S.rows, S.cs, tr, S.sp); };
+    if (MODE == 0) { reset(S); launch(); CK(hipDeviceSynchronize()); check(S, what); }
     const double us = time_it(launch, 20);
     hipFuncAttributes fa;
     CK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_lds<K, D, NT, MODE, WMAX, L8>)));
@@ -413,6 +480,10 @@ int main(int argc, char **argv)
     BOTH((run_lds_mode<24, 3, true, 0, 3, 1>(S, 32, "8 links per statement: everything, D=3")), (run_lds_mode<24, 3, false, 0, 3, 1>(S, 32, "8 links per statement: everything, D=3")));
     BOTH((run_lds_mode<24, 2, true, 2, 3, 2>(S, 32, "8 temporaries: links only, 3 waves")), (run_lds_mode<24, 2, false, 2, 3, 2>(S, 32, "8 temporaries: links only, 3 waves")));
     BOTH((run_lds_mode<24, 2, true, 0, 3, 2>(S, 32, "8 temporaries: everything, 3 waves")), (run_lds_mode<24, 2, false, 0, 3, 2>(S, 32, "8 temporaries: everything, 3 waves")));
+    BOTH((run_lds_mode<24, 2, true, 2, 3, 3>(S, 32, "continuous chain: links only, 3 waves")), (run_lds_mode<24, 2, false, 2, 3, 3>(S, 32, "continuous chain: links only, 3 waves")));
+    BOTH((run_lds_mode<24, 2, true, 0, 3, 3>(S, 32, "continuous chain: everything, 3 waves")), (run_lds_mode<24, 2, false, 0, 3, 3>(S, 32, "continuous chain: everything, 3 waves")));
+    BOTH((run_lds_mode<24, 2, true, 0, 4, 3>(S, 32, "continuous chain: everything, <= 4 waves")), (run_lds_mode<24, 2, false, 0, 4, 3>(S, 32, "continuous chain: everything, <= 4 waves")));
+    BOTH((run_lds_mode<24, 2, true, 0, 3, 1>(S, 32, "8 links per statement again: everything, 3 waves")), (run_lds_mode<24, 2, false, 0, 3, 1>(S, 32, "8 links per statement again: everything, 3 waves")));
     // the other traffic policy at this size, for the record
     BOTH((run_lds<24, 3, false>(S, 64)), (run_lds<24, 3, true>(S, 64)));
     return 0;

@@ -11,6 +11,10 @@ if len(sys.argv) > 2:                                     # pivots per sweep (bl
     L.mi355x_tune_set_block(int(sys.argv[2]))
 if len(sys.argv) > 3:                                     # sweep implementation (mi355x_tune_set_sweep_impl)
     L.mi355x_tune_set_sweep_impl(int(sys.argv[3]))
+if os.environ.get("PROBE_XMAP"):                          # k_sweepw_ring: workgroups -> tiles by XCD
+    L.mi355x_tune_set_sweep_xcd_map(int(os.environ["PROBE_XMAP"]))
+if os.environ.get("PROBE_RING"):
+    L.mi355x_tune_set_sweepw_ring(int(os.environ["PROBE_RING"]))
 h = ctypes.c_void_p()
 lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h), n, m, lp.synth.seed_for(3 if m == 4096 else 5), 0, -1, 0), "create")
 h2 = ctypes.c_void_p()

@@ -33,6 +33,7 @@ ap.add_argument("--block", type=int, default=0, help="pivots per sweep (0 = by s
 ap.add_argument("--tr", type=int, default=0, help="rows per sweep workgroup (0 = default)")
 ap.add_argument("--nt", type=int, default=-1, help="non-temporal sweep accesses (0 / 1, -1 = by size)")
 ap.add_argument("--wait", type=int, default=2, help="status read-back: 2 published control block + memory poll (default), 1 polled stream query, 0 hipStreamSynchronize")
+ap.add_argument("--xmap", type=int, default=-1, help="k_sweepw_ring: workgroups -> tiles by XCD (1) or in grid order (0); -1 = the library's default")
 ap.add_argument("--ring", type=int, default=1, help="wide sweeps through the LDS ring (1, default) or the register form (0)")
 args = ap.parse_args()
 
@@ -41,6 +42,8 @@ L = lp.capi.lib()
 n, m = args.n, args.m
 L.mi355x_tune_set_sweepw_ring(args.ring)
 L.mi355x_tune_set_ctl_wait(args.wait)
+if args.xmap >= 0:
+    L.mi355x_tune_set_sweep_xcd_map(args.xmap)
 if args.block:
     L.mi355x_tune_set_block(args.block)
 if args.tr or args.nt >= 0:
