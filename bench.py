@@ -67,6 +67,9 @@ def parse():
                     help="tuning: pivots selected ahead and applied per sweep (0 = library default, 1 = off)")
     ap.add_argument("--batch-block", type=int, default=0,
                     help="tuning, cfg4: pivots per pass of the blocked per-LP kernel (0 = default, 1 = off)")
+    ap.add_argument("--no-prime", action="store_true",
+                    help="profiling runs: without the EMPTY blocks a handle's first request is preceded by (one launch of "
+                         "every kernel form its requests can pick) -- they would count as launches of the profiled kernels")
     ap.add_argument("--sweepw-ring", type=int, default=1,
                     help="tuning: wide sweeps through the per-wave LDS ring (1, default) or the register form of round 4 (0)")
     ap.add_argument("--sweep-tr", type=int, default=0, help="tuning: rows per sweep workgroup")
@@ -604,6 +607,8 @@ def main():
         L.mi355x_tune_set_sweep_shape(args.sweep_tr, args.sweep_nt)
     if not args.sweepw_ring:
         L.mi355x_tune_set_sweepw_ring(0)
+    if args.no_prime:
+        L.mi355x_tune_set_prime(0)
     # One LP supports only so many pivots before it is optimal (config 3: 5 700-6 100, config 2:
     # 189-416 with these seeds).  If more timed steps are asked for than one LP safely provides,
     # further LPs of the same shape are generated in HBM BEFORE the timed region and the timed

@@ -20,7 +20,7 @@ MI355X_E2E_TIMING=1 python tools/native_end_to_end.py --init > $O/native_end_to_
 python bench.py --workload colpart --steps 112 --warmup 28 > $O/bench_colpart_1gpu.log 2>&1; echo "bench colpart rc=$?"
 (for b in 16 24 28; do python tools/shard_step_cost.py 336 $b; done) 2>&1 | grep -E "per sweep|us per pivot" > $O/shard_step_cost.log; echo "shard step cost rc=$?"
 python tools/wide_block_ab.py 2>&1 | grep "us per pivot" > $O/wide_block_ab.log; echo "wide block A/B rc=$?"
-(python tools/steady_gap.py --repeat 3 --pivots 4200; python tools/steady_gap.py --repeat 3 --pivots 4200 --load 0.25; python tools/steady_gap.py --repeat 3 --pivots 4200 --ring 0) 2>&1 | grep -v amdgpu.ids > $O/steady_gap.log; echo "steady gap rc=$?"
+(python tools/steady_gap.py --repeat 3 --pivots 4200; python tools/steady_gap.py --repeat 3 --pivots 4200 --load 0.25; python tools/steady_gap.py --repeat 3 --pivots 4200 --ring 0; python tools/steady_gap.py --repeat 3 --pivots 4200 --wait 0; python tools/steady_gap.py --repeat 4 --pivots 20 --events 0; python tools/steady_gap.py --repeat 3 --pivots 4200 --xmap 1) 2>&1 | grep -v amdgpu.ids > $O/steady_gap.log; echo "steady gap rc=$?"
 python tools/la_timing.py 2>&1 | grep -v amdgpu.ids | head -26 > $O/la_timing.log; echo "la timing rc=$?"
 (cd tools/microbench && ./sweep_lds && ./sweep_lds 32769 8208) 2>&1 | grep -v "^    " > $O/sweep_lds_microbench.log; echo "sweep_lds microbench rc=$?"
 (cd tools/microbench && ./sweep32 && ./sweep32 32769 65552 && ./sweep32 4097 8208) > $O/sweep32_microbench.log 2>&1; echo "sweep32 microbench rc=$?"
@@ -32,9 +32,9 @@ python tools/resident_lds_ab.py 2>&1 | grep -v "^/opt" > $O/resident_lds_ab.log;
  timeout 300 python tools/fuzz_colpart.py 1500; timeout 300 python tools/fuzz_two_phase.py 2000; timeout 300 python tools/fuzz_batch_extreme.py 200
  timeout 300 python tools/fuzz_colpart_extreme.py 600; timeout 300 python tools/fuzz_colpart_two_phase.py 600; timeout 300 python tools/fuzz_solve_problems.py 300) 2>&1 | grep "cases,\|batches,\|lists,\|MISMATCH" > $O/fuzz_totals.log; echo "fuzzers done"; cat $O/fuzz_totals.log
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats -- python $R/bench.py --no-cpu-baseline --no-per-pivot --no-other-configs > $O/kernel_stats.log 2>&1; echo "rocprof stats rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats -- python $R/bench.py --no-cpu-baseline --no-per-pivot --no-other-configs --no-prime > $O/kernel_stats.log 2>&1; echo "rocprof stats rc=$?"
 for ring in 1 0; do
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ring_ab_$ring -- python $R/tools/steady_gap.py --repeat 2 --pivots 4200 --events 0 --ring $ring > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ring_ab_$ring -- python $R/tools/steady_gap.py --repeat 2 --pivots 4200 --events 0 --prime 0 --ring $ring > /dev/null 2>&1
   f=$(find $O/ring_ab_$ring -name "*kernel_stats.csv" | head -1); echo "ring=$ring (tools/steady_gap.py --pivots 4200 --events 0 --ring $ring under rocprofv3 --kernel-trace --stats)"; head -4 $f
 done > $O/ring_ab_kernel_stats.log 2>&1; echo "ring A/B kernel stats done"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats_cfg4 -- python $R/bench.py --workload cfg4 > $O/kernel_stats_cfg4.log 2>&1; echo "rocprof stats cfg4 rc=$?"

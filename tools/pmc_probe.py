@@ -11,6 +11,7 @@ if len(sys.argv) > 2:                                     # pivots per sweep (bl
     L.mi355x_tune_set_block(int(sys.argv[2]))
 if len(sys.argv) > 3:                                     # sweep implementation (mi355x_tune_set_sweep_impl)
     L.mi355x_tune_set_sweep_impl(int(sys.argv[3]))
+L.mi355x_tune_set_prime(0)                                # (the empty priming blocks would count as launches of the profiled kernels)
 if os.environ.get("PROBE_XMAP"):                          # k_sweepw_ring: workgroups -> tiles by XCD
     L.mi355x_tune_set_sweep_xcd_map(int(os.environ["PROBE_XMAP"]))
 if os.environ.get("PROBE_RING"):
