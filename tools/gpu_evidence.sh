@@ -22,6 +22,7 @@ python bench.py --workload colpart --steps 112 --warmup 28 > $O/bench_colpart_1g
 python tools/wide_block_ab.py 2>&1 | grep "us per pivot" > $O/wide_block_ab.log; echo "wide block A/B rc=$?"
 (python tools/steady_gap.py --repeat 3 --pivots 4200; python tools/steady_gap.py --repeat 3 --pivots 4200 --load 0.25; python tools/steady_gap.py --repeat 3 --pivots 4200 --ring 0; python tools/steady_gap.py --repeat 3 --pivots 4200 --wait 0; python tools/steady_gap.py --repeat 4 --pivots 20 --events 0; python tools/steady_gap.py --repeat 3 --pivots 4200 --xmap 1) 2>&1 | grep -v amdgpu.ids > $O/steady_gap.log; echo "steady gap rc=$?"
 python tools/la_timing.py 2>&1 | grep -v amdgpu.ids | head -26 > $O/la_timing.log; echo "la timing rc=$?"
+(cd tools/microbench && for b in sweep_lds sweep32; do [ -x $b ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o $b $b.hip; done) > /dev/null 2>&1
 (cd tools/microbench && ./sweep_lds && ./sweep_lds 32769 8208) 2>&1 | grep -v "^    " > $O/sweep_lds_microbench.log; echo "sweep_lds microbench rc=$?"
 (cd tools/microbench && ./sweep32 && ./sweep32 32769 65552 && ./sweep32 4097 8208) > $O/sweep32_microbench.log 2>&1; echo "sweep32 microbench rc=$?"
 (python tools/resident_timing.py; python tools/resident_timing.py 512 256) 2>&1 | grep -E "us/pivot|inside" > $O/resident_timing.log; echo "resident timing rc=$?"
