@@ -148,6 +148,9 @@ int         mi355x_debug_repeat_sweep(mi355x_tab *t, int n, double *avg_us);
 /* debugging aid: copies n doubles of the handle's scratch `rhs` buffer (the per-phase clocks of
  * a -DMI355X_LA_TIMING build); clear != 0 zeroes it afterwards */
 int         mi355x_debug_rhs(mi355x_tab *t, double *out, int64_t n, int clear);
+int         mi355x_debug_last_wait(double *out2);            /* host microseconds of the last status read-back:
+                                                                [0] launching k_ctl_publish, [1] polling its
+                                                                sequence number (bench.py's steady-state leg)   */
 
 /* ---- fault injection: TEST BUILD ONLY ---------------------------------------------------- */
 /* Compiled in with -DMI355X_TEST_HOOKS (libmi355x_simplex_test.so, built next to the product

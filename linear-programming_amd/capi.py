@@ -149,6 +149,7 @@ _EXTRA = {
     "mi355x_tab_path_counts": (_int, [_p, _p]),
     "mi355x_tab_timing_read_kind": (_int, [_p, _int, _p, _p, _p]),
     "mi355x_debug_rhs": (_int, [_p, _p, _i64, _int]),
+    "mi355x_debug_last_wait": (_int, [_p]),
     "mi355x_debug_repeat_sweep": (_int, [_p, _int, _p]),
     "mi355x_tune_variant_count": (_int, []),
     "mi355x_tune_variant_name": (ctypes.c_char_p, [_int]),
