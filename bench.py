@@ -27,6 +27,13 @@ import os
 import sys
 import time
 
+# numpy's OpenBLAS wakes one worker per core for a dot product and lets them SPIN for ~100 ms afterwards
+# (THREAD_TIMEOUT): 64 spinning threads use up a container's CPU quota (cgroup cpu.max, 16 cores on the
+# gpurun boxes) and the whole process is frozen until the next 100 ms period -- measured as a read-back
+# 26 - 72 ms late on the request that followed the one dot product of the config-5 leg (DESIGN_experiments.md
+# R5.10).  Nothing here needs a threaded BLAS.
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -386,7 +393,7 @@ def other_configs(lp, L, device, block):
                 "properties": {"min_reduced_cost": float(row5[:n5 + m5].min()), "dual_feasible": bool(row5[:n5 + m5].min() >= -128 * 1.1102230246251568e-16),
                                "min_rhs": float(col5[:m5].min()), "primal_feasible": bool(col5[:m5].min() >= 0.0),
                                "objective": float(col5[m5]),
-                               "ctx_recomputed_rel_err": float(abs(c5 @ x5[:n5] - col5[m5]) / abs(col5[m5]))},
+                               "ctx_recomputed_rel_err": float(abs(float((c5 * x5[:n5]).sum()) - col5[m5]) / abs(col5[m5]))},
                 "parity": {"identical": None, "checked_against": "size-independent properties here (tests/test_gpu_optimum.py adds "
                            "Ax <= b with A regenerated); the first 64 pivots bit for bit against the oracle in "
                            "tests/test_gpu_fullsize.py"}}
@@ -400,11 +407,11 @@ def other_configs(lp, L, device, block):
     # the 60.7 k against 77 k of the round-4 driver run was ONE such wake-up on a 21 ms run) is small
     # against the run, and measured by the GPU's own clock next to the wall clock
     # Three LPs of the shape, the same request each; the record is the run with the shortest WALL time, all three
-    # are listed with where the host's time went (mi355x_debug_last_wait).  Observed on the driver's kind of
-    # box: the FIRST of the three -- the first request after the 17 - 26 GB of the config-5 legs were freed --
-    # sees its read-back 26 - 72 ms late although the GPU's own clock shows the usual 47.6 ms between the first
-    # launch and the last kernel's end (the launch of k_ctl_publish takes 3 us, the poll of its number the rest:
-    # the queue starts late, not the solve); the second and third return 0.02 ms behind the GPU.
+    # are listed with where the host's time went (mi355x_debug_last_wait).  (Until the threaded BLAS was switched
+    # off at the top of this file the FIRST of the three returned 26 - 72 ms late in every run: the config-5 leg's
+    # one dot product left 63 OpenBLAS workers spinning, the container's CPU quota ran out and the process was
+    # frozen until the next period -- the GPU's own clock showed the usual 47.6 ms.  Round 4's single
+    # steady-state run, 60.7 k against 77 k, was that request.)
     runs = []
     for rep in range(3):
         n, m = 8192, 4096
