@@ -21,18 +21,23 @@ def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-@pytest.fixture(params=[(24, 1), (28, 1), (24, 0), (28, 0)], ids=["24-ring", "28-ring", "24-registers", "28-registers"])
+@pytest.fixture(params=[(24, 1, 0), (28, 1, 0), (24, 0, 0), (28, 0, 0), (24, 1, 1), (28, 1, 1)],
+                ids=["24-ring", "28-ring", "24-registers", "28-registers", "24-ring-xcd-map", "28-ring-xcd-map"])
 def wide(request):
-    """Pivots per pass, and the form of the streaming kernel: the tile's rows through a per-wave LDS
-    ring (k_sweepw_ring, the default since round 5) or through two register sets (k_sweepw)."""
+    """Pivots per pass, the form of the streaming kernel -- the tile's rows through a per-wave LDS
+    ring (k_sweepw_ring, the default since round 5) or through two register sets (k_sweepw) -- and,
+    for the ring, which tile a workgroup takes: the grid's own order or one run of tiles per XCD
+    (mi355x_tune_set_sweep_xcd_map: every (strip, tile) exactly once either way)."""
     L = lp.capi.lib()
-    k, ring = request.param
+    k, ring, xmap = request.param
     assert L.mi355x_tune_set_block(k) == k
     L.mi355x_tune_set_sweepw_ring(ring)
+    L.mi355x_tune_set_sweep_xcd_map(xmap)
     L.mi355x_tune_set_select_mode(2)                    # small shapes too: the blocked path
     yield k
     L.mi355x_tune_set_block(0)
     L.mi355x_tune_set_sweepw_ring(1)
+    L.mi355x_tune_set_sweep_xcd_map(0)
     L.mi355x_tune_set_select_mode(0)
 
 
