@@ -4,7 +4,7 @@ solve runs is decided by shape alone -- csrc/capi_tab_impl.inc (`block_size`, `b
 `wide_block_default`, `resident_plan`):
 
   * persistent look-ahead (k_la_block): max(rows, stored_ld / 2) <= 8192, i.e. <= 32 workgroups;
-  * pivots per sweep behind it: 16 below 100 MiB of stored tableau, 24 from there on;
+  * pivots per sweep behind it: 16 below 28 MiB of stored tableau, 24 from there on;
   * without it: 16 below 768 MiB stored, 24 from there on, 28 from 8e9 bytes on;
   * resident (k_resident): <= 1024 constraints and <= 32 column strips of 64 / 32 / 16 columns;
   * dense tableaux (basis not unit columns): single-workgroup select up to 1024 rows and a row pitch
@@ -100,15 +100,17 @@ def _run(n, m, seed, expect_block, expect_paths, full_compare=True):
     (15871, 600, 31, True), (16383, 600, 32, True), (16384, 600, 33, False),       # pairs = padded(n + 1) / 2
 ], ids=["rows-31wg", "rows-32wg", "rows-33wg", "pairs-31wg", "pairs-32wg", "pairs-33wg"])
 def test_persistent_lookahead_limit(n, m, wg, persistent):
-    assert _la_workgroups(n, m) == wg and _stored_bytes(n, m) < (100 << 20)
-    _run(n, m, lp.synth.seed_for(3, 7000 + wg), 16, [LA_PERSISTENT if persistent else LA_TWO_LAUNCH, SWEEP16])
+    assert _la_workgroups(n, m) == wg and (28 << 20) < _stored_bytes(n, m) < (100 << 20)
+    # (37 - 40 MB stored: 24 per pass behind the persistent look-ahead, 16 behind the two-launch form)
+    _run(n, m, lp.synth.seed_for(3, 7000 + wg), 24 if persistent else 16,
+         [LA_PERSISTENT, SWEEP_WIDE] if persistent else [LA_TWO_LAUNCH, SWEEP16])
 
 
-# ---- behind the persistent look-ahead: 16 pivots per sweep below 100 MiB stored, 24 from there on
-@pytest.mark.parametrize("n,m,block", [(4079, 3200, 16), (4095, 3200, 24)], ids=["99.6MiB", "100.03MiB"])
-def test_block_size_switch_at_100_mib(n, m, block):
-    assert (_stored_bytes(n, m) >= (100 << 20)) == (block == 24) and _la_workgroups(n, m) <= 32
-    assert abs(_stored_bytes(n, m) - (100 << 20)) < (1 << 20)
+# ---- behind the persistent look-ahead: 16 pivots per sweep below 28 MiB stored, 24 from there on
+@pytest.mark.parametrize("n,m,block", [(2031, 1791, 16), (2047, 1791, 24)], ids=["27.78MiB", "28.00MiB"])
+def test_block_size_switch_at_28_mib(n, m, block):
+    assert (_stored_bytes(n, m) >= (28 << 20)) == (block == 24) and _la_workgroups(n, m) <= 32
+    assert abs(_stored_bytes(n, m) - (28 << 20)) < (1 << 20)
     _run(n, m, lp.synth.seed_for(3, 7100 + block), block, [LA_PERSISTENT, SWEEP_WIDE if block == 24 else SWEEP16])
 
 

@@ -158,10 +158,10 @@ def test_column_partition_with_wide_blocks(n_shards, exchange, wide):
 def test_wide_blocks_are_the_default_where_the_sweep_dominates():
     """A 0.75 GB+ stored tableau that does not fit the persistent look-ahead takes 24 pivots per
     sweep by default (28 from 8 GB on: config 5, tests/test_gpu_fullsize.py); so does config 3 --
-    the persistent look-ahead holds up to 24 pending pivots, and from 100 MB of stored tableau on
-    the sweep is a pass over HBM; smaller tableaux stay at 16."""
+    the persistent look-ahead holds up to 24 pending pivots, and from 28 MiB of stored tableau on
+    (48 MB at 3000 x 2000) the one-launch pass of 24 beats k_sweep16's 16; smaller tableaux stay at 16."""
     L = lp.capi.lib()
-    for (n, m, want) in ((8192, 4096, 24), (200, 100, 16), (3000, 2000, 16), (12000, 9000, 24)):
+    for (n, m, want) in ((8192, 4096, 24), (200, 100, 16), (2000, 1500, 16), (3000, 2000, 24), (12000, 9000, 24)):
         h = ctypes.c_void_p()
         lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h), n, m, 12345, 0, -1, 0), "create")
         try:
