@@ -5,7 +5,7 @@ solve runs is decided by shape alone -- csrc/capi_tab_impl.inc (`block_size`, `b
 
   * persistent look-ahead (k_la_block): max(rows, stored_ld / 2) <= 8192, i.e. <= 32 workgroups;
   * pivots per sweep behind it: 16 below 28 MiB of stored tableau, 24 from there on;
-  * without it: 16 below 768 MiB stored, 24 from there on, 28 from 8e9 bytes on;
+  * without it: 16 below 240 MiB stored, 24 from there on, 28 from 8e9 bytes on;
   * resident (k_resident): <= 1024 constraints and <= 32 column strips of 64 / 32 / 16 columns;
   * dense tableaux (basis not unit columns): single-workgroup select up to 1024 rows and a row pitch
     of 4096 doubles, split select beyond.
@@ -114,12 +114,12 @@ def test_block_size_switch_at_28_mib(n, m, block):
     _run(n, m, lp.synth.seed_for(3, 7100 + block), block, [LA_PERSISTENT, SWEEP_WIDE if block == 24 else SWEEP16])
 
 
-# ---- without it: 16 below 768 MiB stored, 24 from there on (two-launch look-ahead, wide sweep)
-@pytest.mark.parametrize("n,m,block", [(12271, 8200, 16), (12287, 8200, 24)], ids=["767.8MiB", "768.8MiB"])
-def test_wide_block_switch_at_768_mib(n, m, block):
+# ---- without it: 16 below 240 MiB stored, 24 from there on (two-launch look-ahead, wide sweep)
+@pytest.mark.parametrize("n,m,block", [(3823, 8200, 16), (3839, 8200, 24)], ids=["239.3MiB", "240.3MiB"])
+def test_wide_block_switch_at_240_mib(n, m, block):
     assert _la_workgroups(n, m) > 32
-    assert (_stored_bytes(n, m) >= 768 * 1024 * 1024) == (block == 24)
-    assert abs(_stored_bytes(n, m) - 768 * 1024 * 1024) < (1 << 20)
+    assert (_stored_bytes(n, m) >= 240 * 1024 * 1024) == (block == 24)
+    assert abs(_stored_bytes(n, m) - 240 * 1024 * 1024) < (1 << 20)
     _run(n, m, lp.synth.seed_for(3, 7200 + block), block, [LA_TWO_LAUNCH, SWEEP_WIDE if block == 24 else SWEEP16])
 
 

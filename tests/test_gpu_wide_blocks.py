@@ -1,6 +1,6 @@
 """Wide blocks (round 4): 24 / 28 pivots selected ahead and applied by ONE pass over the stored
-tableau (k_sweepw + k_sweepw_rest), the default where the sweep dominates an iteration (tableaux and
-column shards of 0.75 GB and more) and selectable everywhere with mi355x_tune_set_block.  Same
+tableau (k_sweepw + k_sweepw_rest), the default where the sweep dominates an iteration (tableaux of
+240 MiB and column shards of 0.75 GB and more) and selectable everywhere with mi355x_tune_set_block.  Same
 operands, same roundings, same order as 28 k_update launches (src/simplex.lisp:337-359), so the
 pivots and every bit must be the oracle's -- through the blocking solve, through arbitrary
 sequences of asynchronous requests (full blocks, remainders above and below 16, blocks cut short
@@ -156,7 +156,7 @@ def test_column_partition_with_wide_blocks(n_shards, exchange, wide):
 
 
 def test_wide_blocks_are_the_default_where_the_sweep_dominates():
-    """A 0.75 GB+ stored tableau that does not fit the persistent look-ahead takes 24 pivots per
+    """A 240 MiB+ stored tableau that does not fit the persistent look-ahead takes 24 pivots per
     sweep by default (28 from 8 GB on: config 5, tests/test_gpu_fullsize.py); so does config 3 --
     the persistent look-ahead holds up to 24 pending pivots, and from 28 MiB of stored tableau on
     (48 MB at 3000 x 2000) the one-launch pass of 24 beats k_sweep16's 16; smaller tableaux stay at 16."""
