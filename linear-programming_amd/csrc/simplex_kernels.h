@@ -63,7 +63,7 @@ struct BlockCtl {
     // n_pending on its own; a workgroup that gave up on an exchange (kSyncLost) may be one step
     // behind it, so the sweep applies min(n_pending, min over w of steps) pivots and the host's
     // recovery takes the bookkeeping of the pivot beyond that back (k_la_rollback).
-    int64_t done[32];             // kMaxLaWorkgroups entries
+    int64_t done[64];             // kMaxLaWorkgroups entries
     int64_t ec[kWideBlock];       // persistent look-ahead: the logical columns that entered (k_la_rollback)
 };
 
@@ -76,9 +76,17 @@ struct BlockCtl {
 struct ExchRec {
     unsigned long long g[8];
 };
-constexpr int kMaxLaWorkgroups = 32;
+// Up to kLaWaveRecordsMaxNw workgroups every WAVE publishes a record and every wave polls them all (the
+// launch can sit on one XCD: 32 CUs); from there up to kMaxLaWorkgroups every WORKGROUP publishes one
+// record (its four waves' winners reduced through LDS) and its first wave polls -- the poll traffic of
+// the first form grows with the square of the workgroups, the LDS hop of the second does not
+// (DESIGN_experiments.md R5.16 / R5.18).  Both forms use the same transposed buffers.
+constexpr int kLaWaveRecordsMaxNw = 32;
+constexpr int kMaxLaWorkgroups = 64;
 static_assert(sizeof(BlockCtl::done) / sizeof(int64_t) == kMaxLaWorkgroups, "BlockCtl::done");
-constexpr int kMaxLaRecords = 4 * kMaxLaWorkgroups;     // one record per wave of a 256-thread workgroup
+constexpr int kMaxLaRecords = 4 * kLaWaveRecordsMaxNw;  // one record per wave of a 256-thread workgroup / one per workgroup
+static_assert(kMaxLaWorkgroups <= 64 && kMaxLaWorkgroups <= kMaxLaRecords,
+              "a sweep's wave reads BlockCtl::done with one lane per workgroup; per-workgroup records are collected one per lane");
 
 // Column partition, exchange mode 2 (the shards write into each other's fine-grained buffers):
 // layout of one shard's exchange buffer in 8-byte granules {tag = pivot number, 32 bits of payload}

@@ -3,9 +3,12 @@ solve runs is decided by shape alone -- csrc/capi_tab_impl.inc (`block_size`, `b
 `resident_mode`, `enqueue_select`), csrc/kernels_launch.inc (`la_block_supported`,
 `wide_block_default`, `resident_plan`):
 
-  * persistent look-ahead (k_la_block): max(rows, stored_ld / 2) <= 8192, i.e. <= 32 workgroups;
+  * persistent look-ahead (k_la_block): max(rows, stored_ld / 2) <= 16384, i.e. <= 64 workgroups -- up to 32
+    with a record per wave and every wave polling (one XCD), from 33 on with a record per workgroup and one
+    polling wave (kernels_la_block.inc, la_exchange<., WGR>);
   * pivots per sweep behind it: 16 below 28 MiB of stored tableau, 24 from there on;
-  * without it: 16 below 240 MiB stored, 24 from there on, 28 from 2e9 bytes on;
+  * without it: 16 below 240 MiB stored, 24 from there on, 28 from 2e9 bytes on -- and from 2e9 bytes on
+    "without it" includes the shapes of 33 ... 64 workgroups (28 per pass beat the cheaper step there);
   * resident (k_resident): <= 1024 constraints and <= 32 column strips of 64 / 32 / 16 columns;
   * dense tableaux (basis not unit columns): single-workgroup select up to 1024 rows and a row pitch
     of 4096 doubles, split select beyond.
@@ -94,14 +97,18 @@ def _run(n, m, seed, expect_block, expect_paths, full_compare=True):
             assert np.array_equal(G[r0:r0 + 2048].view(np.int64), M[r0:r0 + 2048].view(np.int64)), r0
 
 
-# ---- persistent look-ahead: 31 / 32 / 33 workgroups, by rows and by column pairs -----------------
+# ---- persistent look-ahead: 31 / 32 / 33 workgroups (records per wave -> per workgroup) and 63 / 64 / 65
+# (the limit), by rows and by column pairs
 @pytest.mark.parametrize("n,m,wg,persistent", [
-    (600, 7935, 31, True), (600, 8191, 32, True), (600, 8192, 33, False),          # rows = m + 1
-    (15871, 600, 31, True), (16383, 600, 32, True), (16384, 600, 33, False),       # pairs = padded(n + 1) / 2
-], ids=["rows-31wg", "rows-32wg", "rows-33wg", "pairs-31wg", "pairs-32wg", "pairs-33wg"])
+    (600, 7935, 31, True), (600, 8191, 32, True), (600, 8192, 33, True),           # rows = m + 1
+    (15871, 600, 31, True), (16383, 600, 32, True), (16384, 600, 33, True),        # pairs = padded(n + 1) / 2
+    (600, 16127, 63, True), (600, 16383, 64, True), (600, 16384, 65, False),
+    (32255, 600, 63, True), (32767, 600, 64, True), (32768, 600, 65, False),
+], ids=["rows-31wg", "rows-32wg", "rows-33wg", "pairs-31wg", "pairs-32wg", "pairs-33wg",
+        "rows-63wg", "rows-64wg", "rows-65wg", "pairs-63wg", "pairs-64wg", "pairs-65wg"])
 def test_persistent_lookahead_limit(n, m, wg, persistent):
-    assert _la_workgroups(n, m) == wg and (28 << 20) < _stored_bytes(n, m) < (100 << 20)
-    # (37 - 40 MB stored: 24 per pass behind the persistent look-ahead, 16 behind the two-launch form)
+    assert _la_workgroups(n, m) == wg and (28 << 20) < _stored_bytes(n, m) < (240 << 20)
+    # (37 - 158 MB stored: 24 per pass behind the persistent look-ahead, 16 behind the two-launch form)
     _run(n, m, lp.synth.seed_for(3, 7000 + wg), 24 if persistent else 16,
          [LA_PERSISTENT, SWEEP_WIDE] if persistent else [LA_TWO_LAUNCH, SWEEP16])
 
@@ -114,21 +121,37 @@ def test_block_size_switch_at_28_mib(n, m, block):
     _run(n, m, lp.synth.seed_for(3, 7100 + block), block, [LA_PERSISTENT, SWEEP_WIDE if block == 24 else SWEEP16])
 
 
-# ---- without it: 16 below 240 MiB stored, 24 from there on (two-launch look-ahead, wide sweep)
-@pytest.mark.parametrize("n,m,block", [(3823, 8200, 16), (3839, 8200, 24)], ids=["239.3MiB", "240.3MiB"])
+# ---- without it (more than 64 look-ahead workgroups): 16 below 240 MiB stored, 24 from there on
+# (two-launch look-ahead, wide sweep)
+@pytest.mark.parametrize("n,m,block", [(1903, 16440, 16), (1919, 16440, 24)], ids=["238.8MiB", "240.8MiB"])
 def test_wide_block_switch_at_240_mib(n, m, block):
-    assert _la_workgroups(n, m) > 32
+    assert _la_workgroups(n, m) > 64
     assert (_stored_bytes(n, m) >= 240 * 1024 * 1024) == (block == 24)
-    assert abs(_stored_bytes(n, m) - 240 * 1024 * 1024) < (1 << 20)
+    assert abs(_stored_bytes(n, m) - 240 * 1024 * 1024) < 1.25 * (1 << 20)
     _run(n, m, lp.synth.seed_for(3, 7200 + block), block, [LA_TWO_LAUNCH, SWEEP_WIDE if block == 24 else SWEEP16])
 
 
-# ---- 24 -> 28 pivots per sweep at 2e9 bytes stored
+# ---- 24 -> 28 pivots per sweep at 2e9 bytes stored: more than 64 look-ahead workgroups (two-launch look-ahead
+# on both sides), and 33 ... 64 (47 here), where the persistent look-ahead with its 24 pivots gives way to
+# the two-launch form with 28 at the same size (capi_tab_impl.inc block_size)
 @pytest.mark.timeout(1500, method="thread")
-@pytest.mark.parametrize("n,m,block", [(20815, 12000, 24), (20847, 12000, 28)], ids=["1.998e9", "2.002e9"])
-def test_wide_block_switch_at_2e9_bytes(n, m, block):
+@pytest.mark.parametrize("n,m,block,persistent", [
+    (15231, 16400, 24, False), (15247, 16400, 28, False),
+    (20815, 12000, 24, True), (20847, 12000, 28, False),
+], ids=["65wg-1.9986e9", "65wg-2.0007e9", "47wg-1.998e9", "47wg-2.002e9"])
+def test_wide_block_switch_at_2e9_bytes(n, m, block, persistent):
+    assert (_la_workgroups(n, m) > 64) == (m == 16400)
     assert (_stored_bytes(n, m) >= 2e9) == (block == 28) and abs(_stored_bytes(n, m) - 2e9) < 0.01e9
-    _run(n, m, lp.synth.seed_for(3, 7400 + block), block, [LA_TWO_LAUNCH, SWEEP_WIDE])
+    _run(n, m, lp.synth.seed_for(3, 7400 + block), block, [LA_PERSISTENT if persistent else LA_TWO_LAUNCH, SWEEP_WIDE],
+         full_compare=(m == 12000))
+
+
+# ---- a large tableau behind the persistent look-ahead (59 workgroups, 1.8 GB stored: 24 per pass)
+@pytest.mark.timeout(1500, method="thread")
+def test_large_tableau_behind_the_persistent_lookahead():
+    n, m = 15000, 15000
+    assert _la_workgroups(n, m) == 59 and 1.7e9 < _stored_bytes(n, m) < 1.9e9
+    _run(n, m, lp.synth.seed_for(3, 7500), 24, [LA_PERSISTENT, SWEEP_WIDE], full_compare=False)
 
 
 # ---- one shape in the middle of the band no BASELINE configuration falls into (268 MB ... 17 GB): 6.4 GB,
