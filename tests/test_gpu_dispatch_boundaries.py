@@ -131,19 +131,16 @@ def test_wide_block_switch_at_240_mib(n, m, block):
     _run(n, m, lp.synth.seed_for(3, 7200 + block), block, [LA_TWO_LAUNCH, SWEEP_WIDE if block == 24 else SWEEP16])
 
 
-# ---- 24 -> 28 pivots per sweep at 2e9 bytes stored: more than 64 look-ahead workgroups (two-launch look-ahead
-# on both sides), and 33 ... 64 (47 here), where the persistent look-ahead with its 24 pivots gives way to
-# the two-launch form with 28 at the same size (capi_tab_impl.inc block_size)
+# ---- 24 -> 28 pivots per sweep at 2e9 bytes stored (wide_block_default) -- on a shape of 47 look-ahead
+# workgroups, where the same switch also takes the look-ahead from the persistent form (it holds 24 pending
+# pivots) to the two-launch form (capi_tab_impl.inc block_size)
 @pytest.mark.timeout(1500, method="thread")
-@pytest.mark.parametrize("n,m,block,persistent", [
-    (15231, 16400, 24, False), (15247, 16400, 28, False),
-    (20815, 12000, 24, True), (20847, 12000, 28, False),
-], ids=["65wg-1.9986e9", "65wg-2.0007e9", "47wg-1.998e9", "47wg-2.002e9"])
+@pytest.mark.parametrize("n,m,block,persistent", [(20815, 12000, 24, True), (20847, 12000, 28, False)],
+                         ids=["1.998e9", "2.002e9"])
 def test_wide_block_switch_at_2e9_bytes(n, m, block, persistent):
-    assert (_la_workgroups(n, m) > 64) == (m == 16400)
+    assert 32 < _la_workgroups(n, m) <= 64
     assert (_stored_bytes(n, m) >= 2e9) == (block == 28) and abs(_stored_bytes(n, m) - 2e9) < 0.01e9
-    _run(n, m, lp.synth.seed_for(3, 7400 + block), block, [LA_PERSISTENT if persistent else LA_TWO_LAUNCH, SWEEP_WIDE],
-         full_compare=(m == 12000))
+    _run(n, m, lp.synth.seed_for(3, 7400 + block), block, [LA_PERSISTENT if persistent else LA_TWO_LAUNCH, SWEEP_WIDE])
 
 
 # ---- a large tableau behind the persistent look-ahead (59 workgroups, 1.8 GB stored: 24 per pass)

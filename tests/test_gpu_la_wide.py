@@ -53,8 +53,8 @@ def knobs():
 def test_workgroup_record_form_matches_the_oracle(knobs, n, m, wg, block):
     L = knobs
     assert _la_workgroups(n, m) == wg
-    if block == 16 and n * m > 50_000_000:
-        pytest.skip("the 16-step form on the small shapes only (oracle time)")
+    if block == 16 and wg not in (33, 40):
+        pytest.skip("the 16-step form on two shapes only (suite time)")
     seed = lp.synth.seed_for(3, 8800 + wg + block)
     L.mi355x_tune_set_block(block if block == 16 else 0)
     h = ctypes.c_void_p()
@@ -87,9 +87,12 @@ def test_workgroup_record_form_matches_the_oracle(knobs, n, m, wg, block):
         assert np.array_equal(G[r0:r0 + 2048].view(np.int64), M[r0:r0 + 2048].view(np.int64)), r0
 
 
-@pytest.mark.parametrize("n,m,wg", [(700, 8300, 33), (700, 8000, 32), (4000, 3000, 12)], ids=["33wg", "32wg", "12wg"])
-@pytest.mark.parametrize("fault_step", [1, 5, 24, -1, -2, -7, -24])
-def test_lost_exchange_behind_blocks_of_24(fault_step, n, m, wg, hooks_lib):
+@pytest.mark.parametrize("n,m,wg,fault_step", [
+    (700, 8300, 33, 1), (700, 8300, 33, 24), (700, 8300, 33, -1), (700, 8300, 33, -7), (700, 8300, 33, -24),
+    (700, 8000, 32, -7), (700, 8000, 32, 5),
+    (4000, 3000, 12, 1), (4000, 3000, 12, -2), (4000, 3000, 12, -7), (4000, 3000, 12, -24),
+])
+def test_lost_exchange_behind_blocks_of_24(n, m, wg, fault_step, hooks_lib):
     """As tests/test_gpu_fullsize.py test_lost_exchange_falls_back_to_two_launch_lookahead (a shape of 16
     pivots per pass), on shapes that run 24 per pass through the ring sweep -- the record-per-workgroup
     form (33 workgroups) and the record-per-wave form (32, 12): the last workgroup stops publishing
