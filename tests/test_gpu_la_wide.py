@@ -128,3 +128,41 @@ def test_lost_exchange_behind_blocks_of_24(n, m, wg, fault_step, hooks_lib):
     assert np.array_equal(t.pivot_trace()[:npiv], trace[:npiv])
     assert np.array_equal(t.matrix.view(np.int64), M.view(np.int64))
     assert np.array_equal(t.basis_columns, b)
+
+
+def test_nonfinite_entering_column_is_flagged_across_workgroup_records():
+    """An inf in the entering column, in a row the LAST of 33 workgroups owns: the ratio records carry a flag
+    (OR over the lanes of a wave, over the four waves of a workgroup in LDS, over the nw records) that sends
+    the solve back to the dense tableau, where the reference's arithmetic on inf / NaN is reproduced entry by
+    entry (src/simplex.lisp:382-397 takes the pivot on whatever the quotients say).  Same pivots, same NaN
+    pattern, same bits as the oracle."""
+    L = lp.capi.lib()
+    n, m = 700, 8300
+    assert _la_workgroups(n, m) == 33
+    seed = lp.synth.seed_for(3, 8899)
+    M0, b0 = lp.synth.tableau(n, m, seed)
+    M, b = M0.copy(), b0.copy()
+    st, npiv, trace = oracle.solve(M, b, max_pivots=4, trace_cap=4, omp=True)
+    assert npiv == 4
+    col, row = int(trace[3][0]), 8250                     # the column that enters fourth; a row of workgroup 32
+    assert row not in [int(r) for r in trace[:, 1]] and col < n
+    M1 = M0.copy()
+    M1[row, col] = float("inf")
+    M, b = M1.copy(), b0.copy()
+    K = 9
+    with np.errstate(all="ignore"):
+        st_o, npiv, trace = oracle.solve(M, b, max_pivots=K, trace_cap=K, omp=True)
+    t = lp.Tableau(None, lp.Problem(type="max"), M1, b0, n + m, m, {})
+    k = ctypes.c_int64(0)
+    rc = L.mi355x_tab_solve(t._h, 1, 1024.0, K, ctypes.byref(k))
+    c = _counts(L, t._h)
+    t._touch()
+    assert (rc, k.value) == (st_o, npiv), (rc, k.value, st_o, npiv)
+    assert c[LA_PERSISTENT] > 0, c
+    assert np.array_equal(t.pivot_trace()[:npiv], trace[:npiv])
+    G = t.matrix
+    nan_o, nan_g = np.isnan(M), np.isnan(G)
+    assert nan_o.any() or np.isinf(M).any()
+    assert np.array_equal(nan_o, nan_g)
+    assert np.array_equal(G[~nan_g].view(np.int64), M[~nan_o].view(np.int64))
+    assert np.array_equal(t.basis_columns, b)
