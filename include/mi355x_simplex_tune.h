@@ -38,7 +38,11 @@ int         mi355x_tune_set_block(int k);                    /* pivots per sweep
                                                                 or a wide block of 28 where the sweep
                                                                 dominates), 1 off, 2 .. 16, 24, 28    */
 int         mi355x_tune_set_lookahead_mode(int mode);        /* 0 auto, 1 two launches per step,
-                                                                2 one persistent launch per block */
+                                                                2 one persistent launch per block
+                                                                (tableaux of up to 64 look-ahead
+                                                                workgroups = 16384 rows and 32768
+                                                                stored columns; auto: of those with more
+                                                                than 32, the ones below 2e9 bytes stored) */
 int         mi355x_tune_set_sweep_shape(int rows_per_workgroup, int nontemporal /* -1 by size */);
 int         mi355x_tune_set_sweep_impl(int impl);            /* 0 k_sweep16 for full blocks, 1 k_sweep
                                                                 always, 3 the two-launch form of the wide
@@ -112,7 +116,9 @@ int         mi355x_tab_resident(mi355x_tab *t);
 
 /* ---- persistent look-ahead (k_la_block) ------------------------------------------------ */
 int         mi355x_tune_set_la_one_xcd(int on);              /* 1 (default): all its workgroups on
-                                                                one XCD, verified inside the launch */
+                                                                one XCD, verified inside the launch
+                                                                (up to 32 workgroups; more are spread
+                                                                over the chip whatever this says)   */
 int         mi355x_tune_set_la_max_spins(unsigned polls);    /* polls before a workgroup gives up
                                                                 on a record; 0 = default (2^21)  */
 /* How often an exchange of the persistent look-ahead was lost on this handle (0 = never).  After a
