@@ -43,12 +43,11 @@ def knobs():
 
 @pytest.mark.parametrize("n,m,wg", [
     (700, 8300, 33),            # rows
-    (700, 12100, 48),
     (500, 16383, 64),
     (20000, 1000, 40),          # column pairs
     (32767, 500, 64),
     (12000, 11000, 43),         # both large (1.06 GB stored): the objective row's and the RHS pair's owners far apart
-], ids=["rows-33", "rows-48", "rows-64", "pairs-40", "pairs-64", "square-43"])
+], ids=["rows-33", "rows-64", "pairs-40", "pairs-64", "square-43"])
 @pytest.mark.parametrize("block", [24, 16])
 def test_workgroup_record_form_matches_the_oracle(knobs, n, m, wg, block):
     L = knobs
@@ -88,9 +87,9 @@ def test_workgroup_record_form_matches_the_oracle(knobs, n, m, wg, block):
 
 
 @pytest.mark.parametrize("n,m,wg,fault_step", [
-    (700, 8300, 33, 1), (700, 8300, 33, 24), (700, 8300, 33, -1), (700, 8300, 33, -7), (700, 8300, 33, -24),
-    (700, 8000, 32, -7), (700, 8000, 32, 5),
-    (4000, 3000, 12, 1), (4000, 3000, 12, -2), (4000, 3000, 12, -7), (4000, 3000, 12, -24),
+    (700, 8300, 33, 1), (700, 8300, 33, -1), (700, 8300, 33, -7), (700, 8300, 33, -24),
+    (700, 8000, 32, -7),
+    (4000, 3000, 12, 5), (4000, 3000, 12, -2), (4000, 3000, 12, -24),
 ])
 def test_lost_exchange_behind_blocks_of_24(n, m, wg, fault_step, hooks_lib):
     """As tests/test_gpu_fullsize.py test_lost_exchange_falls_back_to_two_launch_lookahead (a shape of 16
