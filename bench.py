@@ -207,6 +207,8 @@ def per_pivot_record(lp, L, n, m, seed, device, kernel_bytes, restore_block, piv
     return {"kernel": L.mi355x_update_kernel_name().decode(), "what": "per-pivot path (block = 1): one k_update launch per pivot",
             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
             "traffic": traffic, "traffic_source": src,
+            "note": "read frac as an upper figure, MALL-assisted: the compact tableau is about the size of the 256 MiB "
+                    "Infinity Cache and FETCH_SIZE counts L2 fetches whoever answers them (DESIGN.md 4.1)",
             "kernel_avg_us": avg_ms * 1e3, "kernel_min_us": mn.value * 1e3, "launches_timed": int(nl.value),
             "bytes_moved_per_launch": kernel_bytes, "pivots_per_launch": 1,
             "pivots_per_s_whole_iteration": pivots / dt}
