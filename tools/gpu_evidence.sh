@@ -20,11 +20,13 @@ MI355X_E2E_TIMING=1 python tools/native_end_to_end.py --init > $O/native_end_to_
 python bench.py --workload colpart --steps 112 --warmup 28 > $O/bench_colpart_1gpu.log 2>&1; echo "bench colpart rc=$?"
 (for b in 16 24 28; do python tools/shard_step_cost.py 336 $b; done) 2>&1 | grep -E "per sweep|us per pivot" > $O/shard_step_cost.log; echo "shard step cost rc=$?"
 python tools/wide_block_ab.py 2>&1 | grep "us per pivot" > $O/wide_block_ab.log; echo "wide block A/B rc=$?"
+python tools/la_wide_ab.py 2>&1 | grep "us/pivot" > $O/la_wide_ab.log; echo "wide persistent look-ahead A/B rc=$?"
 (python tools/steady_gap.py --repeat 3 --pivots 4200; python tools/steady_gap.py --repeat 3 --pivots 4200 --load 0.25; python tools/steady_gap.py --repeat 3 --pivots 4200 --ring 0; python tools/steady_gap.py --repeat 3 --pivots 4200 --wait 0; python tools/steady_gap.py --repeat 4 --pivots 20 --events 0; python tools/steady_gap.py --repeat 3 --pivots 4200 --xmap 1) 2>&1 | grep -v amdgpu.ids > $O/steady_gap.log; echo "steady gap rc=$?"
 python tools/la_timing.py 2>&1 | grep -v amdgpu.ids | head -26 > $O/la_timing.log; echo "la timing rc=$?"
-(cd tools/microbench && for b in sweep_lds sweep32; do [ -x $b ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o $b $b.hip; done) > /dev/null 2>&1
+(cd tools/microbench && for b in sweep_lds sweep32 shard_step_skel; do [ -x $b ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o $b $b.hip; done) > /dev/null 2>&1
 (cd tools/microbench && ./sweep_lds && ./sweep_lds 32769 8208) 2>&1 | grep -v "^    " > $O/sweep_lds_microbench.log; echo "sweep_lds microbench rc=$?"
 (cd tools/microbench && ./sweep32 && ./sweep32 32769 65552 && ./sweep32 4097 8208) > $O/sweep32_microbench.log 2>&1; echo "sweep32 microbench rc=$?"
+(cd tools/microbench && timeout 250 ./shard_step_skel) > $O/shard_step_skeleton.log 2>&1; echo "shard step skeleton rc=$?"
 (python tools/resident_timing.py; python tools/resident_timing.py 512 256) 2>&1 | grep -E "us/pivot|inside" > $O/resident_timing.log; echo "resident timing rc=$?"
 python tools/resident_ab.py 2>&1 | grep "poll mode" > $O/resident_ab.log; echo "resident A/B rc=$?"
 python tools/resident_lds_ab.py 2>&1 | grep -v "^/opt" > $O/resident_lds_ab.log; echo "resident LDS-strip A/B rc=$?"

@@ -155,7 +155,8 @@ def main(tag):
                 w_.writerows(keep)
     for log, dst in (("steady_gap.log", "_steady_gap.txt"), ("la_timing.log", "_la_timing.txt"), ("sweep_lds_microbench.log", "_sweep_lds_microbench.txt"),
                      ("ring_ab_kernel_stats.log", "_ring_ab_kernel_stats.txt"), ("wide_block_ab.log", "_wide_block_ab.txt"), ("sweep32_microbench.log", "_sweep32_microbench.txt"),
-                     ("resident_lds_ab.log", "_resident_lds_ab.txt"), ("fuzz_totals.log", "_fuzz_totals.txt")):
+                     ("resident_lds_ab.log", "_resident_lds_ab.txt"), ("fuzz_totals.log", "_fuzz_totals.txt"),
+                     ("la_wide_ab.log", "_la_wide_ab.txt"), ("shard_step_skeleton.log", "_shard_step_skeleton.txt")):
         f = one(log, required=False)
         if f and os.path.getsize(f):
             shutil.copy(f, os.path.join(PR, tag + dst))
