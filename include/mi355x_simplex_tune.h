@@ -144,6 +144,17 @@ int         mi355x_tab_timing_read_kind(mi355x_tab *t, int which, int64_t *n_lau
  * `stride`-th pivot (at most max_samples per shard and per solve call; 0 = off); _read waits for
  * the shards' streams and returns the averages over this process's shards since the last read */
 int         mi355x_colpart_block_size(const mi355x_colpart *p);   /* pivots per sweep of a shard's slice */
+/* exchange mode 2, blocked shards: the look-ahead of a whole block as ONE persistent launch per device
+ * (k_shard_la_block).  out4: [0] blocks enqueued that way, [1] exchanges it lost, [2] the handle is demoted
+ * to the two-launch step right now, [3] the next block would take the persistent form */
+int         mi355x_colpart_la_stats(mi355x_colpart *p, int64_t *out4);
+int         mi355x_tune_set_shard_la_block(int mode);        /* read when a handle is created: 0 (default) the
+                                                                persistent block launch wherever it fits, 1 never */
+int         mi355x_tune_set_shard_self_hop(int on);          /* measurement: a LONE shard runs exchange A (its
+                                                                pricing pair) against its own buffer -- what a
+                                                                shard of several pays minus the wire        */
+int         mi355x_tune_set_p2p_spins(unsigned n);           /* polls before a shard gives a peer's granules
+                                                                up (read at creation; 0 = default 2^24)      */
 int         mi355x_colpart_exchange_timing_enable(mi355x_colpart *p, int stride, int max_samples);
 int         mi355x_colpart_exchange_timing_read(mi355x_colpart *p, int64_t *n_samples,
                                                 double *allgather_us, double *allreduce_us);
@@ -165,6 +176,9 @@ int         mi355x_debug_last_wait(double *out2);            /* host microsecond
 #ifdef MI355X_TEST_HOOKS
 int         mi355x_tune_set_resident_fault(int on);          /* the last workgroup of every LP never
                                                                 publishes (co-residency lost)    */
+int         mi355x_tune_set_shard_la_fault(int step_plus_1); /* the same two faults (below) in the last
+                                                                workgroup of the last local shard of a
+                                                                k_shard_la_block launch                  */
 int         mi355x_tune_set_la_fault(int step_plus_1);       /* > 0: the last workgroup stops
                                                                 publishing from that step on; < 0: it
                                                                 publishes its ratio record of step

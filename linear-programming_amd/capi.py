@@ -140,6 +140,10 @@ _EXTRA = {
     "mi355x_colpart_p2p_handle": (_int, [_p, _p]),
     "mi355x_colpart_p2p_connect": (_int, [_p, _p]),
     "mi355x_colpart_block_size": (_int, [_p]),
+    "mi355x_colpart_la_stats": (_int, [_p, _p]),
+    "mi355x_tune_set_shard_la_block": (_int, [_int]),
+    "mi355x_tune_set_shard_self_hop": (_int, [_int]),
+    "mi355x_tune_set_p2p_spins": (_int, [ctypes.c_uint]),
     "mi355x_colpart_exchange_timing_enable": (_int, [_p, _int, _int]),
     "mi355x_colpart_exchange_timing_read": (_int, [_p, _p, _p, _p]),
     "mi355x_tune_set_la_one_xcd": (_int, [_int]),
@@ -171,6 +175,7 @@ _EXTRA = {
 _TEST_HOOKS = {
     "mi355x_tune_set_resident_fault": (_int, [_int]),
     "mi355x_tune_set_la_fault": (_int, [_int]),
+    "mi355x_tune_set_shard_la_fault": (_int, [_int]),
 }
 TEST_LIB_PATH = os.path.join(HERE, "libmi355x_simplex_test.so")
 

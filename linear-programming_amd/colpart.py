@@ -349,6 +349,13 @@ class NativeColumnPartition:
         """Pivots per sweep of a shard's slice (16, or a wide block of 24 / 28 for large shards)."""
         return int(capi.lib().mi355x_colpart_block_size(self._h))
 
+    def la_stats(self):
+        """Exchange mode 2, blocked: blocks enqueued through the persistent block launch (k_shard_la_block),
+        exchanges it lost, demoted right now, next block persistent."""
+        out = (ctypes.c_int64 * 4)()
+        capi.check(capi.lib().mi355x_colpart_la_stats(self._h, out), "mi355x_colpart_la_stats")
+        return {"blocks": int(out[0]), "losses": int(out[1]), "demoted": bool(out[2]), "live": bool(out[3])}
+
     def p2p_handle(self):
         """Exchange mode 2, one process per GPU: the 64-byte IPC handle of this rank's exchange buffer."""
         buf = ctypes.create_string_buffer(64)

@@ -48,6 +48,11 @@ int g_cp_exchange = 0;                    // column partition over RCCL, exchang
                                           // ncclBroadcast (root = the rank whose pricing winner won, read
                                           // back from the all-gather: one host synchronisation per pivot)
 
+int g_cp_la_block = 0;                    // exchange mode 2, blocked: the shard's look-ahead of a block as ONE persistent
+                                          // launch (k_shard_la_block): 0 wherever it fits, 1 never, 2 = 0 (reserved)
+int g_cp_self_hop = 0;                    // measurement: a lone shard runs exchange A against its own buffer
+unsigned g_cp_p2p_spins = 0;              // polls before a shard gives a peer up (0: 2^24)
+
 // The knobs above as a handle sees them: a handle takes a SNAPSHOT of them when it is created
 // and never looks at the process-wide values again, so a host thread that turns a knob cannot
 // change the path of a solve another thread has in flight on its own handle (handles are

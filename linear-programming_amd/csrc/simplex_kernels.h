@@ -63,8 +63,9 @@ struct BlockCtl {
     // n_pending on its own; a workgroup that gave up on an exchange (kSyncLost) may be one step
     // behind it, so the sweep applies min(n_pending, min over w of steps) pivots and the host's
     // recovery takes the bookkeeping of the pivot beyond that back (k_la_rollback).
-    int64_t done[64];             // kMaxLaWorkgroups entries
+    int64_t done[256];            // kMaxShardLaWorkgroups entries (single tableaux use the first kMaxLaWorkgroups)
     int64_t ec[kWideBlock];       // persistent look-ahead: the logical columns that entered (k_la_rollback)
+    int64_t prev[kWideBlock];     // column shards (k_shard_la_block): basis[cr] as it was before the pivot (k_shard_la_rollback)
 };
 
 // Record one workgroup of the persistent look-ahead kernel publishes per exchange: eight
@@ -83,7 +84,11 @@ struct ExchRec {
 // (DESIGN_experiments.md R5.16 / R5.18).  Both forms use the same transposed buffers.
 constexpr int kLaWaveRecordsMaxNw = 32;
 constexpr int kMaxLaWorkgroups = 64;
-static_assert(sizeof(BlockCtl::done) / sizeof(int64_t) == kMaxLaWorkgroups, "BlockCtl::done");
+// A column shard's persistent look-ahead (k_shard_la_block, round 6) runs one workgroup per 256 rows of the
+// WHOLE column -- 129 for config 5 however many GPUs share it -- with a record (a 64-byte line) per workgroup
+// and one polling wave each; the sweeps read BlockCtl::done with up to four entries per lane.
+constexpr int kMaxShardLaWorkgroups = 256;
+static_assert(sizeof(BlockCtl::done) / sizeof(int64_t) == kMaxShardLaWorkgroups, "BlockCtl::done");
 constexpr int kMaxLaRecords = 4 * kLaWaveRecordsMaxNw;  // one record per wave of a 256-thread workgroup / one per workgroup
 static_assert(kMaxLaWorkgroups <= 64 && kMaxLaWorkgroups <= kMaxLaRecords,
               "a sweep's wave reads BlockCtl::done with one lane per workgroup; per-workgroup records are collected one per lane");
@@ -146,6 +151,17 @@ struct TabView {
     int64_t  n_lps;
     int64_t  zs_M, zs_basis, zs_col, zs_prow, zs_part, zs_p2l, zs_l2p;
     int64_t  zs_bk, zs_bkp, zs_rm, zs_sm;       // per-LP block state: bk_col, bk_prow, bk_rmask, bk_smask (blk: one BlockCtl each)
+};
+
+// One shard of a k_shard_la_block launch (an array of these in device memory, indexed by blockIdx.y:
+// one entry per device-local shard -- one where a shard has its GPU to itself, the logical shards of a
+// one-GPU test box all in ONE launch, whose workgroups are then co-resident by construction).
+struct ShardLaunch {
+    TabView t;
+    unsigned long long *const *peers;   // every shard's exchange buffer as this process maps it
+    unsigned long long *mine;           // this shard's own
+    int64_t col_offset;                 // dense shards: global index of local column 0
+    int rank, pad;
 };
 
 struct UpdateShape {
@@ -232,6 +248,15 @@ int  launch_shard_la_prepare(const TabView &t, int j, const double *col, const i
                              double fp_factor, int is_max, hipStream_t s, const P2pArgs &x = P2pArgs());
 int  launch_shard_p2p_step(const TabView &t, int j, int n_part, int n_shards, int64_t col_offset, double fp_factor,
                            int is_max, int64_t *ec_dev, hipStream_t s, const P2pArgs &x);
+// the look-ahead of a whole block of every device-local shard as ONE persistent launch (exchange mode 2;
+// kernels_shard_block.inc): workgroups a shard needs (0: not available for this view), the launch, and
+// the recovery's bookkeeping roll-back
+int  shard_la_block_workgroups(const TabView &t);
+void launch_shard_la_block(const ShardLaunch *dev_shards, int n_local, int nw_max, const P2pLayout &lay, int ksteps,
+                           int is_max, double fp_factor, unsigned epoch_base, unsigned xepoch_base,
+                           unsigned p2p_spins, int hop, hipStream_t s);
+void launch_shard_la_rollback(const TabView &t, int la_nw, hipStream_t s);
+void set_shard_la_fault(int step_plus_1);  // test hook (test build): as set_la_fault, the last workgroup of the last local shard
 bool shard_la_split(const TabView &t);     // the look-ahead step of this shard is the multi-workgroup pair
 void set_shard_la_split(int mode);         // tuning / test hook: 0 by size, 1 one workgroup, 2 split over many
 // two-phase hand-over (src/simplex.lisp:437-451)

@@ -63,6 +63,7 @@
 //     kernels_lookahead.inc       pending-pivot chain, k_la_gather / k_la_scale
 //     kernels_shard.inc           look-ahead step of a column shard (k_shard_la_*, k_shard_p2p_step)
 //     kernels_la_block.inc        persistent look-ahead k_la_block + hand-off protocol, k_la_rollback
+//     kernels_shard_block.inc     a column shard's look-ahead of a whole block as one persistent launch (k_shard_la_block)
 //     kernels_sweep.inc           k_sweep, k_sweep16
 //     kernels_batch.inc           k_batch_solve, k_batch_block
 //     kernels_resident.inc        k_resident
@@ -78,6 +79,7 @@ namespace mi355x {
 #include "kernels_lookahead.inc"
 #include "kernels_shard.inc"
 #include "kernels_la_block.inc"
+#include "kernels_shard_block.inc"
 #include "kernels_sweep.inc"
 #include "kernels_batch.inc"
 #include "kernels_resident.inc"
