@@ -148,6 +148,8 @@ int         mi355x_colpart_block_size(const mi355x_colpart *p);   /* pivots per 
  * (k_shard_la_block).  out4: [0] blocks enqueued that way, [1] exchanges it lost, [2] the handle is demoted
  * to the two-launch step right now, [3] the next block would take the persistent form */
 int         mi355x_colpart_la_stats(mi355x_colpart *p, int64_t *out4);
+int         mi355x_colpart_debug_set_la_rearm(mi355x_colpart *p, int64_t blocks);   /* as mi355x_debug_set_la_rearm */
+int         mi355x_colpart_debug_rhs(mi355x_colpart *p, int shard, double *out, int64_t n, int clear);   /* mi355x_debug_rhs of a local shard */
 int         mi355x_tune_set_shard_la_block(int mode);        /* read when a handle is created: 0 (default) the
                                                                 persistent block launch wherever it fits, 1 never */
 int         mi355x_tune_set_shard_self_hop(int on);          /* measurement: a LONE shard runs exchange A (its

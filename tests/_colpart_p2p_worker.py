@@ -22,10 +22,13 @@ def main():
     L = lp.capi.lib()
     mode = int(sys.argv[6]) if len(sys.argv) > 6 else 2          # 2: two launches per step where it applies, 3: four
     split = int(sys.argv[7]) if len(sys.argv) > 7 else 0          # 2: the multi-workgroup look-ahead step at any size
+    la_block = int(sys.argv[8]) if len(sys.argv) > 8 else 1       # 0: the persistent block launch (k_shard_la_block), 1: never
     L.mi355x_tune_set_colpart_exchange(mode)
     L.mi355x_tune_set_shard_la_split(split)
+    L.mi355x_tune_set_shard_la_block(la_block)
     tab = cp.NativeColumnPartition.synthetic_rank(n, m, seed, world, rank, 0, None)
     L.mi355x_tune_set_colpart_exchange(0)
+    L.mi355x_tune_set_shard_la_block(0)
     handles = [None] * world
     dist.all_gather_object(handles, tab.p2p_handle())
     tab.p2p_connect(b"".join(handles))
@@ -33,7 +36,9 @@ def main():
     st, k = tab.solve(max_pivots=max_pivots)
     _, basis, _, last_col = tab.download(matrix=False, last_row=False)
     trace = tab.trace(max(k, 1))
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), status=st, npiv=k, basis=basis, last_col=last_col, trace=trace)
+    stats = tab.la_stats()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), status=st, npiv=k, basis=basis, last_col=last_col, trace=trace,
+             la_blocks=stats["blocks"], la_losses=stats["losses"])
     dist.barrier()                       # nobody unmaps a buffer a peer may still be writing to
     tab.close()
     dist.destroy_process_group()

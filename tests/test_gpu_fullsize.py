@@ -450,8 +450,9 @@ def test_colpart_c_abi_cap_resume_synthetic_and_dense_fallback():
     tab.close()
 
 
-@pytest.mark.parametrize("exchange", [0, 1, 2, 12, 13],
-                         ids=["allreduce", "rooted-broadcast", "p2p-push", "p2p-two-launch-step", "p2p-four-launch-step"])
+@pytest.mark.parametrize("exchange", [0, 1, 2, 12, 13, 22],
+                         ids=["allreduce", "rooted-broadcast", "p2p-push", "p2p-two-launch-step", "p2p-four-launch-step",
+                              "p2p-persistent-block"])
 @pytest.mark.parametrize("entry", ["comm-init-all", "comm-init-rank"])
 def test_colpart_c_abi_over_rccl_single_rank(monkeypatch, entry, exchange):
     """The RCCL code path itself on the one GPU this box has: a single shard forced through its
@@ -473,11 +474,15 @@ def test_colpart_c_abi_over_rccl_single_rank(monkeypatch, entry, exchange):
     # 12 / 13: exchange 2 / 3 with the multi-workgroup look-ahead step of large shards forced at this
     # size -- 12 is then the two-launch step (k_shard_p2p_step: the shard has its stream to itself),
     # 13 the same step as four launches
-    split = 2 if exchange >= 10 else 0
+    # 22 (round 6): exchange 2 with the look-ahead of a whole block as ONE persistent launch (k_shard_la_block);
+    # the other P2P cases keep that form off, so that the step kernels they name are what runs
+    persistent = exchange == 22
+    split = 2 if 10 <= exchange < 20 else 0
     exchange = exchange % 10
     try:
         L.mi355x_tune_set_colpart_exchange(exchange)
         L.mi355x_tune_set_shard_la_split(split)
+        L.mi355x_tune_set_shard_la_block(0 if persistent else 1)
         if entry == "comm-init-rank":
             uid = cp.NativeColumnPartition.rccl_unique_id()
             assert len(uid) == 128 and any(uid)
@@ -486,6 +491,7 @@ def test_colpart_c_abi_over_rccl_single_rank(monkeypatch, entry, exchange):
             tab = cp.NativeColumnPartition.synthetic(n, m, seed, 1)
     finally:
         L.mi355x_tune_set_colpart_exchange(0)
+        L.mi355x_tune_set_shard_la_block(0)
     assert tab.info() == {"n_shards": 1, "n_devices_used": 1, "uses_rccl": True}
     tab.exchange_timing(4, 64)
     try:
@@ -493,6 +499,8 @@ def test_colpart_c_abi_over_rccl_single_rank(monkeypatch, entry, exchange):
     finally:
         L.mi355x_tune_set_shard_la_split(0)
     assert (st, k) == (so, no) and np.array_equal(tab.trace(no), trace)
+    stats = tab.la_stats()
+    assert (stats["blocks"] > 0) == persistent and stats["losses"] == 0, stats
     ns, ag_us, ar_us = tab.exchange_timing_read()
     if exchange >= 2:
         assert ns == 0                       # no collective to bracket: the exchanges are inside the step kernels
@@ -503,22 +511,27 @@ def test_colpart_c_abi_over_rccl_single_rank(monkeypatch, entry, exchange):
     tab.close()
 
 
+@pytest.mark.parametrize("persistent", [False, True], ids=["step-kernels", "persistent-block"])
 @pytest.mark.parametrize("n_devices", [1, 2, 3, 8])
 @pytest.mark.parametrize("n,m,seed", [(96, 64, 1), (700, 333, 2)])
-def test_colpart_p2p_exchange_logical_shards_bitwise(n, m, seed, n_devices):
+def test_colpart_p2p_exchange_logical_shards_bitwise(n, m, seed, n_devices, persistent):
     """Exchange mode 2 -- every shard writes its pricing pair and (the owner) the entering column
     straight into the other shards' fine-grained buffers as self-validating granules, the consumers
     poll their own buffer: no collective, no host in the loop.  On this one GPU the shards are
     logical (all producers of an exchange are enqueued before its consumers on the one stream), so
     the data path, the buffer layout, the parities and the tags are what is exercised here; the
     cross-device visibility of the stores needs a multi-GPU node.  Pivots and bits as the oracle's,
-    incl. a capped solve that resumes (the tags go on counting) and the two-phase hand-over."""
+    incl. a capped solve that resumes (the tags go on counting) and the two-phase hand-over.
+    persistent-block (round 6, the default of this mode): the look-ahead of a whole block of ALL the logical
+    shards as ONE launch of k_shard_la_block -- the shards' workgroups are co-resident by construction and
+    wait for each other's pairs / column granules inside the kernel, as the shards of a multi-GPU run do."""
     import importlib
     cp = importlib.import_module("linear-programming_amd.colpart")
     L = lp.capi.lib()
     M0, b0 = lp.synth.tableau(n, m, lp.synth.seed_for(5, seed))
     M, b = M0.copy(), b0.copy()
     st_o, npiv, trace = oracle.solve(M, b, trace_cap=1 << 14)
+    L.mi355x_tune_set_shard_la_block(0 if persistent else 1)
     try:
         L.mi355x_tune_set_colpart_exchange(2)
         tab = cp.NativeColumnPartition.from_arrays(M0, b0, n_devices)
@@ -529,6 +542,8 @@ def test_colpart_p2p_exchange_logical_shards_bitwise(n, m, seed, n_devices):
     st, k = tab.solve()
     assert (st, k) == (st_o, npiv - 23)
     assert np.array_equal(tab.trace(npiv), trace)
+    stats = tab.la_stats()
+    assert (stats["blocks"] > 0) == persistent and stats["losses"] == 0, stats
     G, bg, last_row, last_col = tab.download()
     assert np.array_equal(G.view(np.int64), M.view(np.int64)) and np.array_equal(bg, b)
     tab.close()
@@ -546,6 +561,7 @@ def test_colpart_p2p_exchange_logical_shards_bitwise(n, m, seed, n_devices):
         rc, got, mt = tab.solve_two_phase(main.matrix[-1].copy(), main.is_max, 1024)
     finally:
         L.mi355x_tune_set_colpart_exchange(0)
+        L.mi355x_tune_set_shard_la_block(0)
     assert rc == so
     GA, ga, _, _ = tab.download()
     assert np.array_equal(GA.view(np.int64), A.view(np.int64)) and np.array_equal(ga, ab)
@@ -555,6 +571,7 @@ def test_colpart_p2p_exchange_logical_shards_bitwise(n, m, seed, n_devices):
         assert np.array_equal(GM.view(np.int64), Mm.view(np.int64)) and np.array_equal(gm, mb)
         mt.close()
     tab.close()
+    L.mi355x_tune_set_shard_la_block(0)
 
 
 def test_bench_colpart_one_rank_through_the_multi_gpu_entry():
@@ -694,6 +711,8 @@ def test_colpart_over_rccl_on_real_devices(n_devices, exchange):
     tab.exchange_timing(8, 64)
     st, k = tab.solve()
     assert (st, k) == (so, no) and np.array_equal(tab.trace(no), trace)
+    stats = tab.la_stats()
+    assert (stats["blocks"] > 0) == persistent and stats["losses"] == 0, stats
     ns, ag_us, ar_us = tab.exchange_timing_read()
     assert ns > 0 and ag_us > 0.0 and ar_us > 0.0
     G, bg, _, _ = tab.download()

@@ -1081,10 +1081,10 @@ def test_column_partition_logical_shards_bitwise(n_shards, n, m, compact, block)
     cp.destroy_shards(shards)
 
 
-@pytest.mark.parametrize("mode,split", [(2, 0), (2, 2), (3, 2)],
-                         ids=["by-size", "two-launch-step", "four-launch-step"])
+@pytest.mark.parametrize("mode,split,la_block", [(2, 0, 1), (2, 2, 1), (3, 2, 1), (2, 0, 0)],
+                         ids=["by-size", "two-launch-step", "four-launch-step", "persistent-block"])
 @pytest.mark.parametrize("world,n,m,cap", [(2, 300, 120, 0), (3, 700, 300, 0), (4, 1500, 700, 90)])
-def test_column_partition_p2p_exchange_between_processes(world, n, m, cap, mode, split, tmp_path):
+def test_column_partition_p2p_exchange_between_processes(world, n, m, cap, mode, split, la_block, tmp_path):
     """Exchange mode 2 between real OS processes: every rank owns one shard behind mi355x_colpart_*,
     there is NO communicator (RCCL is not touched), the ranks map each other's fine-grained exchange
     buffers through IPC handles, and the per-pivot loop -- blind enqueue, no host in it -- runs in
@@ -1097,7 +1097,9 @@ def test_column_partition_p2p_exchange_between_processes(world, n, m, cap, mode,
     the form a shard with its device to itself uses -- pricing pair, pairs, column and ratio
     partials as ONE kernel (k_shard_p2p_step), so that a consumer and the producer it waits for are
     the same kernel in different processes; four-launch-step: the same step as the separate kernels
-    shards on one stream use."""
+    shards on one stream use; persistent-block (round 6): every rank's look-ahead of a whole block is ONE
+    persistent launch (k_shard_la_block) -- the ranks' launches are co-resident on the GPU, wait for each
+    other's pairs and column granules INSIDE the kernels, and must have run (la_blocks > 0, nothing lost)."""
     import os
     import socket
     import subprocess
@@ -1109,7 +1111,7 @@ def test_column_partition_p2p_exchange_between_processes(world, n, m, cap, mode,
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_colpart_p2p_worker.py"),
-                                       str(tmp_path), str(n), str(m), str(seed), str(cap), str(mode), str(split)],
+                                       str(tmp_path), str(n), str(m), str(seed), str(cap), str(mode), str(split), str(la_block)],
                                       env=env, cwd=ROOT))
     for p in procs:
         assert p.wait(timeout=600) == 0
@@ -1121,6 +1123,10 @@ def test_column_partition_p2p_exchange_between_processes(world, n, m, cap, mode,
         assert np.array_equal(res["trace"], trace), r
         assert np.array_equal(res["basis"], b), r
         assert np.array_equal(res["last_col"].view(np.int64), M[:, -1].view(np.int64)), r
+        if la_block == 0:
+            assert int(res["la_blocks"]) > 0 and int(res["la_losses"]) == 0, (r, int(res["la_blocks"]), int(res["la_losses"]))
+        else:
+            assert int(res["la_blocks"]) == 0, r
 
 
 @pytest.mark.parametrize("world,n,m,kind", [(2, 96, 64, "dense"), (3, 200, 90, "compact"),
