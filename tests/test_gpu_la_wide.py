@@ -90,6 +90,10 @@ def test_workgroup_record_form_matches_the_oracle(knobs, n, m, wg, block):
     (700, 8300, 33, 1), (700, 8300, 33, -1), (700, 8300, 33, -7), (700, 8300, 33, -24),
     (700, 8000, 32, -7),
     (4000, 3000, 12, 5), (4000, 3000, 12, -2), (4000, 3000, 12, -24),
+    # ONE wave of the last workgroup gives up at the ratio exchange of step 2 / 23 while its workgroup's other
+    # waves see the records and go on (every-wave-polls form; round-5 advisor finding: the workgroup's `done`
+    # entry must be the minimum over its waves, or the sweep applies a pivot whose prow entries that wave never stored)
+    (4000, 3000, 12, -1003), (4000, 3000, 12, -1024), (700, 8000, 32, -1008),
 ])
 def test_lost_exchange_behind_blocks_of_24(n, m, wg, fault_step, hooks_lib):
     """As tests/test_gpu_fullsize.py test_lost_exchange_falls_back_to_two_launch_lookahead (a shape of 16
