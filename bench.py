@@ -117,7 +117,9 @@ def cpu_baseline(lp, n, m, seed, pivots):
     import oracle
     import numpy as np
     M, b = lp.synth.tableau(n, m, seed)
-    threads = oracle.omp_threads()
+    # OpenMP sees every host thread (128 on the GPU box) whatever the container's CPU quota is (16 cores there):
+    # run with what the quota really grants and report THAT as `cores` (round-5 review)
+    threads = oracle.set_omp_threads(min(oracle.omp_threads(), oracle.usable_cores()))
     # the host is shared: one sample swings with whatever else runs on the box (53 ... 235 pivots/s
     # seen for this leg), so the pivots are timed in four consecutive segments (a dense pivot costs
     # the same whichever it is) and the BEST segment is the figure; all of them are listed
@@ -142,6 +144,7 @@ def cpu_baseline(lp, n, m, seed, pivots):
     best = max(segs)
     return {
         "value": best, "unit": "pivots/s", "cores": threads, "kind": "port",
+        "host_threads_visible": os.cpu_count(), "cores_by": "min(sched_getaffinity, cgroup cpu.max quota)",
         "sample": "first %d pivots of the same %dx%d LP in %d segments, best segment (all: %s), OpenMP "
                   "row-parallel C restatement of src/simplex.lisp:337-461 (SBCL unavailable in the image); "
                   "single-thread: %.3f pivots/s (best of two runs of %d further pivots)"
@@ -718,9 +721,17 @@ def main():
         upd_n, upd_avg_ms, upd_min_ms = read_events(0)
         la_n, la_avg_ms, la_min_ms = read_events(1)
         if upd_n < 8 and block > 1:
-            # a short run (the driver's 20 steps are ONE full block): more event samples from full
-            # blocks run right AFTER the timed region on the same tableau -- kernel statistics
-            # only, not part of `value`
+            # a short run (the driver's 20 steps are ONE block, cut short): the kernel statistics come from
+            # WARM full blocks run right AFTER the timed region on the same tableau -- not part of `value`.
+            # Two untimed blocks first (the first full blocks behind a short request run a kernel form the
+            # request did not, on cold caches: round 5's line read 114 us where rocprofv3 and the steady
+            # state read 106-108), then 12 timed ones, and ONLY those are the figure: the one event pair of
+            # the timed region brackets a block cut short, a different launch.
+            L.mi355x_tab_timing_enable(handles[-1], 0)
+            lp.capi.check(L.mi355x_tab_solve_async(handles[-1], 1, 1024.0, 2 * block, 0), "warm blocks")
+            L.mi355x_tab_sync(handles[-1], ctypes.byref(npv))
+            for hk in handles:                                   # (drop what the timed region recorded)
+                L.mi355x_tab_timing_enable(hk, 0)
             L.mi355x_tab_timing_enable(handles[-1], 1)
             lp.capi.check(L.mi355x_tab_solve_async(handles[-1], 1, 1024.0, 12 * block, 0), "extra event samples")
             L.mi355x_tab_sync(handles[-1], ctypes.byref(npv))
@@ -728,13 +739,9 @@ def main():
             l2, la2, lm2 = read_events(1)
             if n2:
                 extra_samples = n2
-                upd_avg_ms = ((upd_avg_ms or 0.0) * upd_n + a2 * n2) / (upd_n + n2)
-                upd_min_ms = m2 if upd_min_ms is None else min(upd_min_ms, m2)
-                upd_n += n2
+                upd_n, upd_avg_ms, upd_min_ms = n2, a2, m2
             if l2:
-                la_avg_ms = ((la_avg_ms or 0.0) * la_n + la2 * l2) / (la_n + l2)
-                la_min_ms = lm2 if la_min_ms is None else min(la_min_ms, lm2)
-                la_n += l2
+                la_n, la_avg_ms, la_min_ms = l2, la2, lm2
 
     if N > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -817,6 +824,12 @@ def main():
             roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                         "kernel": upd_name,
+                        # the honest figures next to `frac`, as scalars up front (the nested records below say how
+                        # they come about): which kernel takes most of a block, and the whole iteration against the peak
+                        "dominant_kernel_by_time": kernels[0]["kernel"],
+                        "dominant_kernel_time_share": kernels[0]["time_share"],
+                        "whole_iteration_frac": whole / HBM_PEAK_GBPS,
+                        "whole_iteration_GBps": whole,
                         "what": "the kernel that moves the tableau (>99 % of the HBM bytes of an iteration); "
                                 "every kernel above 10 % of the time is in `kernels`, largest first",
                         "kernel_avg_us": upd_avg_ms * 1e3, "kernel_time_share": upd_avg_ms / per_block_ms,

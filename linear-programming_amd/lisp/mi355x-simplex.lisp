@@ -1006,6 +1006,10 @@ the GPU(s) instead of one after the other.
     problems marshalled as they are, tableaux assembled, grouped and batched in C++): the result list
     then holds MI355X-SOLUTION objects -- the way to solve BASELINE config 4's 1 024 LPs from Lisp
     without 1 024 boxed tableaux.  (:NATIVE NIL, the default, keeps every member a `tableau`.)
+  * The other keywords are MI355X-SIMPLEX-SOLVER's, applied to every member: :FP-TOLERANCE (the
+    tolerance factor, src/simplex.lisp:506-511), :DEVICE (the GPU of members solved alone), :DEVICES
+    (a count or a list of device ids: the sub-batches' GPUs), :MAX-PIVOTS (a cap per member; 0 = none,
+    as the reference), :FULL-TABLEAU (every entry of every solved tableau written back).
 Every returned solution object's results are bit-identical to the single-problem path's."
   (declare (ignore args))
   (when (and (eq native :many) (not full-tableau) problems)

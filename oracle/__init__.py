@@ -45,6 +45,8 @@ def lib():
         i64, dbl, p = ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
         L.orc_epsilon.restype = dbl
         L.orc_omp_threads.restype = ctypes.c_int
+        L.orc_set_omp_threads.restype = ctypes.c_int
+        L.orc_set_omp_threads.argtypes = [ctypes.c_int]
         L.orc_price.restype = i64
         L.orc_price.argtypes = [p, i64, i64, i64, ctypes.c_int, dbl]
         L.orc_ratio.restype = i64
@@ -68,6 +70,35 @@ def lib():
 def omp_threads():
     """Threads the OpenMP variant uses."""
     return int(lib().orc_omp_threads())
+
+
+def usable_cores():
+    """Cores this process may really use: min(affinity, cgroup CPU quota).  OpenMP only sees the former."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:                                                   # cgroup v2: "max 100000" or "<quota> <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:                                               # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
+
+
+def set_omp_threads(n):
+    """Threads the OpenMP variant uses from now on (returns what OpenMP reports afterwards)."""
+    return int(lib().orc_set_omp_threads(int(n)))
 
 
 def _chk(M, basis=None):

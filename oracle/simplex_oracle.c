@@ -54,8 +54,12 @@ double orc_epsilon(void) { return CL_DOUBLE_FLOAT_EPSILON; }
 #ifdef _OPENMP
 #include <omp.h>
 int orc_omp_threads(void) { return omp_get_max_threads(); }
+/* the caller knows how many cores the container may really use (a cgroup CPU quota is invisible to
+ * OpenMP: 128 threads on a 16-core quota both mislabel and handicap the baseline) */
+int orc_set_omp_threads(int n) { if (n >= 1) omp_set_num_threads(n); return omp_get_max_threads(); }
 #else
 int orc_omp_threads(void) { return 1; }
+int orc_set_omp_threads(int n) { (void)n; return 1; }
 #endif
 
 /* find-entering-column, src/simplex.lisp:362-379.

@@ -5,6 +5,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -255,3 +256,103 @@ def test_python_mirror_replays_the_glue_call_for_call():
     py_calls = set(re.findall(r"\b(mi355x_(?:problem|simplex_solver|solution|var_mapping)\w*)\(", py))
     py_calls -= {"mi355x_problem_read_mps", "mi355x_problem_read_mps_ex", "mi355x_problem_to_json", "mi355x_simplex_solver"}   # (the MPS reader, the one-shot form)
     assert glue_calls == py_calls, (sorted(glue_calls - py_calls), sorted(py_calls - glue_calls))
+
+
+# ---- static guards of the glue (round-5 review, item 5): it cannot be executed here, so everything that CAN be
+# checked without a Lisp reader is a test -- argument and return TYPES of every binding, every imported symbol
+# against the reference's export lists, every keyword of the solver's lambda list against INTEGRATION.md
+_CFFI_OF_C = {"int": ":int", "int64_t": ":int64", "double": ":double", "void": ":void", "unsigned": ":uint",
+              "unsigned int": ":uint", "uint64_t": ":uint64", "int32_t": ":int32"}
+
+
+def _c_params(decl_args):
+    """Parameter type strings of a C declaration's argument list (names and comments stripped)."""
+    out = []
+    for a in decl_args.split(","):
+        a = " ".join(a.split())
+        if not a or a == "void":
+            continue
+        if "*" in a:
+            out.append("pointer")
+            continue
+        toks = [t for t in a.split(" ") if t not in ("const",)]
+        # the last token is the parameter's name unless the declaration is anonymous
+        typ = " ".join(toks[:-1]) if len(toks) > 1 else toks[0]
+        out.append(typ)
+    return out
+
+
+def test_lisp_glue_binding_types_match_the_header():
+    """Every (cffi:defcfun ...) passes arguments of the header's TYPES and takes the header's return type:
+    int <-> :int, int64_t <-> :int64, double <-> :double, any pointer <-> :pointer (const char * may be :string).
+    An :int where the header says int64_t would corrupt the call on the first pivot count above 2^31, or
+    silently pass garbage in the upper half of a register -- nothing a Lisp compiler can notice."""
+    src = _glue_source()
+    header = open(os.path.join(ROOT, "include", "mi355x_simplex.h")).read()
+    flat = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+    bound = list(re.finditer(r'\(cffi:defcfun \("(mi355x_\w+)" %?[\w-]+\)\s+(\S+?)((?:\s*\([\w-]+ [^()]+\))*)\)', src))
+    assert len(bound) == src.count("cffi:defcfun") >= 11
+    checked = 0
+    for m in bound:
+        name, ret = m.group(1), m.group(2)
+        args = [a.split()[-1].rstrip(")") for a in re.findall(r"\([\w-]+ [^()]+\)", m.group(3))]
+        decl = re.search(r"([\w\s\*]+?)\b%s\s*\(([^;]*?)\)\s*;" % name, flat, flags=re.S)
+        assert decl, name
+        c_ret = " ".join(decl.group(1).replace("extern", "").split())
+        if "*" in c_ret:
+            assert ret in (":pointer", ":string"), "%s returns %s, the glue says %s" % (name, c_ret, ret)
+        else:
+            assert _CFFI_OF_C.get(c_ret) == ret, "%s returns %s, the glue says %s" % (name, c_ret, ret)
+        params = _c_params(decl.group(2))
+        assert len(params) == len(args), name
+        for k, (c_t, l_t) in enumerate(zip(params, args)):
+            want = ":pointer" if c_t == "pointer" else _CFFI_OF_C.get(c_t)
+            assert want is not None, "%s: unknown C type %r" % (name, c_t)
+            assert l_t == want or (want == ":pointer" and l_t == ":string"), \
+                "%s: argument %d is %s in the header, %s in the glue" % (name, k + 1, c_t, l_t)
+            checked += 1
+    assert checked > 150
+
+
+def test_lisp_glue_imports_only_what_the_reference_exports():
+    """Every symbol of every (:import-from pkg ...) is in the :export list of the reference file that defines
+    pkg (src/simplex.lisp:14-35, src/problem.lisp:15-40, src/solver.lisp:20-30, src/conditions.lisp:3-11) --
+    from the committed fixture (tools/gen_reference_exports.py), which is itself re-derived from the
+    reference tree wherever that is present."""
+    import json
+    fix = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_exports.json")))
+    ref = "/root/reference"
+    if os.path.isdir(os.path.join(ref, "src")):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import gen_reference_exports
+        assert gen_reference_exports.derive(ref) == fix, "tests/golden/reference_exports.json is stale: python tools/gen_reference_exports.py"
+    src = re.sub(r";[^\n]*", "", _glue_source())
+    imports = re.findall(r"\(:import-from :([\w/.-]+)((?:\s+#:[^\s()]+)+)\)", src)
+    assert len(imports) >= 4
+    n = 0
+    for pkg, syms in imports:
+        assert pkg in fix, "the glue imports from %s, which is not a reference package of the path" % pkg
+        for s in syms.split():
+            s = s[2:].lower()
+            assert s in fix[pkg]["exports"], "%s is not exported by %s (%s)" % (s, pkg, fix[pkg]["file"])
+            n += 1
+    assert n >= 20
+    # and what the glue uses package-qualified
+    for pkg, sym in set(re.findall(r"\b(linear-programming/[\w-]+):([\w*+<>=-]+)", src)):
+        assert sym.lower() in fix[pkg]["exports"], "%s:%s" % (pkg, sym)
+
+
+def test_solver_keywords_are_documented_in_integration_md():
+    """Every keyword of mi355x-simplex-solver's and mi355x-solve-problems' lambda lists appears in
+    INTEGRATION.md (the maintainer's side of the boundary) and in the function's own docstring."""
+    src = _glue_source()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for fn in ("mi355x-simplex-solver", "mi355x-solve-problems"):
+        m = re.search(r"\(defun %s \(problems? &rest args\s+&key(.*?)&allow-other-keys\)\s+\"(.*?)\"" % fn, src, flags=re.S)
+        assert m, fn
+        keys = re.findall(r"\(?([a-z][\w-]*)", re.sub(r"\([\w-]+ [^()]*\)", lambda mm: "(" + mm.group(0)[1:].split()[0] + ")", m.group(1)))
+        keys = [k for k in keys if k not in ("t", "nil")]
+        assert len(keys) >= 6, keys
+        for k in keys:
+            assert ":" + k in m.group(2) or k.upper() in m.group(2), "%s: :%s is not in the docstring" % (fn, k)
+            assert ":" + k in doc, "%s: :%s is not documented in INTEGRATION.md" % (fn, k)
