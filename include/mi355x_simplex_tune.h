@@ -148,6 +148,7 @@ int         mi355x_colpart_block_size(const mi355x_colpart *p);   /* pivots per 
  * (k_shard_la_block).  out4: [0] blocks enqueued that way, [1] exchanges it lost, [2] the handle is demoted
  * to the two-launch step right now, [3] the next block would take the persistent form */
 int         mi355x_colpart_la_stats(mi355x_colpart *p, int64_t *out4);
+int         mi355x_colpart_is_compact(const mi355x_colpart *p);   /* 1 compact shards, 0 dense shards */
 int         mi355x_colpart_debug_set_la_rearm(mi355x_colpart *p, int64_t blocks);   /* as mi355x_debug_set_la_rearm */
 int         mi355x_colpart_debug_rhs(mi355x_colpart *p, int shard, double *out, int64_t n, int clear);   /* mi355x_debug_rhs of a local shard */
 int         mi355x_tune_set_shard_la_block(int mode);        /* read when a handle is created: 0 (default) the

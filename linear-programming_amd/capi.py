@@ -141,6 +141,7 @@ _EXTRA = {
     "mi355x_colpart_p2p_connect": (_int, [_p, _p]),
     "mi355x_colpart_block_size": (_int, [_p]),
     "mi355x_colpart_la_stats": (_int, [_p, _p]),
+    "mi355x_colpart_is_compact": (_int, [_p]),
     "mi355x_colpart_debug_set_la_rearm": (_int, [_p, _i64]),
     "mi355x_colpart_debug_rhs": (_int, [_p, _int, _p, _i64, _int]),
     "mi355x_tune_set_shard_la_block": (_int, [_int]),

@@ -349,6 +349,10 @@ class NativeColumnPartition:
         """Pivots per sweep of a shard's slice (16, or a wide block of 24 / 28 for large shards)."""
         return int(capi.lib().mi355x_colpart_block_size(self._h))
 
+    def is_compact(self):
+        """True: compact shards (non-basic columns only); False: dense shards (every logical column)."""
+        return bool(capi.lib().mi355x_colpart_is_compact(self._h))
+
     def la_stats(self):
         """Exchange mode 2, blocked: blocks enqueued through the persistent block launch (k_shard_la_block),
         exchanges it lost, demoted right now, next block persistent."""

@@ -263,6 +263,7 @@ void set_shard_la_split(int mode);         // tuning / test hook: 0 by size, 1 o
 // unit_basis: the basic columns of `art` are known to be exact unit vectors (column-parallel
 // re-elimination); otherwise the sequential form
 void launch_handover(const TabView &art, const TabView &main_tab, bool unit_basis, hipStream_t s);
+void launch_handover_objective_columns(const TabView &mt, hipStream_t s);   // scales in mt.col[0 .. m)
 // whole-batch solve, one workgroup per LP (false: an LP does not fit the LDS budget)
 bool launch_batch_solve(const TabView &t, int is_max, double fp_factor, hipStream_t s);
 // one block of every LP of a batch: look-ahead (one workgroup per LP, 16 pivots selected ahead)

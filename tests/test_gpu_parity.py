@@ -621,22 +621,17 @@ def test_two_phase_column_partition_drives_degenerate_artificials_out():
         A1, b1 = tabs[0].matrix.copy(), tabs[0].basis_columns.copy()
         _, n_plain, _ = oracle.solve(A1, b1, is_max=False)
         drove = int(npv[0]) > n_plain
-        followed = False
-        for shards in (2, 3):
-            try:
-                rc, got_npv, A, ab, Mm, mb = _colpart_two_phase(tabs, shards)
-            except lp.capi.Mi355xError as e:
-                # a drive-out pivot on a NEGATIVE element leaves -0.0 in basic columns, which compact
-                # shards do not store: declined (MI_UNSUPPORTED), the hook then solves on one device
-                assert e.code == lp.capi.MI_UNSUPPORTED and drove, (seed, shards, str(e))
-                continue
-            followed = True
+        for shards in (1, 2, 3, 8):
+            # (a drive-out pivot on a NEGATIVE element leaves -0.0 in basic columns, which compact shards do
+            # not store: declined with MI_UNSUPPORTED until round 5; since round 6 the partition moves the
+            # tableau to dense shards at that pivot and follows the reference bit for bit, -0.0s included)
+            rc, got_npv, A, ab, Mm, mb = _colpart_two_phase(tabs, shards)
             assert rc == st, (seed, shards, rc, st)
             if st in (oracle.OPTIMAL, oracle.UNBOUNDED):
                 assert got_npv[0] == int(npv[0])
                 assert np.array_equal(A.view(np.int64), A_or.view(np.int64)) and np.array_equal(ab, ab_or)
                 assert np.array_equal(Mm.view(np.int64), M_or.view(np.int64)) and np.array_equal(mb, b_or)
-        # whatever the partition did, the hook ends with the oracle's bits (falling back when declined)
+        # and the hook (:devices 3) ends with the oracle's bits
         if st == oracle.OPTIMAL:
             sol = lp.solve_problem(problem, devices=3)
             assert np.array_equal(sol.matrix.view(np.int64), M_or.view(np.int64)) and np.array_equal(sol.basis_columns, b_or)
@@ -668,6 +663,45 @@ def test_two_phase_column_partition_drives_degenerate_artificials_out():
             assert np.array_equal(Mm.view(np.int64), M_or.view(np.int64)) and np.array_equal(mb, b_or), (seed, shards)
             followed += 1
     assert followed == 33
+
+
+def test_two_phase_column_partition_nonfinite_objective_coefficient_on_a_basic_column():
+    """src/simplex.lisp:444-451 reads every scale of the re-elimination from the objective row AS REDUCED SO FAR.
+    An infinite objective coefficient on a variable that is basic after phase 1 makes the first product
+    inf * 0 a NaN in the objective entries of the OTHER basic columns -- later scales are then NaNs, and the
+    main tableau holds NaNs in columns a compact shard does not store.  Declined (MI_UNSUPPORTED) until round
+    5; since round 6 the partition moves to dense shards, computes the scales with the sequential loop on the
+    basic block (k_handover_scales_seq) and follows the oracle bit for bit -- whatever that outcome is."""
+    seen = 0
+    for seed in range(12):
+        rng = np.random.default_rng(1000 + seed)
+        n = 5
+        names = ["x%d" % i for i in range(n)]
+        x0 = rng.integers(1, 4, n).astype(float)
+        rows = [rng.integers(0, 3, n).astype(float) for _ in range(2)]
+        cons = [("=", list(zip(names, a.tolist())), float(a @ x0)) for a in rows if a.any()]
+        cons.append(("<=", list(zip(names, [1.0] * n)), float(x0.sum() + 2)))
+        cons.append((">=", [(names[0], 1.0)], 1.0))
+        c = rng.integers(1, 4, n).astype(float)
+        c[int(rng.integers(0, n))] = np.inf if seed % 2 else -np.inf
+        problem = lp.Problem(type="max", vars=names, objective_var="obj",
+                             objective_func=list(zip(names, c.tolist())), constraints=cons)
+        tabs = lp.build_tableau(problem, problem)
+        if not isinstance(tabs, list):
+            continue
+        with np.errstate(all="ignore"):
+            st, M_or, b_or, (A_or, ab_or, npv) = _oracle_solve(tabs)
+        if st == oracle.INFEASIBLE:
+            continue
+        nonfinite_basic = not np.all(np.isfinite(tabs[1].matrix[-1][ab_or]))
+        for shards in (1, 2, 3):
+            rc, got_npv, A, ab, Mm, mb = _colpart_two_phase(tabs, shards)
+            assert rc == st, (seed, shards, rc, st)
+            assert got_npv == (int(npv[0]), int(npv[1])), (seed, shards, got_npv, npv)
+            assert _same_bits_nan_aware(A, A_or) and np.array_equal(ab, ab_or), (seed, shards)
+            assert _same_bits_nan_aware(Mm, M_or) and np.array_equal(mb, b_or), (seed, shards)
+        seen += nonfinite_basic
+    assert seen >= 3, "too few draws put the infinite coefficient on a basic column (%d)" % seen
 
 
 def test_degenerate_shapes():
@@ -1318,9 +1352,10 @@ def test_solver_hook_devices_keyword(devices):
 
 
 def test_solver_hook_devices_falls_back_when_the_tableau_overflows():
-    """Entries over hundreds of orders of magnitude: the partitioned solve stops with
-    MI_NONFINITE, the hook solves the untouched tableau on one device -- same result as without
-    the keyword, whatever the reference does with the infinities."""
+    """Entries over hundreds of orders of magnitude: the partitioned solve meets a non-finite entering column
+    (round 6: it then moves to dense shards and goes on; a NaN quotient still ends it with MI_NONFINITE, and the
+    hook solves the untouched tableau on one device) -- same result as without the keyword, whatever the
+    reference does with the infinities."""
     import ctypes
     found = 0
     for seed in range(40):
@@ -1339,8 +1374,9 @@ def test_solver_hook_devices_falls_back_when_the_tableau_overflows():
         lp.capi.check(L.mi355x_colpart_create(ctypes.byref(h), M.shape[0], M.shape[1], M.ctypes.data_as(ctypes.c_void_p),
                                               b.ctypes.data_as(ctypes.c_void_p), 3), "create")
         rc = L.mi355x_colpart_solve(h, 1, 1024.0, 0, None)
-        L.mi355x_colpart_destroy(h)
-        if rc != lp.capi.MI_NONFINITE:
+        went_dense = not L.mi355x_colpart_is_compact(h)         # (round 6: a non-finite entering column moves the
+        L.mi355x_colpart_destroy(h)                               # tableau to dense shards instead of ending the solve)
+        if rc != lp.capi.MI_NONFINITE and not went_dense:
             continue
         found += 1
         outcomes = []
