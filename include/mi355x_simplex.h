@@ -243,6 +243,13 @@ int  mi355x_problem_read_mps(const char *text, int64_t len, int default_is_max, 
  * MI_MPS_SINGLE_VARIABLE_ROWS_AS_MEANT: fold them the way the rows read instead (`<=` tightens the
  * upper bound, `>=` the lower bound, the sense flips for a negative coefficient, `=` fixes). */
 #define MI_MPS_SINGLE_VARIABLE_ROWS_AS_MEANT 1
+/* The default spelled out (flags = 0): the reference's loop, quirks included.  Since round 5 this is what
+ * mi355x_problem_read_mps does (rounds 1-4 folded such rows "as meant": callers that want that behaviour back
+ * pass MI_MPS_SINGLE_VARIABLE_ROWS_AS_MEANT to mi355x_problem_read_mps_ex).  Whenever the reference's loop
+ * changes what a row means -- a `>=` / `=` row turns its variable INTEGER, a `<=` row takes the LARGER bound, the
+ * constraint behind a folded row is skipped (its negative right-hand side not flipped) -- the call still
+ * returns MI_OK and mi355x_last_error() holds a note naming the rows ("mps note: ..."; empty otherwise). */
+#define MI_MPS_REFERENCE_COMPATIBLE 0
 int  mi355x_problem_read_mps_ex(const char *text, int64_t len, int default_is_max, const char *rhs_id,
                                 int read_case, int flags, mi355x_problem **out);
 int64_t     mi355x_mps_var_count(void);

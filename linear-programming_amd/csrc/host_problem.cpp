@@ -748,6 +748,8 @@ int mi355x_simplex_solver_many_begin(const mi355x_problem *const *problems, int6
         if (it == groups.end()) { it = groups.emplace(key, job->units.size()).first; job->units.push_back(ManyUnit()); }
         job->units[it->second].members.push_back(k);
     }
+    int64_t n_singles = 0;
+    const int n_visible = std::max(1, mi355x_device_count());
     for (ManyUnit &u : job->units) {
         const int64_t g = (int64_t)u.members.size();
         const Built &b0 = built[(size_t)u.members[0]];
@@ -762,7 +764,10 @@ int mi355x_simplex_solver_many_begin(const mi355x_problem *const *problems, int6
             job->sol[(size_t)k] = std::move(s);
         }
         if (g == 1) {                                  // alone in its group: the one-problem job
-            const int rc = mi355x_simplex_solver_begin(problems[u.members[0]], fp_tolerance, device_ids ? device_ids[0] : 0, &u.single);
+            // (members alone in their group: dealt round-robin over the devices -- they all sat on the first one)
+            const int dev = device_ids ? device_ids[n_singles % n_devices] : (int)(n_singles % std::min(n_devices, n_visible));
+            ++n_singles;
+            const int rc = mi355x_simplex_solver_begin(problems[u.members[0]], fp_tolerance, dev, &u.single);
             if (rc != MI_OK) return rc;
             continue;
         }
@@ -793,13 +798,21 @@ int mi355x_simplex_solver_many_step(mi355x_solve_many *job, int64_t max_pivots, 
     if (!job) return hfail(MI_BAD_ARG, "job is NULL");
     if (max_pivots < 0) return hfail(MI_BAD_ARG, "max_pivots < 0");
     bool running = false;
+    // A unit that fails (a negative code: device error, out of memory ...) ends as that code in the status of
+    // each of its members and the OTHER units go on (round-5 advisor finding: returning at the first failure
+    // left them half-stepped and their members at MI_RUNNING, which callers read as "pivot cap reached").
+    auto unit_failed = [&](ManyUnit &u, int rc) {
+        for (int64_t k : u.members) job->status[(size_t)k] = rc;
+        u.phase = 3;
+    };
     for (ManyUnit &u : job->units) {
         if (u.phase == 3) continue;
         const int64_t g = (int64_t)u.members.size();
         if (u.single) {
             const int rc = mi355x_simplex_solver_step(u.single, max_pivots, nullptr);
-            if (rc < 0) return rc;
-            if (rc == MI_MAX_PIVOTS && max_pivots > 0) { running = true; continue; }
+            if (rc < 0) { unit_failed(u, rc); continue; }
+            // (a cancelled step is a paused job, not a finished one: the next call carries on)
+            if ((rc == MI_MAX_PIVOTS && max_pivots > 0) || rc == MI_CANCELLED) { running = true; continue; }
             job->status[(size_t)u.members[0]] = rc;
             u.phase = 3;
             continue;
@@ -808,19 +821,21 @@ int mi355x_simplex_solver_many_step(mi355x_solve_many *job, int64_t max_pivots, 
         std::vector<int64_t> np((size_t)g);
         if (u.phase == 1) {                                                  // simplex.lisp:403, all members
             const int rc = mi355x_multibatch_solve(u.art_mb, 0, job->f, max_pivots, st.data(), np.data());
-            if (rc != MI_OK) return rc;
+            if (rc == MI_CANCELLED) { running = true; continue; }
+            if (rc != MI_OK) { unit_failed(u, rc < 0 ? rc : MI_HIP_ERROR); continue; }
             bool more = false;
             for (int64_t q = 0; q < g; ++q) { u.np1[(size_t)q] += np[(size_t)q]; u.st1[(size_t)q] = st[(size_t)q]; more |= st[(size_t)q] == MI_MAX_PIVOTS; }
             if (more && max_pivots > 0) { running = true; continue; }
             std::vector<int64_t> nd((size_t)g, 0);                           // :405-451, per member on the devices
             const int hrc = mi355x_multibatch_two_phase_handover(u.art_mb, u.main_mb, job->f, u.st1.data(), u.between.data(), nd.data());
-            if (hrc != MI_OK) return hrc;
+            if (hrc != MI_OK) { unit_failed(u, hrc < 0 ? hrc : MI_HIP_ERROR); continue; }
             for (int64_t q = 0; q < g; ++q) u.np1[(size_t)q] += nd[(size_t)q];
             u.phase = 2;
             if (max_pivots > 0) { running = true; continue; }                // phase 2 in the next call (the chunk is used up)
         }
         const int rc = mi355x_multibatch_solve(u.main_mb, u.is_max, job->f, max_pivots, st.data(), np.data());   // :452 / :453-461
-        if (rc != MI_OK) return rc;
+        if (rc == MI_CANCELLED) { running = true; continue; }
+        if (rc != MI_OK) { unit_failed(u, rc < 0 ? rc : MI_HIP_ERROR); continue; }
         bool more = false;
         for (int64_t q = 0; q < g; ++q) {
             u.np2[(size_t)q] += np[(size_t)q];

@@ -36,6 +36,7 @@ extern "C" void mi355x_set_last_error_(const char *msg);
 namespace {
 
 int mfail(int code, const std::string &msg) { mi355x_set_last_error_(msg.c_str()); return code; }
+thread_local std::string g_mps_note;
 
 std::string substring(const std::string &s, size_t a, size_t b)
 {
@@ -121,6 +122,7 @@ int mi355x_problem_read_mps(const char *text, int64_t len, int default_is_max, c
 int mi355x_problem_read_mps_ex(const char *text, int64_t len, int default_is_max, const char *rhs_id_in,
                                int read_case, int flags, mi355x_problem **out)
 {
+    g_mps_note.clear();
     if (!text || len < 0 || !out) return mfail(MI_BAD_ARG, "bad arguments");
     *out = nullptr;
     if (read_case < 0 || read_case > 3) return mfail(MI_BAD_ARG, "read_case must be 0..3");
@@ -286,6 +288,9 @@ int mi355x_problem_read_mps_ex(const char *text, int64_t len, int default_is_max
         // NIL in its place.
         std::vector<Row> L(cons.rbegin(), cons.rend());
         std::vector<char> flag_is_number(vinfo.size(), 0);
+        std::string notes;                                     // what the reference's loop did to the rows' meaning (round-5 advisor finding)
+        int n_notes = 0;
+        auto note = [&](const std::string &what) { if (++n_notes <= 8) notes += (notes.empty() ? "" : "; ") + what; };
         size_t i = 0;
         while (i < L.size()) {
             Row &c = L[i];
@@ -294,10 +299,15 @@ int mi355x_problem_read_mps_ex(const char *text, int64_t len, int default_is_max
                 VarInfo &vi = vinfo[v];
                 if (c.coef[0] == 0.0) return mfail(MI_BAD_ARG, "single-variable row with a zero coefficient: the reference divides by it (:315)");
                 const double bound = c.rhs / c.coef[0];
-                if (c.type == 0 || c.type == 2) { vi.ub = vi.has_ub ? std::max(vi.ub, bound) : bound; vi.has_ub = true; }
+                if (c.type == 0 || c.type == 2) {
+                    if (vi.has_ub && bound > vi.ub) note("<= row on " + var_names[v] + " RAISES its upper bound (lb-max, :316)");
+                    if (c.coef[0] < 0) note("the negative coefficient of the single-variable row on " + var_names[v] + " is not looked at");
+                    vi.ub = vi.has_ub ? std::max(vi.ub, bound) : bound; vi.has_ub = true;
+                }
                 if (c.type == 1 || c.type == 2) {
                     if (vi.integer && !flag_is_number[v])
                         return mfail(MI_BAD_ARG, "a >= / = single-variable row on an integer variable: the reference calls (min t bound) (:317-318)");
+                    if (!vi.integer) note(std::string(c.type == 1 ? ">=" : "=") + " row on " + var_names[v] + " turns it INTEGER (ub-min on the integer flag, :317-318)");
                     vi.integer = true;
                     flag_is_number[v] = 1;
                 }
@@ -305,6 +315,8 @@ int mi355x_problem_read_mps_ex(const char *text, int64_t len, int default_is_max
                     return mfail(MI_UNSUPPORTED, "a single-variable row ends the reference's constraint list: it leaves NIL among the "
                                                  "problem's constraints (:320-321), which no solver accepts");
                 L.erase(L.begin() + (std::ptrdiff_t)i);           // the next cell's contents move here ...
+                if (L[i].var.size() == 1 || L[i].rhs < 0)
+                    note("the constraint behind the folded row on " + var_names[v] + " is stepped over (:320-321): neither folded nor sign-normalised");
                 i += 1;                                            // ... and are stepped over
                 continue;
             }
@@ -316,6 +328,8 @@ int mi355x_problem_read_mps_ex(const char *text, int64_t len, int default_is_max
             i += 1;
         }
         kept = L;
+        g_mps_note = notes.empty() ? "" : "mps note: " + notes + (n_notes > 8 ? " (+" + std::to_string(n_notes - 8) + " more)" : "") +
+                                          " -- the reference's loop, src/external-formats.lisp:312-323; MI_MPS_SINGLE_VARIABLE_ROWS_AS_MEANT reads the rows as written";
     }
 
     mi355x_problem *p = nullptr;
@@ -338,6 +352,7 @@ int mi355x_problem_read_mps_ex(const char *text, int64_t len, int default_is_max
     g_names.vars = var_names;
     g_names.objective = objective;
     *out = p;
+    mi355x_set_last_error_(g_mps_note.c_str());                // (MI_OK with a note, or an empty string)
     return MI_OK;
 }
 

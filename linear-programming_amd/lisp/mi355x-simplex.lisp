@@ -675,14 +675,17 @@ list parallel to PROBLEMS: a MI355X-SOLUTION, or the condition object the one-pr
 signal for that member.  No boxed tableau exists for any member (BASELINE config 4 from Lisp: 1 024
 build-tableau results would be 2e8 boxed entries)."
   (let* ((n (length problems))
-         (marshalled (mapcar (lambda (problem) (multiple-value-list (marshal-problem problem))) problems))
-         (n-dev (device-count-of devices))
+         (marshalled '())                ; (handle var-index) per problem, filled INSIDE the unwind-protect: a
+         (n-dev (device-count-of devices))   ; marshalling error midway must not leak the handles made so far
          (rows (1+ (reduce #'max problems :key (lambda (p) (length (problem-constraints p))))))
          (cols (+ rows (reduce #'max problems :key (lambda (p) (length (problem-vars p))))))
          (chunk (chunk-pivots rows cols)))
     (unwind-protect
          (cffi:with-foreign-objects ((handles :pointer n) (ids :int (max n-dev 1)) (out :pointer)
                                      (status :int32 n) (solutions :pointer n))
+           (dolist (problem problems)
+             (push (multiple-value-list (marshal-problem problem)) marshalled))
+           (setf marshalled (nreverse marshalled))
            (loop for (handle nil) in marshalled for k from 0
                  do (setf (cffi:mem-aref handles :pointer k) handle))
            (when (listp devices)
@@ -716,6 +719,11 @@ build-tableau results would be 2e8 boxed entries)."
                                                        :constraint (cons 'integer (problem-integer-vars problem))
                                                        :solver-name "mi355x-simplex"))
                                       ((= st +mi-running+) (outcome-condition +mi-max-pivots+))
+                                      ;; a member whose unit FAILED (device error, out of memory ...: the
+                                      ;; other units went on) carries that negative code
+                                      ((minusp st)
+                                       (make-condition 'mi355x-error :code st
+                                                                     :message (format nil "member ~D failed" k)))
                                       (t (outcome-condition st))))))
                (unless consumed (%solver-many-abandon job)))))
       (loop for (handle nil) in marshalled do (%problem-destroy handle)))))

@@ -244,6 +244,11 @@ def read_mps(text, problem_type=None, rhs_id=None, read_case="upcase", single_va
     if rc in (capi.MI_BAD_ARG, capi.MI_UNSUPPORTED):
         raise ParsingError(L.mi355x_last_error().decode("utf-8", "replace"))
     capi.check(rc, "mi355x_problem_read_mps")
+    # (MI_OK with a note: the reference's loop changed what a single-variable row means -- see the header)
+    note = L.mi355x_last_error().decode("utf-8", "replace")
+    if note.startswith("mps note:"):
+        import warnings
+        warnings.warn(note, stacklevel=2)
     try:
         n = L.mi355x_problem_to_json(h, None, 0)
         buf = ctypes.create_string_buffer(n + 1)

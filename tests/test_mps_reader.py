@@ -196,9 +196,17 @@ def test_single_variable_rows_as_the_reference_folds_them():
                 "    r         both      100             keep      -3\n"
                 "    r         upx       6               loy       2\n"
                 "    r         fixw      10\n")
-    p = read_mps(text, "max", read_case="preserve")
+    # (round-5 advisor finding: the quirks change what the rows MEAN, so the reader says so -- MI_OK plus a note in
+    # mi355x_last_error, a Python warning in the mirror -- naming the rows; nothing when no quirk applied)
+    with pytest.warns(UserWarning, match=r"mps note: .*= row on w turns it INTEGER.*stepped over.*external-formats\.lisp:312-323"):
+        p = read_mps(text, "max", read_case="preserve")
     assert p.vars == ["x", "y", "w"] and p.integer_vars == ["w"]
     assert dict(p.var_bounds) == {"x": (0.0, 3.0), "w": (0.0, 2.0)}
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                          # as-meant, and files without such rows: no note
+        read_mps(text, "max", read_case="preserve", single_variable_rows="as-meant")
+        read_mps(_text("simple-problem.mps"), "max")
     assert p.constraints == [(">=", [("y", 4.0)], 2.0),
                              (">=", [("x", 1.0), ("y", 1.0)], -3.0),
                              ("<=", [("x", 1.0), ("y", 1.0), ("w", 1.0)], 100.0)]
