@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # (round-5 review: the suite must stay well inside the driver's step limit.  `-m gpu` still runs everything;
+    # the full-size / multi-GB cases -- ten seconds and more each, a third of the suite's time -- can be run apart:
+    # `-m "gpu and not slow"` and `-m "gpu and slow"` are two shards of about equal length)
+    config.addinivalue_line("markers", "slow: a gpu test of a full-size shape (>= 10 s); included by -m gpu")
 
 
 def pytest_collection_modifyitems(config, items):

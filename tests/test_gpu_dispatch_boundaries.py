@@ -137,6 +137,7 @@ def test_wide_block_switch_at_240_mib(n, m, block):
 @pytest.mark.timeout(1500, method="thread")
 @pytest.mark.parametrize("n,m,block,persistent", [(20815, 12000, 24, True), (20847, 12000, 28, False)],
                          ids=["1.998e9", "2.002e9"])
+@pytest.mark.slow
 def test_wide_block_switch_at_2e9_bytes(n, m, block, persistent):
     assert 32 < _la_workgroups(n, m) <= 64
     assert (_stored_bytes(n, m) >= 2e9) == (block == 28) and abs(_stored_bytes(n, m) - 2e9) < 0.01e9
@@ -144,6 +145,7 @@ def test_wide_block_switch_at_2e9_bytes(n, m, block, persistent):
 
 
 # ---- a large tableau behind the persistent look-ahead (59 workgroups, 1.8 GB stored: 24 per pass)
+@pytest.mark.slow
 @pytest.mark.timeout(1500, method="thread")
 def test_large_tableau_behind_the_persistent_lookahead():
     n, m = 15000, 15000
@@ -153,6 +155,7 @@ def test_large_tableau_behind_the_persistent_lookahead():
 
 # ---- one shape in the middle of the band no BASELINE configuration falls into (268 MB ... 17 GB): 6.4 GB,
 # 28 per pass on 128-row tiles
+@pytest.mark.slow
 @pytest.mark.timeout(1500, method="thread")
 def test_mid_band_shape_6_4_gb():
     n, m = 40000, 20000

@@ -184,6 +184,7 @@ def test_config5_full_size_64_pivots_rederived():
     L.mi355x_tab_destroy(h)
 
 
+@pytest.mark.slow
 @pytest.mark.timeout(1500, method="thread")
 def test_config5_full_size_64_pivots_vs_the_oracle():
     """The same 32769 x 98305 tableau through the CPU ORACLE (OpenMP row-parallel restatement of

@@ -62,6 +62,7 @@ def _note(name, rec):
         pass
 
 
+@pytest.mark.slow
 @pytest.mark.timeout(1500, method="thread")
 def test_config3_full_solve_bitwise_vs_the_oracle():
     n, m = 8192, 4096
@@ -88,6 +89,7 @@ def test_config3_full_solve_bitwise_vs_the_oracle():
     assert lp.tableau_objective_value(t) == M[m, -1]
 
 
+@pytest.mark.slow
 @pytest.mark.timeout(2400, method="thread")
 def test_config5_solved_to_optimality_on_one_gpu():
     L = lp.capi.lib()
