@@ -481,7 +481,7 @@ def pmc_traffic(workload, kernel):
     WRITE_SIZE in separate runs, FETCH doubled per the gfx950 correction, calibrated on a copy of
     the same buffer -- profiles/rNN_cfg3_pmc_traffic.json).  PMC counters cannot be collected
     from inside this process, so the number is the last profiled one for this kernel, or None."""
-    for tag in ("r05", "r04", "r03", "r02", "r01"):
+    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_%s_pmc_traffic.json" % (tag, workload))
         try:
             with open(path) as f:

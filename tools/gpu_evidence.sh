@@ -10,7 +10,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/evidence
 rm -rf $O; mkdir -p $O
 cd $R
-python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
+python -m pytest tests -m gpu -x -q --durations=12 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
+grep -A 14 "slowest 12 durations" $O/pytest_gpu.log > $O/pytest_gpu_summary.log; tail -1 $O/pytest_gpu.log >> $O/pytest_gpu_summary.log
 python bench.py > $O/bench.log 2>&1; echo "bench rc=$?"; tail -1 $O/bench.log | cut -c1-400
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_flags.log 2>&1; echo "bench (driver flags) rc=$?"
 python bench.py --workload cfg4 > $O/bench_cfg4.log 2>&1; echo "bench cfg4 rc=$?"; tail -1 $O/bench_cfg4.log | cut -c1-300
@@ -58,3 +59,9 @@ done
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --kernel-trace --output-format csv -d $O/pmc_SQ -- python $R/tools/pmc_probe.py 64 > $O/pmc_SQ.log 2>&1; echo "pmc SQ rc=$?"
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY SQ_WAVES --kernel-trace --output-format csv -d $O/pmc_resident_SQ -- python $R/tools/pmc_probe_resident.py > $O/pmc_resident_SQ.log 2>&1; echo "pmc resident SQ rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats_shard_step -- python $R/tools/shard_step_cost.py 336 24 "two launches" > $O/kernel_stats_shard_step.log 2>&1; echo "rocprof stats shard step rc=$?"
+# round 6: the shard's look-ahead of a whole block as ONE persistent launch (k_shard_la_block) on the same shard
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats_shard_block -- python $R/tools/shard_step_cost.py 336 24 "persistent" > $O/kernel_stats_shard_block.log 2>&1; echo "rocprof stats shard block rc=$?"
+cd $R
+(python tools/shard_la_timing.py 1; python tools/shard_la_timing.py 0) 2>&1 | grep -v "amdgpu.ids\|^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" > $O/shard_la_timing.log; echo "shard la timing rc=$?"
+bash tools/la_policy_ab.sh > /dev/null 2>&1; cp gpurun_out/la_mall_policy_ab.txt $O/la_policy_ab.log; echo "la policy A/B done"
+bash tools/ring_waves_ab.sh > $O/ring_waves_ab.log 2>&1; echo "ring waves A/B done"

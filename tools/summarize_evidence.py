@@ -144,6 +144,14 @@ def main(tag):
     f = one("kernel_stats_shard_step/*/*kernel_stats.csv", required=False)
     if f:                                                   # the two-launch step of one 8-GPU-sized shard
         shutil.copy(f, os.path.join(PR, tag + "_shard_step_kernel_stats.csv"))
+    f = one("kernel_stats_shard_block/*/*kernel_stats.csv", required=False)
+    if f:                                                   # the same shard behind the persistent block launch (k_shard_la_block)
+        shutil.copy(f, os.path.join(PR, tag + "_shard_block_kernel_stats.csv"))
+    for log, dst in (("shard_la_timing.log", "_shard_la_timing.txt"), ("la_policy_ab.log", "_la_policy_ab.txt"),
+                     ("ring_waves_ab.log", "_ring_waves_ab.txt"), ("pytest_gpu_summary.log", "_pytest_gpu_summary.txt")):
+        f = one(log, required=False)
+        if f and os.path.getsize(f):
+            shutil.copy(f, os.path.join(PR, tag + dst))
     f = one("pmc_resident_SQ/*/*counter_collection.csv", required=False)
     if f:                                                   # instruction counters of the resident launches
         rows_ = list(csv.DictReader(open(f)))
