@@ -49,9 +49,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_perpivot_$c -- python $R/tools/pmc_probe.py 24 1 > $O/pmc_perpivot_$c.log 2>&1; echo "pmc per-pivot $c rc=$?"
 done
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats_cfg5 -- python $R/bench.py --workload colpart --steps 112 --warmup 28 > $O/kernel_stats_cfg5.log 2>&1; echo "rocprof stats cfg5 rc=$?"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats_shard -- python $R/tools/pmc_probe.py 96 0 0 8192 32768 > $O/kernel_stats_shard.log 2>&1; echo "rocprof stats shard rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernel_stats_shard -- python $R/tools/pmc_probe.py 96 24 0 8192 32768 > $O/kernel_stats_shard.log 2>&1; echo "rocprof stats shard rc=$?"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_shard_$c -- python $R/tools/pmc_probe.py 96 0 0 8192 32768 > $O/pmc_shard_$c.log 2>&1; echo "pmc shard $c rc=$?"
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_shard_$c -- python $R/tools/pmc_probe.py 96 24 0 8192 32768 > $O/pmc_shard_$c.log 2>&1; echo "pmc shard $c rc=$?"
 done
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_resident_$c -- python $R/tools/pmc_probe_resident.py > $O/pmc_resident_$c.log 2>&1; echo "pmc resident $c rc=$?"
