@@ -557,7 +557,16 @@ def bench(args, rank, local_rank, world, progress=None):
     baseline = None
     exchange_modes = None
 
-    def make_native(exchange):
+    def make_native(exchange, la_block=0):
+        # (exchange 2: la_block 0 = the look-ahead of a block as ONE persistent launch per device -- k_shard_la_block,
+        # the default of that mode since round 6 --, 1 = the step kernels of round 5)
+        L.mi355x_tune_set_shard_la_block(la_block)
+        try:
+            return _make_native(exchange)
+        finally:
+            L.mi355x_tune_set_shard_la_block(0)
+
+    def _make_native(exchange):
         if staged:                                    # exchange mode 2, host-connected, RCCL never touched
             L.mi355x_tune_set_colpart_exchange(2)
             try:
@@ -691,11 +700,16 @@ def bench(args, rank, local_rank, world, progress=None):
                                                          "all-gathered pricing winners: one stream synchronisation per pivot"),
                                  (2, "p2p_push", "no collective: every shard writes its pricing pair, the owner the entering "
                                                  "column, straight into the peers' fine-grained buffers (peer access / IPC "
-                                                 "over xGMI) as self-validating granules; consumers poll their own memory")):
+                                                 "over xGMI) as self-validating granules; consumers poll their own memory -- "
+                                                 "inside ONE persistent launch per block and device (k_shard_la_block) where "
+                                                 "the shard's block fits it (la_stats says)"),
+                                 (12, "p2p_push_step_kernels", "the same exchanges with round 5's step kernels (two launches "
+                                                               "per step): what the persistent launch is measured against")):
             tab.close()
             entry = {"value": None, "unit": "pivots/s", "what": what}
             try:
-                tab = make_native(mode)
+                tab = make_native(mode % 10, la_block=1 if mode >= 10 else 0)
+                entry["persistent_block_launch"] = tab.la_stats()
                 tab.solve_async(args.warmup, reset=True)
                 tab.sync()
                 dtb, stb, doneb = _timed_pivots(tab, args.steps, torch, dist, world)
@@ -725,7 +739,8 @@ def bench(args, rank, local_rank, world, progress=None):
         rec["best_mode"] = {
             "mode": best, "value": bv, "steady_state_pivots_per_s": bs, "us_per_pivot": 1e6 / bv,
             "opt_in": None if best == "int64_sum_allreduce" else
-                      "mi355x_tune_set_colpart_exchange(%d) before the handle is created" % (1 if best == "rooted_broadcast" else 2),
+                      "mi355x_tune_set_colpart_exchange(%d) before the handle is created%s"
+                      % ((1 if best == "rooted_broadcast" else 2), " (+ mi355x_tune_set_shard_la_block(1))" if best == "p2p_push_step_kernels" else ""),
             "speedup_vs_one_gpu": (bv / baseline["value"]) if baseline else None,
             "steady_state_speedup_vs_one_gpu": (bs / baseline["steady_state_pivots_per_s"])
                                                if baseline and bs and baseline.get("steady_state_pivots_per_s") else None}

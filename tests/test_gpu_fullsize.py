@@ -598,6 +598,9 @@ def test_bench_colpart_one_rank_through_the_multi_gpu_entry():
     assert modes["p2p_push"]["value"] > 0
     # every mode must end in the default mode's state bit for bit; the headline is the fastest of them
     assert modes["rooted_broadcast"]["identical_to_default_mode"] and modes["p2p_push"]["identical_to_default_mode"]
+    # (round 6) the P2P leg runs the look-ahead of a block as one persistent launch; the step kernels beside it
+    assert modes["p2p_push"]["persistent_block_launch"]["live"] and not modes["p2p_push_step_kernels"]["persistent_block_launch"]["live"]
+    assert modes["p2p_push_step_kernels"]["value"] > 0 and modes["p2p_push_step_kernels"]["identical_to_default_mode"]
     # the headline is the library's DEFAULT exchange; the fastest bit-identical mode is reported next to it
     assert rec["value_mode"] == "int64_sum_allreduce" and rec["value"] == modes["int64_sum_allreduce"]["value"]
     assert rec["best_mode"]["mode"] in modes and rec["best_mode"]["value"] >= rec["value"]
