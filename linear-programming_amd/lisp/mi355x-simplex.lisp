@@ -607,7 +607,9 @@ handle (mi355x_problem_destroy)."
 
 (defun native-var-mapping (problem variable)
   "The var-mapping entry the library's build-tableau gives VARIABLE, in the reference's form
-(src/simplex.lisp:44-46): (positive col offset), (negative col offset) or (signed col)."
+(src/simplex.lisp:44-46): (positive col offset), (negative col offset) or (signed col) -- with the
+reference's OWN symbols (internal to linear-programming/simplex, src/simplex.lisp:197-210), so that an
+entry compares EQUAL with what (gethash variable (tableau-var-mapping tableau)) holds there."
   (multiple-value-bind (handle var-index) (marshal-problem problem)
     (unwind-protect
          (cffi:with-foreign-objects ((kind :int) (col :int64) (offset :double))
@@ -615,9 +617,9 @@ handle (mi355x_problem_destroy)."
                                            (error "~S is not a variable of the problem" variable))
                                 kind col offset))
            (ecase (cffi:mem-ref kind :int)
-             (0 (list 'positive (cffi:mem-ref col :int64) (cffi:mem-ref offset :double)))
-             (1 (list 'negative (cffi:mem-ref col :int64) (cffi:mem-ref offset :double)))
-             (2 (list 'signed (cffi:mem-ref col :int64)))))
+             (0 (list 'linear-programming/simplex::positive (cffi:mem-ref col :int64) (cffi:mem-ref offset :double)))
+             (1 (list 'linear-programming/simplex::negative (cffi:mem-ref col :int64) (cffi:mem-ref offset :double)))
+             (2 (list 'linear-programming/simplex::signed (cffi:mem-ref col :int64)))))
       (%problem-destroy handle))))
 
 (defun native-number-p (x)
