@@ -58,18 +58,17 @@ int         mi355x_tune_set_prime(int on);                   /* 1 (default): a h
                                                                 preceded by one EMPTY block of every kernel
                                                                 form its requests can pick, so that no later
                                                                 request pays a kernel's first launch; 0 off */
-int         mi355x_tune_set_sweep_xcd_map(int on);           /* k_sweepw_ring: bit 0 the (strip, tile) pairs in
+int         mi355x_tune_set_sweep_xcd_map(int on);           /* k_sweepw_ring: 1 the (strip, tile) pairs in
                                                                 strip-major order cut into one run per XCD
                                                                 (traffic 1.06 x instead of 1.14 x, 1.5 %
-                                                                slower), 0 (default) the grid's own order;
-                                                                bits 8 ..: rows by which the first / last
-                                                                third of the tiles are taller / shorter
-                                                                (measurement only: DESIGN_experiments R6.10) */
-int         mi355x_tune_set_sweep_dyn(int on);               /* wide ring sweeps: 1 (default) the rows of a pass
-                                                                are drawn chunk by chunk from per-column-group
-                                                                counters by one round of resident waves
-                                                                (k_sweepw_dyn) wherever one round covers the
-                                                                tableau; 0 static tiles (k_sweepw_ring) */
+                                                                slower), 0 (default) the grid's own order */
+int         mi355x_tune_set_sweep_skew(int rows);            /* k_sweepw_ring where ONE round of workgroups (three
+                                                                per CU) covers the tableau: the thirds of the
+                                                                tiles in dispatch order are tr + rows / tr /
+                                                                tr - rows tall -- a SIMD serves its oldest wave
+                                                                first.  -1 (default): 5/16 of the tile height
+                                                                (config 3: 28 of 92, 108.5 -> 102.5 us per
+                                                                pass); 0: equal tiles */
 int         mi355x_tune_set_ctl_wait(int mode);              /* how a status read-back waits: 2 (default) a
                                                                 kernel publishes the control block to pinned
                                                                 memory and the host polls its sequence number,

@@ -129,7 +129,7 @@ _EXTRA = {
     "mi355x_tune_set_sweepw_ring": (_int, [_int]),
     "mi355x_tune_set_prime": (_int, [_int]),
     "mi355x_tune_set_sweep_xcd_map": (_int, [_int]),
-    "mi355x_tune_set_sweep_dyn": (_int, [_int]),
+    "mi355x_tune_set_sweep_skew": (_int, [_int]),
     "mi355x_tune_set_ctl_wait": (_int, [_int]),
     "mi355x_tune_set_shard_la_split": (_int, [_int]),
     "mi355x_tune_set_tail_policy": (_int, [_int]),

@@ -146,8 +146,6 @@ struct TabView {
     // bk_smask[pair]: the even / odd column of that pair is the slot pending pivot i gave up
     uint32_t *bk_rmask, *bk_smask;
     uint32_t *bk_smask2;          // slot hand-overs of pending pivots 16 .. 31 (wide blocks; null for batches)
-    uint32_t *sweep_ctr;          // k_sweepw_dyn: per column group of 64 pairs {next chunk of rows, waves that have left};
-    int       sweep_groups;       // zero between passes (the last wave of a group to leave resets them); null for batches
     ExchRec  *la_px, *la_rx;      // kMaxLaRecords pricing / ratio records (persistent look-ahead)
     // batch of n_lps same-shape LPs: per-LP element strides (all zero for a single tableau)
     int64_t  n_lps;
@@ -196,7 +194,7 @@ int  launch_sweep(const TabView &t, int kmax, double sgn, hipStream_t s, unsigne
 // with (0: stay at kMaxBlock)
 bool wide_block_size_ok(int k);
 int  wide_block_default(const TabView &t);
-void set_sweep_dyn(int on);                // wide ring sweeps: rows drawn dynamically (k_sweepw_dyn) where one round of workgroups covers the tableau
+void set_sweep_skew(int rows);             // k_sweepw_ring, one round of workgroups: rows by which the first / last third of the tiles are taller / shorter (-1: by the tile height)
 void set_sweep_xmap(int on);               // k_sweepw_ring: workgroup -> (strip, tile) by XCD (see the kernel)
 void set_sweepw_ring(int on);              // wide sweeps through the LDS ring (default) or the register form
 int  sweep_kind(int kmax);                 // 2 wide pair, 1 k_sweep16, 0 k_sweep<..>: what launch_sweep picks

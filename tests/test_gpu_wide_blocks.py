@@ -21,23 +21,28 @@ def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-@pytest.fixture(params=[(24, 1, 0), (28, 1, 0), (24, 0, 0), (28, 0, 0), (24, 1, 1), (28, 1, 1)],
-                ids=["24-ring", "28-ring", "24-registers", "28-registers", "24-ring-xcd-map", "28-ring-xcd-map"])
+@pytest.fixture(params=[(24, 1, 0, 0), (28, 1, 0, 0), (24, 0, 0, 0), (28, 0, 0, 0), (24, 1, 1, 0), (28, 1, 1, 0), (24, 1, 0, 12), (28, 1, 0, 20)],
+                ids=["24-ring", "28-ring", "24-registers", "28-registers", "24-ring-xcd-map", "28-ring-xcd-map", "24-ring-skew", "28-ring-skew"])
 def wide(request):
     """Pivots per pass, the form of the streaming kernel -- the tile's rows through a per-wave LDS
     ring (k_sweepw_ring, the default since round 5) or through two register sets (k_sweepw) -- and,
     for the ring, which tile a workgroup takes: the grid's own order or one run of tiles per XCD
-    (mi355x_tune_set_sweep_xcd_map: every (strip, tile) exactly once either way)."""
+    (mi355x_tune_set_sweep_xcd_map: every (strip, tile) exactly once either way), and how tall the
+    tiles are: all alike, or (round 6, mi355x_tune_set_sweep_skew: the default where one round of
+    workgroups covers the tableau; forced here on every shape) the thirds of the tiles in dispatch
+    order tr + skew / tr / tr - skew rows tall -- every row exactly once whatever the heights."""
     L = lp.capi.lib()
-    k, ring, xmap = request.param
+    k, ring, xmap, skew = request.param
     assert L.mi355x_tune_set_block(k) == k
     L.mi355x_tune_set_sweepw_ring(ring)
     L.mi355x_tune_set_sweep_xcd_map(xmap)
+    L.mi355x_tune_set_sweep_skew(skew)
     L.mi355x_tune_set_select_mode(2)                    # small shapes too: the blocked path
     yield k
     L.mi355x_tune_set_block(0)
     L.mi355x_tune_set_sweepw_ring(1)
     L.mi355x_tune_set_sweep_xcd_map(0)
+    L.mi355x_tune_set_sweep_skew(-1)
     L.mi355x_tune_set_select_mode(0)
 
 
@@ -56,7 +61,7 @@ def test_request_sequences_with_wide_blocks(n, m, seed, wide, request):
     pivots (split into a block of 16 and a short one above 16), and the LP ending inside a block."""
     L = lp.capi.lib()
     form = request.node.callspec.id
-    if n == 1500 and ("xcd-map" in form or "28-registers" in form):
+    if n == 1500 and ("xcd-map" in form or "28-registers" in form or "24-ring-skew" in form):
         pytest.skip("the largest shape (14 s: the oracle replays every request) on the default forms and one register form (suite time)")
     M0, b0 = lp.synth.tableau(n, m, lp.synth.seed_for(9, seed))
     t = lp.Tableau(None, lp.Problem(type="max"), M0, b0, n + m, m, {})

@@ -26,10 +26,3 @@ def test_no_instruction_touches_an_in_flight_scalar_load_destination():
     assert sites >= 100, "the audit did not find the hand-issued scalar loads (%d)" % sites
     assert not findings, "in-flight SGPR destinations touched: %s" % findings[:5]
 
-
-def test_no_instruction_touches_the_ticket_register_of_an_asynchronous_draw():
-    """k_sweepw_dyn: the returning atomic that draws a wave's next chunk of rows is issued in one asm statement and
-    read in another several steps later; in between the compiler must not copy, spill or reuse the register."""
-    kernels, sites, findings = _audit_module().audit_draws()
-    assert kernels >= 16 and sites >= 2 * kernels, "the audit did not find k_sweepw_dyn's draws (%d kernels, %d sites)" % (kernels, sites)
-    assert not findings, "ticket registers touched while in flight: %s" % findings[:5]

@@ -44,67 +44,6 @@ def assembly(extra_flags=()):
     return _ASM_CACHE[key]
 
 
-def _vregs(text):
-    out = set()
-    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", text):
-        out |= set(range(int(a), int(b) + 1))
-    for a in re.findall(r"\bv(\d+)\b", text):
-        out.add(int(a))
-    return out
-
-
-def audit_draws(extra_flags=()):
-    """k_sweepw_dyn draws its chunks with a returning atomic that is issued inside one asm statement and whose
-    value is read by another (v_readfirstlane_b32) several steps later, behind a counted wait -- the compiler does
-    not know that the register is in flight in between.  -> (kernels with draws, draw sites, findings): every
-    draw of a kernel targets ONE VGPR, and from its first draw to its last read no instruction outside those
-    asm statements mentions that register (a copy, a spill, a reuse)."""
-    kernels, sites, findings = 0, 0, []
-    lines = assembly(extra_flags)
-    bounds = [i for i, ln in enumerate(lines) if re.match(r"^_Z\w+:", ln.strip())] + [len(lines)]
-    for a, b in zip(bounds, bounds[1:]):
-        name = lines[a].strip().split(":")[0]
-        body, in_asm, draws, reads, others = lines[a:b], False, [], [], []
-        for i, ln in enumerate(body):
-            t = ln.strip()
-            if t.startswith(";;#ASMSTART"):
-                in_asm = True
-                continue
-            if t.startswith(";;#ASMEND"):
-                in_asm = False
-                continue
-            if not t or t[0] in ";.":
-                continue
-            t = t.split(";")[0]
-            m = re.match(r"global_atomic_add v(\d+), v\[\d+:\d+\], v\d+, off sc0\s*$", t)
-            if in_asm and m:
-                draws.append((i, int(m.group(1))))
-                continue
-            m = re.match(r"v_readfirstlane_b32 s\d+, v(\d+)\s*$", t)
-            if in_asm and m:
-                reads.append((i, int(m.group(1))))
-                continue
-            others.append((i, t))
-        if not draws:
-            continue
-        kernels += 1
-        sites += len(draws)
-        reg = draws[0][1]
-        if any(r != reg for _, r in draws):
-            findings.append((name, "draws into different registers: %s" % sorted({r for _, r in draws})))
-        mine = [i for i, r in reads if r == reg]
-        if not mine:
-            findings.append((name, "no asm read of the ticket register v%d" % reg))
-            continue
-        first, last = draws[0][0], max(mine)
-        if max(i for i, _ in draws) > last:
-            findings.append((name, "a draw behind the last read of v%d" % reg))
-        for i, t in others:
-            if first < i < last and reg in _vregs(t):
-                findings.append((name, "v%d in flight: %s" % (reg, t.strip())))
-    return kernels, sites, findings
-
-
 def audit(extra_flags=()):
     """-> (asm s_load sites seen, [(kernel, instruction)] that touch an in-flight destination)."""
     lines = assembly(extra_flags)
@@ -146,8 +85,4 @@ if __name__ == "__main__":
     for k, ins in bad[:20]:
         print("%s: %s" % ((k or "?")[:70], ins))
     print("%d hand-issued scalar loads checked, %d instruction(s) touching an in-flight destination" % (n, len(bad)))
-    nk, nd, bad2 = audit_draws()
-    for k, what in bad2[:20]:
-        print("%s: %s" % ((k or "?")[:70], what))
-    print("%d kernels with %d asynchronous chunk draws checked, %d finding(s)" % (nk, nd, len(bad2)))
-    sys.exit(1 if bad or n == 0 or bad2 or nk == 0 else 0)
+    sys.exit(1 if bad or n == 0 else 0)

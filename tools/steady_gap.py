@@ -34,7 +34,7 @@ ap.add_argument("--tr", type=int, default=0, help="rows per sweep workgroup (0 =
 ap.add_argument("--nt", type=int, default=-1, help="non-temporal sweep accesses (0 / 1, -1 = by size)")
 ap.add_argument("--wait", type=int, default=2, help="status read-back: 2 published control block + memory poll (default), 1 polled stream query, 0 hipStreamSynchronize")
 ap.add_argument("--xmap", type=int, default=-1, help="k_sweepw_ring: workgroups -> tiles by XCD (1) or in grid order (0); -1 = the library's default")
-ap.add_argument("--dyn", type=int, default=-1, help="wide ring sweeps: rows drawn dynamically (1, k_sweepw_dyn) or static tiles (0); -1 = the library's default")
+ap.add_argument("--skew", type=int, default=-1, help="k_sweepw_ring, one round of workgroups: rows by which the thirds of the tiles differ (0 = equal tiles); -1 = the library's default")
 ap.add_argument("--prime", type=int, default=1, help="0: without the empty priming blocks in front of a handle's first request (profiling runs)")
 ap.add_argument("--one-xcd", type=int, default=1, help="persistent look-ahead: all workgroups on one XCD (1, default) or wherever they land (0)")
 ap.add_argument("--ring", type=int, default=1, help="wide sweeps through the LDS ring (1, default) or the register form (0)")
@@ -49,8 +49,8 @@ L.mi355x_tune_set_prime(args.prime)
 L.mi355x_tune_set_la_one_xcd(args.one_xcd)
 if args.xmap >= 0:
     L.mi355x_tune_set_sweep_xcd_map(args.xmap)
-if args.dyn >= 0:
-    L.mi355x_tune_set_sweep_dyn(args.dyn)
+if args.skew >= 0:
+    L.mi355x_tune_set_sweep_skew(args.skew)
 if args.block:
     L.mi355x_tune_set_block(args.block)
 if args.tr or args.nt >= 0:

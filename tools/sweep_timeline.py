@@ -4,7 +4,7 @@ wall_clock64 stamps, its XCC id and HW_ID into the handle's otherwise unused `rh
 prints the timeline of the LAST pass of the request: launch skew, prologue, end-time distribution (the tail a
 static one-round schedule leaves), per XCD.
 
-    python tools/sweep_timeline.py [n_vars n_cons] [--tr ROWS] [--xmap BITS] [--dyn 0|1]
+    python tools/sweep_timeline.py [n_vars n_cons] [--tr ROWS] [--xmap 0|1] [--skew ROWS]
 """
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,10 +24,10 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 n, m = (int(args[0]), int(args[1])) if len(args) >= 2 else (8192, 4096)
 if "--tr" in sys.argv:
     L.mi355x_tune_set_sweep_shape(int(sys.argv[sys.argv.index("--tr") + 1]), -1)
-if "--dyn" in sys.argv:
-    L.mi355x_tune_set_sweep_dyn(int(sys.argv[sys.argv.index("--dyn") + 1]))
+if "--skew" in sys.argv:
+    L.mi355x_tune_set_sweep_skew(int(sys.argv[sys.argv.index("--skew") + 1]))
 if "--xmap" in sys.argv:
-    L.mi355x_tune_set_sweep_xcd_map(int(sys.argv[sys.argv.index("--xmap") + 1]))   # (bit 0: XCD map, bits 8..: row skew)
+    L.mi355x_tune_set_sweep_xcd_map(int(sys.argv[sys.argv.index("--xmap") + 1]))
 h = ctypes.c_void_p()
 lp.capi.check(L.mi355x_tab_create_synthetic(ctypes.byref(h), n, m, lp.synth.seed_for(3), 0, -1, 0), "create")
 npv = ctypes.c_int64(0)
