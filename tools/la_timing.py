@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "linear-programming_amd"))
 import build as _build
-out = os.path.join(ROOT, "gpurun_out", "libmi355x_simplex_la_timing.so")
+out = os.path.join(ROOT, "tools", "libmi355x_simplex_la_timing.so")   # (in-tree: travels to the GPU box; *.so is git-ignored)
 os.makedirs(os.path.dirname(out), exist_ok=True)
 if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(s) for s in _build.sources()):
     _build.build(extra_flags=["-DMI355X_LA_TIMING"], out=out)
