@@ -41,6 +41,9 @@ for case in range(cases):
     if npiv == total:
         st_o = 100        # exactly the requested pivots were made: the device has not looked at the tableau again
     L.mi355x_tune_set_lookahead_mode(int(meta.choice([0, 0, 1]))); L.mi355x_tune_set_block(int(meta.choice([0, 0, 16, 8, 1, 24, 28])))
+    # (round 6) the wide ring pass with tiles of unequal heights: an explicit skew of the thirds on whatever grid
+    # the tile height gives (mi355x_tune_set_sweep_skew; -1 = the library's own rule)
+    L.mi355x_tune_set_sweep_skew(int(meta.choice([-1, 0, 4, 8, 12, 20]))); L.mi355x_tune_set_sweep_shape(int(meta.choice([0, 0, 8, 16, 32])), -1)
     h = ctypes.c_void_p()
     lp.capi.check(L.mi355x_tab_create(ctypes.byref(h), m + 1, n + m + 1, ptr(M0), ptr(b0), 0), "create")
     k = ctypes.c_int64(0)
