@@ -4,7 +4,7 @@ import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "linear-programming_amd"))
 import build as _build
-out = os.path.join(ROOT, "gpurun_out", "libmi355x_simplex_la_timing.so")
+out = os.path.join(ROOT, "tools", "libmi355x_simplex_la_timing.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 out = out.replace("la_timing", "la_skew")
 _build.build(extra_flags=["-DMI355X_LA_TIMING=2"], out=out)
